@@ -1,0 +1,52 @@
+/* parsenet_hip.h — C ABI of the MI355X (gfx950) ParSeNet hot-path library.
+ *
+ * The reference (Hippogriff/parsenet-codebase) is pure Python on PyTorch: it has no FFI
+ * of its own, so every entry point below replaces a *composition of stock torch ops*
+ * inside one reference function (cited as file:line, paths relative to the upstream
+ * repository).  The binding a maintainer adds is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless named h_*;
+ *   - every tensor is dense row-major ("contiguous") in the stated shape;
+ *   - floating data is fp32, index data is int64 (torch defaults), unless stated;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - buffers are caller-owned; scratch space is passed in, its size queried with the
+ *     matching pn_*_workspace();
+ *   - return value 0 = success, negative = error (PN_ERR_*); pn_last_error() returns a
+ *     thread-local description.  Functions are re-entrant and keep no global state.
+ */
+#ifndef PARSENET_HIP_H
+#define PARSENET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_OK 0
+#define PN_ERR_ARG (-1)
+#define PN_ERR_HIP (-2)
+#define PN_ERR_WORKSPACE (-3)
+#define PN_ERR_UNSUPPORTED (-4)
+
+const char* pn_last_error(void);
+int pn_abi_version(void);
+
+/* ---- Chamfer nearest neighbour ---------------------------------------------------
+ * Replaces the (M,N,3) broadcast + torch.min of src/utils.py:286-296 (chamfer_distance),
+ * :313-323 (chamfer_distance_one_side), :338-358 (chamfer_distance_single_shape).
+ * a (B,Na,3), b (B,Nb,3).  minA/argA (B,Na): squared distance to / index of the nearest
+ * point of b for every point of a; minB/argB (B,Nb) the other way.  Any output pointer
+ * may be NULL (a side whose two outputs are NULL is skipped).  Ties -> smallest index.
+ * d = ((dx*dx + dy*dy) + dz*dz), each operation rounded to fp32. */
+size_t pn_chamfer_nn_workspace(int B, int Na, int Nb);
+int pn_chamfer_nn_f32(const float* a, const float* b, int B, int Na, int Nb, float* minA,
+                      int64_t* argA, float* minB, int64_t* argB, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARSENET_HIP_H */

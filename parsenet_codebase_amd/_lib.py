@@ -1,0 +1,88 @@
+"""ctypes binding of ``libparsenet_hip.so`` (the C ABI of include/parsenet_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a symbol
+cannot be resolved, importing any compute entry point raises.  ``torch`` is
+imported first so that the HIP runtime already mapped by PyTorch-ROCm
+(SONAME ``libamdhip64.so.7``) is the one the kernels launch on; streams and
+device pointers are then shared between torch and this library.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparsenet_hip.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+c_double = ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
+SIGNATURES = {
+    "pn_last_error": (ctypes.c_char_p, []),
+    "pn_abi_version": (c_int, []),
+    "pn_chamfer_nn_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "pn_chamfer_nn_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load():
+    """Return the loaded library handle, raising loudly when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            "%s not found: build it with `python -m parsenet_codebase_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise HipExtensionError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipExtensionError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pn_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "parsenet_codebase_amd runs on MI355X only: got a %s tensor; there is no CPU "
+                "path in the product (the CPU restatement lives in oracle/ and is test-only)"
+                % t.device)
