@@ -34,6 +34,22 @@ extern "C" {
 const char* pn_last_error(void);
 int pn_abi_version(void);
 
+/* ---- kNN graph ------------------------------------------------------------------
+ * pn_knn_f32 replaces src/model.py:9-22 knn(x,k) and src/PointNet.py:9-26 knn(x,k1,k2)
+ * (k1 == k2; a dilation k2 > k1 is a strided slice of the k2 result done by the caller);
+ * pn_knn_pn_f32 replaces src/PointNet.py:29-69 knn_points_normals (rows 0:3 xyz, 3:6 unit
+ * normals, metric |dp|^2 * (1 + (2 - 2 ni.nj))).
+ * x (B,C,N) channel-first.  idx (B,N,k): for every point the k candidates with the LARGEST
+ * negated distance, best first, the point itself included; equal values -> smaller index.
+ * Arithmetic: dot products / squared norms are channel-ordered fp32 fma chains, combined as
+ * (-xx[j] - (-2*dot)) - xx[i] like the reference, every step rounded to fp32.
+ * Limits: 1 <= k <= 128, k <= N. */
+size_t pn_knn_workspace(int B, int C, int N, int k);
+int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx, void* workspace,
+               size_t workspace_bytes, void* stream);
+int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
 /* ---- Chamfer nearest neighbour ---------------------------------------------------
  * Replaces the (M,N,3) broadcast + torch.min of src/utils.py:286-296 (chamfer_distance),
  * :313-323 (chamfer_distance_one_side), :338-358 (chamfer_distance_single_shape).

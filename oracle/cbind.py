@@ -31,3 +31,25 @@ def chamfer_nn(q, c):
     arg = np.empty((B, Nq), np.int64)
     lib().pno_chamfer_nn(_p(q), _p(c), B, Nq, Nc, _p(mind), _p(arg))
     return mind, arg
+
+
+def knn(x, k, mode=0):
+    """x (B,C,N) float32 channel-first -> idx (B,N,k) int64, best first (see pno_knn)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, C, N = x.shape
+    idx = np.empty((B, N, k), np.int64)
+    lib().pno_knn(_p(x), B, C, N, k, mode, _p(idx))
+    return idx
+
+
+def knn_row_values(xb, i, mode=0):
+    """One row of the reference's (negated) pairwise-distance matrix for a single (C,N) item."""
+    xb = np.ascontiguousarray(xb, dtype=np.float32)
+    C, N = xb.shape
+    c1 = C if mode == 0 else 3
+    xx = np.zeros(N, np.float32)
+    for c in range(c1):
+        xx = (xb[c].astype(np.float64) * xb[c].astype(np.float64) + xx.astype(np.float64)).astype(np.float32)
+    v = np.empty(N, np.float32)
+    lib().pno_knn_values(_p(xb), C, N, mode, int(i), _p(xx), _p(v))
+    return v

@@ -24,6 +24,9 @@ c_double = ctypes.c_double
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
     "pn_abi_version": (c_int, []),
+    "pn_knn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "pn_knn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_knn_pn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_chamfer_nn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_chamfer_nn_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -47,3 +47,33 @@ def chamfer_nn(a, b, side_a=True, side_b=True):
                                    ptr(argB), ptr(ws), wsz, current_stream(dev))
     check(rc, "pn_chamfer_nn_f32")
     return minA, argA, minB, argB
+
+
+def knn(x, k, metric="feature"):
+    """k nearest neighbours in feature space, self included, best first.
+
+    x: (B, C, N) fp32 channel-first (the layout the reference's encoders use).
+    metric: "feature" (src/model.py:9-22, src/PointNet.py:9-26) or "points_normals"
+    (src/PointNet.py:29-69, C must be 6).  Returns idx (B, N, k) int64.
+    """
+    require_cuda(x)
+    x = _f32c(x, "x")
+    if x.dim() != 3:
+        raise ValueError("knn expects (B,C,N), got %s" % (tuple(x.shape),))
+    B, C, N = x.shape
+    lib = _lib.load()
+    dev = x.device
+    idx = torch.empty((B, N, k), dtype=torch.int64, device=dev)
+    wsz = lib.pn_knn_workspace(B, C, N, k)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        if metric == "feature":
+            rc = lib.pn_knn_f32(ptr(x), B, C, N, k, ptr(idx), ptr(ws), wsz, current_stream(dev))
+        elif metric == "points_normals":
+            if C != 6:
+                raise ValueError("points_normals metric needs 6 channels, got %d" % C)
+            rc = lib.pn_knn_pn_f32(ptr(x), B, N, k, ptr(idx), ptr(ws), wsz, current_stream(dev))
+        else:
+            raise ValueError("unknown metric %r" % (metric,))
+    check(rc, "pn_knn")
+    return idx

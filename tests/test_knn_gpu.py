@@ -1,0 +1,75 @@
+"""Parity of the HIP kNN kernels against the C oracle: indices bit-exact on arbitrary inputs
+(same fma chain, same tie rule), including ragged sizes, duplicates and the k limits."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_knn(x, k, gpu, metric="feature"):
+    from parsenet_codebase_amd import kernels
+    return kernels.knn(torch.from_numpy(x).to(gpu), k, metric).cpu().numpy()
+
+
+@pytest.mark.parametrize("B,C,N,k", [(1, 3, 64, 10), (2, 3, 700, 10), (3, 64, 333, 10),
+                                     (1, 128, 700, 10), (2, 6, 1000, 80), (1, 64, 2500, 80),
+                                     (1, 256, 450, 10), (1, 3, 130, 128), (1, 5, 40, 1)])
+def test_feature_metric_bit_exact(gpu, B, C, N, k):
+    from oracle import cbind
+    rng = np.random.RandomState(100 * C + N)
+    x = rng.uniform(-1, 1, (B, C, N)).astype(np.float32)
+    got = _gpu_knn(x, k, gpu)
+    want = cbind.knn(x, k, 0)
+    assert got.shape == (B, N, k)
+    assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
+
+
+@pytest.mark.parametrize("B,N,k", [(2, 700, 80), (1, 3000, 80), (1, 97, 20)])
+def test_points_normals_metric_bit_exact(gpu, B, N, k):
+    from oracle import cbind
+    rng = np.random.RandomState(N)
+    p = rng.uniform(-0.5, 0.5, (B, 3, N)).astype(np.float32)
+    n = rng.normal(size=(B, 3, N)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    x = np.concatenate([p, n], 1).astype(np.float32)
+    got = _gpu_knn(x, k, gpu, "points_normals")
+    want = cbind.knn(x, k, 1)
+    assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
+
+
+def test_duplicate_points_tie_rule(gpu):
+    """Coincident points give exactly equal values: the smaller index must come first."""
+    from oracle import cbind
+    rng = np.random.RandomState(3)
+    base = rng.uniform(-1, 1, (1, 3, 50)).astype(np.float32)
+    x = np.concatenate([base, base, base, base], 2)  # every point 4 times
+    got = _gpu_knn(x, 8, gpu)
+    want = cbind.knn(x, 8, 0)
+    assert np.array_equal(got, want)
+
+
+def test_self_is_first_and_sorted(gpu):
+    """Known answers of the reference: for distinct points the point itself is
+    neighbour 0 and values are non-increasing along k."""
+    from oracle import cbind
+    rng = np.random.RandomState(11)
+    x = rng.uniform(-0.5, 0.5, (1, 3, 10000)).astype(np.float32)
+    idx = _gpu_knn(x, 80, gpu)[0]
+    assert np.array_equal(idx[:, 0], np.arange(10000))
+    for i in (0, 1234, 9999):
+        v = cbind.knn_row_values(x[0], i)
+        vs = v[idx[i]]
+        assert (np.diff(vs) <= 0).all()
+        assert np.sort(v)[::-1][79] == vs[-1]
+
+
+def test_argument_errors(gpu):
+    from parsenet_codebase_amd import kernels
+    x = torch.zeros(1, 3, 16, device=gpu)
+    with pytest.raises(RuntimeError):
+        kernels.knn(x, 17)
+    with pytest.raises(RuntimeError):
+        kernels.knn(x, 0)
+    with pytest.raises(RuntimeError):
+        kernels.knn(torch.zeros(1, 3, 300, device=gpu), 129)

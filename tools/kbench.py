@@ -1,0 +1,50 @@
+"""Micro-benchmarks of individual HIP kernels (HIP-event timing on torch's current stream).
+Usage: python tools/kbench.py [knn] [chamfer] [edge] [meanshift] ..."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from parsenet_codebase_amd import kernels
+
+
+def timeit(fn, warmup=2, iters=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def bench_knn():
+    dev = torch.device("cuda:0")
+    for (B, C, N, k, metric) in [(4, 64, 10000, 80, "feature"), (4, 6, 10000, 80, "points_normals"),
+                                 (4, 3, 10000, 80, "feature"), (32, 64, 700, 10, "feature"),
+                                 (32, 3, 700, 10, "feature"), (32, 128, 700, 10, "feature")]:
+        x = torch.randn(B, C, N, device=dev)
+        if metric == "points_normals":
+            x[:, 3:] = torch.nn.functional.normalize(x[:, 3:], dim=1)
+        ms = timeit(lambda: kernels.knn(x, k, metric))
+        flops = B * N * N * (2 * C + 3)
+        print("knn B=%d C=%d N=%d k=%d %s: %.3f ms  %.1f TFLOP/s" % (B, C, N, k, metric, ms, flops / ms / 1e9))
+
+
+def bench_chamfer():
+    dev = torch.device("cuda:0")
+    for (B, Na, Nb) in [(1, 10000, 10000), (32, 1600, 700), (1, 900, 2000)]:
+        a = torch.rand(B, Na, 3, device=dev)
+        b = torch.rand(B, Nb, 3, device=dev)
+        ms = timeit(lambda: kernels.chamfer_nn(a, b))
+        print("chamfer B=%d %dx%d: %.3f ms  %.2f TFLOP/s (8 flop/pair, both sides)" %
+              (B, Na, Nb, ms, 2 * 8.0 * B * Na * Nb / ms / 1e9))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["knn", "chamfer"]
+    for w in which:
+        globals()["bench_" + w]()
