@@ -24,142 +24,7 @@
 //            v = -(p * (1 + n))                                     (PointNet.py:41-59)
 // The k LARGEST v are returned, best first; ties in v resolve to the smaller index
 // (torch.topk leaves ties unspecified).
-#include "common.h"
-
-#define KNN_TC 32        // candidates per step (accumulators per lane)
-#define KNN_CAP 1024     // list capacity per query (keys)
-#define KNN_CAP0 256     // first compaction after this many keys (tightens tau early)
-#define KNN_MAXK 128
-#define KNN_EPL (KNN_CAP / 64)  // list entries per lane during a wave-wide select
-
-typedef unsigned long long u64;
-
-__device__ static inline u64 knn_key(float v, int j) {
-  return ((u64)pn_f2ord(v) << 32) | (u64)(0xffffffffu - (uint32_t)j);
-}
-
-__device__ static inline u64 readlane_u64(u64 v, int l) {
-  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
-  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
-  return ((u64)hi << 32) | lo;
-}
-
-// Wave-cooperative: among the n keys at lp[0..n) keep the k largest (compacted to
-// lp[0..k), unordered) and return the k-th largest key.  Requires k <= n <= KNN_CAP.
-__device__ static u64 knn_wave_select(u64* __restrict__ lp, int n, int k,
-                                      uint32_t* __restrict__ hist) {
-  const int lane = threadIdx.x & 63;
-  u64 key[KNN_EPL];
-#pragma unroll
-  for (int e = 0; e < KNN_EPL; ++e) {
-    int s = e * 64 + lane;
-    key[e] = (s < n) ? lp[s] : 0ull;
-  }
-  u64 prefix = 0, pmask = 0, kth = 0;
-  int rem = k;
-  bool done = false;
-  for (int p = 7; p >= 0 && !done; --p) {
-    const int sh = p * 8;
-    reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0, 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < KNN_EPL; ++e) {
-      if (e * 64 + lane < n && (key[e] & pmask) == prefix)
-        atomicAdd(&hist[(uint32_t)(key[e] >> sh) & 255u], 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    uint4 h = reinterpret_cast<uint4*>(hist)[lane];
-    int hb[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
-    int tot = hb[0] + hb[1] + hb[2] + hb[3];
-    // inclusive prefix over lanes, then exclusive suffix (bins above this lane's)
-    int inc = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      int t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    int total = __builtin_amdgcn_readlane(inc, 63);
-    int cum = total - inc;
-    int found = -1, newrem = 0, fcount = 0;
-#pragma unroll
-    for (int bb = 3; bb >= 0; --bb) {
-      int c = hb[bb];
-      if (found < 0 && cum < rem && cum + c >= rem) {
-        found = lane * 4 + bb;
-        newrem = rem - cum;
-        fcount = c;
-      }
-      cum += c;
-    }
-    u64 fm = __ballot(found >= 0);
-    int src = __builtin_ctzll(fm);
-    int bin = __builtin_amdgcn_readlane(found, src);
-    rem = __builtin_amdgcn_readlane(newrem, src);
-    int bc = __builtin_amdgcn_readlane(fcount, src);
-    prefix |= (u64)bin << sh;
-    pmask |= 0xffull << sh;
-    if (bc == 1) {
-      // the k-th key is the only one with this prefix: fetch it and stop early
-      u64 cand = 0;
-#pragma unroll
-      for (int e = 0; e < KNN_EPL; ++e)
-        if (e * 64 + lane < n && (key[e] & pmask) == prefix) cand = key[e];
-      u64 cm = __ballot(cand != 0);
-      kth = readlane_u64(cand, __builtin_ctzll(cm));
-      done = true;
-    }
-  }
-  if (!done) kth = prefix;
-  // compact: exactly k keys are >= kth because keys are pairwise distinct
-  int mine = 0;
-#pragma unroll
-  for (int e = 0; e < KNN_EPL; ++e) mine += (e * 64 + lane < n && key[e] >= kth) ? 1 : 0;
-  int inc = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  int off = inc - mine;
-#pragma unroll
-  for (int e = 0; e < KNN_EPL; ++e)
-    if (e * 64 + lane < n && key[e] >= kth) lp[off++] = key[e];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  return kth;
-}
-
-// Bitonic sort (descending) of 128 keys held as 2 per lane: element e = r*64 + lane.
-__device__ static inline void knn_wave_sort128(u64& k0, u64& k1) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int size = 2; size <= 128; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      if (stride == 64) {
-        u64 a = k0 > k1 ? k0 : k1, b = k0 > k1 ? k1 : k0;
-        k0 = a;
-        k1 = b;
-      } else {
-        const bool lower = (lane & stride) == 0;
-        {
-          u64 pv = __shfl_xor(k0, stride, 64);
-          const bool up = ((lane & size) == 0);  // e = lane (bit 6 clear)
-          const bool keep_max = (lower == up);
-          k0 = keep_max ? (k0 > pv ? k0 : pv) : (k0 < pv ? k0 : pv);
-        }
-        {
-          u64 pv = __shfl_xor(k1, stride, 64);
-          const bool up = (((lane + 64) & size) == 0);
-          const bool keep_max = (lower == up);
-          k1 = keep_max ? (k1 > pv ? k1 : pv) : (k1 < pv ? k1 : pv);
-        }
-      }
-    }
-  }
-}
+#include "knn_common.h"
 
 // xx[b,j] = fma chain over channels [c0, c1) of x[b,c,j]^2
 __global__ void pn_knn_sqnorm_kernel(const float* __restrict__ x, int C, int N, int c0, int c1,
@@ -178,8 +43,9 @@ __global__ void pn_knn_sqnorm_kernel(const float* __restrict__ x, int C, int N, 
 
 template <int MODE, bool TAIL>
 __device__ static inline void knn_tile(const float* __restrict__ xb, const float* __restrict__ xxb,
-                                       int C, int N, int j0, int qc, float xxq, float tau,
-                                       int& cnt, u64* __restrict__ mylist) {
+                                       int C, int Nend, int j0, int qc, int N, float xxq,
+                                       float tau, int& cnt, u64* __restrict__ mylist) {
+  // N: row stride of x (points per item); Nend: one past the last candidate of this slice
   float acc[KNN_TC];
   float accn[MODE == 1 ? KNN_TC : 1];
 #pragma unroll
@@ -194,7 +60,7 @@ __device__ static inline void knn_tile(const float* __restrict__ xb, const float
       const float* __restrict__ row = xb + (size_t)c * N;  // wave-uniform
 #pragma unroll
       for (int t = 0; t < KNN_TC; ++t) {
-        const int j = TAIL ? min(j0 + t, N - 1) : j0 + t;
+        const int j = TAIL ? min(j0 + t, Nend - 1) : j0 + t;
         acc[t] = __builtin_fmaf(xq, row[j], acc[t]);
       }
     }
@@ -207,7 +73,7 @@ __device__ static inline void knn_tile(const float* __restrict__ xb, const float
       const float* __restrict__ rown = xb + (size_t)(c + 3) * N;
 #pragma unroll
       for (int t = 0; t < KNN_TC; ++t) {
-        const int j = TAIL ? min(j0 + t, N - 1) : j0 + t;
+        const int j = TAIL ? min(j0 + t, Nend - 1) : j0 + t;
         acc[t] = __builtin_fmaf(xq, row[j], acc[t]);
         accn[t] = __builtin_fmaf(nq, rown[j], accn[t]);
       }
@@ -215,7 +81,7 @@ __device__ static inline void knn_tile(const float* __restrict__ xb, const float
   }
 #pragma unroll
   for (int t = 0; t < KNN_TC; ++t) {
-    const int j = TAIL ? min(j0 + t, N - 1) : j0 + t;
+    const int j = TAIL ? min(j0 + t, Nend - 1) : j0 + t;
     const float xxj = xxb[j];  // wave-uniform
     float v;
     if (MODE == 0) {
@@ -227,7 +93,7 @@ __device__ static inline void knn_tile(const float* __restrict__ xb, const float
       const float pn = __fsub_rn(2.0f, __fmul_rn(2.0f, accn[t]));
       v = -__fmul_rn(pp, __fadd_rn(1.0f, pn));
     }
-    const bool ok = TAIL ? (j0 + t < N) : true;
+    const bool ok = TAIL ? (j0 + t < Nend) : true;
     if (ok && v >= tau) {
       mylist[cnt] = knn_key(v, j0 + t);
       ++cnt;
@@ -236,22 +102,34 @@ __device__ static inline void knn_tile(const float* __restrict__ xb, const float
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void pn_knn_kernel(const float* __restrict__ x,
-                                                     const float* __restrict__ xx, int C, int N,
-                                                     int k, u64* __restrict__ lists,
-                                                     int64_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void pn_knn_scan_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ xx, int C,
+                                                          int N, int k, int S, int slice_len,
+                                                          u64* __restrict__ lists,
+                                                          int* __restrict__ counts,
+                                                          int64_t* __restrict__ out,
+                                                          const int* __restrict__ gate) {
+  // grid: (ceil(N/256), S, B).  Wave = 64 queries x one slice of the candidates.
+  // S == 1: the sorted result goes straight to `out`; S > 1: every (query, slice) list is
+  // reduced to its k best and pn_knn_merge_kernel finishes the job.
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
-  const int b = blockIdx.y;
+  const int b = blockIdx.z;
+  const int slice = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qbase = (blockIdx.x * 4 + wave) * 64;
   if (qbase >= N) return;  // wave-uniform
   const int q = qbase + lane;
   const bool qvalid = q < N;
   const int qc = qvalid ? q : N - 1;
+  const int Np = (N + 63) & ~63;
+  // gated mode (fallback of the MFMA path): only waves owning a flagged query do any work
+  if (gate && !__any(qvalid && gate[(size_t)b * N + qc] != 0)) return;
   const float* __restrict__ xb = x + (size_t)b * C * N;
   const float* __restrict__ xxb = xx + (size_t)b * N;
-  u64* __restrict__ wlists = lists + ((size_t)b * N + qbase) * KNN_CAP;  // wave-uniform
-  u64* __restrict__ mylist = wlists + (size_t)lane * KNN_CAP;
+  // list of (b, q, slice): ((b*Np + q)*S + slice)*CAP
+  u64* __restrict__ wlists = lists + (((size_t)b * Np + qbase) * S + slice) * KNN_CAP;
+  const size_t lstride = (size_t)S * KNN_CAP;  // between consecutive queries
+  u64* __restrict__ mylist = wlists + (size_t)lane * lstride;
   uint32_t* hist = s_hist[wave];
   const float xxq = xxb[qc];
   // invalid lanes never pass the filter (comparison with NaN is false)
@@ -260,11 +138,13 @@ __global__ __launch_bounds__(256) void pn_knn_kernel(const float* __restrict__ x
   int trig = KNN_CAP0 - KNN_TC;
   if (trig < k) trig = k;  // never compact below k entries
 
-  for (int j0 = 0; j0 < N; j0 += KNN_TC) {
-    if (j0 + KNN_TC <= N)
-      knn_tile<MODE, false>(xb, xxb, C, N, j0, qc, xxq, tau, cnt, mylist);
+  const int j_begin = slice * slice_len;
+  const int j_end = min(N, j_begin + slice_len);
+  for (int j0 = j_begin; j0 < j_end; j0 += KNN_TC) {
+    if (j0 + KNN_TC <= j_end)
+      knn_tile<MODE, false>(xb, xxb, C, j_end, j0, qc, N, xxq, tau, cnt, mylist);
     else
-      knn_tile<MODE, true>(xb, xxb, C, N, j0, qc, xxq, tau, cnt, mylist);
+      knn_tile<MODE, true>(xb, xxb, C, j_end, j0, qc, N, xxq, tau, cnt, mylist);
     u64 m = __ballot(cnt > trig);
     if (m) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -272,7 +152,7 @@ __global__ __launch_bounds__(256) void pn_knn_kernel(const float* __restrict__ x
         const int L = __builtin_ctzll(m);
         m &= m - 1;
         const int n = __builtin_amdgcn_readlane(cnt, L);
-        const u64 kth = knn_wave_select(wlists + (size_t)L * KNN_CAP, n, k, hist);
+        const u64 kth = knn_wave_select(wlists + (size_t)L * lstride, n, k, hist);
         if (lane == L) {
           cnt = k;
           tau = pn_ord2f((uint32_t)(kth >> 32));
@@ -281,60 +161,127 @@ __global__ __launch_bounds__(256) void pn_knn_kernel(const float* __restrict__ x
       }
     }
   }
-  // final: reduce every list to its k best, sort, emit indices (best first)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   const int nvalid = min(64, N - qbase);
   for (int L = 0; L < nvalid; ++L) {
     const int n = __builtin_amdgcn_readlane(cnt, L);
-    u64* lp = wlists + (size_t)L * KNN_CAP;
+    u64* lp = wlists + (size_t)L * lstride;
     if (n > k) knn_wave_select(lp, n, k, hist);
-    const int m = n < k ? n : k;  // n < k only if the input held NaNs
+    const int m = n < k ? n : k;  // n < k: short slice (S > 1) or NaNs in the input
+    if (S > 1) {
+      if (lane == 0) counts[((size_t)b * Np + qbase + L) * S + slice] = m;
+      continue;
+    }
     u64 k0 = lane < m ? lp[lane] : 0ull;
     u64 k1 = lane + 64 < m ? lp[lane + 64] : 0ull;
     knn_wave_sort128(k0, k1);
     int64_t* o = out + ((size_t)b * N + qbase + L) * k;
-    if (lane < k) o[lane] = k0 ? (int64_t)(0xffffffffu - (uint32_t)(k0 & 0xffffffffu)) : 0;
-    if (lane + 64 < k) o[lane + 64] = k1 ? (int64_t)(0xffffffffu - (uint32_t)(k1 & 0xffffffffu)) : 0;
+    if (lane < k) o[lane] = knn_key_index(k0);
+    if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
   }
 }
 
-extern "C" size_t pn_knn_workspace(int B, int C, int N, int k) {
-  (void)C;
-  (void)k;
-  return pn_align_up((size_t)B * N * sizeof(float), 256) +
-         pn_align_up((size_t)B * pn_align_up(N, 64) * KNN_CAP * sizeof(u64), 256);
+// One wave per query: gather the <= S*k survivors of its slices into LDS, select the k best,
+// sort, emit.  S*k <= KNN_CAP is guaranteed by the launcher.
+__global__ __launch_bounds__(256) void pn_knn_merge_kernel(const u64* __restrict__ lists,
+                                                           const int* __restrict__ counts, int N,
+                                                           int k, int S, long long nq_total,
+                                                           int64_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
+  __shared__ u64 s_keys[4][KNN_CAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long qi = (long long)blockIdx.x * 4 + wave;  // index over B*N real queries
+  if (qi >= nq_total) return;
+  const int Np = (N + 63) & ~63;
+  const long long b = qi / N;
+  const int q = (int)(qi - b * N);
+  const size_t qslot = (size_t)b * Np + q;
+  u64* keys = s_keys[wave];
+  int n = 0;
+  for (int s = 0; s < S; ++s) {
+    const int c = counts[qslot * S + s];
+    const u64* lp = lists + (qslot * S + s) * KNN_CAP;
+    for (int e = lane; e < c; e += 64) keys[n + e] = lp[e];
+    n += c;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (n > k) knn_wave_select(keys, n, k, s_hist[wave]);
+  const int m = n < k ? n : k;
+  u64 k0 = lane < m ? keys[lane] : 0ull;
+  u64 k1 = lane + 64 < m ? keys[lane + 64] : 0ull;
+  knn_wave_sort128(k0, k1);
+  int64_t* o = out + (size_t)qi * k;
+  if (lane < k) o[lane] = knn_key_index(k0);
+  if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
 }
 
-static int knn_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
-                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static void knn_plan(int B, int N, int k, bool single, int* S_out, int* slice_len_out) {
+  if (single) {
+    *S_out = 1;
+    *slice_len_out = (int)pn_align_up(N, KNN_TC);
+    return;
+  }
+  const long long waves_q = (long long)B * pn_cdiv(N, 64);
+  int S = (int)(6144 / (waves_q > 0 ? waves_q : 1));
+  if (S > 8) S = 8;
+  if (S * k > KNN_CAP) S = KNN_CAP / k;
+  if (S < 1) S = 1;
+  int len = (int)pn_align_up(pn_cdiv(N, S), KNN_TC);
+  if (len < 128) len = 128;  // keep slices long enough to be worth a wave
+  if (len < k) len = (int)pn_align_up(k, KNN_TC);
+  S = pn_cdiv(N, len);
+  *S_out = S;
+  *slice_len_out = len;
+}
+
+size_t pn_knn_v1_workspace(int B, int C, int N, int k, bool gated) {
+  (void)C;
+  int S, len;
+  knn_plan(B, N, k, gated, &S, &len);
+  const size_t Np = pn_align_up(N, 64);
+  return pn_align_up((size_t)B * N * sizeof(float), 256) +
+         pn_align_up((size_t)B * Np * S * sizeof(int), 256) +
+         pn_align_up((size_t)B * Np * S * KNN_CAP * sizeof(u64), 256);
+}
+
+int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream,
+                     const int* gate) {
   PN_CHECK_ARG(x && idx, "pn_knn: null pointer");
   PN_CHECK_ARG(B > 0 && C > 0 && N > 0, "pn_knn: empty input (B=%d C=%d N=%d)", B, C, N);
   PN_CHECK_ARG(k >= 1 && k <= KNN_MAXK, "pn_knn: k=%d unsupported (1..%d)", k, KNN_MAXK);
   PN_CHECK_ARG(k <= N, "pn_knn: k=%d exceeds the number of points N=%d", k, N);
   PN_CHECK_ARG(mode == 0 || C == 6, "pn_knn_pn: points+normals metric needs C=6, got %d", C);
-  PN_CHECK_ARG(workspace && workspace_bytes >= pn_knn_workspace(B, C, N, k),
+  PN_CHECK_ARG(workspace && workspace_bytes >= pn_knn_v1_workspace(B, C, N, k, gate != nullptr),
                "pn_knn: workspace too small");
-  float* xx = (float*)workspace;
-  u64* lists = (u64*)((char*)workspace + pn_align_up((size_t)B * N * sizeof(float), 256));
+  int S, slice_len;
+  knn_plan(B, N, k, gate != nullptr, &S, &slice_len);
+  const size_t Np = pn_align_up(N, 64);
+  char* w = (char*)workspace;
+  float* xx = (float*)w;
+  w += pn_align_up((size_t)B * N * sizeof(float), 256);
+  int* counts = (int*)w;
+  w += pn_align_up((size_t)B * Np * S * sizeof(int), 256);
+  u64* lists = (u64*)w;
   dim3 g1(pn_cdiv(N, 256), B);
   hipLaunchKernelGGL(pn_knn_sqnorm_kernel, g1, dim3(256), 0, stream, x, C, N, 0,
                      mode == 0 ? C : 3, xx);
   PN_CHECK_LAUNCH();
-  dim3 grid(pn_cdiv(N, 256), B);
+  dim3 grid(pn_cdiv(N, 256), S, B);
   if (mode == 0)
-    hipLaunchKernelGGL(pn_knn_kernel<0>, grid, dim3(256), 0, stream, x, xx, C, N, k, lists, idx);
+    hipLaunchKernelGGL(pn_knn_scan_kernel<0>, grid, dim3(256), 0, stream, x, xx, C, N, k, S,
+                       slice_len, lists, counts, idx, gate);
   else
-    hipLaunchKernelGGL(pn_knn_kernel<1>, grid, dim3(256), 0, stream, x, xx, C, N, k, lists, idx);
+    hipLaunchKernelGGL(pn_knn_scan_kernel<1>, grid, dim3(256), 0, stream, x, xx, C, N, k, S,
+                       slice_len, lists, counts, idx, gate);
   PN_CHECK_LAUNCH();
+  if (S > 1) {
+    const long long nq = (long long)B * N;
+    hipLaunchKernelGGL(pn_knn_merge_kernel, dim3(pn_cdiv(nq, 4)), dim3(256), 0, stream, lists,
+                       counts, N, k, S, nq, idx);
+    PN_CHECK_LAUNCH();
+  }
   return PN_OK;
 }
 
-extern "C" int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  return knn_launch(0, x, B, C, N, k, idx, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-extern "C" int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
-                             size_t workspace_bytes, void* stream) {
-  return knn_launch(1, x6, B, 6, N, k, idx, workspace, workspace_bytes, (hipStream_t)stream);
-}
