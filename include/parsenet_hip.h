@@ -50,6 +50,56 @@ int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx, void* w
 int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* ---- layout helper: (B,R,C) -> (B,C,R) --------------------------------------------- */
+int pn_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
+
+/* ---- edge features, API form ------------------------------------------------------
+ * Replaces the gather + repeat + cat of src/model.py:25-53 (get_graph_feature) and
+ * src/PointNet.py:72-103, :106-140.  xt (B,N,C) is the point-major copy of x (the
+ * reference builds it with x.transpose(2,1).contiguous(), model.py:42); idx (B,N,k) are
+ * per-item indices (the reference's idx_base offset is applied internally).
+ * feat (B,N,k,2C): [x_j - x_i | x_i] — the memory behind the (B,2C,N,k) permuted view the
+ * reference returns.  The backward scatters a gradient of that shape into gxt (B,N,C). */
+int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int B, int N, int k, int C,
+                            float* feat, void* stream);
+int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N, int k, int C,
+                            float* gxt, void* stream);
+
+/* ---- fused edge convolution ---------------------------------------------------------
+ * Replaces get_graph_feature -> Conv2d 1x1 (no bias) -> GroupNorm / BatchNorm2d ->
+ * LeakyReLU -> max over k of src/PointNet.py:157-165,180-191,203-214 and
+ * src/model.py:75-86,146-159, without the (B,2C,N,k) tensor: the convolution is applied to
+ * points (PQ = xt @ [Wa ; Wb-Wa]^T, a plain GEMM done by the caller), the edge stage reduces
+ * y = P[idx] + Q over the k neighbours.
+ *   reduce_fwd : PQ (B,N,2*Cout), idx (B,N,k), gamma (Cout; only its sign is used: max where
+ *                gamma >= 0, min otherwise) -> yext, s1 = sum_k y (B,N,Cout) fp32, argk uint8
+ *                (B,N,Cout), stats fp64 [(per_sample ? B : 1)][groups][2] = sum y, sum y^2.
+ *                per_sample = 1: GroupNorm statistics; 0: BatchNorm statistics (groups = Cout).
+ *   moments    : stats -> mean, rstd = 1/sqrt(var + eps) (fp32), n = number of groups in total.
+ *   finalize   : out (B,Cout,N) = LeakyReLU(gamma*(yext-mean)*rstd + beta).
+ *   bwd_prep   : gout (B,Cout,N) -> gz = gout * LeakyReLU'(z), yhat, both (B,N,Cout).
+ *   bwd        : exact Group/BatchNorm gradient on every edge -> dPQ (B,N,2*Cout);
+ *                t = gamma*gz, c1c2 fp32 [(per_sample?B:1)][groups][2] = group means of t and
+ *                t*yhat over the edge activations; dense = 0 when the statistics were constants
+ *                (eval-mode BatchNorm). */
+int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma, int B,
+                               int N, int k, int Cout, int groups, int per_sample, float* yext,
+                               uint8_t* argk, float* s1, double* stats, void* stream);
+int pn_moments_f32(const double* stats, int n, double count, float eps, float* mean, float* rstd,
+                   void* stream);
+int pn_edgeconv_finalize_fwd_f32(const float* yext, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int B, int N, int Cout,
+                                 int groups, int per_sample, float slope, float* out,
+                                 void* stream);
+int pn_edgeconv_bwd_prep_f32(const float* gout, const float* yext, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, int B,
+                             int N, int Cout, int groups, int per_sample, float slope, float* gz,
+                             float* yhat, void* stream);
+int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t, const float* s1,
+                        const uint8_t* argk, const float* mean, const float* rstd,
+                        const float* c1c2, int B, int N, int k, int Cout, int groups,
+                        int per_sample, int dense, float* dPQ, void* stream);
+
 /* ---- Chamfer nearest neighbour ---------------------------------------------------
  * Replaces the (M,N,3) broadcast + torch.min of src/utils.py:286-296 (chamfer_distance),
  * :313-323 (chamfer_distance_one_side), :338-358 (chamfer_distance_single_shape).

@@ -27,6 +27,19 @@ SIGNATURES = {
     "pn_knn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pn_knn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_knn_pn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pn_edge_feature_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_edge_feature_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_edgeconv_reduce_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_moments_f32": (c_int, [c_void_p, c_int, c_double, c_float, c_void_p, c_void_p, c_void_p]),
+    "pn_edgeconv_finalize_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                             c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "pn_edgeconv_bwd_prep_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "pn_edgeconv_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p]),
     "pn_chamfer_nn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_chamfer_nn_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,553 @@
+// Edge features and fused edge convolution for gfx950.
+//
+// (1) pn_edge_feature_*: the API form of get_graph_feature
+//       src/model.py:25-53, src/PointNet.py:72-103, :106-140
+//     feat[b,n,kk,:] = cat(x[:,idx[b,n,kk]] - x[:,n], x[:,n])  laid out (B,N,k,2C) — the
+//     memory the reference's permuted (B,2C,N,k) view aliases.  Pure HBM streaming: rows of
+//     the point-major copy of x are read with 16-byte lanes, 512-byte rows are written.
+//
+// (2) pn_edgeconv_*: what the encoders actually run,
+//       conv1x1(no bias) -> Group/BatchNorm -> LeakyReLU -> max over k
+//       src/PointNet.py:157-165,180-191,203-214; src/model.py:75-86,146-159
+//     restructured for the hardware instead of materialising the (B,2C,N,k) tensor:
+//       W [xj - xi ; xi] = Wa xj + (Wb - Wa) xi = P[j] + Q[i]
+//     so the 1x1 convolution collapses to ONE dense (B*N, C) x (C, 2*Cout) GEMM on points
+//     (80x fewer FLOPs than on edges), and the edge stage is a gather-reduce over rows of P:
+//     per (point, channel) the extreme of y = P[j]+Q[i] over the k neighbours (max if the
+//     norm scale gamma >= 0, min otherwise: norm and LeakyReLU are monotone per channel),
+//     its arg, the sum over k (needed by the backward), and the group statistics
+//     sum(y), sum(y^2) accumulated in fp64.  The backward applies the full Group/BatchNorm
+//     gradient analytically, edge by edge (see pn_edgeconv_bwd_f32).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------
+// transpose (B,R,C) -> (B,C,R)
+// ------------------------------------------------------------------------------------
+__global__ void pn_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                    int C) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const float* ib = in + (size_t)b * R * C;
+  float* ob = out + (size_t)b * R * C;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < R && c < C) tile[i][tx] = ib[(size_t)r * C + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) ob[(size_t)c * R + r] = tile[tx][i];
+  }
+}
+
+extern "C" int pn_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream) {
+  PN_CHECK_ARG(in && out && B > 0 && R > 0 && C > 0, "pn_transpose_f32: bad arguments");
+  dim3 grid(pn_cdiv(C, 32), pn_cdiv(R, 32), B);
+  hipLaunchKernelGGL(pn_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// (1) edge features, API form
+// ------------------------------------------------------------------------------------
+// vector path: C % 4 == 0.  LPR = C/4 lanes per row; a wave covers 64/LPR edges per step.
+__global__ __launch_bounds__(256) void pn_edge_feature_vec_kernel(
+    const float* __restrict__ xt, const int64_t* __restrict__ idx, int N, int k, int C,
+    float* __restrict__ feat) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const int C4 = C >> 2;
+  const float4* __restrict__ xb = reinterpret_cast<const float4*>(xt + (size_t)b * N * C);
+  const int64_t* __restrict__ ib = idx + ((size_t)b * N + n) * k;
+  float4* __restrict__ fo = reinterpret_cast<float4*>(feat + ((size_t)b * N + n) * k * 2 * C);
+  if (C4 <= 64) {
+    const int epw = 64 / C4;            // edges per wave step
+    const int e = lane / C4, c4 = lane - e * C4;
+    if (e >= epw) return;
+    const float4 ctr = xb[(size_t)n * C4 + c4];
+    for (int kk = e; kk < k; kk += epw) {
+      const int j = (int)ib[kk];
+      const float4 nb = xb[(size_t)j * C4 + c4];
+      float4 d;
+      d.x = nb.x - ctr.x;
+      d.y = nb.y - ctr.y;
+      d.z = nb.z - ctr.z;
+      d.w = nb.w - ctr.w;
+      fo[(size_t)kk * 2 * C4 + c4] = d;
+      fo[(size_t)kk * 2 * C4 + C4 + c4] = ctr;
+    }
+  } else {
+    for (int kk = 0; kk < k; ++kk) {
+      const int j = (int)ib[kk];
+      for (int c4 = lane; c4 < C4; c4 += 64) {
+        const float4 ctr = xb[(size_t)n * C4 + c4];
+        const float4 nb = xb[(size_t)j * C4 + c4];
+        float4 d;
+        d.x = nb.x - ctr.x;
+        d.y = nb.y - ctr.y;
+        d.z = nb.z - ctr.z;
+        d.w = nb.w - ctr.w;
+        fo[(size_t)kk * 2 * C4 + c4] = d;
+        fo[(size_t)kk * 2 * C4 + C4 + c4] = ctr;
+      }
+    }
+  }
+}
+
+// scalar path for the narrow first layer (C = 3 or 6): one thread per output element
+__global__ void pn_edge_feature_scalar_kernel(const float* __restrict__ xt,
+                                              const int64_t* __restrict__ idx, int N, int k, int C,
+                                              long long total, float* __restrict__ feat) {
+  const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= total) return;
+  const int c2 = (int)(o % (2 * C));
+  const long long e = o / (2 * C);          // edge = (b*N + n)*k + kk
+  const long long pn = e / k;               // b*N + n
+  const long long b = pn / N;
+  const float ctr = xt[pn * C + (c2 < C ? c2 : c2 - C)];
+  if (c2 < C) {
+    const int j = (int)idx[e];
+    feat[o] = xt[(b * N + j) * C + c2] - ctr;
+  } else {
+    feat[o] = ctr;
+  }
+}
+
+extern "C" int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int B, int N, int k,
+                                       int C, float* feat, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(xt && idx && feat, "pn_edge_feature_fwd_f32: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && C > 0, "pn_edge_feature_fwd_f32: empty input");
+  if ((C & 3) == 0) {
+    dim3 grid(pn_cdiv(N, 4), B);
+    hipLaunchKernelGGL(pn_edge_feature_vec_kernel, grid, dim3(256), 0, stream, xt, idx, N, k, C,
+                       feat);
+  } else {
+    const long long total = (long long)B * N * k * 2 * C;
+    hipLaunchKernelGGL(pn_edge_feature_scalar_kernel, dim3(pn_cdiv(total, 256)), dim3(256), 0,
+                       stream, xt, idx, N, k, C, total, feat);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// backward of the API form: gxt[b,n,:] += sum_kk (g[n,kk,C:2C] - g[n,kk,0:C]);
+// gxt[b,idx[n,kk],:] += g[n,kk,0:C].  gxt (B,N,C) must be zero on entry.
+__global__ __launch_bounds__(256) void pn_edge_feature_bwd_kernel(
+    const float* __restrict__ g, const int64_t* __restrict__ idx, int N, int k, int C,
+    float* __restrict__ gxt) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  const int64_t* __restrict__ ib = idx + ((size_t)b * N + n) * k;
+  const float* __restrict__ gb = g + ((size_t)b * N + n) * k * 2 * C;
+  float* __restrict__ gx = gxt + (size_t)b * N * C;
+  for (int c = lane; c < C; c += 64) {
+    float ctr = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+      const float gd = gb[(size_t)kk * 2 * C + c];
+      const float gc = gb[(size_t)kk * 2 * C + C + c];
+      ctr += gc - gd;
+      atomicAdd(&gx[(size_t)ib[kk] * C + c], gd);
+    }
+    atomicAdd(&gx[(size_t)n * C + c], ctr);
+  }
+}
+
+extern "C" int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N, int k,
+                                       int C, float* gxt, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(gfeat && idx && gxt, "pn_edge_feature_bwd_f32: null pointer");
+  PN_CHECK_HIP(hipMemsetAsync(gxt, 0, (size_t)B * N * C * sizeof(float), stream));
+  dim3 grid(pn_cdiv(N, 4), B);
+  hipLaunchKernelGGL(pn_edge_feature_bwd_kernel, grid, dim3(256), 0, stream, gfeat, idx, N, k, C,
+                     gxt);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// (2) fused edge convolution: gather-reduce over rows of P
+// ------------------------------------------------------------------------------------
+#define EC_PPW 16  // points per wave
+#define EC_WAVES 4
+
+struct float4x {
+  float v[4];
+};
+__device__ static inline float4x ld4(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  return {{t.x, t.y, t.z, t.w}};
+}
+__device__ static inline void st4(float* p, const float4x& a) {
+  *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+// PQ (B,N,2*COUT): [P | Q] per point.  LPR = COUT/4 lanes cover one row; RPI rows per wave step.
+// Group statistics: Cg channels per group (group g = c / Cg).
+// stats: double [(per_sample ? B : 1)][COUT/Cg][2] accumulated with atomics (zero on entry).
+template <int COUT>
+__global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
+    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ gamma,
+    int N, int k, int Cg, int per_sample, float* __restrict__ yext, uint8_t* __restrict__ argk,
+    float* __restrict__ s1out, double* __restrict__ stats) {
+  constexpr int NCH = COUT <= 256 ? 1 : COUT / 256;  // float4 chunks per lane
+  constexpr int LPR = COUT <= 256 ? COUT / 4 : 64;   // lanes per row
+  constexpr int RPI = 64 / LPR;                      // rows per wave step
+  __shared__ double s_part[EC_WAVES][2][COUT];
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rg = lane / LPR, cl = lane - rg * LPR;
+  const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * COUT;
+  float sgn[NCH][4];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sgn[h][u] = gamma[(cl + h * 64) * 4 + u] >= 0.f ? 1.f : -1.f;
+  double d1[NCH][4], d2[NCH][4];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d1[h][u] = d2[h][u] = 0.0;
+
+  const int p0 = (blockIdx.x * EC_WAVES + wave) * EC_PPW;
+  for (int pi = 0; pi < EC_PPW; ++pi) {
+    const int i = p0 + pi;
+    if (i >= N) break;  // wave-uniform
+    const int64_t* __restrict__ ib = idx + ((size_t)b * N + i) * k;
+    float4x q[NCH], best[NCH], s1[NCH], s2[NCH];
+    int arg[NCH][4];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      q[h] = ld4(PQb + (size_t)i * 2 * COUT + COUT + (cl + h * 64) * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        best[h].v[u] = -__builtin_inff();
+        s1[h].v[u] = 0.f;
+        s2[h].v[u] = 0.f;
+        arg[h][u] = 0;
+      }
+    }
+    for (int kk0 = 0; kk0 < k; kk0 += RPI) {
+      const int kk = kk0 + rg;
+      if (kk < k) {
+        const int j = (int)ib[kk];
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+          const float4x v = ld4(PQb + (size_t)j * 2 * COUT + (cl + h * 64) * 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float y = v.v[u] + q[h].v[u];
+            const float ys = y * sgn[h][u];
+            if (ys > best[h].v[u]) {
+              best[h].v[u] = ys;
+              arg[h][u] = kk;
+            }
+            s1[h].v[u] += y;
+            s2[h].v[u] = __builtin_fmaf(y, y, s2[h].v[u]);
+          }
+        }
+      }
+    }
+    // combine the RPI row groups (lanes cl, cl+LPR, ...); ties -> smaller kk
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float ob = __shfl_xor(best[h].v[u], o, 64);
+          const int oa = __shfl_xor(arg[h][u], o, 64);
+          if (ob > best[h].v[u] || (ob == best[h].v[u] && oa < arg[h][u])) {
+            best[h].v[u] = ob;
+            arg[h][u] = oa;
+          }
+          s1[h].v[u] += __shfl_xor(s1[h].v[u], o, 64);
+          s2[h].v[u] += __shfl_xor(s2[h].v[u], o, 64);
+        }
+    }
+    if (rg == 0) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const size_t o = ((size_t)b * N + i) * COUT + (cl + h * 64) * 4;
+        float4x e;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          e.v[u] = best[h].v[u] * sgn[h][u];
+          d1[h][u] += (double)s1[h].v[u];
+          d2[h][u] += (double)s2[h].v[u];
+        }
+        st4(yext + o, e);
+        st4(s1out + o, s1[h]);
+        *reinterpret_cast<uchar4*>(argk + o) =
+            make_uchar4((uint8_t)arg[h][0], (uint8_t)arg[h][1], (uint8_t)arg[h][2], (uint8_t)arg[h][3]);
+      }
+    }
+  }
+  // block reduction of the statistics, then one fp64 atomic per (group, moment)
+  if (rg == 0) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s_part[wave][0][(cl + h * 64) * 4 + u] = d1[h][u];
+        s_part[wave][1][(cl + h * 64) * 4 + u] = d2[h][u];
+      }
+  }
+  __syncthreads();
+  const int G = COUT / Cg;
+  for (int t = threadIdx.x; t < 2 * G; t += blockDim.x) {
+    const int g = t >> 1, which = t & 1;
+    double acc = 0.0;
+    for (int w = 0; w < EC_WAVES; ++w)
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c) acc += s_part[w][which][c];
+    atomicAdd(&stats[((size_t)(per_sample ? b : 0) * G + g) * 2 + which], acc);
+  }
+}
+
+// generic (any Cout): one thread per (point, channel); used for unusual widths only
+__global__ void pn_edgeconv_reduce_generic_kernel(
+    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ gamma,
+    int N, int k, int Cout, int Cg, int per_sample, float* __restrict__ yext,
+    uint8_t* __restrict__ argk, float* __restrict__ s1out, double* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)N * Cout) return;
+  const int i = (int)(t / Cout), c = (int)(t - (long long)i * Cout);
+  const float* PQb = PQ + (size_t)b * N * 2 * Cout;
+  const int64_t* ib = idx + ((size_t)b * N + i) * k;
+  const float q = PQb[(size_t)i * 2 * Cout + Cout + c];
+  const float sg = gamma[c] >= 0.f ? 1.f : -1.f;
+  float best = -__builtin_inff(), s1 = 0.f, s2 = 0.f;
+  int arg = 0;
+  for (int kk = 0; kk < k; ++kk) {
+    const float y = PQb[(size_t)ib[kk] * 2 * Cout + c] + q;
+    const float ys = y * sg;
+    if (ys > best) {
+      best = ys;
+      arg = kk;
+    }
+    s1 += y;
+    s2 = __builtin_fmaf(y, y, s2);
+  }
+  const size_t o = ((size_t)b * N + i) * Cout + c;
+  yext[o] = best * sg;
+  s1out[o] = s1;
+  argk[o] = (uint8_t)arg;
+  const int G = Cout / Cg, g = c / Cg;
+  atomicAdd(&stats[((size_t)(per_sample ? b : 0) * G + g) * 2 + 0], (double)s1);
+  atomicAdd(&stats[((size_t)(per_sample ? b : 0) * G + g) * 2 + 1], (double)s2);
+}
+
+extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma,
+                                          int B, int N, int k, int Cout, int groups,
+                                          int per_sample, float* yext, uint8_t* argk, float* s1,
+                                          double* stats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(PQ && idx && gamma && yext && argk && s1 && stats,
+               "pn_edgeconv_reduce_fwd_f32: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && k <= 255 && Cout > 0,
+               "pn_edgeconv_reduce_fwd_f32: bad sizes (B=%d N=%d k=%d Cout=%d)", B, N, k, Cout);
+  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_reduce_fwd_f32: groups=%d", groups);
+  const int Cg = Cout / groups;
+  PN_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * (per_sample ? B : 1), stream));
+  dim3 grid(pn_cdiv(N, EC_WAVES * EC_PPW), B);
+#define EC_GO(CO)                                                                              \
+  hipLaunchKernelGGL(pn_edgeconv_reduce_kernel<CO>, grid, dim3(256), 0, stream, PQ, idx, gamma, \
+                     N, k, Cg, per_sample, yext, argk, s1, stats)
+  if (Cout == 64)
+    EC_GO(64);
+  else if (Cout == 128)
+    EC_GO(128);
+  else if (Cout == 256)
+    EC_GO(256);
+  else if (Cout == 512)
+    EC_GO(512);
+  else {
+    dim3 g2(pn_cdiv((long long)N * Cout, 256), B);
+    hipLaunchKernelGGL(pn_edgeconv_reduce_generic_kernel, g2, dim3(256), 0, stream, PQ, idx, gamma,
+                       N, k, Cout, Cg, per_sample, yext, argk, s1, stats);
+  }
+#undef EC_GO
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// mean / rstd of every group from the fp64 moments (count = elements per group)
+__global__ void pn_moments_kernel(const double* __restrict__ stats, int n, double count, float eps,
+                                  float* __restrict__ mean, float* __restrict__ rstd) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const double m = stats[2 * t] / count;
+  double var = stats[2 * t + 1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[t] = (float)m;
+  rstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int pn_moments_f32(const double* stats, int n, double count, float eps, float* mean,
+                              float* rstd, void* stream) {
+  PN_CHECK_ARG(stats && mean && rstd && n > 0 && count > 0, "pn_moments_f32: bad arguments");
+  hipLaunchKernelGGL(pn_moments_kernel, dim3(pn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     stats, n, count, eps, mean, rstd);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// out[b,c,n] = lrelu(gamma[c] * (yext[b,n,c] - mean) * rstd + beta[c]); mean/rstd indexed by
+// (per_sample ? b : 0, c / Cg).  Point-major in, channel-first out (LDS transpose).
+__global__ void pn_edgeconv_finalize_kernel(const float* __restrict__ yext,
+                                            const float* __restrict__ mean,
+                                            const float* __restrict__ rstd,
+                                            const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, int N, int Cout, int Cg,
+                                            int per_sample, float slope, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int G = Cout / Cg;
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    if (n < N && c < Cout) {
+      const int sidx = (per_sample ? b : 0) * G + c / Cg;
+      const float yh = (yext[((size_t)b * N + n) * Cout + c] - mean[sidx]) * rstd[sidx];
+      const float z = __builtin_fmaf(gamma[c], yh, beta[c]);
+      tile[i][tx] = z > 0.f ? z : z * slope;
+    }
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    if (n < N && c < Cout) out[((size_t)b * Cout + c) * N + n] = tile[tx][i];
+  }
+}
+
+extern "C" int pn_edgeconv_finalize_fwd_f32(const float* yext, const float* mean,
+                                            const float* rstd, const float* gamma,
+                                            const float* beta, int B, int N, int Cout, int groups,
+                                            int per_sample, float slope, float* out, void* stream) {
+  PN_CHECK_ARG(yext && mean && rstd && gamma && beta && out, "pn_edgeconv_finalize_fwd_f32: null");
+  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_finalize_fwd_f32: groups=%d", groups);
+  dim3 grid(pn_cdiv(Cout, 32), pn_cdiv(N, 32), B);
+  hipLaunchKernelGGL(pn_edgeconv_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, yext,
+                     mean, rstd, gamma, beta, N, Cout, Cout / groups, per_sample, slope, out);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// Backward, step A (elementwise, with the transpose back to point-major):
+//   yhat = (yext - mean) * rstd ; z = gamma*yhat + beta ; gz = gout * (z > 0 ? 1 : slope)
+// writes gz and yhat as (B,N,Cout).
+__global__ void pn_edgeconv_bwd_prep_kernel(const float* __restrict__ gout,
+                                            const float* __restrict__ yext,
+                                            const float* __restrict__ mean,
+                                            const float* __restrict__ rstd,
+                                            const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, int N, int Cout, int Cg,
+                                            int per_sample, float slope, float* __restrict__ gz,
+                                            float* __restrict__ yhat) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int G = Cout / Cg;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    if (n < N && c < Cout) tile[i][tx] = gout[((size_t)b * Cout + c) * N + n];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, c = c0 + tx;
+    if (n < N && c < Cout) {
+      const int sidx = (per_sample ? b : 0) * G + c / Cg;
+      const size_t o = ((size_t)b * N + n) * Cout + c;
+      const float yh = (yext[o] - mean[sidx]) * rstd[sidx];
+      const float z = __builtin_fmaf(gamma[c], yh, beta[c]);
+      gz[o] = tile[tx][i] * (z > 0.f ? 1.f : slope);
+      yhat[o] = yh;
+    }
+  }
+}
+
+extern "C" int pn_edgeconv_bwd_prep_f32(const float* gout, const float* yext, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta,
+                                        int B, int N, int Cout, int groups, int per_sample,
+                                        float slope, float* gz, float* yhat, void* stream) {
+  PN_CHECK_ARG(gout && yext && mean && rstd && gamma && beta && gz && yhat,
+               "pn_edgeconv_bwd_prep_f32: null pointer");
+  dim3 grid(pn_cdiv(Cout, 32), pn_cdiv(N, 32), B);
+  hipLaunchKernelGGL(pn_edgeconv_bwd_prep_kernel, grid, dim3(256), 0, (hipStream_t)stream, gout,
+                     yext, mean, rstd, gamma, beta, N, Cout, Cout / groups, per_sample, slope, gz,
+                     yhat);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// Backward, step B: the exact normalisation gradient on every edge.
+// With t = gamma*gz (per point/channel), c1 = mean_group(t), c2 = mean_group(t*yhat) over the
+// M = Cg*N*k (x B for batch statistics) edge activations of the group:
+//   dy_e = rstd * ( [e is the extreme edge] * t  -  c1  -  c2 * yhat_e ),  yhat_e = (P[j]+Q[i]-mean)*rstd
+//   dQ[i] = sum_kk dy  = rstd * ( t - k*c1 - c2 * rstd * (s1 - k*mean) )
+//   dP[j] += dy_e      (scatter over the kNN graph, fp32 atomics, rows are contiguous)
+// dPQ (B,N,2*Cout) must be zero on entry.  c1c2: float [(per_sample?B:1)][G][2].
+__global__ __launch_bounds__(256) void pn_edgeconv_bwd_kernel(
+    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ t,
+    const float* __restrict__ s1, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cout, int Cg,
+    int per_sample, int dense, float* __restrict__ dPQ) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= N) return;
+  const int G = Cout / Cg;
+  const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * Cout;
+  float* __restrict__ dPQb = dPQ + (size_t)b * N * 2 * Cout;
+  const int64_t* __restrict__ ib = idx + ((size_t)b * N + i) * k;
+  for (int c = lane; c < Cout; c += 64) {
+    const int sidx = (per_sample ? b : 0) * G + c / Cg;
+    const float mu = mean[sidx], r = rstd[sidx];
+    const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
+    const size_t o = ((size_t)b * N + i) * Cout + c;
+    const float tt = t[o];
+    const float q = PQb[(size_t)i * 2 * Cout + Cout + c];
+    const int ak = argk[o];
+    const float fk = (float)k;
+    dPQb[(size_t)i * 2 * Cout + Cout + c] = r * (tt - fk * c1 - c2 * r * (s1[o] - fk * mu));
+    if (dense) {
+      for (int kk = 0; kk < k; ++kk) {
+        const int j = (int)ib[kk];
+        const float yh = (PQb[(size_t)j * 2 * Cout + c] + q - mu) * r;
+        float dy = -r * (c1 + c2 * yh);
+        if (kk == ak) dy += r * tt;
+        atomicAdd(&dPQb[(size_t)j * 2 * Cout + c], dy);
+      }
+    } else {
+      // statistics are constants (eval-mode BatchNorm): only the extreme edge carries gradient
+      atomicAdd(&dPQb[(size_t)ib[ak] * 2 * Cout + c], r * tt);
+    }
+  }
+}
+
+extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t,
+                                   const float* s1, const uint8_t* argk, const float* mean,
+                                   const float* rstd, const float* c1c2, int B, int N, int k,
+                                   int Cout, int groups, int per_sample, int dense, float* dPQ,
+                                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(PQ && idx && t && s1 && argk && mean && rstd && c1c2 && dPQ,
+               "pn_edgeconv_bwd_f32: null pointer");
+  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_bwd_f32: groups=%d", groups);
+  PN_CHECK_HIP(hipMemsetAsync(dPQ, 0, (size_t)B * N * 2 * Cout * sizeof(float), stream));
+  dim3 grid(pn_cdiv(N, 4), B);
+  hipLaunchKernelGGL(pn_edgeconv_bwd_kernel, grid, dim3(256), 0, stream, PQ, idx, t, s1, argk,
+                     mean, rstd, c1c2, N, k, Cout, Cout / groups, per_sample, dense, dPQ);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

@@ -1,0 +1,181 @@
+"""kNN graph, edge features and the fused edge convolution, with autograd.
+
+Public names mirror the reference (src/model.py:9-53, src/PointNet.py:9-140); everything
+numerically heavy is a HIP kernel reached through ``kernels`` (C ABI).  Only tiny
+per-channel reductions and the point-level GEMM are left to torch (rocBLAS).
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+# --------------------------------------------------------------------------------------
+# kNN — no gradient flows through the indices (the reference wraps them in no_grad)
+# --------------------------------------------------------------------------------------
+def _as_bcn(x):
+    if x.dim() != 3:
+        raise ValueError("expected a (B,C,N) tensor, got %s" % (tuple(x.shape),))
+    return x.detach()
+
+
+def knn(x, k):
+    """src/model.py:9-22.  x (B,C,N) -> idx (B,N,k) int64, nearest first, self included."""
+    with torch.no_grad():
+        return K.knn(_as_bcn(x), int(k), "feature")
+
+
+def knn_dilated(x, k1, k2):
+    """src/PointNet.py:9-26: top-k2, keeping columns arange(0, k2, k2 // k1)."""
+    with torch.no_grad():
+        idx = K.knn(_as_bcn(x), int(k2), "feature")
+        if k1 != k2:
+            cols = torch.as_tensor(np.arange(0, k2, k2 // k1), device=idx.device)
+            idx = idx.index_select(2, cols).contiguous()
+        return idx
+
+
+def knn_points_normals(x, k1, k2):
+    """src/PointNet.py:29-69: rows 0:3 xyz, 3:6 unit normals; metric |dp|^2 (1 + (2 - 2 ni.nj))."""
+    with torch.no_grad():
+        idx = K.knn(_as_bcn(x), int(k2), "points_normals")
+        if k1 != k2:
+            cols = torch.as_tensor(np.arange(0, k2, k2 // k1), device=idx.device)
+            idx = idx.index_select(2, cols).contiguous()
+        return idx
+
+
+# --------------------------------------------------------------------------------------
+# get_graph_feature, API form
+# --------------------------------------------------------------------------------------
+class _EdgeFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        xt = K.transpose12(x)  # (B,N,C)
+        feat = K.edge_feature_fwd(xt, idx)
+        ctx.save_for_backward(idx)
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        (idx,) = ctx.saved_tensors
+        gxt = K.edge_feature_bwd(gfeat.contiguous(), idx)
+        return K.transpose12(gxt), None
+
+
+def graph_feature(x, idx):
+    """x (B,C,N), idx (B,N,k) per-item indices -> (B,2C,N,k) view of (B,N,k,2C) memory,
+    exactly the tensor src/model.py:49-51 returns."""
+    x = x.contiguous()
+    feat = _EdgeFeature.apply(x, idx)
+    return feat.permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------------------
+# fused edge convolution: conv1x1 -> norm -> LeakyReLU -> max_k
+# --------------------------------------------------------------------------------------
+class _EdgeConvNormMax(torch.autograd.Function):
+    """PQ (B,N,2*Cout) point-level products, idx (B,N,k) -> out (B,Cout,N).
+
+    ``per_sample`` selects GroupNorm statistics (per item and group) or BatchNorm statistics
+    (per channel over the batch).  ``fixed`` = (mean, rstd) replaces the batch statistics by
+    constants (eval-mode BatchNorm).  Also returns the fp64 moments so that BatchNorm can
+    update its running estimates.
+    """
+
+    @staticmethod
+    def forward(ctx, PQ, idx, gamma, beta, groups, per_sample, eps, slope, fixed):
+        PQ = PQ.contiguous()
+        B, N, C2 = PQ.shape
+        Cout = C2 // 2
+        k = idx.shape[2]
+        yext, argk, s1, stats = K.edgeconv_reduce_fwd(PQ, idx, gamma.detach(), groups, per_sample)
+        if fixed is None:
+            count = (Cout // groups) * N * k * (1 if per_sample else B)
+            mean, rstd = K.moments(stats, count, eps)
+            dense = True
+        else:
+            mean, rstd = fixed
+            mean = mean.reshape(1, groups).contiguous().float()
+            rstd = rstd.reshape(1, groups).contiguous().float()
+            dense = False
+        out = K.edgeconv_finalize_fwd(yext, mean, rstd, gamma.detach(), beta.detach(), groups, per_sample,
+                                      slope)
+        ctx.save_for_backward(PQ, idx, gamma, beta, yext, argk, s1, mean, rstd)
+        ctx.cfg = (groups, per_sample, slope, dense, k)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, gout, _gstats):
+        PQ, idx, gamma, beta, yext, argk, s1, mean, rstd = ctx.saved_tensors
+        groups, per_sample, slope, dense, k = ctx.cfg
+        B, N, Cout = yext.shape
+        gz, yhat = K.edgeconv_bwd_prep(gout, yext, mean, rstd, gamma, beta, groups, per_sample, slope)
+        dbeta = gz.sum((0, 1))
+        dgamma = (gz * yhat).sum((0, 1))
+        t = gz * gamma
+        Cg = Cout // groups
+        if dense:
+            tv = t.view(B, N, groups, Cg).double()
+            yv = yhat.view(B, N, groups, Cg).double()
+            if per_sample:
+                S1 = tv.sum((1, 3))
+                S2 = (tv * yv).sum((1, 3))
+                M = float(Cg * N * k)
+            else:
+                S1 = tv.sum((0, 1, 3)).unsqueeze(0)
+                S2 = (tv * yv).sum((0, 1, 3)).unsqueeze(0)
+                M = float(Cg * N * k * B)
+            c1c2 = torch.stack([S1 / M, S2 / M], -1).float().contiguous()
+        else:
+            c1c2 = torch.zeros((1, groups, 2), dtype=torch.float32, device=PQ.device)
+        dPQ = K.edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense)
+        return dPQ, None, dgamma, dbeta, None, None, None, None, None
+
+
+def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
+    """One DGCNN edge-conv layer on the kNN graph ``idx``:
+    max_k LeakyReLU(norm(conv1x1(cat(x_j - x_i, x_i)))) -> (B,Cout,N).
+
+    x (B,C,N); weight (Cout, 2C, 1, 1) or (Cout, 2C) without bias; ``norm`` is the layer's
+    torch.nn.GroupNorm / BatchNorm2d module (its parameters, statistics mode and running
+    buffers are honoured, including the running-statistics update in training mode).
+    """
+    B, C, N = x.shape
+    w = weight.reshape(weight.shape[0], -1)
+    Cout = w.shape[0]
+    if w.shape[1] != 2 * C:
+        raise ValueError("edge conv weight expects %d input channels, got %d" % (2 * C, w.shape[1]))
+    wa, wb = w[:, :C], w[:, C:]
+    # W [xj - xi ; xi] = Wa xj + (Wb - Wa) xi: one GEMM on points
+    wcat = torch.cat([wa, wb - wa], 0)                     # (2Cout, C)
+    PQ = torch.matmul(x.transpose(1, 2), wcat.t())          # (B,N,2Cout)
+    if isinstance(norm, torch.nn.GroupNorm):
+        out, _ = _EdgeConvNormMax.apply(PQ, idx, norm.weight, norm.bias, norm.num_groups, True, norm.eps,
+                                        slope, None)
+        return out
+    if isinstance(norm, torch.nn.modules.batchnorm._BatchNorm):
+        gamma = norm.weight if norm.weight is not None else torch.ones(Cout, device=x.device)
+        beta = norm.bias if norm.bias is not None else torch.zeros(Cout, device=x.device)
+        use_batch = norm.training or norm.running_mean is None
+        if use_batch:
+            out, stats = _EdgeConvNormMax.apply(PQ, idx, gamma, beta, Cout, False, norm.eps, slope, None)
+            if norm.training and norm.track_running_stats:
+                with torch.no_grad():
+                    k = idx.shape[2]
+                    M = float(B * N * k)
+                    mean = stats[0, :, 0] / M
+                    var = (stats[0, :, 1] / M - mean * mean).clamp_min(0.0)
+                    norm.num_batches_tracked += 1
+                    mom = norm.momentum
+                    if mom is None:
+                        mom = 1.0 / float(norm.num_batches_tracked)
+                    norm.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
+                    norm.running_var.mul_(1 - mom).add_((var * (M / max(M - 1.0, 1.0))).float(), alpha=mom)
+            return out
+        rstd = torch.rsqrt(norm.running_var + norm.eps)
+        out, _ = _EdgeConvNormMax.apply(PQ, idx, gamma, beta, Cout, False, norm.eps, slope,
+                                        (norm.running_mean, rstd))
+        return out
+    raise TypeError("unsupported norm layer %r" % (norm,))

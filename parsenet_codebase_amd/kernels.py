@@ -77,3 +77,134 @@ def knn(x, k, metric="feature"):
             raise ValueError("unknown metric %r" % (metric,))
     check(rc, "pn_knn")
     return idx
+
+
+def _i64c(t, name):
+    if t.dtype != torch.int64:
+        raise TypeError("%s must be int64, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def transpose12(x):
+    """(B,R,C) -> contiguous (B,C,R) through the LDS-tiled HIP transpose."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    B, R, C = x.shape
+    out = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pn_transpose_f32(ptr(x), ptr(out), B, R, C, current_stream(x.device))
+    check(rc, "pn_transpose_f32")
+    return out
+
+
+def edge_feature_fwd(xt, idx):
+    """xt (B,N,C) point-major, idx (B,N,k) -> feat (B,N,k,2C) = cat(x_j - x_i, x_i)."""
+    require_cuda(xt, idx)
+    xt = _f32c(xt, "xt")
+    idx = _i64c(idx, "idx")
+    B, N, C = xt.shape
+    k = idx.shape[2]
+    feat = torch.empty((B, N, k, 2 * C), dtype=torch.float32, device=xt.device)
+    with torch.cuda.device(xt.device):
+        rc = _lib.load().pn_edge_feature_fwd_f32(ptr(xt), ptr(idx), B, N, k, C, ptr(feat),
+                                                 current_stream(xt.device))
+    check(rc, "pn_edge_feature_fwd_f32")
+    return feat
+
+
+def edge_feature_bwd(gfeat, idx):
+    """gfeat (B,N,k,2C) -> gradient w.r.t. xt (B,N,C)."""
+    require_cuda(gfeat, idx)
+    gfeat = _f32c(gfeat, "gfeat")
+    idx = _i64c(idx, "idx")
+    B, N, k, C2 = gfeat.shape
+    C = C2 // 2
+    gxt = torch.empty((B, N, C), dtype=torch.float32, device=gfeat.device)
+    with torch.cuda.device(gfeat.device):
+        rc = _lib.load().pn_edge_feature_bwd_f32(ptr(gfeat), ptr(idx), B, N, k, C, ptr(gxt),
+                                                 current_stream(gfeat.device))
+    check(rc, "pn_edge_feature_bwd_f32")
+    return gxt
+
+
+def edgeconv_reduce_fwd(PQ, idx, gamma, groups, per_sample):
+    """PQ (B,N,2*Cout) = [P | Q], idx (B,N,k).  Returns yext, argk (uint8), s1 (all (B,N,Cout))
+    and the fp64 group moments stats ((B or 1), groups, 2) of y = P[j] + Q[i] over all edges."""
+    require_cuda(PQ, idx, gamma)
+    PQ = _f32c(PQ, "PQ")
+    idx = _i64c(idx, "idx")
+    gamma = _f32c(gamma, "gamma")
+    B, N, C2 = PQ.shape
+    Cout = C2 // 2
+    k = idx.shape[2]
+    dev = PQ.device
+    yext = torch.empty((B, N, Cout), dtype=torch.float32, device=dev)
+    s1 = torch.empty((B, N, Cout), dtype=torch.float32, device=dev)
+    argk = torch.empty((B, N, Cout), dtype=torch.uint8, device=dev)
+    stats = torch.empty((B if per_sample else 1, groups, 2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_edgeconv_reduce_fwd_f32(ptr(PQ), ptr(idx), ptr(gamma), B, N, k, Cout, groups,
+                                                    int(per_sample), ptr(yext), ptr(argk), ptr(s1),
+                                                    ptr(stats), current_stream(dev))
+    check(rc, "pn_edgeconv_reduce_fwd_f32")
+    return yext, argk, s1, stats
+
+
+def moments(stats, count, eps):
+    """fp64 (sum, sum of squares) -> fp32 (mean, rstd) per group."""
+    require_cuda(stats)
+    n = stats.numel() // 2
+    mean = torch.empty(stats.shape[:-1], dtype=torch.float32, device=stats.device)
+    rstd = torch.empty_like(mean)
+    with torch.cuda.device(stats.device):
+        rc = _lib.load().pn_moments_f32(ptr(stats), n, float(count), float(eps), ptr(mean), ptr(rstd),
+                                        current_stream(stats.device))
+    check(rc, "pn_moments_f32")
+    return mean, rstd
+
+
+def edgeconv_finalize_fwd(yext, mean, rstd, gamma, beta, groups, per_sample, slope):
+    """out (B,Cout,N) = LeakyReLU(gamma * (yext - mean) * rstd + beta), channel-first."""
+    require_cuda(yext)
+    B, N, Cout = yext.shape
+    out = torch.empty((B, Cout, N), dtype=torch.float32, device=yext.device)
+    with torch.cuda.device(yext.device):
+        rc = _lib.load().pn_edgeconv_finalize_fwd_f32(ptr(yext), ptr(_f32c(mean, "mean")),
+                                                      ptr(_f32c(rstd, "rstd")), ptr(_f32c(gamma, "gamma")),
+                                                      ptr(_f32c(beta, "beta")), B, N, Cout, groups,
+                                                      int(per_sample), float(slope), ptr(out),
+                                                      current_stream(yext.device))
+    check(rc, "pn_edgeconv_finalize_fwd_f32")
+    return out
+
+
+def edgeconv_bwd_prep(gout, yext, mean, rstd, gamma, beta, groups, per_sample, slope):
+    """gout (B,Cout,N) -> gz, yhat as (B,N,Cout)."""
+    require_cuda(gout, yext)
+    gout = _f32c(gout, "gout")
+    B, N, Cout = yext.shape
+    gz = torch.empty_like(yext)
+    yhat = torch.empty_like(yext)
+    with torch.cuda.device(yext.device):
+        rc = _lib.load().pn_edgeconv_bwd_prep_f32(ptr(gout), ptr(yext), ptr(mean), ptr(rstd),
+                                                  ptr(_f32c(gamma, "gamma")), ptr(_f32c(beta, "beta")), B, N,
+                                                  Cout, groups, int(per_sample), float(slope), ptr(gz),
+                                                  ptr(yhat), current_stream(yext.device))
+    check(rc, "pn_edgeconv_bwd_prep_f32")
+    return gz, yhat
+
+
+def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense):
+    """Edge-level normalisation gradient -> dPQ (B,N,2*Cout); see csrc/edge.hip."""
+    require_cuda(PQ, idx, t)
+    B, N, C2 = PQ.shape
+    Cout = C2 // 2
+    k = idx.shape[2]
+    dPQ = torch.empty_like(PQ)
+    with torch.cuda.device(PQ.device):
+        rc = _lib.load().pn_edgeconv_bwd_f32(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk),
+                                             ptr(mean), ptr(rstd), ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout,
+                                             groups, int(per_sample), int(dense), ptr(dPQ),
+                                             current_stream(PQ.device))
+    check(rc, "pn_edgeconv_bwd_f32")
+    return dPQ
