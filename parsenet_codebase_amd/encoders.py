@@ -1,0 +1,183 @@
+"""DGCNN encoders of the ParSeNet hot path on the HIP kernels.
+
+Parameter names and shapes are those of the reference modules, so its checkpoints load
+unchanged (with or without DataParallel's ``module.`` prefix):
+  DGCNNControlPoints          src/model.py:56-180     (SplineNet, BatchNorm)
+  DGCNNEncoderGn              src/PointNet.py:143-220 (GroupNorm)
+  PrimitivesEmbeddingDGCNGn   src/PointNet.py:223-289
+Edge-conv layers run through graph.edge_conv_norm_max (kNN + fused gather-reduce kernels);
+the per-point heads are dense GEMMs left to rocBLAS via torch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import graph
+from ._lib import require_cuda
+
+
+def _edge_layer(cin2, cout, norm):
+    # Sequential only to reproduce the reference's parameter names ("convN.0.weight"); the
+    # forward pass feeds the weight to the fused kernel instead of calling it.
+    return nn.Sequential(nn.Conv2d(cin2, cout, kernel_size=1, bias=False), norm,
+                         nn.LeakyReLU(negative_slope=0.2))
+
+
+class DGCNNControlPoints(nn.Module):
+    """Control-point regression network: (B,3,N) points -> (B, G*G, 3) control grid.
+
+    mode 0: open SplineNet, mode 1: closed SplineNet.  ``num_points`` is the number of
+    neighbours (the reference's name).  ``weights`` (only with B == 1): per-point membership
+    multiplying the 1024-d point features before the global max pool (src/model.py:165-167).
+    """
+
+    _WIDTHS = {0: (64, 64, 128, 256), 1: (128, 256, 256, 512)}
+
+    def __init__(self, num_control_points, num_points=40, mode=0):
+        super().__init__()
+        if mode not in self._WIDTHS:
+            raise ValueError("mode must be 0 or 1")
+        self.k = num_points
+        self.mode = mode
+        self.drop = 0.0
+        self.controlpoints = num_control_points
+        w = self._WIDTHS[mode]
+        self.bn1 = nn.BatchNorm2d(w[0])
+        self.bn2 = nn.BatchNorm2d(w[1])
+        self.bn3 = nn.BatchNorm2d(w[2])
+        self.bn4 = nn.BatchNorm2d(w[3])
+        self.bn5 = nn.BatchNorm1d(1024)
+        self.conv1 = _edge_layer(6, w[0], self.bn1)
+        self.conv2 = _edge_layer(2 * w[0], w[1], self.bn2)
+        self.conv3 = _edge_layer(2 * w[1], w[2], self.bn3)
+        self.conv4 = _edge_layer(2 * w[2], w[3], self.bn4)
+        self.conv5 = nn.Sequential(nn.Conv1d(sum(w), 1024, kernel_size=1, bias=False), self.bn5,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.conv6 = nn.Conv1d(1024, 1024, 1)
+        self.conv7 = nn.Conv1d(1024, 1024, 1)
+        self.conv8 = nn.Conv1d(1024, 3 * (num_control_points ** 2), 1)
+        self.bn6 = nn.BatchNorm1d(1024)
+        self.bn7 = nn.BatchNorm1d(1024)
+        self.tanh = nn.Tanh()
+
+    def forward(self, x, weights=None):
+        require_cuda(x)
+        batch_size = x.size(0)
+        feats = []
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3),
+                         (self.conv4, self.bn4)):
+            idx = graph.knn(x, self.k)
+            x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
+            feats.append(x)
+        x = self.conv5(torch.cat(feats, dim=1))
+        if isinstance(weights, torch.Tensor):
+            x = x * weights.reshape((1, 1, -1))
+        x = F.adaptive_max_pool1d(x, 1)
+        x = F.relu(self.bn6(self.conv6(x)))
+        x = F.relu(self.bn7(self.conv7(x)))
+        x = self.tanh(self.conv8(x)[:, :, 0])
+        return x.view(batch_size, self.controlpoints * self.controlpoints, 3)
+
+
+class DGCNNEncoderGn(nn.Module):
+    """Three edge-conv layers (k = nn_nb) + global 1024-d feature.  mode 5 uses the
+    points+normals metric for the first graph (6 input channels)."""
+
+    def __init__(self, mode=0, input_channels=3, nn_nb=80):
+        super().__init__()
+        self.k = nn_nb
+        self.dilation_factor = 1
+        self.mode = mode
+        self.drop = 0.0
+        if mode not in (0, 1, 5):
+            raise ValueError("DGCNNEncoderGn: unsupported mode %r" % (mode,))
+        self.bn1 = nn.GroupNorm(2, 64)
+        self.bn2 = nn.GroupNorm(2, 64)
+        self.bn3 = nn.GroupNorm(2, 128)
+        # bn4 / bn5 are never used by the reference's forward either; they exist so that
+        # its checkpoints load (src/PointNet.py:154-155)
+        self.bn4 = nn.GroupNorm(4, 256)
+        self.bn5 = nn.GroupNorm(8, 1024)
+        self.conv1 = _edge_layer(input_channels * 2, 64, self.bn1)
+        self.conv2 = _edge_layer(64 * 2, 64, self.bn2)
+        self.conv3 = _edge_layer(64 * 2, 128, self.bn3)
+        self.mlp1 = nn.Conv1d(256, 1024, 1)
+        self.bnmlp1 = nn.GroupNorm(8, 1024)
+
+    def forward(self, x):
+        require_cuda(x)
+        k = self.k
+        if self.mode == 5:
+            idx = graph.knn_points_normals(x, k, k)
+        else:
+            idx = graph.knn_dilated(x, k, k)
+        x1 = graph.edge_conv_norm_max(x, idx, self.conv1[0].weight, self.bn1, slope=0.2)
+        x2 = graph.edge_conv_norm_max(x1, graph.knn_dilated(x1, k, k), self.conv2[0].weight, self.bn2, 0.2)
+        x3 = graph.edge_conv_norm_max(x2, graph.knn_dilated(x2, k, k), self.conv3[0].weight, self.bn3, 0.2)
+        x_features = torch.cat((x1, x2, x3), dim=1)
+        x = F.relu(self.bnmlp1(self.mlp1(x_features)))
+        x4 = x.max(dim=2)[0]
+        return x4, x_features
+
+
+class PrimitivesEmbeddingDGCNGn(nn.Module):
+    """Segmentation network: per-point embedding (emb_size) and primitive-type log
+    probabilities.  The embedding loss is evaluated inside forward, as in the reference, so
+    that every data-parallel rank computes it on its own shard."""
+
+    def __init__(self, emb_size=50, num_primitives=8, primitives=False, embedding=False, mode=0,
+                 num_channels=3, loss_function=None, nn_nb=80):
+        super().__init__()
+        self.mode = mode
+        self.encoder = DGCNNEncoderGn(mode=mode, input_channels=num_channels, nn_nb=nn_nb)
+        self.drop = 0.0
+        self.loss_function = loss_function
+        if mode in (0, 3, 4, 5, 6):
+            self.conv1 = nn.Conv1d(1024 + 256, 512, 1)
+        elif mode in (1, 2):
+            self.conv1 = nn.Conv1d(1024 + 512, 512, 1)
+        else:
+            raise ValueError("unsupported mode %r" % (mode,))
+        self.bn1 = nn.GroupNorm(8, 512)
+        self.conv2 = nn.Conv1d(512, 256, 1)
+        self.bn2 = nn.GroupNorm(4, 256)
+        self.softmax = nn.Softmax(dim=1)
+        self.logsoftmax = nn.LogSoftmax(dim=1)
+        self.tanh = nn.Tanh()
+        self.emb_size = emb_size
+        self.primitives = primitives
+        self.embedding = embedding
+        if self.embedding:
+            self.mlp_seg_prob1 = nn.Conv1d(256, 256, 1)
+            self.mlp_seg_prob2 = nn.Conv1d(256, self.emb_size, 1)
+            self.bn_seg_prob1 = nn.GroupNorm(4, 256)
+        if primitives:
+            self.mlp_prim_prob1 = nn.Conv1d(256, 256, 1)
+            self.mlp_prim_prob2 = nn.Conv1d(256, num_primitives, 1)
+            self.bn_prim_prob1 = nn.GroupNorm(4, 256)
+
+    def forward(self, points, labels, compute_loss=True):
+        require_cuda(points)
+        x, first_layer_features = self.encoder(points)
+        # conv1 on cat(global repeated over N, local): the global part is the same for every
+        # point, so it is applied once per item and broadcast (same sum, 5x fewer FLOPs)
+        ng = x.shape[1]
+        w = self.conv1.weight[:, :, 0]
+        glob = torch.addmm(self.conv1.bias, x, w[:, :ng].t())            # (B,512)
+        x = F.conv1d(first_layer_features, self.conv1.weight[:, ng:], None) + glob.unsqueeze(2)
+        x = F.relu(self.bn1(x))
+        x_all = F.relu(self.bn2(self.conv2(x)))
+        embedding = None
+        primitives_log_prob = None
+        if self.embedding:
+            x = F.relu(self.bn_seg_prob1(self.mlp_seg_prob1(x_all)))
+            embedding = self.mlp_seg_prob2(x)
+        if self.primitives:
+            x = F.relu(self.bn_prim_prob1(self.mlp_prim_prob1(x_all)))
+            primitives_log_prob = self.logsoftmax(self.mlp_prim_prob2(x))
+        if compute_loss:
+            lab = labels.data.cpu().numpy() if torch.is_tensor(labels) else labels
+            embed_loss = self.loss_function(embedding, lab)
+        else:
+            embed_loss = torch.zeros(1, device=points.device)
+        return embedding, primitives_log_prob, embed_loss

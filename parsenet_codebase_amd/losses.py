@@ -1,0 +1,98 @@
+"""Training losses of the segmentation network (src/segment_loss.py)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class EmbeddingLoss:
+    """src/segment_loss.py:20-124.  Same sampling (numpy RNG, same call order, so a seeded run
+    draws the same triplets as the reference), but the <= 25 segment pairs of a shape are
+    evaluated as one batched tensor expression instead of a Python loop of tiny kernels."""
+
+    def __init__(self, margin=1.0, if_mean_shift=False):
+        self.margin = margin
+        self.if_mean_shift = if_mean_shift
+
+    def triplet_loss(self, output, labels, iterations=5):
+        """output (B,D,N) embedding, labels (B,N) integer array -> loss tensor of shape (1,)."""
+        max_segments = 5
+        B, _, N = output.shape
+        dev = output.device
+        labels = np.asarray(labels)
+        out = F.normalize(output.permute(0, 2, 1), p=2, dim=2)
+        if self.if_mean_shift:
+            from .mean_shift import MeanShift
+            ms = MeanShift()
+            out = torch.stack([ms.mean_shift(out[b], 4000, 0.015, iterations=iterations, nms=False)[0]
+                               for b in range(B)], 0)
+
+        # phase 1 (reference :62-76): sample points of every segment of every shape
+        samples = []
+        for i in range(B):
+            p = labels[i]
+            uniq = np.unique(p)
+            num = min([N // uniq.shape[0] + 1, 30])
+            per_label = []
+            for l in uniq:
+                ids = np.where(p == l)[0]
+                per_label.append(np.random.choice(ids, num, replace=True))
+            samples.append(np.stack(per_label, 0))            # (S_i, num)
+
+        # phase 2 (reference :85-123): random ordered segment pairs per shape
+        loss_diff = torch.zeros(1, device=dev)
+        only_one = 0
+        for i in range(B):
+            S = samples[i].shape[0]
+            if S == 1:
+                only_one += 1
+                continue
+            num_iterations = min([max_segments * max_segments, S * S])
+            pairs = []
+            for _ in range(num_iterations):
+                k1 = np.random.choice(S, 1)[0]
+                k2 = np.random.choice(S, 1)[0]
+                if k1 != k2:
+                    pairs.append((k1, k2))
+            normalization = len(pairs)
+            if normalization == 0:
+                continue
+            pairs = np.asarray(pairs)
+            sel = torch.from_numpy(samples[i]).to(dev)          # (S,num)
+            pred = out[i][sel]                                   # (S,num,D)
+            pa = torch.from_numpy(pairs[:, 0]).to(dev)
+            pb = torch.from_numpy(pairs[:, 1]).to(dev)
+            p1, p2 = pred[pa], pred[pb]                          # (P,num,D)
+            anchor = p1.unsqueeze(2)
+            diff_pos = ((anchor - p1.unsqueeze(1)) ** 2).sum(3)  # (P,num,num)
+            diff_neg = ((anchor - p2.unsqueeze(1)) ** 2).sum(3)
+            constraint = F.relu(diff_pos - diff_neg + self.margin)
+            loss = constraint.sum((1, 2)) - torch.diagonal(constraint, dim1=1, dim2=2).sum(1)
+            satisfied = ((constraint > 0).sum((1, 2)) + 1.0).to(loss.dtype)
+            loss_shape = (loss / satisfied.detach()).sum() / (normalization + 1e-8)
+            loss_diff = loss_diff + loss_shape
+        return loss_diff / (B - only_one + 1e-8)
+
+
+def evaluate_miou(gt_labels, pred_labels):
+    """src/segment_loss.py:127-148 (numpy, metrics only)."""
+    N = gt_labels.shape[0]
+    C = pred_labels.shape[2]
+    pred = np.argmax(pred_labels, 2)
+    eps = np.finfo(np.float32).eps
+    total = 0.0
+    for n in range(N):
+        part = 0.0
+        for c in range(C):
+            g = gt_labels[n] == c
+            p = pred[n] == c
+            part += (np.sum(g & p) + eps) / (np.sum(g | p) + eps)
+        total += part / C
+    return total / N
+
+
+_nll = torch.nn.NLLLoss()
+
+
+def primitive_loss(pred, gt):
+    """src/segment_loss.py:151-152."""
+    return _nll(pred, gt)
