@@ -1,0 +1,182 @@
+"""Headline benchmark: shapes/s for forward+backward(+all-reduce+Adam) of the ParSeNet hot path
+on synthetic 10 000-point clouds (BASELINE.json).  One process per GPU; for N > 1 launch with
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.  See DESIGN.md (Measurement) for the definitions of ``roofline``
+and ``cpu_baseline``.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_workload(name, device, rank):
+    from parsenet_codebase_amd import workloads
+    if name == "cfg4":
+        B, N = 4, 10000
+        return workloads.ParsenetSegStep(device, batch=B, num_points=N, first_shape=rank * B), {
+            "workload": "cfg4: ParSeNet seg-only points+normals, 10k pts, batch 4 per GPU "
+                        "(PrimitivesEmbeddingDGCNGn mode 5, k=80, triplet+NLL, fwd+bwd+allreduce+Adam)",
+            "batch_per_gpu": B, "points": N, "k": 80}
+    raise SystemExit("unknown workload %r" % name)
+
+
+def kernel_roofline(step, nprof):
+    """Average launch duration of every kernel family over ``nprof`` profiled steps (HIP events
+    on the launch stream, recorded inside the C library), and the roofline entry of the
+    dominant one."""
+    from parsenet_codebase_amd import _lib
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    for _ in range(nprof):
+        step.step()
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    res = _lib.prof_results()
+    if not res:
+        return None, {}
+    table = {k: {"ms_total": v[0], "calls": v[1], "avg_ms": v[0] / max(v[1], 1)} for k, v in res.items()}
+    dom = max(table, key=lambda k: table[k]["ms_total"])
+    B, N, k = step.batch, step.num_points, 80
+    avg_s = table[dom]["avg_ms"] * 1e-3
+    # algorithmic work per launch (DESIGN.md / SURVEY.md §8d)
+    if dom.startswith("knn_mfma_pass"):
+        C = 64 if dom.endswith("c64") else (6 if dom.endswith("pn") else 3)
+        # one kNN layer needs B*N^2*(2C+3) FLOP once; the exact two-pass selection launches the
+        # distance kernel twice, so each launch is credited with half of the layer's work
+        flops = 0.5 * B * N * N * (2 * C + 3)
+        ach = flops / avg_s / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": table[dom]["avg_ms"]}
+    elif dom.startswith("edgeconv"):
+        # fused edge-conv: read x-products (B,N,2Cout) + idx, write (B,N,Cout) x3 small outputs
+        Cout = 64
+        nbytes = 4.0 * B * N * 2 * Cout + 8.0 * B * N * k + 4.0 * B * N * Cout * 2 + B * N * Cout
+        ach = nbytes / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": table[dom]["avg_ms"]}
+    else:
+        roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None, "traffic": None, "avg_launch_ms": table[dom]["avg_ms"]}
+    return roof, table
+
+
+def cpu_baseline(name):
+    """The torch-CPU oracle (restatement of the reference's algorithm) on ONE shape of the
+    same workload, all host cores; bounded to a few tens of seconds."""
+    import numpy as np
+    from oracle import ref_torch as R
+    from parsenet_codebase_amd import synthetic
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    model = R.PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True, num_primitives=10,
+                                        loss_function=R.EmbeddingLoss(1.0).triplet_loss, mode=5,
+                                        num_channels=6, nn_nb=80)
+    pts, nrm, lab, prim = synthetic.make_batch(0, 1, 10000)
+    x = torch.from_numpy(np.ascontiguousarray(np.concatenate([pts, nrm], 2).transpose(0, 2, 1)))
+    primt = torch.from_numpy(prim)
+    times = []
+    t_all = time.time()
+    for it in range(3):
+        t0 = time.time()
+        model.zero_grad()
+        e, p, l = model(x, lab, True)
+        loss = l.mean() + R.primitive_loss(p, primt)
+        loss.backward()
+        times.append(time.time() - t0)
+        if time.time() - t_all > 25:
+            break
+    best = min(times)
+    return {"value": 1.0 / best, "unit": "shapes/s", "cores": cores, "kind": "port",
+            "sample": "torch-CPU oracle (reference algorithm restated), %s, 1 shape x 10000 pts fwd+bwd, "
+                      "best of %d" % (name, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from parsenet_codebase_amd import dp
+    rank, world, device = dp.init_from_env()
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+
+    step, cfg = build_workload(args.workload, device, rank)
+    import numpy as np
+    np.random.seed(1000 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof, table = (None, {})
+    cpu = None
+    if rank == 0:
+        roof, table = kernel_roofline(step, args.profile_steps)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        shapes = step.shapes_per_step() * world * args.steps
+        out = {
+            "metric": "shapes/sec fwd+bwd on 10k-pt clouds",
+            "value": shapes / elapsed,
+            "unit": "shapes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": dict(cfg, parallelism="dp%d" % world, global_batch=step.shapes_per_step() * world),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(table.items())},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,15 @@ extern "C" {
 const char* pn_last_error(void);
 int pn_abi_version(void);
 
+/* ---- per-kernel timing (HIP events on the launch stream; off by default) -----------
+ * enable(1) brackets every kernel family launched through this library with an event pair;
+ * count() resolves outstanding events and returns the number of families seen; get(i, ...)
+ * returns name, accumulated milliseconds and number of launches; reset() clears. */
+void pn_prof_enable(int on);
+void pn_prof_reset(void);
+int pn_prof_count(void);
+int pn_prof_get(int i, char* name, int name_len, double* total_ms, long long* calls);
+
 /* ---- kNN graph ------------------------------------------------------------------
  * pn_knn_f32 replaces src/model.py:9-22 knn(x,k) and src/PointNet.py:9-26 knn(x,k1,k2)
  * (k1 == k2; a dilation k2 > k1 is a strided slice of the k2 result done by the caller);

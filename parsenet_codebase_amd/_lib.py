@@ -24,6 +24,11 @@ c_double = ctypes.c_double
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
     "pn_abi_version": (c_int, []),
+    "pn_prof_enable": (None, [c_int]),
+    "pn_prof_reset": (None, []),
+    "pn_prof_count": (c_int, []),
+    "pn_prof_get": (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_double),
+                            ctypes.POINTER(ctypes.c_longlong)]),
     "pn_knn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pn_knn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_knn_pn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -102,3 +107,24 @@ def require_cuda(*tensors):
                 "parsenet_codebase_amd runs on MI355X only: got a %s tensor; there is no CPU "
                 "path in the product (the CPU restatement lives in oracle/ and is test-only)"
                 % t.device)
+
+
+def prof_enable(on=True):
+    load().pn_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    load().pn_prof_reset()
+
+
+def prof_results():
+    """{kernel family: (total_ms, calls)} measured with HIP events on the launch stream."""
+    lib = load()
+    out = {}
+    buf = ctypes.create_string_buffer(128)
+    for i in range(lib.pn_prof_count()):
+        ms = c_double()
+        calls = ctypes.c_longlong()
+        if lib.pn_prof_get(i, buf, 128, ctypes.byref(ms), ctypes.byref(calls)) == 0:
+            out[buf.value.decode()] = (ms.value, calls.value)
+    return out

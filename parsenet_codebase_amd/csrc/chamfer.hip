@@ -92,8 +92,11 @@ static int chamfer_one_side(const float* q, int Nq, const float* c, int Nc, int 
   chunk = (int)pn_align_up(chunk, 64);
   splits = pn_cdiv(Nc, chunk);
   dim3 grid(qblocks, splits, B);
-  hipLaunchKernelGGL(pn_chamfer_nn_kernel, grid, dim3(CH_THREADS), 0, stream, q, Nq, c,
-                     Nc, chunk, packed);
+  {
+    PN_PROF("chamfer_nn", stream);
+    hipLaunchKernelGGL(pn_chamfer_nn_kernel, grid, dim3(CH_THREADS), 0, stream, q, Nq, c,
+                       Nc, chunk, packed);
+  }
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_chamfer_unpack_kernel, dim3(pn_cdiv(n, 256)), dim3(256), 0, stream,
                      packed, n, mind, arg);

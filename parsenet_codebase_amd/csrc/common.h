@@ -47,6 +47,17 @@ void pn_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// ---- optional per-kernel HIP-event timing (prof.hip) -------------------------------
+void pn_prof_begin(const char* name, hipStream_t s, int* token);
+void pn_prof_end(hipStream_t s, int token);
+struct PnProfScope {
+  hipStream_t s;
+  int token;
+  PnProfScope(const char* name, hipStream_t st) : s(st) { pn_prof_begin(name, st, &token); }
+  ~PnProfScope() { pn_prof_end(s, token); }
+};
+#define PN_PROF(name, stream) PnProfScope _pn_prof_scope_##__LINE__(name, stream)
+
 static inline size_t pn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int pn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

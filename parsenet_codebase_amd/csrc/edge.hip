@@ -123,6 +123,7 @@ extern "C" int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int 
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(xt && idx && feat, "pn_edge_feature_fwd_f32: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && C > 0, "pn_edge_feature_fwd_f32: empty input");
+  PN_PROF("edge_feature_fwd", stream);
   if ((C & 3) == 0) {
     dim3 grid(pn_cdiv(N, 4), B);
     hipLaunchKernelGGL(pn_edge_feature_vec_kernel, grid, dim3(256), 0, stream, xt, idx, N, k, C,
@@ -165,6 +166,7 @@ extern "C" int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, i
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(gfeat && idx && gxt, "pn_edge_feature_bwd_f32: null pointer");
   PN_CHECK_HIP(hipMemsetAsync(gxt, 0, (size_t)B * N * C * sizeof(float), stream));
+  PN_PROF("edge_feature_bwd", stream);
   dim3 grid(pn_cdiv(N, 4), B);
   hipLaunchKernelGGL(pn_edge_feature_bwd_kernel, grid, dim3(256), 0, stream, gfeat, idx, N, k, C,
                      gxt);
@@ -357,6 +359,7 @@ extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, c
   PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_reduce_fwd_f32: groups=%d", groups);
   const int Cg = Cout / groups;
   PN_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * (per_sample ? B : 1), stream));
+  PN_PROF("edgeconv_reduce_fwd", stream);
   dim3 grid(pn_cdiv(N, EC_WAVES * EC_PPW), B);
 #define EC_GO(CO)                                                                              \
   hipLaunchKernelGGL(pn_edgeconv_reduce_kernel<CO>, grid, dim3(256), 0, stream, PQ, idx, gamma, \
@@ -545,6 +548,7 @@ extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const fl
                "pn_edgeconv_bwd_f32: null pointer");
   PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_bwd_f32: groups=%d", groups);
   PN_CHECK_HIP(hipMemsetAsync(dPQ, 0, (size_t)B * N * 2 * Cout * sizeof(float), stream));
+  PN_PROF("edgeconv_bwd", stream);
   dim3 grid(pn_cdiv(N, 4), B);
   hipLaunchKernelGGL(pn_edgeconv_bwd_kernel, grid, dim3(256), 0, stream, PQ, idx, t, s1, argk,
                      mean, rstd, c1c2, N, k, Cout, Cout / groups, per_sample, dense, dPQ);

@@ -269,6 +269,7 @@ int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64
                      mode == 0 ? C : 3, xx);
   PN_CHECK_LAUNCH();
   dim3 grid(pn_cdiv(N, 256), S, B);
+  PN_PROF(gate ? "knn_scan_gated" : "knn_scan", stream);
   if (mode == 0)
     hipLaunchKernelGGL(pn_knn_scan_kernel<0>, grid, dim3(256), 0, stream, x, xx, C, N, k, S,
                        slice_len, lists, counts, idx, gate);

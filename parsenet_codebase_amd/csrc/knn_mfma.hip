@@ -445,12 +445,21 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
   const KnnPerm perm = knn_make_perm(N);
 
   PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * N * 4, stream));
-  hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Np, 256), B), dim3(256), 0, stream, x,
+  {
+    PN_PROF("knn_prep", stream);
+    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Np, 256), B), dim3(256), 0, stream, x,
                      C, N, p.Cp, p.Np, mode, perm, xp, xxp);
+  }
   PN_CHECK_LAUNCH();
   dim3 grid(pn_cdiv(p.Np, 32 * p.qsets * 4), p.S, B);
   for (int pass = 0; pass < 2; ++pass) {
     const bool collect = pass == 1;
+    static const char* const pass_names[2][4] = {
+        {"knn_mfma_pass1_c4", "knn_mfma_pass1_c64", "knn_mfma_pass1_wide", "knn_mfma_pass1_pn"},
+        {"knn_mfma_pass2_c4", "knn_mfma_pass2_c64", "knn_mfma_pass2_wide", "knn_mfma_pass2_pn"}};
+    const int fam = mode == 1 ? 3 : (p.ksteps <= 4 ? 0 : (p.ksteps == 32 ? 1 : 2));
+    {
+    PN_PROF(pass_names[pass][fam], stream);
 #define KM_GO(KS, QS, MD)                                                                     \
   knn_mfma_launch_pass<KS, QS, MD>(collect, grid, stream, xp, xxp, N, p.Np, p.tiles_per_slice, \
                                    tilemax, tau, lists, cnt, p.subcap, perm)
@@ -467,16 +476,22 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
     else
       KM_GO(128, 1, 0);
 #undef KM_GO
+    }
     PN_CHECK_LAUNCH();
     if (!collect) {
+      PN_PROF("knn_tau", stream);
       hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream,
                          tilemax, N, p.Np, k, tau);
       PN_CHECK_LAUNCH();
     }
   }
-  hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, lists,
-                     cnt, N, p.Np, k, p.S, p.subcap, perm, idx, flags);
+  {
+    PN_PROF("knn_final", stream);
+    hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, lists,
+                       cnt, N, p.Np, k, p.S, p.subcap, perm, idx, flags);
+  }
   PN_CHECK_LAUNCH();
+  PN_PROF("knn_fallback_gate", stream);
   // degenerate queries (flagged) are redone by the generic scan kernel; waves without a
   // flagged query exit immediately
   return pn_knn_v1_launch(mode, x, B, C, N, k, idx, base + w.v1,

@@ -1,0 +1,64 @@
+"""Data parallelism for the hot path: one process per GPU, shapes sharded across ranks, and
+exactly ONE RCCL all-reduce of a flat fp32 gradient bucket per optimizer step (the reference
+uses torch.nn.DataParallel: train_parsenet.py:90-91).  Nothing finer crosses
+GPUs: kNN graphs, GroupNorm statistics, clustering and fitting are all per shape."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if device.type == "cuda" else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def shard_range(num_items, rank, world):
+    """Contiguous shard [lo, hi) of ``num_items`` shapes owned by ``rank``."""
+    per = num_items // world
+    extra = num_items % world
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+class FlatGradBucket:
+    """All parameter gradients live in one contiguous fp32 buffer (``p.grad`` are views), so
+    the data-parallel reduction is a single collective on a pre-flattened bucket.  Parameters
+    that never receive a gradient (the reference's unused ``encoder.bn4/bn5``) stay zero."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        """Average gradients over ranks with one all-reduce (no-op on a single rank)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+        return self.flat
