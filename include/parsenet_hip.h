@@ -59,6 +59,42 @@ int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx, void* w
 int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* ---- dot-product selection between two point sets ------------------------------------
+ * Replaces src/mean_shift.py:125-137 (compute_bandwidth: 2 - 2 X X^T, topk(K, largest=False),
+ * the K-th smallest distance per row) and :146-149 (nms: argmin over centres of 2 - 2 C X^T).
+ * 2 - 2*dot is an exact decreasing map of dot for unit vectors, so both are selections on the
+ * dot products.  q (B,Nq,C), c (B,Nc,C) point-major.  Exactly one of out_idx (B,Nq,k) int64
+ * (indices of the k largest dots, best first, ties -> smaller index, k <= 128) and out_val
+ * (B,Nq) fp32 (the k-th largest dot, k <= 512) is non-NULL.  flags (B,Nq) int32 is set to 1
+ * for queries whose result is invalid (survivor overflow on massively tied data): the caller
+ * recomputes those rows.  PN_ERR_UNSUPPORTED if the shape is outside the fast path
+ * (needs Nc/16 >= 2k and C <= 256); pn_dot_select_workspace then returns 0. */
+size_t pn_dot_select_workspace(int B, int C, int Nq, int Nc, int k, int want_value);
+int pn_dot_select_f32(const float* q, int Nq, const float* c, int Nc, int B, int C, int k,
+                      int64_t* out_idx, float* out_val, int* flags, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- mean-shift iterations ----------------------------------------------------------
+ * Replaces src/mean_shift.py:45-79 (mean_shift_, gaussian kernel) and the autograd graph the
+ * reference keeps through it.  All tensors point-major (B,N,D) with D = 128; bsq (B) = b^2.
+ *   slices   : number S of column slices the launch uses for (B,N) (sizes the scratch).
+ *   pack     : x (B,N,D) -> xt (B,D,Np), Np = N rounded up to 64, zero padded.
+ *   iter_fwd : y = normalise(q + ((K X) / rowsum(K) - q)), K = exp(clamp(-(2 - 2 q x^T)/b^2/2)).
+ *              Scratch opart (B,S,N,D), rpart (B,S,N).  Saves rsum, unorm (B,N).
+ *   iter_bwd : given gy = dL/dy: sum_s opart_q = dL/dq, sum_s opart_x = this iteration's
+ *              contribution to dL/dx (recomputes K; nothing of size N x N is stored).
+ *              Scratch gu, go (B,N,D), cs (B,N), qt, gut (B,D,Np), opart_q, opart_x (B,S,N,D). */
+int pn_meanshift_slices(int B, int N);
+int pn_meanshift_pack_f32(const float* x, int B, int N, int D, float* xt, void* stream);
+int pn_meanshift_iter_fwd_f32(const float* q, const float* x, const float* xt, const float* bsq,
+                              int B, int N, int D, float* opart, float* rpart, float* y,
+                              float* rsum, float* unorm, void* stream);
+int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const float* q, const float* x,
+                              const float* xt, const float* rsum, const float* unorm,
+                              const float* bsq, int B, int N, int D, float* gu, float* go,
+                              float* cs, float* qt, float* gut, float* opart_q, float* opart_x,
+                              void* stream);
+
 /* ---- layout helper: (B,R,C) -> (B,C,R) --------------------------------------------- */
 int pn_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
 

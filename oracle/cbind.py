@@ -53,3 +53,20 @@ def knn_row_values(xb, i, mode=0):
     v = np.empty(N, np.float32)
     lib().pno_knn_values(_p(xb), C, N, mode, int(i), _p(xx), _p(v))
     return v
+
+
+def dot_argmax(centers, x):
+    """centers (Nc,D), x (Nq,D) float32 -> (Nq,) int64 index of the centre with the largest dot."""
+    centers = np.ascontiguousarray(centers, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape[0], np.int64)
+    lib().pno_dot_argmax(_p(centers), centers.shape[0], _p(x), x.shape[0], x.shape[1], _p(out))
+    return out
+
+
+def kth_largest_dot(x, K):
+    """x (N,D) -> (N,) K-th largest entry of every row of x x^T (fmaf-chain dots)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape[0], np.float32)
+    lib().pno_kth_largest_dot(_p(x), x.shape[0], x.shape[1], int(K), _p(out))
+    return out

@@ -45,6 +45,14 @@ SIGNATURES = {
     "pn_edgeconv_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p]),
+    "pn_dot_select_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pn_dot_select_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_meanshift_slices": (c_int, [c_int, c_int]),
+    "pn_meanshift_pack_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_meanshift_iter_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_meanshift_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
     "pn_chamfer_nn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_chamfer_nn_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1,16 +1,20 @@
-// kNN graph build, fast path: exact two-pass selection on the fp32 matrix cores (gfx950).
+// Exact k-best selection on the fp32 matrix cores (gfx950): kNN graphs, bandwidth quantiles,
+// nearest-centre assignment.
 //
-// Replaces src/model.py:9-22, src/PointNet.py:9-26 and :29-69 (N x N GEMM + torch.topk).
+// Replaces, without ever materialising an N x N matrix,
+//   src/model.py:9-22, src/PointNet.py:9-26, :29-69   (N x N GEMM + torch.topk -> kNN graph)
+//   src/mean_shift.py:125-137   (2 - 2 X X^T + topk(K, largest=False) -> K-th distance per row)
+//   src/mean_shift.py:146-149   (argmin over centres of 2 - 2 C X^T -> membership)
 //
-// The neighbour values are k-ordered fp32 fma chains; v_mfma_f32_32x32x2_f32 evaluates
-// exactly such a chain (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product,
-// no wider accumulation), so the matrix-core result is bit-identical to the oracle's
-// scalar loop.  A 32(candidates) x 32(queries) tile is accumulated per wave with the query
-// operands resident in VGPRs; candidate operands stream from L2 with one dword per lane per
-// k-step (two 128-byte segments per load).
+// The values are k-ordered fp32 fma chains; v_mfma_f32_32x32x2_f32 evaluates exactly such a
+// chain (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product, no wider
+// accumulation), so the matrix-core result is bit-identical to the oracle's scalar loop.
+// A 32(candidates) x 32(queries) tile is accumulated per wave with the query operands resident
+// in VGPRs; candidate operands stream from L2 with one dword per lane per k-step (two 128-byte
+// segments per load).
 //
 // Selection never sorts more than a handful of values per query:
-//   K0  gather x into a decorrelated candidate order (golden-ratio affine bijection; tile
+//   K0  gather the candidates into a decorrelated order (golden-ratio affine bijection; tile
 //       statistics then do not depend on how the caller ordered the points), pad to
 //       multiples of 64 points / 2 channels, compute squared norms.
 //   K1  pass 1: for every query and every group of 16 candidates keep only the maximum
@@ -18,18 +22,24 @@
 //       at least k distinct candidates have value >= T_k.
 //   K2  wave-per-query bisection on the register-resident tile maxima -> tau
 //       (count(tilemax >= tau) >= k, as close to k as the bisection gets).  With N/16 tiles
-//       the expected number of candidates >= tau is ~1.07 k.
+//       the expected number of candidates >= tau is ~1.07 k for k << N/16.
 //   K3  pass 2: recompute the values (same arithmetic), append the survivors (v >= tau) as
 //       64-bit (value, index) keys to a sub-list private to (query, slice, half-wave): no
 //       atomics, the fill count lives in a register.
-//   K4  one wave per query: gather the sub-lists, bitonic sort of <= 128 keys (select first
-//       if more), emit the k best indices, best first, ties -> smaller original index.
-//   Lists that overflow (degenerate inputs: masses of exactly equal values) are flagged
-//   and recomputed by the generic scan kernel (knn.hip), gated on the flags.
+//   K4  one wave per query: gather the sub-lists, select/sort, emit either the k best
+//       indices (best first, ties -> smaller original index) or the k-th best value.
+//   Lists that overflow (degenerate inputs: masses of exactly equal values) are flagged; for
+//   kNN graphs they are recomputed on the device by the generic scan kernel (knn.hip),
+//   gated on the flags; the other entry points hand the flags to the caller.
+//
+// Value semantics (each operation rounded to fp32, in the reference's order):
+//   MODE 0:  v = (-xx[j] - (-2*dot)) - xx[i]                      (model.py:14-16)
+//   MODE 1:  p = (xxp[j] - 2*dot_p) + xxp[i]; n = 2 - 2*dot_n;
+//            v = -(p * (1 + n))                                     (PointNet.py:41-59)
+//   MODE 2:  v = dot(q_i, c_j)     (mean_shift.py: 2 - 2*dot is a decreasing, exact map)
 #include "knn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 
 size_t pn_knn_v1_workspace(int B, int C, int N, int k, bool gated);
 int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
@@ -42,7 +52,7 @@ struct KnnPerm {
 };
 
 // bijection on [0, n): affine map modulo 2^m (odd multiplier near 2^m / golden ratio) with
-// cycle walking.  Consecutive positions land ~0.618 * 2^m apart.
+// cycle walking.  Consecutive positions land ~0.618 * 2^m apart.  a = 1, c = 0: identity.
 __host__ __device__ static inline int knn_perm(const KnnPerm& p, int i) {
   uint32_t v = (uint32_t)i;
   do {
@@ -51,22 +61,23 @@ __host__ __device__ static inline int knn_perm(const KnnPerm& p, int i) {
   return (int)v;
 }
 
-static KnnPerm knn_make_perm(int N) {
+static KnnPerm knn_make_perm(int N, bool identity) {
   KnnPerm p;
   int m = 1;
   while ((1u << m) < (uint32_t)N) ++m;
   p.mask = (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
-  p.a = ((uint32_t)(0.6180339887498949 * (double)(1ull << m))) | 1u;
-  p.c = (0x9E3779B9u >> (32 - m)) | 1u;
+  p.a = identity ? 1u : (((uint32_t)(0.6180339887498949 * (double)(1ull << m))) | 1u);
+  p.c = identity ? 0u : ((0x9E3779B9u >> (32 - m)) | 1u);
   p.n = N;
   return p;
 }
 
 // K0: xp (B, Cp, Np) zero padded, permuted columns; xxp (B, Np) squared norms (fma chain over
 // the first `cnorm` source channels).  MODE 1 channel map: [p0 p1 p2 0 n0 n1 n2 0].
+// Source layout: channel-first (B,C,N) or point-major (B,N,C).
 __global__ void pn_knn_prep_kernel(const float* __restrict__ x, int C, int N, int Cp, int Np,
-                                   int mode, KnnPerm perm, float* __restrict__ xp,
-                                   float* __restrict__ xxp) {
+                                   int mode, int point_major, KnnPerm perm,
+                                   float* __restrict__ xp, float* __restrict__ xxp) {
   const int b = blockIdx.y;
   const int jp = blockIdx.x * blockDim.x + threadIdx.x;
   if (jp >= Np) return;
@@ -75,9 +86,9 @@ __global__ void pn_knn_prep_kernel(const float* __restrict__ x, int C, int N, in
   float acc = 0.f;
   if (jp < N) {
     const int j = knn_perm(perm, jp);
-    const int cnorm = mode == 0 ? C : 3;
+    const int cnorm = mode == 1 ? 3 : C;
     for (int c = 0; c < C; ++c) {
-      const float v = xb[(size_t)c * N + j];
+      const float v = point_major ? xb[(size_t)j * C + c] : xb[(size_t)c * N + j];
       const int cd = (mode == 1 && c >= 3) ? c + 1 : c;
       xpb[(size_t)cd * Np + jp] = v;
       if (c < cnorm) acc = __builtin_fmaf(v, v, acc);
@@ -95,44 +106,46 @@ __global__ void pn_knn_prep_kernel(const float* __restrict__ x, int C, int N, in
 }
 
 // K1 / K3.  KSTEPS = Cp / 2 (MODE 1: 4 = two steps xyz + two steps normals), QSETS = number of
-// 32-query column blocks per wave.
+// 32-query column blocks per wave.  Queries (xq, Nq valid of Nqp padded) and candidates
+// (xc, Nc of Ncp) may be the same array.
 template <int KSTEPS, int QSETS, int MODE, bool COLLECT>
 __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
-    const float* __restrict__ xp, const float* __restrict__ xxp, int N, int Np,
+    const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
+    const float* __restrict__ xc, const float* __restrict__ xxc_, int Nc, int Ncp,
     int tiles_per_slice, float* __restrict__ tilemax, const float* __restrict__ tau,
-    u64* __restrict__ lists, int* __restrict__ counts, int subcap, KnnPerm perm) {
+    u64* __restrict__ lists, int* __restrict__ counts, int subcap) {
   const int b = blockIdx.z;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = lane & 31, h = lane >> 5;
   const int q0 = (blockIdx.x * 4 + wave) * (32 * QSETS);
-  if (q0 >= N) return;  // wave-uniform
+  if (q0 >= Nq) return;  // wave-uniform
   constexpr int CP = 2 * KSTEPS;
-  const float* __restrict__ xb = xp + (size_t)b * CP * Np;
-  const float* __restrict__ xxb = xxp + (size_t)b * Np;
-  const int ntiles = Np / 32;
+  const float* __restrict__ xqb = xq + (size_t)b * CP * Nqp;
+  const float* __restrict__ xcb = xc + (size_t)b * CP * Ncp;
+  const float* __restrict__ xxqb = xxq_ + (size_t)b * Nqp;
+  const float* __restrict__ xxcb = xxc_ + (size_t)b * Ncp;
+  const int ntiles = Ncp / 32;
   const int S = gridDim.y, slice = blockIdx.y;
   const int t_begin = slice * tiles_per_slice;
   const int t_end = min(ntiles, t_begin + tiles_per_slice);
-  const int T16 = Np / 16;
+  const int T16 = Ncp / 16;
 
   // resident query operands: B[k = lane>>5][j = lane&31] of every k-step
   float bq[QSETS][KSTEPS];
   float xxq[QSETS], tq[QSETS];
-  bool qok[QSETS];
   int mycnt[QSETS];
   u64* sub[QSETS];
 #pragma unroll
   for (int s = 0; s < QSETS; ++s) {
     const int q = q0 + 32 * s + col;
-    const int qcl = q < Np ? q : Np - 1;
+    const int qcl = q < Nqp ? q : Nqp - 1;
 #pragma unroll
-    for (int m = 0; m < KSTEPS; ++m) bq[s][m] = xb[(size_t)(2 * m + h) * Np + qcl];
-    xxq[s] = xxb[qcl];
-    qok[s] = q < N;
-    tq[s] = (COLLECT && qok[s]) ? tau[(size_t)b * Np + qcl] : __builtin_inff();
+    for (int m = 0; m < KSTEPS; ++m) bq[s][m] = xqb[(size_t)(2 * m + h) * Nqp + qcl];
+    xxq[s] = xxqb[qcl];
+    tq[s] = (COLLECT && q < Nq) ? tau[(size_t)b * Nqp + qcl] : __builtin_inff();
     mycnt[s] = 0;
-    // sub-list of (query, slice, half): (((b*Np + q)*S + slice)*2 + h) * subcap
-    sub[s] = lists + ((((size_t)b * Np + qcl) * S + slice) * 2 + h) * (size_t)subcap;
+    // sub-list of (query, slice, half): (((b*Nqp + q)*S + slice)*2 + h) * subcap
+    sub[s] = lists + ((((size_t)b * Nqp + qcl) * S + slice) * 2 + h) * (size_t)subcap;
   }
 
   for (int mt = t_begin; mt < t_end; ++mt) {
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     for (int m0 = 0; m0 < KSTEPS; m0 += KCH) {
       float av[KCH];
 #pragma unroll
-      for (int m = 0; m < KCH; ++m) av[m] = xb[(size_t)(2 * (m0 + m) + h) * Np + j0 + col];
+      for (int m = 0; m < KCH; ++m) av[m] = xcb[(size_t)(2 * (m0 + m) + h) * Ncp + j0 + col];
 #pragma unroll
       for (int m = 0; m < KCH; ++m) {
 #pragma unroll
@@ -168,13 +181,15 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     }
     // D[i][j]: lane holds column j = col (query), rows i = (r&3) + 8*(r>>2) + 4*h (candidates)
     float xxj[16];
+    if (MODE != 2) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 t4 = *reinterpret_cast<const float4*>(&xxb[j0 + 8 * g + 4 * h]);
-      xxj[4 * g + 0] = t4.x;
-      xxj[4 * g + 1] = t4.y;
-      xxj[4 * g + 2] = t4.z;
-      xxj[4 * g + 3] = t4.w;
+      for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&xxcb[j0 + 8 * g + 4 * h]);
+        xxj[4 * g + 0] = t4.x;
+        xxj[4 * g + 1] = t4.y;
+        xxj[4 * g + 2] = t4.z;
+        xxj[4 * g + 3] = t4.w;
+      }
     }
 #pragma unroll
     for (int s = 0; s < QSETS; ++s) {
@@ -188,13 +203,15 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
           // reference's subtraction
           const float t = __builtin_fmaf(2.0f, acc[s][r], -xxj[r]);
           v = __fsub_rn(t, xxq[s]);
-        } else {
+        } else if (MODE == 1) {
           const float t = __builtin_fmaf(-2.0f, acc[s][r], xxj[r]);  // xx[j] - 2*dot_p
           const float pp = __fadd_rn(t, xxq[s]);
           const float pn = __builtin_fmaf(-2.0f, accn[s][r], 2.0f);  // 2 - 2*dot_n
           v = -__fmul_rn(pp, __fadd_rn(1.0f, pn));
+        } else {
+          v = acc[s][r];
         }
-        const bool ok = (j0 + row) < N;
+        const bool ok = (j0 + row) < Nc;
         if (!COLLECT) {
           tm = fmaxf(tm, ok ? v : -__builtin_inff());
         } else {
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
       }
       if (!COLLECT) {
         const int q = q0 + 32 * s + col;
-        if (q < Np) tilemax[((size_t)b * Np + q) * T16 + (2 * mt + h)] = tm;
+        if (q < Nqp) tilemax[((size_t)b * Nqp + q) * T16 + (2 * mt + h)] = tm;
       }
     }
   }
@@ -215,24 +232,24 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
 #pragma unroll
     for (int s = 0; s < QSETS; ++s) {
       const int q = q0 + 32 * s + col;
-      if (q < Np) counts[(((size_t)b * Np + q) * S + slice) * 2 + h] = mycnt[s];
+      if (q < Nqp) counts[(((size_t)b * Nqp + q) * S + slice) * 2 + h] = mycnt[s];
     }
   }
 }
 
-// K2: one wave per query; the T = Np/16 tile maxima of the query are contiguous and live in
-// registers (16 per lane cover N <= 16384; the rare remainder is re-read each round).
+// K2: one wave per query; the T = Ncp/16 tile maxima of the query are contiguous and live in
+// registers (16 per lane cover Nc <= 16384; the rare remainder is re-read each round).
 // Bisection on order-preserving uint keys for tau with count(tilemax >= tau) >= k, stopping
 // as soon as the count is within a small slack of k.
 #define KM_TR 16
-__global__ __launch_bounds__(256) void pn_knn_tau_kernel(const float* __restrict__ tilemax, int N,
-                                                         int Np, int k, float* __restrict__ tau) {
+__global__ __launch_bounds__(256) void pn_knn_tau_kernel(const float* __restrict__ tilemax, int Nq,
+                                                         int Nqp, int T, int k,
+                                                         float* __restrict__ tau) {
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + wave;
-  if (q >= N) return;
-  const int T = Np / 16;
-  const float* __restrict__ row = tilemax + ((size_t)b * Np + q) * T;
+  if (q >= Nq) return;
+  const float* __restrict__ row = tilemax + ((size_t)b * Nqp + q) * T;
   float v[KM_TR];
   float vmin = __builtin_inff(), vmax = -__builtin_inff();
 #pragma unroll
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(256) void pn_knn_tau_kernel(const float* __restrict
     vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
     vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
   }
-  uint32_t lo = pn_f2ord(vmin);       // count(>= lo) = #finite tiles >= 2k (host checked)
+  uint32_t lo = pn_f2ord(vmin);       // count(>= lo) = #finite tiles >= k (host checked)
   uint32_t hi = pn_f2ord(vmax) + 1u;  // count(>= hi) = 0 < k
   const int slack = k / 16 + 1;
   while (hi - lo > 1u) {
@@ -272,27 +289,27 @@ __global__ __launch_bounds__(256) void pn_knn_tau_kernel(const float* __restrict
       hi = mid;
     }
   }
-  if (lane == 0) tau[(size_t)b * Np + q] = pn_ord2f(lo);
+  if (lane == 0) tau[(size_t)b * Nqp + q] = pn_ord2f(lo);
 }
 
-// K4: one wave per (permuted) query: gather its 2*S sub-lists into LDS, sort, emit.
-__global__ __launch_bounds__(256) void pn_knn_final_kernel(const u64* __restrict__ lists,
-                                                           const int* __restrict__ counts, int N,
-                                                           int Np, int k, int S, int subcap,
-                                                           KnnPerm perm,
-                                                           int64_t* __restrict__ out,
-                                                           int* __restrict__ flags) {
+// K4: one wave per query: gather its 2*S sub-lists into LDS, select/sort, emit.
+//   out_idx != null: the k best original candidate indices (k <= 128), row perm_q(q).
+//   out_val != null: the value of the k-th best (k <= KNN_CAP), row perm_q(q).
+__global__ __launch_bounds__(256) void pn_knn_final_kernel(
+    const u64* __restrict__ lists, const int* __restrict__ counts, int Nq, int Nqp, int k, int S,
+    int subcap, KnnPerm perm_q, KnnPerm perm_c, int64_t* __restrict__ out_idx,
+    float* __restrict__ out_val, int* __restrict__ flags) {
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
   __shared__ u64 s_keys[4][KNN_CAP];
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int qp = blockIdx.x * 4 + wave;
-  if (qp >= N) return;
-  const size_t ql = (size_t)b * Np + qp;
-  const int qo = knn_perm(perm, qp);
+  if (qp >= Nq) return;
+  const size_t ql = (size_t)b * Nqp + qp;
+  const int qo = knn_perm(perm_q, qp);
   u64* keys = s_keys[wave];
   // all 2S fill counts with one coalesced load, then register-only bookkeeping
-  const int nsub = 2 * S;  // <= 16
+  const int nsub = 2 * S;  // <= 32
   const int myc = lane < nsub ? counts[ql * nsub + lane] : 0;
   int n = 0;
   bool bad = false;
@@ -308,23 +325,36 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(const u64* __restrict
       // candidate index: permuted -> original, so that ties order by the caller's indices
       const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
       keys[n + e] = (key & 0xffffffff00000000ull) |
-                    (u64)(0xffffffffu - (uint32_t)knn_perm(perm, jp));
+                    (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
     }
     n += c;
   }
   if (bad || n < k) {
-    // overflow (or NaNs): recomputed by the gated generic kernel
-    if (lane == 0) flags[(size_t)b * N + qo] = 1;
+    // overflow (or NaNs): the caller recomputes flagged queries
+    if (lane == 0) flags[(size_t)b * Nq + qo] = 1;
+    if (out_val && lane == 0) out_val[(size_t)b * Nq + qo] = __builtin_nanf("");
     return;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
+  if (out_val) {
+    u64 kth;
+    if (n > k) {
+      kth = knn_wave_select(keys, n, k, s_hist[wave]);
+    } else {  // n == k: the k-th best is the minimum
+      u64 m = ~0ull;
+      for (int e = lane; e < n; e += 64) m = keys[e] < m ? keys[e] : m;
+      kth = pn_wave_min_u64(m);
+    }
+    if (lane == 0) out_val[(size_t)b * Nq + qo] = pn_ord2f((uint32_t)(kth >> 32));
+    return;
+  }
   if (n > 128) knn_wave_select(keys, n, k, s_hist[wave]);
   const int m = n > 128 ? k : n;
   u64 k0 = lane < m ? keys[lane] : 0ull;
   u64 k1 = lane + 64 < m ? keys[lane + 64] : 0ull;
   knn_wave_sort128(k0, k1);
-  int64_t* o = out + ((size_t)b * N + qo) * k;
+  int64_t* o = out_idx + ((size_t)b * Nq + qo) * k;
   if (lane < k) o[lane] = knn_key_index(k0);
   if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
 }
@@ -332,13 +362,14 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(const u64* __restrict
 // ---------------------------------------------------------------------------------------
 struct KnnPlan {
   bool fast;
-  int ksteps, qsets, Cp, Np, S, tiles_per_slice, subcap;
+  int ksteps, qsets, Cp, Nqp, Ncp, S, tiles_per_slice, subcap;
 };
 
-static KnnPlan knn_mfma_plan(int mode, int B, int C, int N, int k) {
+static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool want_value) {
   KnnPlan p;
   memset(&p, 0, sizeof(p));
-  p.Np = (int)pn_align_up(N, 64);
+  p.Nqp = (int)pn_align_up(Nq, 64);
+  p.Ncp = (int)pn_align_up(Nc, 64);
   if (mode == 1) {
     p.ksteps = 4;
   } else if (C <= 4) {
@@ -356,18 +387,19 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int N, int k) {
   }
   p.qsets = p.ksteps <= 32 ? 2 : 1;
   p.Cp = 2 * p.ksteps;
-  // the threshold needs at least 2k tile maxima to be tight; small clouds use the scan path
-  p.fast = p.ksteps > 0 && (N / 16) >= 2 * k && k <= KNN_MAXK;
+  // the threshold needs at least 2k tile maxima to be tight; other shapes use the scan path
+  const int kmax = want_value ? KNN_CAP / 2 : KNN_MAXK;
+  p.fast = p.ksteps > 0 && (Nc / 16) >= 2 * k && k <= kmax;
   if (p.fast) {
-    const long long waves_q = (long long)B * pn_cdiv(p.Np, 32 * p.qsets);
+    const long long waves_q = (long long)B * pn_cdiv(p.Nqp, 32 * p.qsets);
     int S = (int)(8192 / (waves_q > 0 ? waves_q : 1));
-    const int ntiles = p.Np / 32;
+    const int ntiles = p.Ncp / 32;
     if (S > 8) S = 8;
     if (S > ntiles) S = ntiles;
     if (S < 1) S = 1;
     p.tiles_per_slice = pn_cdiv(ntiles, S);
     p.S = pn_cdiv(ntiles, p.tiles_per_slice);
-    // expected survivors per sub-list ~ 1.1 k / (2 S); leave generous head-room
+    // expected survivors per sub-list ~ 1.1-1.3 k / (2 S); leave generous head-room
     p.subcap = (int)pn_align_up(3 * k / (2 * p.S) + 16, 8);
     if (2 * p.S * p.subcap > KNN_CAP) p.subcap = KNN_CAP / (2 * p.S);
   }
@@ -375,10 +407,10 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int N, int k) {
 }
 
 struct KnnWs {
-  size_t xp, xxp, tilemax, tau, cnt, flags, lists, v1, total;
+  size_t xq, xxq, xc, xxc, tilemax, tau, cnt, flags, lists, v1, total;
 };
 
-static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int N, int k) {
+static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool self, bool v1) {
   KnnWs w;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -386,38 +418,134 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int N, int k) {
     o += pn_align_up(bytes, 256);
     return at;
   };
-  w.xp = take((size_t)B * p.Cp * p.Np * 4);
-  w.xxp = take((size_t)B * p.Np * 4);
-  w.tilemax = take((size_t)B * (p.Np / 16) * p.Np * 4);
-  w.tau = take((size_t)B * p.Np * 4);
-  w.cnt = take((size_t)B * p.Np * 2 * p.S * 4);
-  w.flags = take((size_t)B * N * 4);
-  w.lists = take((size_t)B * p.Np * 2 * p.S * p.subcap * 8);
-  w.v1 = take(pn_knn_v1_workspace(B, C, N, k, true));
+  w.xc = take((size_t)B * p.Cp * p.Ncp * 4);
+  w.xxc = take((size_t)B * p.Ncp * 4);
+  if (self) {
+    w.xq = w.xc;
+    w.xxq = w.xxc;
+  } else {
+    w.xq = take((size_t)B * p.Cp * p.Nqp * 4);
+    w.xxq = take((size_t)B * p.Nqp * 4);
+  }
+  w.tilemax = take((size_t)B * p.Nqp * (p.Ncp / 16) * 4);
+  w.tau = take((size_t)B * p.Nqp * 4);
+  w.cnt = take((size_t)B * p.Nqp * 2 * p.S * 4);
+  w.flags = take((size_t)B * Nq * 4);
+  w.lists = take((size_t)B * p.Nqp * 2 * p.S * p.subcap * 8);
+  w.v1 = take(v1 ? pn_knn_v1_workspace(B, C, Nq, k, true) : 0);
   w.total = o;
   return w;
 }
 
-extern "C" size_t pn_knn_workspace(int B, int C, int N, int k) {
-  // mode 1 (points+normals) has C = 6 and plans like mode 0 with ksteps = 4
-  KnnPlan p = knn_mfma_plan(C == 6 ? 1 : 0, B, C, N, k);
-  KnnPlan p0 = knn_mfma_plan(0, B, C, N, k);
-  size_t a = p.fast ? knn_mfma_ws(p, B, C, N, k).total : pn_knn_v1_workspace(B, C, N, k, false);
-  size_t b = p0.fast ? knn_mfma_ws(p0, B, C, N, k).total : pn_knn_v1_workspace(B, C, N, k, false);
-  return a > b ? a : b;
-}
-
 template <int KSTEPS, int QSETS, int MODE>
-static void knn_mfma_launch_pass(bool collect, dim3 grid, hipStream_t stream, const float* xp,
-                                 const float* xxp, int N, int Np, int tps, float* tilemax,
-                                 const float* tau, u64* lists, int* cnt, int subcap,
-                                 KnnPerm perm) {
+static void knn_mfma_launch_pass(bool collect, dim3 grid, hipStream_t stream, const float* xq,
+                                 const float* xxq, int Nq, int Nqp, const float* xc,
+                                 const float* xxc, int Nc, int Ncp, int tps, float* tilemax,
+                                 const float* tau, u64* lists, int* cnt, int subcap) {
   if (!collect)
     hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, false>), grid, dim3(256), 0,
-                       stream, xp, xxp, N, Np, tps, tilemax, tau, lists, cnt, subcap, perm);
+                       stream, xq, xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau, lists, cnt,
+                       subcap);
   else
     hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, true>), grid, dim3(256), 0,
-                       stream, xp, xxp, N, Np, tps, tilemax, tau, lists, cnt, subcap, perm);
+                       stream, xq, xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau, lists, cnt,
+                       subcap);
+}
+
+// The shared engine.  self: queries use the candidates' permuted copy (kNN graph of one set).
+static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, const float* q,
+                      int q_pm, int Nq, const float* c, int c_pm, int Nc, int B, int C, int k,
+                      int64_t* out_idx, float* out_val, int* flags_out, char* base,
+                      hipStream_t stream) {
+  float* xc = (float*)(base + w.xc);
+  float* xxc = (float*)(base + w.xxc);
+  float* xq = (float*)(base + w.xq);
+  float* xxq = (float*)(base + w.xxq);
+  float* tilemax = (float*)(base + w.tilemax);
+  float* tau = (float*)(base + w.tau);
+  int* cnt = (int*)(base + w.cnt);
+  int* flags = flags_out ? flags_out : (int*)(base + w.flags);
+  u64* lists = (u64*)(base + w.lists);
+  const KnnPerm perm_c = knn_make_perm(Nc, false);
+  const KnnPerm perm_q = self ? perm_c : knn_make_perm(Nq, true);
+
+  PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * Nq * 4, stream));
+  {
+    PN_PROF("knn_prep", stream);
+    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Ncp, 256), B), dim3(256), 0, stream, c,
+                       C, Nc, p.Cp, p.Ncp, mode, c_pm, perm_c, xc, xxc);
+    if (!self)
+      hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Nqp, 256), B), dim3(256), 0, stream,
+                         q, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
+  }
+  PN_CHECK_LAUNCH();
+  dim3 grid(pn_cdiv(p.Nqp, 32 * p.qsets * 4), p.S, B);
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool collect = pass == 1;
+    static const char* const pass_names[2][5] = {
+        {"knn_mfma_pass1_c4", "knn_mfma_pass1_c64", "knn_mfma_pass1_wide", "knn_mfma_pass1_pn",
+         "sel_mfma_pass1_dot"},
+        {"knn_mfma_pass2_c4", "knn_mfma_pass2_c64", "knn_mfma_pass2_wide", "knn_mfma_pass2_pn",
+         "sel_mfma_pass2_dot"}};
+    const int fam =
+        mode == 2 ? 4 : (mode == 1 ? 3 : (p.ksteps <= 4 ? 0 : (p.ksteps == 32 ? 1 : 2)));
+    {
+      PN_PROF(pass_names[pass][fam], stream);
+#define KM_GO(KS, QS, MD)                                                                        \
+  knn_mfma_launch_pass<KS, QS, MD>(collect, grid, stream, xq, xxq, Nq, p.Nqp, xc, xxc, Nc, p.Ncp, \
+                                   p.tiles_per_slice, tilemax, tau, lists, cnt, p.subcap)
+      if (mode == 1)
+        KM_GO(4, 2, 1);
+      else if (mode == 2 && p.ksteps == 2)
+        KM_GO(2, 2, 2);
+      else if (mode == 2 && p.ksteps == 4)
+        KM_GO(4, 2, 2);
+      else if (mode == 2 && p.ksteps == 32)
+        KM_GO(32, 2, 2);
+      else if (mode == 2 && p.ksteps == 64)
+        KM_GO(64, 1, 2);
+      else if (mode == 2)
+        KM_GO(128, 1, 2);
+      else if (p.ksteps == 2)
+        KM_GO(2, 2, 0);
+      else if (p.ksteps == 4)
+        KM_GO(4, 2, 0);
+      else if (p.ksteps == 32)
+        KM_GO(32, 2, 0);
+      else if (p.ksteps == 64)
+        KM_GO(64, 1, 0);
+      else
+        KM_GO(128, 1, 0);
+#undef KM_GO
+    }
+    PN_CHECK_LAUNCH();
+    if (!collect) {
+      PN_PROF("knn_tau", stream);
+      hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream,
+                         tilemax, Nq, p.Nqp, p.Ncp / 16, k, tau);
+      PN_CHECK_LAUNCH();
+    }
+  }
+  {
+    PN_PROF("knn_final", stream);
+    hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists,
+                       cnt, Nq, p.Nqp, k, p.S, p.subcap, perm_q, perm_c, out_idx, out_val, flags);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ---- kNN graph entry points ---------------------------------------------------------------
+extern "C" size_t pn_knn_workspace(int B, int C, int N, int k) {
+  size_t best = 0;
+  for (int mode = 0; mode < 2; ++mode) {
+    if (mode == 1 && C != 6) continue;
+    KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
+    size_t a = p.fast ? knn_mfma_ws(p, B, C, N, k, true, true).total
+                      : pn_knn_v1_workspace(B, C, N, k, false);
+    if (a > best) best = a;
+  }
+  return best;
 }
 
 static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
@@ -429,73 +557,19 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
   PN_CHECK_ARG(mode == 0 || C == 6, "pn_knn_pn: points+normals metric needs C=6, got %d", C);
   PN_CHECK_ARG(workspace && workspace_bytes >= pn_knn_workspace(B, C, N, k),
                "pn_knn: workspace too small");
-  const KnnPlan p = knn_mfma_plan(mode, B, C, N, k);
+  const KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
   if (!p.fast)
     return pn_knn_v1_launch(mode, x, B, C, N, k, idx, workspace, workspace_bytes, stream, nullptr);
-
-  const KnnWs w = knn_mfma_ws(p, B, C, N, k);
+  const KnnWs w = knn_mfma_ws(p, B, C, N, k, true, true);
   char* base = (char*)workspace;
-  float* xp = (float*)(base + w.xp);
-  float* xxp = (float*)(base + w.xxp);
-  float* tilemax = (float*)(base + w.tilemax);
-  float* tau = (float*)(base + w.tau);
-  int* cnt = (int*)(base + w.cnt);
-  int* flags = (int*)(base + w.flags);
-  u64* lists = (u64*)(base + w.lists);
-  const KnnPerm perm = knn_make_perm(N);
-
-  PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * N * 4, stream));
-  {
-    PN_PROF("knn_prep", stream);
-    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Np, 256), B), dim3(256), 0, stream, x,
-                     C, N, p.Cp, p.Np, mode, perm, xp, xxp);
-  }
-  PN_CHECK_LAUNCH();
-  dim3 grid(pn_cdiv(p.Np, 32 * p.qsets * 4), p.S, B);
-  for (int pass = 0; pass < 2; ++pass) {
-    const bool collect = pass == 1;
-    static const char* const pass_names[2][4] = {
-        {"knn_mfma_pass1_c4", "knn_mfma_pass1_c64", "knn_mfma_pass1_wide", "knn_mfma_pass1_pn"},
-        {"knn_mfma_pass2_c4", "knn_mfma_pass2_c64", "knn_mfma_pass2_wide", "knn_mfma_pass2_pn"}};
-    const int fam = mode == 1 ? 3 : (p.ksteps <= 4 ? 0 : (p.ksteps == 32 ? 1 : 2));
-    {
-    PN_PROF(pass_names[pass][fam], stream);
-#define KM_GO(KS, QS, MD)                                                                     \
-  knn_mfma_launch_pass<KS, QS, MD>(collect, grid, stream, xp, xxp, N, p.Np, p.tiles_per_slice, \
-                                   tilemax, tau, lists, cnt, p.subcap, perm)
-    if (mode == 1)
-      KM_GO(4, 2, 1);
-    else if (p.ksteps == 2)
-      KM_GO(2, 2, 0);
-    else if (p.ksteps == 4)
-      KM_GO(4, 2, 0);
-    else if (p.ksteps == 32)
-      KM_GO(32, 2, 0);
-    else if (p.ksteps == 64)
-      KM_GO(64, 1, 0);
-    else
-      KM_GO(128, 1, 0);
-#undef KM_GO
-    }
-    PN_CHECK_LAUNCH();
-    if (!collect) {
-      PN_PROF("knn_tau", stream);
-      hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream,
-                         tilemax, N, p.Np, k, tau);
-      PN_CHECK_LAUNCH();
-    }
-  }
-  {
-    PN_PROF("knn_final", stream);
-    hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, lists,
-                       cnt, N, p.Np, k, p.S, p.subcap, perm, idx, flags);
-  }
-  PN_CHECK_LAUNCH();
-  PN_PROF("knn_fallback_gate", stream);
+  int rc = select_run(p, w, mode, true, x, 0, N, x, 0, N, B, C, k, idx, nullptr, nullptr, base,
+                      stream);
+  if (rc) return rc;
   // degenerate queries (flagged) are redone by the generic scan kernel; waves without a
   // flagged query exit immediately
+  PN_PROF("knn_fallback_gate", stream);
   return pn_knn_v1_launch(mode, x, B, C, N, k, idx, base + w.v1,
-                          pn_knn_v1_workspace(B, C, N, k, true), stream, flags);
+                          pn_knn_v1_workspace(B, C, N, k, true), stream, (int*)(base + w.flags));
 }
 
 extern "C" int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx,
@@ -506,4 +580,36 @@ extern "C" int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* i
 extern "C" int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
                              size_t workspace_bytes, void* stream) {
   return knn_dispatch(1, x6, B, 6, N, k, idx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- dot-product selection between two point-major sets ------------------------------------
+// q (B,Nq,C), c (B,Nc,C) point-major.  For every query either the indices of the k candidates
+// with the largest dot product (out_idx (B,Nq,k), best first, ties -> smaller index) or the
+// k-th largest dot product (out_val (B,Nq)).  flags (B,Nq) int32: 1 where the result of a query
+// is NOT valid (survivor list overflow on massively tied data) — the caller must recompute
+// those rows.  Returns PN_ERR_UNSUPPORTED when the shape is outside the fast path
+// (needs Nc/16 >= 2k, C <= 256).
+extern "C" size_t pn_dot_select_workspace(int B, int C, int Nq, int Nc, int k, int want_value) {
+  KnnPlan p = knn_mfma_plan(2, B, C, Nq, Nc, k, want_value != 0);
+  if (!p.fast) return 0;
+  return knn_mfma_ws(p, B, C, Nq, k, false, false).total;
+}
+
+extern "C" int pn_dot_select_f32(const float* q, int Nq, const float* c, int Nc, int B, int C,
+                                 int k, int64_t* out_idx, float* out_val, int* flags,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  PN_CHECK_ARG(q && c && flags && (out_idx || out_val), "pn_dot_select_f32: null pointer");
+  PN_CHECK_ARG(!(out_idx && out_val), "pn_dot_select_f32: ask for indices or the value, not both");
+  PN_CHECK_ARG(B > 0 && C > 0 && Nq > 0 && Nc > 0 && k >= 1 && k <= Nc,
+               "pn_dot_select_f32: bad sizes (B=%d C=%d Nq=%d Nc=%d k=%d)", B, C, Nq, Nc, k);
+  const KnnPlan p = knn_mfma_plan(2, B, C, Nq, Nc, k, out_val != nullptr);
+  if (!p.fast) {
+    pn_set_error("pn_dot_select_f32: shape outside the fast path (Nc/16 >= 2k, C <= 256, k <= %d)",
+                 out_val ? KNN_CAP / 2 : KNN_MAXK);
+    return PN_ERR_UNSUPPORTED;
+  }
+  const KnnWs w = knn_mfma_ws(p, B, C, Nq, k, false, false);
+  PN_CHECK_ARG(workspace && workspace_bytes >= w.total, "pn_dot_select_f32: workspace too small");
+  return select_run(p, w, 2, false, q, 1, Nq, c, 1, Nc, B, C, k, out_idx, out_val, flags,
+                    (char*)workspace, (hipStream_t)stream);
 }

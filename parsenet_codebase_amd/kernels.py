@@ -208,3 +208,92 @@ def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, den
                                              current_stream(PQ.device))
     check(rc, "pn_edgeconv_bwd_f32")
     return dPQ
+
+
+def dot_select(q, c, k, want_value):
+    """q (B,Nq,C), c (B,Nc,C) point-major.  Returns (result, flags) where result is either the
+    (B,Nq,k) int64 indices of the k largest dot products (best first) or the (B,Nq) k-th largest
+    dot product, and flags (B,Nq) int32 marks rows the caller must recompute.  Returns None when
+    the shape is outside the kernel's fast path."""
+    require_cuda(q, c)
+    q = _f32c(q, "q")
+    c = _f32c(c, "c")
+    B, Nq, C = q.shape
+    Nc = c.shape[1]
+    lib = _lib.load()
+    wsz = lib.pn_dot_select_workspace(B, C, Nq, Nc, int(k), int(bool(want_value)))
+    if wsz == 0:
+        return None
+    dev = q.device
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    flags = torch.empty((B, Nq), dtype=torch.int32, device=dev)
+    if want_value:
+        out = torch.empty((B, Nq), dtype=torch.float32, device=dev)
+        args = (None, ptr(out))
+    else:
+        out = torch.empty((B, Nq, k), dtype=torch.int64, device=dev)
+        args = (ptr(out), None)
+    with torch.cuda.device(dev):
+        rc = lib.pn_dot_select_f32(ptr(q), Nq, ptr(c), Nc, B, C, int(k), args[0], args[1], ptr(flags),
+                                   ptr(ws), wsz, current_stream(dev))
+    check(rc, "pn_dot_select_f32")
+    return out, flags
+
+
+class MeanShiftWorkspace:
+    """Scratch buffers of the mean-shift kernels for one (B,N,D) problem, allocated once per
+    mean_shift call and reused by every iteration."""
+
+    def __init__(self, B, N, D, device, backward=False):
+        lib = _lib.load()
+        self.B, self.N, self.D = B, N, D
+        self.Np = (N + 63) // 64 * 64
+        self.S = lib.pn_meanshift_slices(B, N)
+        f = dict(dtype=torch.float32, device=device)
+        self.opart = torch.empty((B, self.S, N, D), **f)
+        self.rpart = torch.empty((B, self.S, N), **f)
+        if backward:
+            self.gu = torch.empty((B, N, D), **f)
+            self.go = torch.empty((B, N, D), **f)
+            self.cs = torch.empty((B, N), **f)
+            self.qt = torch.empty((B, D, self.Np), **f)
+            self.gut = torch.empty((B, D, self.Np), **f)
+            self.opart_x = torch.empty((B, self.S, N, D), **f)
+
+
+def meanshift_pack(x):
+    require_cuda(x)
+    x = _f32c(x, "x")
+    B, N, D = x.shape
+    Np = (N + 63) // 64 * 64
+    xt = torch.empty((B, D, Np), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pn_meanshift_pack_f32(ptr(x), B, N, D, ptr(xt), current_stream(x.device))
+    check(rc, "pn_meanshift_pack_f32")
+    return xt
+
+
+def meanshift_iter_fwd(q, x, xt, bsq, ws):
+    B, N, D = x.shape
+    y = torch.empty_like(x)
+    rsum = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    unorm = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pn_meanshift_iter_fwd_f32(ptr(q), ptr(x), ptr(xt), ptr(bsq), B, N, D, ptr(ws.opart),
+                                                   ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
+                                                   current_stream(x.device))
+    check(rc, "pn_meanshift_iter_fwd_f32")
+    return y, rsum, unorm
+
+
+def meanshift_iter_bwd(gy, y, q, x, xt, rsum, unorm, bsq, ws):
+    """Returns (dL/dq, contribution to dL/dx), both (B,N,D)."""
+    B, N, D = x.shape
+    gy = _f32c(gy, "gy")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pn_meanshift_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(xt), ptr(rsum),
+                                                   ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.go),
+                                                   ptr(ws.cs), ptr(ws.qt), ptr(ws.gut), ptr(ws.opart),
+                                                   ptr(ws.opart_x), current_stream(x.device))
+    check(rc, "pn_meanshift_iter_bwd_f32")
+    return ws.opart.sum(1), ws.opart_x.sum(1)

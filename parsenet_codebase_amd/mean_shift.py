@@ -1,0 +1,197 @@
+"""Differentiable mean-shift clustering on the unit hypersphere (src/mean_shift.py) on the HIP
+kernels: bandwidth quantile and nearest-centre assignment through the matrix-core selection
+engine, iterations through the fused flash-style kernels with a recompute backward.  Same class,
+method names and return values as the reference."""
+import numpy as np
+import torch
+
+from . import kernels as K
+from ._lib import require_cuda
+
+
+class _MeanShiftIterations(torch.autograd.Function):
+    """X (B,N,D) unit rows, bsq (B) squared bandwidths -> iterate after ``iterations`` steps.
+    Saves only the iterates, row sums and norms (O(T N D)); the backward recomputes the kernel."""
+
+    @staticmethod
+    def forward(ctx, X, bsq, iterations):
+        x = X.contiguous()
+        B, N, D = x.shape
+        xt = K.meanshift_pack(x)
+        ws = K.MeanShiftWorkspace(B, N, D, x.device)
+        iterates, rsums, norms = [x], [], []
+        q = x
+        for _ in range(iterations):
+            q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
+            iterates.append(q)
+            rsums.append(r)
+            norms.append(n)
+        ctx.iterations = iterations
+        ctx.save_for_backward(xt, bsq, *iterates, *rsums, *norms)
+        return q if iterations > 0 else x.clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        T = ctx.iterations
+        saved = ctx.saved_tensors
+        xt, bsq = saved[0], saved[1]
+        iterates = saved[2:3 + T]
+        rsums = saved[3 + T:3 + 2 * T]
+        norms = saved[3 + 2 * T:3 + 3 * T]
+        x = iterates[0]
+        B, N, D = x.shape
+        ws = K.MeanShiftWorkspace(B, N, D, x.device, backward=True)
+        gX = torch.zeros_like(x)
+        g = gy.contiguous()
+        for it in reversed(range(T)):
+            gq, gx = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it],
+                                          bsq, ws)
+            gX += gx
+            g = gq
+        gX += g  # the first iterate is X itself
+        return gX, None, None
+
+
+def mean_shift_iterations(X, b, iterations):
+    """X (N,D) or (B,N,D); b scalar / 0-dim tensor / (B,) tensor of bandwidths."""
+    require_cuda(X)
+    squeeze = X.dim() == 2
+    Xb = X.unsqueeze(0) if squeeze else X
+    B = Xb.shape[0]
+    bt = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(-1)
+    if bt.numel() == 1:
+        bt = bt.expand(B)
+    bsq = (bt.detach() ** 2).contiguous()
+    out = _MeanShiftIterations.apply(Xb, bsq, int(iterations))
+    return out[0] if squeeze else out
+
+
+def _first_argmax(vals, dim):
+    """argmax with the smallest index among ties (torch's GPU reduction leaves it unspecified)."""
+    m = vals.max(dim, keepdim=True)[0]
+    n = vals.shape[dim]
+    shape = [1] * vals.dim()
+    shape[dim] = n
+    ar = torch.arange(n, device=vals.device).view(shape)
+    return torch.where(vals == m, ar, torch.full_like(ar, n)).min(dim)[0]
+
+
+class MeanShift:
+    def __init__(self):
+        pass
+
+    # -- src/mean_shift.py:19-43 ---------------------------------------------------------
+    def mean_shift(self, X, num_samples, quantile, iterations, kernel_type="gaussian", bw=None, nms=True):
+        """X (N,d) unit rows.  Returns (new_X, center, bw, labels), or (new_X, bw) if not nms."""
+        if bw is None:
+            with torch.no_grad():
+                bw = self.compute_bandwidth(X, num_samples, quantile)
+                bw = torch.clamp(bw, min=0.003)   # avoid numerical issues
+        new_X, _ = self.mean_shift_(X, b=bw, iterations=iterations, kernel_type=kernel_type)
+        if not nms:
+            return new_X, bw
+        with torch.no_grad():
+            _, indices, new_labels = self.nms(new_X, X, b=bw)
+        center = new_X[indices]
+        return new_X, center, bw, new_labels
+
+    # -- src/mean_shift.py:45-79 ---------------------------------------------------------
+    def mean_shift_(self, X, b, iterations=10, kernel_type="gaussian"):
+        if kernel_type == "gaussian" and X.shape[-1] == 128:
+            return mean_shift_iterations(X, b, iterations), X
+        # Epanechnikov kernel / other embedding sizes: never used by the training path; plain
+        # tensor expressions on the GPU (materialises N x N like the reference)
+        new_X = X.clone()
+        for _ in range(iterations):
+            Kmat = self.kernel_between(new_X, X, kernel_type, b)
+            D = 1 / torch.sum(Kmat, 1, keepdim=True)
+            new_X = new_X + ((Kmat @ X) * D - new_X)
+            new_X = new_X / torch.norm(new_X, dim=1, p=2, keepdim=True)
+        return new_X, X
+
+    # -- src/mean_shift.py:81-96 ---------------------------------------------------------
+    def guard_mean_shift(self, embedding, quantile, iterations, kernel_type="gaussian"):
+        while True:
+            _, center, bandwidth, cluster_ids = self.mean_shift(embedding, 5000, quantile, iterations,
+                                                                kernel_type=kernel_type)
+            if torch.unique(cluster_ids).shape[0] > 49:
+                quantile *= 2
+            else:
+                break
+        return center, bandwidth, cluster_ids
+
+    # -- src/mean_shift.py:98-113 --------------------------------------------------------
+    def kernel_between(self, A, X, kernel_type, bw):
+        dist = 2.0 - 2.0 * A @ torch.transpose(X, 1, 0)
+        if kernel_type == "gaussian":
+            return torch.exp(torch.clamp(-dist / (bw ** 2) / 2, max=75, min=-75))
+        return torch.nn.functional.relu(3 / 4 * (1 - dist / (bw ** 2)))
+
+    def kernel(self, X, kernel_type, bw):
+        """N x N kernel matrix (diagnostics only; nothing on the training path calls it)."""
+        return self.kernel_between(X, X, "gaussian" if kernel_type == "gaussian" else "epa", bw)
+
+    # -- src/mean_shift.py:115-137 -------------------------------------------------------
+    def compute_bandwidth(self, X, num_samples, quantile):
+        """Mean over rows of the K-th smallest distance sqrt(2 - 2 x_i.x_j), K = int(quantile *
+        num_samples).  Consumes numpy's RNG exactly like the reference (one shuffle of N)."""
+        require_cuda(X)
+        N = X.shape[0]
+        L = np.arange(N)
+        np.random.shuffle(L)
+        if num_samples < N:
+            X = X[torch.from_numpy(L[0:num_samples]).to(X.device)]
+        # with num_samples >= N every row is used: the statistic does not depend on the order
+        Kq = int(quantile * num_samples)
+        Xc = X.detach().contiguous().unsqueeze(0)
+        res = K.dot_select(Xc, Xc, Kq, want_value=True) if 1 <= Kq <= Xc.shape[1] else None
+        if res is not None:
+            kth_dot, flags = res
+            kth_dot = kth_dot[0]
+            bad = torch.nonzero(flags[0]).flatten()
+            if bad.numel() > 0:   # massively tied rows: redo those rows densely
+                d = X[bad] @ X.t()
+                kth_dot[bad] = torch.topk(d, Kq, dim=1, largest=True)[0][:, -1]
+            kth = 2.0 - 2.0 * kth_dot
+        else:
+            kth = torch.empty(X.shape[0], device=X.device)
+            for s in range(0, X.shape[0], 2048):   # shapes outside the kernel's fast path
+                d = 2 - 2 * X[s:s + 2048] @ X.t()
+                kth[s:s + 2048] = torch.topk(d, Kq, dim=1, largest=False)[0][:, -1]
+        return torch.mean(torch.sqrt(torch.clamp(kth, min=1e-6)))
+
+    # -- src/mean_shift.py:139-179 -------------------------------------------------------
+    def nms(self, centers, X, b):
+        """Non-maximum suppression of the shifted points.  Returns (pruned centres, their row
+        indices, per-point labels)."""
+        require_cuda(centers, X)
+        N = X.shape[0]
+        centers = centers.detach()
+        X = X.detach()
+        # nearest centre of every point = largest dot product (2 - 2 dot is exact and decreasing)
+        membership = None
+        res = K.dot_select(X.contiguous().unsqueeze(0), centers.contiguous().unsqueeze(0), 1, want_value=False)
+        if res is not None:
+            idx, flags = res
+            membership = idx[0, :, 0]
+            bad = torch.nonzero(flags[0]).flatten()
+            if bad.numel() > 0:
+                membership[bad] = _first_argmax(X[bad] @ centers.t(), 1)
+        else:
+            membership = torch.empty(N, dtype=torch.int64, device=X.device)
+            for s in range(0, N, 2048):
+                membership[s:s + 2048] = _first_argmax(X[s:s + 2048] @ centers.t(), 1)
+        uniques, counts_ = np.unique(membership.cpu().numpy(), return_counts=True)
+        num_mem_cluster = torch.zeros(N, device=X.device)
+        uq = torch.from_numpy(uniques).to(X.device)
+        num_mem_cluster[uq] = torch.from_numpy(counts_.astype(np.float32)).to(X.device)
+        # neighbours (distance < b, not b^2, as in the reference) of the occupied centres only
+        dist = 2.0 - 2.0 * centers[uq] @ centers.t()
+        score = (dist < b).float() * num_mem_cluster.reshape(1, -1)
+        cluster_center_ids = torch.unique(_first_argmax(score, 1))
+        centers = centers[cluster_center_ids]
+        labels = _first_argmax(centers @ X.t(), 0)
+        return centers, cluster_center_ids, labels
+
+    def pdist(self, x, y):
+        return torch.sum((x.unsqueeze(1) - y.unsqueeze(0)) ** 2, 2)
