@@ -95,6 +95,13 @@ int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const float* q, c
                               float* cs, float* qt, float* gut, float* opart_q, float* opart_x,
                               void* stream);
 
+/* ---- batched symmetric 3x3 eigen-decomposition (fp64) ---------------------------------
+ * Serves the right singular vectors the primitive fits need (torch.svd of a tall n x 3 matrix in
+ * src/fitting_utils.py:440 used by src/primitive_forward.py:725,794): they are the eigenvectors
+ * of the 3x3 Gram matrix.  G (M,3,3) row-major -> evals (M,3) descending, evecs (M,3,3) with
+ * eigenvectors in COLUMNS, each signed so that its largest-magnitude component is positive. */
+int pn_sym3_eig_f64(const double* G, int M, double* evals, double* evecs, void* stream);
+
 /* ---- layout helper: (B,R,C) -> (B,C,R) --------------------------------------------- */
 int pn_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
 

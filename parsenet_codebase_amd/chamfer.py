@@ -1,0 +1,74 @@
+"""Chamfer distances (src/utils.py:273-358) on the HIP nearest-neighbour kernel.
+
+The kernel finds the arg-mins (the O(M N) part, never materialising the (M,N,3) broadcast); the
+squared distances to those neighbours are then re-evaluated with the reference's own expression
+on (N,3)-sized tensors, so autograd delivers exactly the reference's gradient (to the point and
+to its nearest neighbour) and the forward value is bit-identical to min over the full matrix."""
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def _to_cuda(t):
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t.astype(np.float32)).cuda()
+    return t
+
+
+def _guard_sqrt(x, minimum=1e-5):
+    return torch.sqrt(torch.clamp(x, min=minimum))
+
+
+def nn_sqdist(a, b, side_a=True, side_b=True):
+    """a (B,Na,3), b (B,Nb,3) -> (dA (B,Na), dB (B,Nb)): squared distance of every point to its
+    nearest neighbour in the other cloud, differentiable w.r.t. both clouds."""
+    with torch.no_grad():
+        _, argA, _, argB = K.chamfer_nn(a.detach(), b.detach(), side_a, side_b)
+    dA = dB = None
+    if side_a:
+        nb = torch.gather(b, 1, argA.unsqueeze(-1).expand(-1, -1, 3))
+        dA = torch.sum((a - nb) ** 2, 2)
+    if side_b:
+        na = torch.gather(a, 1, argB.unsqueeze(-1).expand(-1, -1, 3))
+        dB = torch.sum((na - b) ** 2, 2)
+    return dA, dB
+
+
+def chamfer_distance(pred, gt, sqrt=False):
+    """pred (B,N,3), gt (B,M,3) -> scalar (mean_i min_j + mean_j min_i) / 2 averaged over B."""
+    pred, gt = _to_cuda(pred), _to_cuda(gt)
+    d_pred, d_gt = nn_sqdist(pred, gt)
+    if sqrt:
+        d_pred, d_gt = _guard_sqrt(d_pred), _guard_sqrt(d_gt)
+    cd = torch.mean(d_pred, 1) + torch.mean(d_gt, 1)
+    return torch.mean(cd) / 2.0
+
+
+def chamfer_distance_one_side(pred, gt, side=1):
+    """side 1: mean over gt of the distance to the nearest prediction; side 0: the converse."""
+    pred, gt = _to_cuda(pred), _to_cuda(gt)
+    if side == 0:
+        d, _ = nn_sqdist(pred, gt, True, False)
+    elif side == 1:
+        _, d = nn_sqdist(pred, gt, False, True)
+    else:
+        raise ValueError("side must be 0 or 1")
+    return torch.mean(torch.mean(d, 1))
+
+
+def chamfer_distance_single_shape(pred, gt, one_side=False, sqrt=False, reduce=True):
+    """pred (N,3), gt (M,3).  one_side: per-gt distance to the nearest prediction."""
+    pred, gt = _to_cuda(pred), _to_cuda(gt)
+    d_pred, d_gt = nn_sqdist(pred.unsqueeze(0), gt.unsqueeze(0), not one_side, True)
+    d_gt = d_gt[0]
+    if sqrt:
+        d_gt = _guard_sqrt(d_gt)
+    if one_side:
+        return torch.mean(d_gt, 0) if reduce else d_gt
+    d_pred = d_pred[0]
+    if sqrt:
+        d_pred = _guard_sqrt(d_pred)
+    if reduce:
+        d_pred, d_gt = torch.mean(d_pred), torch.mean(d_gt)
+    return (d_pred + d_gt) / 2.0

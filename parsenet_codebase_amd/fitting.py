@@ -1,0 +1,734 @@
+"""Differentiable fitting stage of the ParSeNet hot path: least squares, custom-gradient SVD,
+membership normalisation, segment matching, PCA standardisation, weighted primitive fits,
+SplineNet forward wrappers, residual losses and the end-to-end driver.
+
+Same names, arguments and return values as the reference modules
+  src/fitting_utils.py, src/primitive_forward.py, src/fitting_optimization.py,
+  src/primitives.py, src/residual_utils.py, src/segment_utils.py (to_one_hot, relaxed_iou_fast)
+with the numeric guards preserved (clamps, ridge search, minimum sizes).  Debugger traps of the
+reference (ipdb) are exceptions here.  Everything runs on the GPU; the only host work is what the
+reference also does on the host (Hungarian matching, the 3x3 PCA rotation, control flow on segment
+sizes)."""
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from . import kernels as K
+from .bspline import sample_points_from_control_points_, uniform_knot_bspline
+from .chamfer import chamfer_distance_single_shape
+from .mean_shift import MeanShift
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+def guard_exp(x, max_value=75, min_value=-75):
+    return torch.exp(torch.clamp(x, max=max_value, min=min_value))
+
+
+def guard_sqrt(x, minimum=1e-5):
+    return torch.sqrt(torch.clamp(x, min=minimum))
+
+
+# ---------------------------------------------------------------------------------------
+# small dense algebra
+# ---------------------------------------------------------------------------------------
+def _gram_spectrum(A):
+    """Singular values (descending, fp64) and right singular vectors (columns) of a tall (n,3)
+    matrix from the eigen-decomposition of its fp64 Gram matrix (HIP Jacobi kernel)."""
+    Ad = A.detach().double()
+    G = (Ad.t() @ Ad).unsqueeze(0)
+    evals, evecs = K.sym3_eig(G) if A.shape[1] == 3 else _eigh_desc(G)
+    return torch.sqrt(torch.clamp(evals[0], min=0.0)), evecs[0]
+
+
+def _eigh_desc(G):
+    w, v = torch.linalg.eigh(G)
+    return w.flip(-1), v.flip(-1)
+
+
+def _numerical_rank(sv, shape):
+    """numpy / torch.matrix_rank convention: #(s > max(m,n) * eps * s_max)."""
+    tol = sv.max() * max(shape) * EPS
+    return int((sv > tol).sum().item())
+
+
+class LeastSquares:
+    """src/fitting_utils.py:32-65."""
+
+    def lstsq(self, A, Y, lamb=0.0):
+        """Differentiable least squares min ||A x - Y||.  Full column rank: the QR solution of
+        the reference (evaluated through the fp64 normal equations, same minimiser); otherwise
+        ridge regression with the smallest lambda in {1e-6 * 10^i} restoring full rank."""
+        cols = A.shape[1]
+        if cols == 3:
+            sv, _ = _gram_spectrum(A)
+        else:
+            sv = torch.linalg.svdvals(A.detach().double())
+        if not bool(torch.isfinite(sv).all()):
+            raise RuntimeError("lstsq: non-finite entries in the design matrix")
+        if cols == _numerical_rank(sv, A.shape):
+            Ad, Yd = A.double(), Y.double()
+            if A.shape[0] == cols:     # square (the ridge system): solve it directly
+                x = torch.linalg.solve(Ad, Yd)
+            else:
+                x = torch.linalg.solve(Ad.t() @ Ad, Ad.t() @ Yd)
+            return x.to(A.dtype)
+        AtA = A.transpose(1, 0) @ A
+        with torch.no_grad():
+            lamb = best_lambda(AtA)
+        A_dash = AtA + lamb * torch.eye(cols, device=A.device)
+        Y_dash = A.transpose(1, 0) @ Y
+        return self.lstsq(A_dash, Y_dash, 1)
+
+
+def best_lambda(A):
+    """src/fitting_utils.py:68-85."""
+    lamb = 1e-6
+    cols = A.shape[0]
+    for _ in range(7):
+        A_dash = A + lamb * torch.eye(cols, device=A.device)
+        # fp32 singular values, like torch.matrix_rank in the reference: when lambda is close
+        # to the rank tolerance the outcome is decided by fp32 noise there as well
+        sv = torch.linalg.svdvals(A_dash)
+        if cols == _numerical_rank(sv, A_dash.shape):
+            break
+        lamb *= 10
+    return lamb
+
+
+def svd_grad_K(S):
+    """src/fitting_utils.py:394-417."""
+    N = S.shape[0]
+    s1, s2 = S.view((1, N)), S.view((N, 1))
+    diff, plus = s2 - s1, s2 + s1
+    eps = torch.full((N, N), 1e-6, device=S.device, dtype=S.dtype)
+    K_neg = torch.sign(diff) * torch.max(torch.abs(diff), eps)
+    ar = torch.arange(N, device=S.device)
+    K_neg[ar, ar] = 1e-6
+    K_neg = 1 / K_neg
+    K_pos = 1 / plus
+    rm_diag = torch.ones((N, N), device=S.device, dtype=S.dtype) - torch.eye(N, device=S.device, dtype=S.dtype)
+    return K_neg * K_pos * rm_diag
+
+
+def compute_grad_V(U, S, V, grad_V):
+    """src/fitting_utils.py:385-391."""
+    N = S.shape[0]
+    Kmat = svd_grad_K(S)
+    Sd = torch.eye(N, device=S.device, dtype=S.dtype) * S.reshape((N, 1))
+    inner = Kmat.T * (V.T @ grad_V)
+    inner = (inner + inner.T) / 2.0
+    return 2 * U @ Sd @ inner @ V.T
+
+
+class CustomSVD(torch.autograd.Function):
+    """SVD of a tall matrix whose backward only propagates grad_V with guarded denominators
+    (src/fitting_utils.py:420-455).  Forward through the 3x3 Gram eigen kernel for n x 3 inputs;
+    singular vectors are defined up to sign, here fixed by the kernel's convention."""
+
+    @staticmethod
+    def forward(ctx, input):
+        if input.shape[1] == 3 and input.is_cuda:
+            S64, V64 = _gram_spectrum(input)
+            S, V = S64.to(input.dtype), V64.to(input.dtype)
+            U = (input @ V) / torch.clamp(S, min=1e-30)
+        else:
+            U, S, Vh = torch.linalg.svd(input, full_matrices=False)
+            V = Vh.transpose(-2, -1)
+        ctx.save_for_backward(U, S, V)
+        return U, S, V
+
+    @staticmethod
+    def backward(ctx, grad_U, grad_S, grad_V):
+        U, S, V = ctx.saved_tensors
+        return compute_grad_V(U, S, V, grad_V)
+
+
+customsvd = CustomSVD.apply
+
+
+def weights_normalize(weights, bw):
+    """src/fitting_utils.py:306-325: soft memberships (C,N) from centre/point dot products."""
+    prob = guard_exp(weights / (bw ** 2) / 2)
+    prob = prob / torch.sum(prob, 0, keepdim=True)
+    if weights.shape[0] == 1:
+        return prob
+    prob = prob - torch.min(prob, 1, keepdim=True)[0]
+    prob = prob / (torch.max(prob, 1, keepdim=True)[0] + EPS)
+    return prob
+
+
+def to_one_hot(target, maxx=50, device_id=0):
+    """src/segment_utils.py:283-292."""
+    if isinstance(target, np.ndarray):
+        target = torch.from_numpy(target.astype(np.int64)).cuda(device_id)
+    N = target.shape[0]
+    one_hot = torch.zeros((N, maxx), device=target.device)
+    return one_hot.scatter_(1, target.unsqueeze(1).long(), 1)
+
+
+def relaxed_iou_fast(pred, gt, max_clusters=50):
+    """src/segment_utils.py:356-374: (B,N,K) one-hots -> (B,K,K) IoU matrix."""
+    norms_p = torch.sum(pred, 1).unsqueeze(2)
+    norms_g = torch.sum(gt, 1).unsqueeze(1)
+    dots = pred.transpose(2, 1) @ gt
+    return dots / (norms_p + norms_g - dots + 1e-7)
+
+
+def solve_dense(cost):
+    """Hungarian assignment (the reference uses lapsolver.solve_dense)."""
+    return linear_sum_assignment(cost)
+
+
+def match(target, pred_labels):
+    """src/fitting_utils.py:362-376: Hungarian matching of predicted to ground-truth segments on
+    the relaxed IoU of their one-hot encodings."""
+    dev = torch.cuda.current_device()
+    labels_one_hot = to_one_hot(target, device_id=dev)
+    cluster_ids_one_hot = to_one_hot(pred_labels, device_id=dev)
+    cost = relaxed_iou_fast(cluster_ids_one_hot.unsqueeze(0).float(), labels_one_hot.unsqueeze(0).float())
+    cost_ = 1.0 - cost.data.cpu().numpy()
+    rids, cids = solve_dense(cost_[0])
+    return rids, cids, np.unique(target), np.unique(pred_labels)
+
+
+# ---------------------------------------------------------------------------------------
+# PCA standardisation (src/fitting_utils.py:493-590)
+# ---------------------------------------------------------------------------------------
+def rotation_matrix_a_to_b(A, B):
+    """Rotation taking unit vector A to B (numpy, float64)."""
+    cos = np.dot(A, B)
+    sin = np.linalg.norm(np.cross(B, A))
+    u = A
+    v = B - np.dot(A, B) * A
+    v = v / (np.linalg.norm(v) + EPS)
+    w = np.cross(B, A)
+    w = w / (np.linalg.norm(w) + EPS)
+    Fm = np.stack([u, v, w], 1)
+    G = np.array([[cos, -sin, 0], [sin, cos, 0], [0, 0, 1]])
+    try:
+        return Fm @ G @ np.linalg.inv(Fm)
+    except np.linalg.LinAlgError:
+        return np.eye(3, dtype=np.float32)
+
+
+def pca_torch(X):
+    """Eigen-decomposition of X^T X as (S (3,2) [real, imag], U (3,3)) like torch.eig.  The 3x3
+    problem is solved on the host with the same LAPACK routine (geev) the reference ends up in,
+    because the SIGN of the returned eigenvector decides the canonical frame of the spline
+    patches (fitting_utils.py:532-540 moves it to the host anyway)."""
+    cov = (torch.transpose(X, 1, 0) @ X).detach().cpu()
+    w, v = torch.linalg.eig(cov)
+    S = torch.stack([w.real, w.imag], 1)
+    return S, v.real
+
+
+def standardize_point_torch(point, weights):
+    """src/fitting_utils.py:512-553: centre on the confident points, rotate the minor PCA axis to
+    +x, scale by the weighted extent.  Returns (point, std (1,3), mean (3), R (3,3))."""
+    higher_indices = weights[:, 0] > 0.8
+    if torch.sum(higher_indices) < 400:
+        if weights.shape[0] >= 7500:
+            _, higher_indices = torch.topk(weights[:, 0], weights.shape[0] // 4)
+        else:
+            _, higher_indices = torch.topk(weights[:, 0], weights.shape[0] // 2)
+    weighted_points = point[higher_indices] * weights[higher_indices]
+    mean = torch.sum(weighted_points, 0) / (torch.sum(weights[higher_indices]) + EPS)
+    point = point - mean
+    S, U = pca_torch(point[higher_indices])
+    smallest_ev = U[:, torch.min(S[:, 0], 0)[1]].numpy()
+    R = rotation_matrix_a_to_b(smallest_ev, np.array([1, 0, 0])).astype(np.float32)
+    R = torch.from_numpy(R).to(point.device).detach()
+    point = torch.transpose(R @ torch.transpose(point, 1, 0), 1, 0)
+    weighted_points = point[higher_indices] * weights[higher_indices]
+    std = torch.abs(torch.max(weighted_points, 0)[0] - torch.min(weighted_points, 0)[0])
+    std = std.reshape((1, 3)).detach()
+    point = point / (std + EPS)
+    return point, std, mean, R
+
+
+def standardize_points_torch(points, weights):
+    Points, stds, Rs, means = [], [], [], []
+    for i in range(points.shape[0]):
+        point, std, mean, R = standardize_point_torch(points[i], weights)
+        Points.append(point)
+        stds.append(std)
+        means.append(mean)
+        Rs.append(R)
+    return torch.stack(Points, 0), stds, means, Rs
+
+
+def project_to_plane(points, a, d):
+    a = a.reshape((3, 1))
+    a = a / torch.norm(a, 2)
+    projections = points - ((points @ a).permute(1, 0) * a).permute(1, 0)
+    return projections + a.transpose(1, 0) * d
+
+
+def up_sample_points_torch(points, times=1):
+    """src/fitting_utils.py:150-164: append the centroid of the 4 nearest neighbours of every
+    point (the kNN kernel replaces the N x N broadcast)."""
+    for _ in range(times):
+        idx = K.knn(points.t().contiguous().unsqueeze(0), 5, "feature")[0]
+        centers = torch.mean(points[idx[:, 1:]], 1)
+        points = torch.cat([points, centers])
+    return points
+
+
+def up_sample_points_in_range(points, weights, a_min, a_max):
+    """src/fitting_utils.py:202-219."""
+    N = points.shape[0]
+    if N > a_max:
+        L = np.random.choice(np.arange(N), a_max, replace=False)
+        return points[L], weights[L]
+    while True:
+        points = up_sample_points_torch(points)
+        weights = torch.cat([weights, weights], 0)
+        if points.shape[0] >= a_max:
+            break
+    L = np.random.choice(np.arange(points.shape[0]), a_max, replace=False)
+    return points[L], weights[L]
+
+
+# ---------------------------------------------------------------------------------------
+# SplineNet forward wrappers (src/primitive_forward.py:34-102, 347-415)
+# ---------------------------------------------------------------------------------------
+def _restore(points_std, scale, R, mean):
+    """undo standardisation: x * std -> R^-1 -> + mean."""
+    tmp = points_std * scale.reshape((1, 3))
+    tmp = torch.inverse(R) @ torch.transpose(tmp, 1, 0)
+    return torch.transpose(tmp, 1, 0) + mean
+
+
+def forward_pass_open_spline(input_points_, control_decoder, nu, nv, viz=False, weights=None,
+                             if_optimize=True):
+    """Standardise -> SplineNet (open, 20x20 grid) -> evaluate on (nu, nv) -> de-standardise.
+    input_points_ (1,n,3), weights (n,1).  Returns (samples, samples) like the reference."""
+    if if_optimize:
+        raise NotImplementedError("if_optimize=True is the evaluation-only refit (SURVEY §8f rank 2)")
+    nu, nv = nu.to(input_points_.device), nv.to(input_points_.device)
+    with torch.no_grad():
+        points_, scales, means, RS = standardize_points_torch(input_points_, weights)
+    batch_size = points_.shape[0]
+    output = control_decoder(points_.permute(0, 2, 1), weights.T)
+    reconstructed_points = sample_points_from_control_points_(nu, nv, output, batch_size)
+    output = output.view(1, 400, 3)
+    rec = torch.stack([_restore(reconstructed_points[b].clone(), scales[b], RS[b], means[b])
+                       for b in range(batch_size)], 0)
+    return rec, rec
+
+
+def forward_closed_splines(input_points_, control_decoder, nu, nv, viz=False, weights=None,
+                           if_optimize=True):
+    """Closed (u-periodic) variant: the first sample row is appended again (31 x 30 = 930 points).
+    Returns (samples (1,930,3), None, samples)."""
+    if if_optimize and input_points_.shape[1] > 200:
+        raise NotImplementedError("if_optimize=True is the evaluation-only refit (SURVEY §8f rank 2)")
+    batch_size = input_points_.shape[0]
+    nu, nv = nu.to(input_points_.device), nv.to(input_points_.device)
+    with torch.no_grad():
+        points_, scales, means, RS = standardize_points_torch(input_points_, weights)
+    output = control_decoder(points_.permute(0, 2, 1), weights.T)
+    reconstructed_points = sample_points_from_control_points_(nu, nv, output, batch_size)
+    closed = []
+    for b in range(batch_size):
+        tmp = _restore(reconstructed_points[b].clone(), scales[b], RS[b], means[b]).reshape((30, 30, 3))
+        closed.append(torch.cat([tmp, tmp[0:1]], 0))
+    rec = torch.stack(closed, 0).reshape((1, 930, 3))
+    return rec, None, rec
+
+
+def _load_splinenet(model_or_path, mode):
+    from .encoders import DGCNNControlPoints
+    if isinstance(model_or_path, torch.nn.Module):
+        net = model_or_path
+    else:
+        net = DGCNNControlPoints(20, num_points=10, mode=mode)
+        state = torch.load(model_or_path, map_location="cpu")
+        state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+        net.load_state_dict(state)
+    net.cuda(torch.cuda.current_device())
+    net.eval()
+    return net
+
+
+def initialize_open_spline_model(modelname, mode):
+    """Checkpoint path (saved through DataParallel, ``module.`` prefixes) or a ready module."""
+    return _load_splinenet(modelname, mode)
+
+
+def initialize_closed_spline_model(modelname, mode):
+    return _load_splinenet(modelname, mode)
+
+
+# ---------------------------------------------------------------------------------------
+# weighted primitive fits (src/primitive_forward.py:708-843)
+# ---------------------------------------------------------------------------------------
+class Fit:
+    def __init__(self):
+        self.lstsq = LeastSquares().lstsq
+        self.parameters = {}
+
+    def fit_plane_torch(self, points, normals, weights, ids=0, show_warning=False):
+        """points (n,3), weights (n,1) -> unit normal a (1,3), offset d: a.x = d."""
+        weights_sum = torch.sum(weights) + EPS
+        X = points - torch.sum(weights * points, 0).reshape((1, 3)) / weights_sum
+        U, s, V = customsvd(weights * X)
+        a = torch.reshape(V[:, -1], (1, 3))
+        d = torch.sum(weights * (a @ points.permute(1, 0)).permute(1, 0)) / weights_sum
+        return a, d
+
+    def fit_sphere_torch(self, points, normals, weights, ids=0, show_warning=False):
+        N = weights.shape[0]
+        sum_weights = torch.sum(weights) + EPS
+        A = 2 * (-points + torch.sum(points * weights, 0) / sum_weights)
+        dot_points = weights * torch.sum(points * points, 1, keepdim=True)
+        normalization = torch.sum(dot_points) / sum_weights
+        Y = (dot_points - normalization).reshape((N, 1))
+        A = weights * A
+        Y = weights * Y
+        center = -self.lstsq(A, Y, 0.01).reshape((1, 3))
+        radius_square = torch.sum(weights[:, 0] * torch.sum((points - center) ** 2, 1)) / sum_weights
+        radius_square = torch.clamp(radius_square, min=1e-3)
+        return center, guard_sqrt(radius_square)
+
+    def fit_cylinder_torch(self, points, normals, weights, ids=0, show_warning=False):
+        U, s, V = customsvd(weights * normals)
+        a = torch.reshape(V[:, -1], (3, 1))
+        a = a / (torch.norm(a, 2) + EPS)
+        prj_circle = points - ((points @ a).permute(1, 0) * a).permute(1, 0)
+        center, radius = self.fit_sphere_torch(prj_circle, normals, weights)
+        return a, center, radius
+
+    def fit_cone_torch(self, points, normals, weights, ids=0, show_warning=False):
+        N = points.shape[0]
+        A = weights * normals
+        Y = weights * torch.sum(normals * points, 1).reshape((N, 1))
+        sv, _ = _gram_spectrum(A)
+        if float(sv[0] / torch.clamp(sv[-1], min=1e-300)) > 1e5:
+            # ill-conditioned: the reference returns a null cone
+            dev = points.device
+            return (torch.zeros((1, 3), device=dev), torch.tensor([[1.0, 0.0, 0.0]], device=dev),
+                    torch.zeros(1, device=dev))
+        c = self.lstsq(A, Y, lamb=1e-3)
+        a, _ = self.fit_plane_torch(normals, None, weights)
+        # normals point outside, the axis inside the cone
+        a = torch.where(torch.sum(normals @ a.transpose(1, 0)) > 0, -a, a)
+        diff = torch.nn.functional.normalize(points - c.transpose(1, 0), p=2, dim=1)
+        diff = torch.clamp(torch.abs(diff @ a.transpose(1, 0)), max=0.999)
+        theta = torch.sum(weights * torch.acos(diff)) / (torch.sum(weights) + EPS)
+        theta = torch.clamp(theta, min=1e-3, max=3.142 / 2 - 1e-3)
+        return c, a, theta
+
+
+class FittingModule:
+    """src/fitting_optimization.py:117-242: owns the two frozen SplineNets and a ``Fit``."""
+
+    def __init__(self, closed_splinenet_path, open_splinenet_path):
+        self.fitting = Fit()
+        self.closed_splinenet_path = closed_splinenet_path
+        self.open_splinenet_path = open_splinenet_path
+        nu, nv = uniform_knot_bspline(20, 20, 3, 3, 30)
+        self.nu = torch.from_numpy(nu.astype(np.float32))
+        self.nv = torch.from_numpy(nv.astype(np.float32))
+        self.open_control_decoder = initialize_open_spline_model(open_splinenet_path, 0)
+        self.closed_control_decoder = initialize_closed_spline_model(closed_splinenet_path, 1)
+
+    def forward_pass_open_spline(self, points, ids, weights, if_optimize=False):
+        points = torch.unsqueeze(points, 0).detach()   # no gradient into the SplineNet encoder
+        reconst_points = forward_pass_open_spline(points, self.open_control_decoder, self.nu, self.nv,
+                                                  if_optimize=if_optimize, weights=weights)[1]
+        self.fitting.parameters[ids] = ["open-spline", reconst_points]
+        return reconst_points
+
+    def forward_pass_closed_spline(self, points, ids, weights, if_optimize=False):
+        points = torch.unsqueeze(points, 0).detach()
+        reconst_points = forward_closed_splines(points, self.closed_control_decoder, self.nu, self.nv,
+                                                if_optimize=if_optimize, weights=weights)[2]
+        self.fitting.parameters[ids] = ["closed-spline", reconst_points]
+        return reconst_points
+
+    def forward_pass_plane(self, points, normals, weights, ids, sample_points=False):
+        axis, distance = self.fitting.fit_plane_torch(points=points, normals=normals, weights=weights, ids=ids)
+        self.fitting.parameters[ids] = ["plane", axis.reshape((3, 1)), distance]
+        return None
+
+    def forward_pass_cone(self, points, normals, weights, ids, sample_points=False):
+        apex, axis, theta = self.fitting.fit_cone_torch(points, normals, weights=weights, ids=ids)
+        self.fitting.parameters[ids] = ["cone", apex.reshape((1, 3)), axis.reshape((3, 1)), theta]
+        return None
+
+    def forward_pass_cylinder(self, points, normals, weights, ids, sample_points=False):
+        a, center, radius = self.fitting.fit_cylinder_torch(points, normals, weights, ids=ids)
+        self.fitting.parameters[ids] = ["cylinder", a, center, radius]
+        return None
+
+    def forward_pass_sphere(self, points, normals, weights, ids, sample_points=False):
+        center, radius = self.fitting.fit_sphere_torch(points, normals, weights, ids=ids)
+        self.fitting.parameters[ids] = ["sphere", center, radius]
+        return None
+
+
+def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=False, if_optimize=False,
+                        if_visualize=False):
+    """src/primitive_forward.py:925-1047 (training mode): per matched segment pick the weight
+    column, keep every 2nd point (every 4th for analytic primitives), at most 4 splines per shape,
+    skip segments under 20 (splines: 100) points, dispatch on the ground-truth primitive type."""
+    if eval:
+        raise NotImplementedError("evaluation-mode fitting is SURVEY §8f rank 2")
+    reconstructed_shape = []
+    fitter.fitting.parameters = {}
+    gt_points = {}
+    spline_count = 0
+
+    def skip(label_index):
+        reconstructed_shape.append(None)
+        gt_points[label_index] = None
+        fitter.fitting.parameters[label_index] = None
+
+    for d in data:
+        points, normals, labels, gpoints, segment_indices, part_index = d
+        part_index, label_index = part_index
+        labels = int(labels)
+        weight = weights[:, part_index:part_index + 1] + EPS
+        points, normals, weight = points[0::2], normals[0::2], weight[0::2]
+        if labels in [0, 2, 6, 7, 9, 8]:
+            spline_count += 1
+            if spline_count > 4:
+                skip(label_index)
+                continue
+        else:
+            points, normals, weight = points[0::2], normals[0::2], weight[0::2]
+        if points.shape[0] < 20:
+            skip(label_index)
+            continue
+        if labels in [0, 9, 6, 7]:
+            if points.shape[0] < 100:
+                skip(label_index)
+                continue
+            recon_points = fitter.forward_pass_closed_spline(points, weights=weight, ids=label_index,
+                                                             if_optimize=False)
+        elif labels == 1:
+            recon_points = fitter.forward_pass_plane(points, normals, weight, ids=label_index)
+        elif labels == 3:
+            recon_points = fitter.forward_pass_cone(points, normals, weight, ids=label_index)
+        elif labels == 4:
+            recon_points = fitter.forward_pass_cylinder(points, normals, weight, ids=label_index)
+        elif labels == 5:
+            recon_points = fitter.forward_pass_sphere(points, normals, weight, ids=label_index)
+        elif labels in [2, 8]:
+            if points.shape[0] < 100:
+                skip(label_index)
+                continue
+            recon_points = fitter.forward_pass_open_spline(points, weights=weight, ids=label_index,
+                                                           if_optimize=False)
+        else:
+            raise ValueError("unknown primitive type %r" % (labels,))
+        gt_points[label_index] = gpoints
+        reconstructed_shape.append(recon_points)
+    return gt_points, reconstructed_shape
+
+
+# ---------------------------------------------------------------------------------------
+# residuals (src/primitives.py:18-206)
+# ---------------------------------------------------------------------------------------
+class ComputePrimitiveDistance:
+    def __init__(self, reduce=True, one_side=False):
+        self.reduce = reduce
+        self.one_side = one_side
+
+    def _finish(self, distance, sqrt):
+        if sqrt:
+            distance = guard_sqrt(distance)
+        return torch.mean(distance) if self.reduce else distance
+
+    def distance_from_torus(self, points, params, sqrt=False):
+        axis, center, major_radius, minor_radius = params
+        axis = axis.reshape((3, 1)) / torch.norm(axis, p=2)
+        c2p = points - center.reshape((1, 3))
+        z_new = c2p @ axis
+        x_new = guard_sqrt(torch.sum(c2p ** 2, 1, keepdim=True) - z_new ** 2)
+        right = (guard_sqrt((x_new - major_radius) ** 2 + z_new ** 2) - minor_radius) ** 2
+        left = (guard_sqrt((x_new + major_radius) ** 2 + z_new ** 2) - minor_radius) ** 2
+        return self._finish(torch.min(right, left).squeeze(), sqrt)
+
+    def distance_from_plane(self, points, params, sqrt=False):
+        a, d = params
+        return self._finish(torch.sum((points @ a.reshape((3, 1)) - d) ** 2, 1), sqrt)
+
+    def distance_from_sphere(self, points, params, sqrt=False):
+        center, radius = params
+        return self._finish((torch.norm(points - center.reshape((1, 3)), p=2, dim=1) - radius) ** 2, sqrt)
+
+    def distance_from_cylinder(self, points, params, sqrt=False):
+        axis, center, radius = params
+        v = points - center.reshape((1, 3))
+        prj = (v @ axis.reshape((3, 1))) ** 2
+        dist_from_surface = torch.clamp(torch.sum(v * v, 1) - prj[:, 0], min=1e-5)
+        distance = (torch.sqrt(dist_from_surface) - radius) ** 2
+        if sqrt:
+            distance = guard_sqrt(distance)
+        if bool(torch.isnan(distance).any()):
+            raise RuntimeError("distance_from_cylinder produced NaN")
+        return torch.mean(distance) if self.reduce else distance
+
+    def distance_from_cone(self, points, params, sqrt=False):
+        apex, axis, theta = params
+        v = points - apex.reshape((1, 3)) + 1e-8
+        mod_v = torch.norm(v, dim=1, p=2)
+        alpha_x = torch.clamp((v @ axis.reshape((3, 1)))[:, 0] / (mod_v + 1e-7), min=-.999, max=0.999)
+        alpha = torch.acos(alpha_x)
+        dist_angle = torch.clamp(torch.abs(alpha - theta), max=3.142 / 2.0)
+        return self._finish((mod_v * torch.sin(dist_angle)) ** 2, sqrt)
+
+    def distance_from_bspline(self, points, params, sqrt=False):
+        """Chamfer distance between the sampled spline (params[0][0]) and the segment's points."""
+        return chamfer_distance_single_shape(params[0][0], points, one_side=self.one_side, sqrt=sqrt,
+                                             reduce=self.reduce)
+
+
+class ResidualLoss:
+    def __init__(self, reduce=True, one_side=False):
+        cp = ComputePrimitiveDistance(reduce, one_side=one_side)
+        self.routines = {"torus": cp.distance_from_torus, "sphere": cp.distance_from_sphere,
+                         "cylinder": cp.distance_from_cylinder, "cone": cp.distance_from_cone,
+                         "plane": cp.distance_from_plane, "closed-spline": cp.distance_from_bspline,
+                         "open-spline": cp.distance_from_bspline}
+
+    def residual_loss(self, Points, parameters, sqrt=False):
+        distances = {}
+        for k, v in parameters.items():
+            if v is None:
+                continue
+            distances[k] = [v[0], self.routines[v[0]](points=Points[k], params=v[1:], sqrt=sqrt)]
+        return distances
+
+
+# ---------------------------------------------------------------------------------------
+# metrics returned by fitting_loss (src/segment_utils.py:139-255)
+# ---------------------------------------------------------------------------------------
+def _merge_types(p):
+    p = np.array(p, copy=True)
+    p[p == 0] = 9
+    p[p == 6] = 9
+    p[p == 7] = 9
+    p[p == 8] = 2
+    return p
+
+
+def SIOU_matched_segments(target, pred_labels, primitives_pred, primitives, weights):
+    """Segment IoU and primitive-type accuracy over Hungarian-matched segments.  (The reference
+    rewrites the primitive-id arrays in place; copies are used here.)"""
+    primitives, primitives_pred = _merge_types(primitives), _merge_types(primitives_pred)
+    dev = weights.device.index
+    labels_one_hot = to_one_hot(target, device_id=dev)
+    cluster_ids_one_hot = to_one_hot(pred_labels, device_id=dev)
+    cost = relaxed_iou_fast(cluster_ids_one_hot.unsqueeze(0).float(), labels_one_hot.unsqueeze(0).float())
+    rids, cids = solve_dense(1.0 - cost.data.cpu().numpy()[0])
+    prim_hot = to_one_hot(primitives_pred, 10, dev).float()
+    prim_pred = torch.max(torch.sum(prim_hot.unsqueeze(2) * weights.unsqueeze(1), 0), 0)[1].cpu().numpy()
+    ious, prim_ok, pairs = [], [], []
+    for r, c in zip(rids, cids):
+        pi, gi = pred_labels == r, target == c
+        if gi.sum() == 0 or pi.sum() == 0 or gi.sum() < 100:
+            continue
+        ious.append(np.sum(pi & gi) / (np.sum(pi | gi) + 1e-8))
+        gt_type = primitives[gi][0]
+        prim_ok.append(gt_type == prim_pred[r])
+        pairs.append([gt_type, prim_pred[r]])
+    return (np.mean(ious) if ious else float("nan"), np.mean(prim_ok) if prim_ok else float("nan"),
+            [[rids, cids]], pairs)
+
+
+# ---------------------------------------------------------------------------------------
+# end-to-end driver (src/residual_utils.py:49-208, 333-378)
+# ---------------------------------------------------------------------------------------
+class Evaluation:
+    def __init__(self, userspace=None, closed_path=None, open_path=None):
+        """closed_path / open_path: SplineNet checkpoints (or ready DGCNNControlPoints modules)."""
+        if closed_path is None:
+            closed_path = "logs/pretrained_models/closed_spline.pth"
+        if open_path is None:
+            open_path = "logs/pretrained_models/open_spline.pth"
+        self.res_loss = ResidualLoss()
+        self.fitter = FittingModule(closed_path, open_path)
+        for net in (self.fitter.closed_control_decoder, self.fitter.open_control_decoder):
+            for p in net.parameters():
+                p.requires_grad = False
+        self.ms = MeanShift()
+
+    def guard_mean_shift(self, embedding, quantile, iterations, kernel_type="gaussian"):
+        """Re-run with a 1.2x larger quantile while more than 49 clusters come out."""
+        while True:
+            _, center, bandwidth, cluster_ids = self.ms.mean_shift(embedding, 10000, quantile, iterations,
+                                                                   kernel_type=kernel_type)
+            if torch.unique(cluster_ids).shape[0] > 49:
+                quantile *= 1.2
+            else:
+                break
+        return center, bandwidth, cluster_ids
+
+    def fitting_loss(self, embedding, points, normals, labels, primitives, primitives_log_prob,
+                     quantile=0.125, iterations=5, lamb=1.0, debug=False, eval=False):
+        """embedding (B,N,128), points/normals (B,N,3) tensors; labels, primitives (B,N) integer
+        arrays; primitives_log_prob (B,10,N).  Returns ([Loss, geometric mean, spline mean, s_iou,
+        p_iou], [parameters, cluster ids, weights]) of the last shape, like the reference (which
+        is written for B = 1)."""
+        if eval:
+            raise NotImplementedError("evaluation-mode fitting is SURVEY §8f rank 2")
+        batch_size = embedding.shape[0]
+        embedding = torch.nn.functional.normalize(embedding, p=2, dim=2)
+        prim_pred = torch.max(primitives_log_prob, 1)[1].data.cpu().numpy()
+        labels = np.asarray(labels)
+        primitives = np.asarray(primitives)
+        loss = parameters = cluster_ids = weights = None
+        for b in range(batch_size):
+            center, bandwidth, cluster_ids = self.guard_mean_shift(embedding[b], quantile, iterations,
+                                                                   kernel_type="gaussian")
+            weights = center @ torch.transpose(embedding[b], 1, 0)
+            loss, parameters, _, rows, cols, distance = self.residual_train_mode(
+                points[b], normals[b], labels[b], cluster_ids, primitives[b], weights, bandwidth, lamb=lamb)
+            with torch.no_grad():
+                s_iou, p_iou, _, _ = SIOU_matched_segments(labels[b], cluster_ids.data.cpu().numpy(),
+                                                           prim_pred[b], primitives[b], weights.T)
+            loss = loss + [s_iou, p_iou]
+        return loss, [parameters, cluster_ids.data.cpu().numpy(), weights]
+
+    def residual_train_mode(self, points, normals, labels, cluster_ids, primitives, weights, bw, lamb=1.0):
+        if not isinstance(cluster_ids, np.ndarray):
+            cluster_ids = cluster_ids.data.cpu().numpy()
+        rows, cols, unique_target, unique_pred = match(labels, cluster_ids)
+        data = []
+        for index, i in enumerate(unique_pred):
+            gt_indices_i = labels == cols[i]
+            pred_indices_i = cluster_ids == i
+            if (np.sum(gt_indices_i) == 0) or (np.sum(pred_indices_i) == 0):
+                continue
+            # modal ground-truth primitive type of the matched segment (smallest on ties)
+            seg_type = int(np.bincount(primitives[gt_indices_i].astype(np.int64)).argmax())
+            gi = torch.from_numpy(np.nonzero(gt_indices_i)[0]).to(points.device)
+            data.append([points, normals, seg_type, points[gi], None, (index, i)])
+        w = torch.transpose(weights_normalize(weights, float(bw)), 1, 0)
+        gt_points, recon_points = fit_one_shape_torch(data, self.fitter, w, bw, eval=False)
+        distance = self.res_loss.residual_loss(gt_points, self.fitter.fitting.parameters)
+        Loss = self.separate_losses(distance, gt_points, lamb=lamb)
+        return Loss, self.fitter.fitting.parameters, None, rows, cols, distance
+
+    def separate_losses(self, distance, gt_points, lamb=1.0):
+        Loss, geometric_loss, spline_loss = [], [], []
+        for v in sorted(gt_points.keys()):
+            if gt_points[v] is None:
+                continue
+            if distance[v][1] > 1:
+                # most probably a degenerate case
+                distance[v][1] = torch.ones(1, device=distance[v][1].device)[0] * 0.1
+            if distance[v][0] in ["closed-spline", "open-spline"]:
+                spline_loss.append(distance[v][1].item())
+                Loss.append(distance[v][1] * lamb)
+            else:
+                geometric_loss.append(distance[v][1].item())
+                Loss.append(distance[v][1])
+        Loss = torch.mean(torch.stack(Loss)) if Loss else torch.zeros(1, device="cuda")
+        geometric_loss = np.mean(geometric_loss) if geometric_loss else None
+        spline_loss = np.mean(spline_loss) if spline_loss else None
+        return [Loss, geometric_loss, spline_loss]

@@ -297,3 +297,18 @@ def meanshift_iter_bwd(gy, y, q, x, xt, rsum, unorm, bsq, ws):
                                                    ptr(ws.opart_x), current_stream(x.device))
     check(rc, "pn_meanshift_iter_bwd_f32")
     return ws.opart.sum(1), ws.opart_x.sum(1)
+
+
+def sym3_eig(G):
+    """G (M,3,3) float64 symmetric -> (evals (M,3) descending, evecs (M,3,3), columns)."""
+    require_cuda(G)
+    if G.dtype != torch.float64:
+        raise TypeError("sym3_eig expects float64")
+    G = G.contiguous()
+    M = G.shape[0]
+    evals = torch.empty((M, 3), dtype=torch.float64, device=G.device)
+    evecs = torch.empty((M, 3, 3), dtype=torch.float64, device=G.device)
+    with torch.cuda.device(G.device):
+        rc = _lib.load().pn_sym3_eig_f64(ptr(G), M, ptr(evals), ptr(evecs), current_stream(G.device))
+    check(rc, "pn_sym3_eig_f64")
+    return evals, evecs

@@ -1,0 +1,9 @@
+"""The hot-path part of src/fitting_utils.py of the reference."""
+from parsenet_codebase_amd.bspline import sample_points_from_control_points_  # noqa: F401
+from parsenet_codebase_amd.fitting import (EPS, CustomSVD, LeastSquares, best_lambda,  # noqa: F401
+                                           compute_grad_V, customsvd, match, pca_torch,
+                                           project_to_plane, relaxed_iou_fast,
+                                           rotation_matrix_a_to_b, standardize_point_torch,
+                                           standardize_points_torch, svd_grad_K, to_one_hot,
+                                           up_sample_points_in_range, up_sample_points_torch,
+                                           weights_normalize)

@@ -1,0 +1,2 @@
+"""src/residual_utils.py of the reference (end-to-end fitting loss, training mode)."""
+from parsenet_codebase_amd.fitting import Evaluation  # noqa: F401

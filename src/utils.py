@@ -1,0 +1,29 @@
+"""The hot-path part of src/utils.py of the reference: Chamfer distances, the anisotropic
+rescaling helper and the gradient-norm check (visualisation / mesh utilities are out of scope)."""
+import numpy as np
+import torch
+
+from parsenet_codebase_amd.chamfer import (chamfer_distance, chamfer_distance_one_side,  # noqa: F401
+                                           chamfer_distance_single_shape)
+from parsenet_codebase_amd.fitting import rotation_matrix_a_to_b  # noqa: F401
+
+
+def rescale_input_outputs(scales, output, points, control_points, batch_size):
+    """src/utils.py:361-390: undo anisotropic scaling so that every axis is divided by the
+    largest scale of its shape."""
+    scales = torch.from_numpy(np.stack(scales, 0).astype(np.float32)).cuda().reshape((batch_size, 1, 3))
+    smax = torch.max(scales.reshape((batch_size, 3)), 1)[0]
+    output = output * scales / smax.reshape((batch_size, 1, 1))
+    points = points * scales.reshape((batch_size, 3, 1)) / smax.reshape((batch_size, 1, 1))
+    control_points = control_points * scales.reshape((batch_size, 1, 1, 3)) / smax.reshape((batch_size, 1, 1, 1))
+    return scales, output, points, control_points
+
+
+def grad_norm(model):
+    """True when the total gradient norm is NaN or infinite (src/utils.py:393-399)."""
+    total = 0
+    for p in model.parameters():
+        if p.grad is not None:
+            total = total + p.grad.data.norm(2)
+    total = float(total)
+    return bool(np.isnan(total) or np.isinf(total))

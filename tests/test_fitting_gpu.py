@@ -1,0 +1,209 @@
+"""Fitting stage on the GPU against the torch-CPU oracle (src/fitting_utils.py,
+src/primitive_forward.py, src/primitives.py, src/loss.py semantics): values and gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _sample(kind, n, seed):
+    from parsenet_codebase_amd import synthetic as S
+    rng = np.random.RandomState(seed)
+    maker = {"plane": S._plane, "sphere": S._sphere, "cylinder": S._cylinder, "cone": S._cone}[kind]
+    p, nr = maker(rng, n)
+    return torch.from_numpy(p.astype(np.float32)), torch.from_numpy(nr.astype(np.float32))
+
+
+def test_lstsq_full_rank_and_ridge(gpu):
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd.fitting import LeastSquares, best_lambda
+    torch.manual_seed(0)
+    A = torch.randn(500, 3)
+    Y = torch.randn(500, 1)
+    # full column rank: the QR solution of the reference
+    ar = A.clone().requires_grad_(True)
+    xr = RF.lstsq(ar, Y)
+    xr.sum().backward()
+    ag = A.to(gpu).requires_grad_(True)
+    xg = LeastSquares().lstsq(ag, Y.to(gpu))
+    xg.sum().backward()
+    assert _rel(xg, xr) < 1e-5
+    assert _rel(ag.grad, ar.grad) < 1e-4
+    # rank 2: ridge with the smallest lambda of {1e-6 * 10^i} that restores full rank.  The
+    # ridge system has condition number ~1e6, so the reference's fp32 QR solve carries a few
+    # per cent of noise of its own; the product solves the same system in fp64.
+    A2 = torch.cat([A[:, :2], A[:, :1] * 2.0], 1)
+    AtA = A2.t() @ A2
+    # The lambda at which (AtA + lambda I) counts as full rank is decided by fp32 SVD noise when
+    # lambda is near the rank tolerance, so implementations may land one decade apart.
+    lam_r, lam_g = RF.best_lambda(AtA), best_lambda(AtA.to(gpu))
+    assert 0.1 <= lam_r / lam_g <= 10.0
+    xg = LeastSquares().lstsq(A2.to(gpu), Y.to(gpu))
+    xr = RF.lstsq(A2, Y)
+    for x, lam in ((xg, lam_g), (xr, lam_r)):
+        exact = torch.linalg.solve(AtA.double() + lam * torch.eye(3, dtype=torch.float64), (A2.t() @ Y).double())
+        assert _rel(x, exact) < 0.1
+    exact_g = torch.linalg.solve(AtA.double() + lam_g * torch.eye(3, dtype=torch.float64), (A2.t() @ Y).double())
+    assert _rel(xg, exact_g) < 1e-4
+
+
+def test_customsvd_gradient(gpu):
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd.fitting import customsvd
+    torch.manual_seed(1)
+    A = torch.randn(300, 3) * torch.tensor([3.0, 1.0, 0.2])
+    w = torch.randn(3)
+    ar = A.clone().requires_grad_(True)
+    _, sr, vr = RF.customsvd(ar)
+    sign = torch.sign(vr[:, -1] @ w)
+    (sign * (vr[:, -1] @ w)).backward()
+    ag = A.to(gpu).requires_grad_(True)
+    _, sg, vg = customsvd(ag)
+    signg = torch.sign(vg[:, -1] @ w.to(gpu))
+    (signg * (vg[:, -1] @ w.to(gpu))).backward()
+    assert _rel(sg, sr) < 1e-5
+    assert _rel(vg[:, -1].abs(), vr[:, -1].abs()) < 1e-5     # singular vectors are sign-free
+    assert _rel(ag.grad, ar.grad) < 1e-4
+
+
+@pytest.mark.parametrize("kind", ["plane", "sphere", "cylinder", "cone"])
+def test_primitive_fits_and_residuals(gpu, kind):
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd.fitting import ComputePrimitiveDistance, Fit
+    p, n = _sample(kind, 800, 3)
+    torch.manual_seed(2)
+    # noisy samples: on exact samples the fit does not depend on the weights (zero gradient)
+    p = p + 0.01 * torch.randn_like(p)
+    n = torch.nn.functional.normalize(n + 0.05 * torch.randn_like(n), dim=1)
+    w0 = torch.rand(800, 1) * 0.9 + 0.1
+    fit, dist = Fit(), ComputePrimitiveDistance()
+    wr = w0.clone().requires_grad_(True)
+    wg = w0.to(gpu).requires_grad_(True)
+    pg, ng = p.to(gpu), n.to(gpu)
+    if kind == "plane":
+        pr_ = RF.fit_plane(p, wr)
+        pg_ = fit.fit_plane_torch(pg, ng, wg)
+        lr = RF.distance("plane", p, [pr_[0].reshape(3, 1), pr_[1]])
+        lg = dist.distance_from_plane(pg, [pg_[0].reshape(3, 1), pg_[1]])
+        assert _rel(pg_[0].abs(), pr_[0].abs()) < 1e-4
+    elif kind == "sphere":
+        pr_ = RF.fit_sphere(p, wr)
+        pg_ = fit.fit_sphere_torch(pg, ng, wg)
+        lr, lg = RF.distance("sphere", p, list(pr_)), dist.distance_from_sphere(pg, list(pg_))
+        assert _rel(pg_[0], pr_[0]) < 1e-4 and _rel(pg_[1], pr_[1]) < 1e-4
+    elif kind == "cylinder":
+        pr_ = RF.fit_cylinder(p, n, wr)
+        pg_ = fit.fit_cylinder_torch(pg, ng, wg)
+        lr, lg = RF.distance("cylinder", p, list(pr_)), dist.distance_from_cylinder(pg, list(pg_))
+        # the circle fit on points projected along the axis is rank deficient by construction and
+        # always takes the ridge branch, whose lambda / fp32 solve are noise limited in the
+        # reference itself (see test_lstsq_full_rank_and_ridge)
+        assert _rel(pg_[2], pr_[2]) < 5e-3
+    else:
+        pr_ = RF.fit_cone(p, n, wr)
+        pg_ = fit.fit_cone_torch(pg, ng, wg)
+        lr = RF.distance("cone", p, [pr_[0].reshape(1, 3), pr_[1].reshape(3, 1), pr_[2]])
+        lg = dist.distance_from_cone(pg, [pg_[0].reshape(1, 3), pg_[1].reshape(3, 1), pg_[2]])
+        assert _rel(pg_[2], pr_[2]) < 1e-4
+    # 1 % noise on the samples: both fits explain the points to about noise level
+    assert lr.item() < 5e-3 and lg.item() < 5e-3
+    assert abs(lg.item() - lr.item()) / lr.item() < (5e-2 if kind == "cylinder" else 1e-3)
+    # gradient of a non-degenerate functional of the fit w.r.t. the membership weights
+    fr = sum((t ** 2).sum() for t in pr_ if torch.is_tensor(t))
+    fg = sum((t ** 2).sum() for t in pg_ if torch.is_tensor(t))
+    fr.backward()
+    fg.backward()
+    if kind != "cylinder":
+        assert _rel(fg, fr) < 1e-4
+        assert _rel(wg.grad, wr.grad) < 2e-3
+
+
+def test_weights_normalize_and_match(gpu):
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd.fitting import match, weights_normalize
+    torch.manual_seed(3)
+    w = torch.rand(7, 500) * 2 - 1
+    assert _rel(weights_normalize(w.to(gpu), 0.4), RF.weights_normalize(w, 0.4)) < 1e-5
+    rng = np.random.RandomState(0)
+    gt = rng.randint(0, 9, 3000)
+    pred = (gt + (rng.rand(3000) < 0.1) * rng.randint(0, 9, 3000)) % 9
+    perm = rng.permutation(9)
+    pred = perm[pred]
+    torch.cuda.set_device(gpu)
+    r1, c1, u1, p1 = match(gt, pred)
+    r2, c2, u2, p2 = RF.match(gt, pred)
+    assert np.array_equal(c1[:9], c2[:9]) and np.array_equal(u1, u2) and np.array_equal(p1, p2)
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 900, 700), (1, 1600, 2000)])
+def test_chamfer_api(gpu, B, N, M):
+    from oracle import ref_torch as R
+    from parsenet_codebase_amd import chamfer as C
+    torch.manual_seed(4)
+    a, b = torch.rand(B, N, 3), torch.rand(B, M, 3)
+    for fn_g, fn_r, kw in [(C.chamfer_distance, R.chamfer_distance, {}),
+                           (C.chamfer_distance, R.chamfer_distance, {"sqrt": True}),
+                           (C.chamfer_distance_one_side, R.chamfer_distance_one_side, {"side": 1}),
+                           (C.chamfer_distance_one_side, R.chamfer_distance_one_side, {"side": 0})]:
+        ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ag, bg = a.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+        vr, vg = fn_r(ar, br, **kw), fn_g(ag, bg, **kw)
+        vr.backward()
+        vg.backward()
+        assert abs(vg.item() - vr.item()) / abs(vr.item()) < 1e-5
+        assert _rel(ag.grad, ar.grad) < 1e-5 and _rel(bg.grad, br.grad) < 1e-5
+    for kw in [{}, {"one_side": True}, {"sqrt": True}, {"one_side": True, "reduce": False}]:
+        vr = R.chamfer_distance_single_shape(a[0], b[0], **kw)
+        vg = C.chamfer_distance_single_shape(a[0].to(gpu), b[0].to(gpu), **kw)
+        assert _rel(vg, vr) < 1e-5
+
+
+def test_chamfer_10k_matches_reference_expression(gpu):
+    """BASELINE target: Chamfer within 1e-5 of the reference on identical 10k-point inputs."""
+    from oracle import ref_torch as R
+    from parsenet_codebase_amd import chamfer as C
+    torch.manual_seed(5)
+    a, b = torch.rand(10000, 3) - 0.5, torch.rand(10000, 3) - 0.5
+    vr = R.chamfer_distance_single_shape(a, b)
+    vg = C.chamfer_distance_single_shape(a.to(gpu), b.to(gpu))
+    assert abs(vg.item() - vr.item()) / vr.item() < 1e-5
+
+
+def test_spline_losses(gpu):
+    from types import SimpleNamespace
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd import spline_losses as L
+    torch.manual_seed(6)
+    B = 3
+    out = torch.rand(B, 400, 3) - 0.5
+    cp = torch.rand(B, 20, 20, 3) - 0.5
+    pts = torch.rand(B, 3, 700) - 0.5
+    nu, nv = L.uniform_knot_bspline(20, 20, 3, 3, 40)
+    nur, nvr = RF.uniform_knot_bspline(20, 20, 3, 3, 40)
+    assert np.array_equal(nu, nur) and np.array_equal(nv, nvr)
+    assert abs(nu.sum(1) - 1).max() < 1e-12
+    nut, nvt = torch.from_numpy(nu.astype(np.float32)), torch.from_numpy(nv.astype(np.float32))
+    cfg = SimpleNamespace(batch_size=B, grid_size=20)
+    og = out.to(gpu).requires_grad_(True)
+    orr = out.clone().requires_grad_(True)
+    l1g, best_g = L.control_points_permute_reg_loss(og, cp.to(gpu), 20)
+    l1r, best_r = RF.control_points_permute_reg_loss(orr, cp, 20)
+    l2g, _ = L.control_points_permute_closed_reg_loss(og, cp.to(gpu), 20, 20)
+    l2r, _ = RF.control_points_permute_closed_reg_loss(orr, cp, 20, 20)
+    l3g, rec_g = L.spline_reconstruction_loss_one_sided(nut.to(gpu), nvt.to(gpu), og, pts.to(gpu), cfg)
+    l3r, rec_r = RF.spline_reconstruction_loss_one_sided(nut, nvt, orr, pts, B, 20)
+    l4g = L.laplacian_loss(og.view(B, 20, 20, 3), best_g)
+    l4r = RF.laplacian_loss(orr.view(B, 20, 20, 3), best_r)
+    for g, r in ((l1g, l1r), (l2g, l2r), (l3g, l3r), (l4g, l4r)):
+        assert abs(g.item() - r.item()) / abs(r.item()) < 1e-5
+    assert _rel(best_g, best_r) == 0 and _rel(rec_g, rec_r) < 1e-5
+    (l1g + l2g + l3g + l4g).backward()
+    (l1r + l2r + l3r + l4r).backward()
+    assert _rel(og.grad, orr.grad) < 1e-5
