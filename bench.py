@@ -30,6 +30,12 @@ def build_workload(name, device, rank):
             "workload": "cfg4: ParSeNet seg-only points+normals, 10k pts, batch 4 per GPU "
                         "(PrimitivesEmbeddingDGCNGn mode 5, k=80, triplet+NLL, fwd+bwd+allreduce+Adam)",
             "batch_per_gpu": B, "points": N, "k": 80}
+    if name == "cfg5":
+        B, N = 4, 10000
+        return workloads.ParsenetE2EStep(device, batch=B, num_points=N, first_shape=rank * B), {
+            "workload": "cfg5: ParSeNet e2e (seg + mean-shift 10 it. + per-segment spline/primitive fit + "
+                        "Chamfer/residual), 10k pts, batch 4 per GPU, fwd+bwd+allreduce+Adam",
+            "batch_per_gpu": B, "points": N, "k": 80}
     raise SystemExit("unknown workload %r" % name)
 
 

@@ -44,3 +44,45 @@ class ParsenetSegStep:
         self.bucket.all_reduce_mean()
         self.opt.step()
         return loss
+
+
+class ParsenetE2EStep(ParsenetSegStep):
+    """cfg5: the end-to-end step of train_parsenet_e2e.py:190-277 per shape — segmentation
+    network (norm layers frozen: model.eval()), then for every shape of the batch mean-shift
+    clustering of the embedding (quantile 0.025, 10 iterations), Hungarian matching, weighted
+    primitive / SplineNet fits and residual losses (lamb 0.1); loss = triplet + NLL + residual,
+    backward through everything, one gradient all-reduce, Adam.  The SplineNets are frozen
+    random-init DGCNNControlPoints (no pretrained weights ship with the reference)."""
+
+    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-4):
+        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr)
+        from .encoders import DGCNNControlPoints
+        from .fitting import Evaluation
+        torch.manual_seed(seed + 1)
+        open_net = DGCNNControlPoints(20, num_points=10, mode=0)
+        closed_net = DGCNNControlPoints(20, num_points=10, mode=1)
+        self.evaluation = Evaluation(closed_path=closed_net, open_path=open_net)
+        self.model.eval()
+        pts, nrm, lab, prim = synthetic.make_batch(first_shape, batch, num_points)
+        self.points = torch.from_numpy(pts).to(device)
+        self.normals = torch.from_numpy(nrm).to(device)
+        self.prim_np = prim
+        self.last_res = None
+
+    def step(self):
+        self.bucket.zero()
+        embedding, log_prob, embed_loss = self.model(self.x, self.labels, True)
+        loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
+        emb = embedding.permute(0, 2, 1)
+        res_total = 0
+        for b in range(self.batch):     # the fitting stage is per shape (reference: batch 1)
+            res, _ = self.evaluation.fitting_loss(emb[b:b + 1], self.points[b:b + 1], self.normals[b:b + 1],
+                                                  self.labels[b:b + 1], self.prim_np[b:b + 1],
+                                                  log_prob[b:b + 1], quantile=0.025, iterations=10, lamb=0.1)
+            res_total = res_total + res[0]
+        loss = loss + res_total / self.batch
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        self.last_res = res_total
+        return loss
