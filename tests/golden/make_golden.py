@@ -197,19 +197,23 @@ def main():
     save("networks", **out)
 
     # ---- mean shift ---------------------------------------------------------------------------
+    # 2500 points in 6 well separated clusters: K = int(0.025 * 10000) = 250 stays inside a cluster.
+    # The 128-d iterates / gradients are stored as seeded 8-d random projections to keep the file small.
     g = torch.Generator().manual_seed(3)
     cen = torch.nn.functional.normalize(torch.randn(6, 128, generator=g), dim=1)
-    lab6 = torch.randint(0, 6, (1500,), generator=g)
-    X = torch.nn.functional.normalize(cen[lab6] + 0.2 * torch.randn(1500, 128, generator=g) / np.sqrt(128), dim=1)
+    lab6 = torch.randint(0, 6, (2500,), generator=g)
+    X = torch.nn.functional.normalize(cen[lab6] + 0.2 * torch.randn(2500, 128, generator=g) / np.sqrt(128), dim=1)
+    proj = torch.randn(128, 8, generator=torch.Generator().manual_seed(77))
+    wdir = torch.randn(2500, 128, generator=torch.Generator().manual_seed(78))
     ms = ref_ms.MeanShift()
     np.random.seed(2)
     Xr = X.clone().requires_grad_(True)
     new_X, center, bw, labels = ms.mean_shift(Xr, 10000, 0.025, 10)
-    wdir = torch.randn(1500, 128, generator=g)
     (new_X * wdir).sum().backward()
+    assert torch.unique(labels).numel() == 6
     save("mean_shift", X=X.numpy(), truth=lab6.numpy().astype(np.int32), bw=np.float32(bw.item()),
-         new_X=new_X.detach().numpy(), labels=labels.numpy().astype(np.int32),
-         n_centers=np.int32(center.shape[0]), wdir=wdir.numpy(), grad_X=Xr.grad.numpy())
+         new_X_proj=(new_X.detach() @ proj).numpy(), labels=labels.numpy().astype(np.int32),
+         n_centers=np.int32(center.shape[0]), grad_X_proj=(Xr.grad @ proj).numpy())
 
     # ---- Chamfer + spline losses ----------------------------------------------------------------
     g = torch.Generator().manual_seed(9)

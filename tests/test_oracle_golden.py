@@ -61,12 +61,14 @@ def test_mean_shift():
     X = torch.from_numpy(g["X"]).requires_grad_(True)
     np.random.seed(2)
     new_X, center, bw, labels = R.MeanShift().mean_shift(X, 10000, 0.025, 10)
-    (new_X * torch.from_numpy(g["wdir"])).sum().backward()
+    proj = torch.randn(128, 8, generator=torch.Generator().manual_seed(77))
+    wdir = torch.randn(2500, 128, generator=torch.Generator().manual_seed(78))
+    (new_X * wdir).sum().backward()
     assert abs(bw.item() - float(g["bw"])) / float(g["bw"]) < 1e-6
-    assert rel(new_X.detach(), g["new_X"]) < 1e-5
+    assert rel(new_X.detach() @ proj, g["new_X_proj"]) < 1e-5
     assert np.array_equal(labels.numpy(), g["labels"])
-    assert center.shape[0] == int(g["n_centers"])
-    assert rel(X.grad, g["grad_X"]) < 1e-4
+    assert center.shape[0] == int(g["n_centers"]) == 6
+    assert rel(X.grad @ proj, g["grad_X_proj"]) < 1e-4
 
 
 def test_chamfer_and_losses():
