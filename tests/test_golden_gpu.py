@@ -199,3 +199,18 @@ def test_end_to_end_fitting_loss(gpu):
     ga = emb.grad.cpu().numpy().astype(np.float64).ravel()
     gb = g["grad_emb"].astype(np.float64).ravel()
     assert float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb))) > 0.99
+
+
+def test_ls_control_point_solve(gpu):
+    """cfg3's LS control-point solve (approximation.py:338-364) against numpy.linalg.lstsq run by
+    the reference: numpy in / numpy out, and the differentiable tensor form."""
+    torch.cuda.set_device(gpu)
+    from src.approximation import fit_bezier_surface_fit_kronecker
+    g = load("fitting")
+    ctrl = fit_bezier_surface_fit_kronecker(g["kron_P"], g["kron_bu"], g["kron_bv"])
+    assert isinstance(ctrl, np.ndarray) and ctrl.shape == (10, 10, 3)
+    assert rel(ctrl, g["kron_ctrl"]) < 1e-7
+    P = torch.from_numpy(g["kron_P"]).to(gpu).requires_grad_(True)
+    c2 = fit_bezier_surface_fit_kronecker(P, torch.from_numpy(g["kron_bu"]), torch.from_numpy(g["kron_bv"]))
+    c2.sum().backward()
+    assert rel(c2, g["kron_ctrl"]) < 1e-7 and float(P.grad.abs().sum()) > 0
