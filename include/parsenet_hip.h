@@ -95,6 +95,34 @@ int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const float* q, c
                               float* cs, float* qt, float* gut, float* opart_q, float* opart_x,
                               void* stream);
 
+/* ---- GroupNorm (+ReLU) (+max over points) of the per-point heads -------------------------
+ * Replaces torch GroupNorm -> ReLU (-> max over N) of src/PointNet.py:216-218, 274-283 on
+ * channel-first (B,C,N) tensors.  One block per (b,c) row.
+ *   rows_fwd      : per-row sum and sum of squares (B,C); with rmax != NULL also the row maximum /
+ *                   minimum and their positions (int32) for the max-over-N variant.
+ *   group_moments : (B,groups) mean and rstd = 1/sqrt(var+eps) from the row sums (fp64 inside).
+ *   apply_fwd     : out = [relu](gamma*(y-mean)*rstd + beta).
+ *   rows_bwd      : ra = sum_n gz, rb = sum_n gz*yhat per row, gz = gout*[z>0] (or gout if !relu).
+ *   group_bwd     : c1c2 (B,groups,2) = group means of gamma*gz and gamma*gz*yhat.
+ *   apply_bwd     : dy = rstd*(gamma*gz - c1 - yhat*c2); with gsp/arg non-NULL gz is the sparse
+ *                   gradient gsp (B,C) placed at position arg (B,C) of every row (gout ignored). */
+int pn_gn_rows_fwd_f32(const float* y, int B, int C, int N, float* rsum, float* rsq, float* rmax,
+                       int* amax, float* rmin, int* amin, void* stream);
+int pn_gn_group_moments_f32(const float* rsum, const float* rsq, int B, int C, int groups, int N,
+                            float eps, float* mean, float* rstd, void* stream);
+int pn_gn_apply_fwd_f32(const float* y, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, int B, int C, int groups, int N, int relu, float* out,
+                        void* stream);
+int pn_gn_rows_bwd_f32(const float* gout, const float* y, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int B, int C, int groups, int N,
+                       int relu, float* ra, float* rb, void* stream);
+int pn_gn_group_bwd_f32(const float* ra, const float* rb, const float* gamma, int B, int C,
+                        int groups, int N, float* c1c2, void* stream);
+int pn_gn_apply_bwd_f32(const float* gout, const float* y, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const float* c1c2, int B, int C,
+                        int groups, int N, int relu, const float* gsp, const int* arg, float* dy,
+                        void* stream);
+
 /* ---- batched symmetric 3x3 eigen-decomposition (fp64) ---------------------------------
  * Serves the right singular vectors the primitive fits need (torch.svd of a tall n x 3 matrix in
  * src/fitting_utils.py:440 used by src/primitive_forward.py:725,794): they are the eigenvectors

@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import graph
+from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
@@ -115,8 +116,8 @@ class DGCNNEncoderGn(nn.Module):
         x2 = graph.edge_conv_norm_max(x1, graph.knn_dilated(x1, k, k), self.conv2[0].weight, self.bn2, 0.2)
         x3 = graph.edge_conv_norm_max(x2, graph.knn_dilated(x2, k, k), self.conv3[0].weight, self.bn3, 0.2)
         x_features = torch.cat((x1, x2, x3), dim=1)
-        x = F.relu(self.bnmlp1(self.mlp1(x_features)))
-        x4 = x.max(dim=2)[0]
+        # GroupNorm + ReLU + max over the points in one pass (norm and ReLU are monotone per channel)
+        x4 = group_norm_relu_max(self.mlp1(x_features), self.bnmlp1)
         return x4, x_features
 
 
@@ -165,15 +166,15 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         w = self.conv1.weight[:, :, 0]
         glob = torch.addmm(self.conv1.bias, x, w[:, :ng].t())            # (B,512)
         x = F.conv1d(first_layer_features, self.conv1.weight[:, ng:], None) + glob.unsqueeze(2)
-        x = F.relu(self.bn1(x))
-        x_all = F.relu(self.bn2(self.conv2(x)))
+        x = group_norm_relu(x, self.bn1)
+        x_all = group_norm_relu(self.conv2(x), self.bn2)
         embedding = None
         primitives_log_prob = None
         if self.embedding:
-            x = F.relu(self.bn_seg_prob1(self.mlp_seg_prob1(x_all)))
+            x = group_norm_relu(self.mlp_seg_prob1(x_all), self.bn_seg_prob1)
             embedding = self.mlp_seg_prob2(x)
         if self.primitives:
-            x = F.relu(self.bn_prim_prob1(self.mlp_prim_prob1(x_all)))
+            x = group_norm_relu(self.mlp_prim_prob1(x_all), self.bn_prim_prob1)
             primitives_log_prob = self.logsoftmax(self.mlp_prim_prob2(x))
         if compute_loss:
             lab = labels.data.cpu().numpy() if torch.is_tensor(labels) else labels

@@ -1,0 +1,138 @@
+"""GroupNorm (+ReLU) (+max over points) on channel-first (B,C,N) tensors through the row-per-block
+HIP kernels of csrc/gn.hip, with autograd.  Numerically these are torch.nn.GroupNorm followed by
+ReLU (and max over N); see the kernel file for why they exist."""
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr, require_cuda
+
+
+def _f(t):
+    return t.contiguous().float()
+
+
+def _rows_fwd(y, want_ext):
+    B, C, N = y.shape
+    dev = y.device
+    rsum = torch.empty((B, C), dtype=torch.float32, device=dev)
+    rsq = torch.empty_like(rsum)
+    ext = [None] * 4
+    if want_ext:
+        ext = [torch.empty_like(rsum), torch.empty((B, C), dtype=torch.int32, device=dev),
+               torch.empty_like(rsum), torch.empty((B, C), dtype=torch.int32, device=dev)]
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_gn_rows_fwd_f32(ptr(y), B, C, N, ptr(rsum), ptr(rsq), ptr(ext[0]), ptr(ext[1]),
+                                            ptr(ext[2]), ptr(ext[3]), current_stream(dev))
+    check(rc, "pn_gn_rows_fwd_f32")
+    return rsum, rsq, ext
+
+
+def _group_moments(rsum, rsq, groups, N, eps):
+    B, C = rsum.shape
+    mean = torch.empty((B, groups), dtype=torch.float32, device=rsum.device)
+    rstd = torch.empty_like(mean)
+    with torch.cuda.device(rsum.device):
+        rc = _lib.load().pn_gn_group_moments_f32(ptr(rsum), ptr(rsq), B, C, groups, N, float(eps), ptr(mean),
+                                                 ptr(rstd), current_stream(rsum.device))
+    check(rc, "pn_gn_group_moments_f32")
+    return mean, rstd
+
+
+def _group_bwd(ra, rb, gamma, groups, N):
+    B, C = ra.shape
+    c1c2 = torch.empty((B, groups, 2), dtype=torch.float32, device=ra.device)
+    with torch.cuda.device(ra.device):
+        rc = _lib.load().pn_gn_group_bwd_f32(ptr(ra), ptr(rb), ptr(gamma), B, C, groups, N, ptr(c1c2),
+                                             current_stream(ra.device))
+    check(rc, "pn_gn_group_bwd_f32")
+    return c1c2
+
+
+def _apply_bwd(gout, y, mean, rstd, gamma, beta, c1c2, groups, relu, gsp=None, arg=None):
+    B, C, N = y.shape
+    dy = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        rc = _lib.load().pn_gn_apply_bwd_f32(ptr(gout), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                             ptr(c1c2), B, C, groups, N, int(relu), ptr(gsp), ptr(arg), ptr(dy),
+                                             current_stream(y.device))
+    check(rc, "pn_gn_apply_bwd_f32")
+    return dy
+
+
+class _GroupNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, groups, eps, relu):
+        y = _f(y)
+        B, C, N = y.shape
+        gamma_c, beta_c = _f(gamma.detach()), _f(beta.detach())
+        rsum, rsq, _ = _rows_fwd(y, False)
+        mean, rstd = _group_moments(rsum, rsq, groups, N, eps)
+        out = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            rc = _lib.load().pn_gn_apply_fwd_f32(ptr(y), ptr(mean), ptr(rstd), ptr(gamma_c), ptr(beta_c), B, C,
+                                                 groups, N, int(relu), ptr(out), current_stream(y.device))
+        check(rc, "pn_gn_apply_fwd_f32")
+        ctx.save_for_backward(y, gamma_c, beta_c, mean, rstd)
+        ctx.cfg = (groups, relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        B, C, N = y.shape
+        gout = _f(gout)
+        ra = torch.empty((B, C), dtype=torch.float32, device=y.device)
+        rb = torch.empty_like(ra)
+        with torch.cuda.device(y.device):
+            rc = _lib.load().pn_gn_rows_bwd_f32(ptr(gout), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B,
+                                                C, groups, N, int(relu), ptr(ra), ptr(rb),
+                                                current_stream(y.device))
+        check(rc, "pn_gn_rows_bwd_f32")
+        c1c2 = _group_bwd(ra, rb, gamma, groups, N)
+        dy = _apply_bwd(gout, y, mean, rstd, gamma, beta, c1c2, groups, relu)
+        return dy, rb.sum(0), ra.sum(0), None, None, None
+
+
+class _GroupNormReLUMax(torch.autograd.Function):
+    """max_n relu(GroupNorm(y))[b,c,n] -> (B,C) without materialising the normalised tensor."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, groups, eps):
+        y = _f(y)
+        B, C, N = y.shape
+        gamma_c, beta_c = _f(gamma.detach()), _f(beta.detach())
+        rsum, rsq, (rmax, amax, rmin, amin) = _rows_fwd(y, True)
+        mean, rstd = _group_moments(rsum, rsq, groups, N, eps)
+        Cg = C // groups
+        pos = gamma_c.view(1, C) >= 0
+        ext = torch.where(pos, rmax, rmin)
+        arg = torch.where(pos, amax, amin).contiguous()
+        yhat = (ext - mean.repeat_interleave(Cg, 1)) * rstd.repeat_interleave(Cg, 1)
+        z = gamma_c.view(1, C) * yhat + beta_c.view(1, C)
+        ctx.save_for_backward(y, gamma_c, beta_c, mean, rstd, yhat, z, arg)
+        ctx.groups = groups
+        return torch.relu(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma, beta, mean, rstd, yhat, z, arg = ctx.saved_tensors
+        groups = ctx.groups
+        B, C, N = y.shape
+        gz = (g * (z > 0)).contiguous().float()
+        rb = (gz * yhat).contiguous()
+        c1c2 = _group_bwd(gz, rb, gamma, groups, N)
+        dy = _apply_bwd(None, y, mean, rstd, gamma, beta, c1c2, groups, True, gsp=gz, arg=arg)
+        return dy, rb.sum(0), gz.sum(0), None, None
+
+
+def group_norm_relu(y, gn, relu=True):
+    """relu(gn(y)) for y (B,C,N) and a torch.nn.GroupNorm module ``gn`` (its weight/bias/eps)."""
+    require_cuda(y)
+    return _GroupNormReLU.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, relu)
+
+
+def group_norm_relu_max(y, gn):
+    """max over the last axis of relu(gn(y)): (B,C,N) -> (B,C)."""
+    require_cuda(y)
+    return _GroupNormReLUMax.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps)

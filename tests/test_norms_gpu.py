@@ -1,0 +1,58 @@
+"""Fused GroupNorm(+ReLU)(+max over N) kernels against plain PyTorch fp32 ops on the same device."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("B,C,N,G,relu", [(2, 64, 1000, 4, True), (3, 512, 333, 8, True), (1, 256, 10000, 4, True),
+                                          (2, 32, 77, 2, False)])
+def test_group_norm_relu(gpu, B, C, N, G, relu):
+    from parsenet_codebase_amd.norms import group_norm_relu
+    torch.manual_seed(C + N)
+    gn = torch.nn.GroupNorm(G, C).to(gpu)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C))
+        gn.bias.copy_(torch.randn(C) * 0.3)
+    y = (torch.randn(B, C, N, device=gpu) * 2 + 0.5)
+    w = torch.randn(B, C, N, device=gpu)
+    y1 = y.clone().requires_grad_(True)
+    o1 = gn(y1)
+    o1 = F.relu(o1) if relu else o1
+    (o1 * w).sum().backward()
+    g1 = [y1.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()]
+    gn.zero_grad()
+    y2 = y.clone().requires_grad_(True)
+    o2 = group_norm_relu(y2, gn, relu)
+    (o2 * w).sum().backward()
+    assert _rel(o2, o1) < 1e-5
+    assert _rel(y2.grad, g1[0]) < 2e-5
+    assert _rel(gn.weight.grad, g1[1]) < 2e-5 and _rel(gn.bias.grad, g1[2]) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,N,G", [(2, 1024, 2000, 8), (4, 64, 301, 2)])
+def test_group_norm_relu_max(gpu, B, C, N, G):
+    from parsenet_codebase_amd.norms import group_norm_relu_max
+    torch.manual_seed(N)
+    gn = torch.nn.GroupNorm(G, C).to(gpu)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C))
+        gn.bias.copy_(torch.randn(C) * 0.3)
+    y = torch.randn(B, C, N, device=gpu)
+    w = torch.randn(B, C, device=gpu)
+    y1 = y.clone().requires_grad_(True)
+    o1 = F.relu(gn(y1)).max(dim=2)[0]
+    (o1 * w).sum().backward()
+    g1 = [y1.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()]
+    gn.zero_grad()
+    y2 = y.clone().requires_grad_(True)
+    o2 = group_norm_relu_max(y2, gn)
+    (o2 * w).sum().backward()
+    assert _rel(o2, o1) < 1e-5
+    assert _rel(y2.grad, g1[0]) < 2e-5
+    assert _rel(gn.weight.grad, g1[1]) < 2e-5 and _rel(gn.bias.grad, g1[2]) < 2e-5
