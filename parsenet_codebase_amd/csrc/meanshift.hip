@@ -29,13 +29,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MS_D 128
 #define MS_KS (MS_D / 2)  // k-steps of the 128-d dot products
 
-__device__ static inline float ms_kernel_value(float s, float bsq, bool* inside) {
-  // reference order: dist = 2 - 2 s ; arg = -dist / b^2 / 2 ; clamp ; exp
+__device__ static inline float ms_kernel_value(float s, float hinv, bool* inside) {
+  // reference: dist = 2 - 2 s ; arg = -dist / b^2 / 2 ; clamp(+-75) ; exp.
+  // Evaluated as arg = -dist * (0.5 / b^2) (one rounding instead of the division's; <= 1 ulp of
+  // arg) and with the hardware exp2 (v_exp_f32, ~1e-7 relative): the two division/exp library
+  // sequences were a third of this kernel's time and the difference is far below the 1e-5 bar.
   const float dist = __builtin_fmaf(-2.0f, s, 2.0f);
-  float arg = __fmul_rn(__fdiv_rn(-dist, bsq), 0.5f);
+  float arg = -dist * hinv;
   *inside = (arg >= -75.0f) && (arg <= 75.0f);
   arg = fminf(fmaxf(arg, -75.0f), 75.0f);
-  return expf(arg);
+  return __builtin_amdgcn_exp2f(arg * 1.4426950408889634f);
 }
 
 // PASS 0: forward          resident rows = Q,  streamed cols = X : out[f][row] += X[col][f] * K
@@ -47,22 +50,59 @@ __device__ static inline float ms_kernel_value(float s, float bsq, bool* inside)
 // P0 (B,N,D)  point-major streamed operand of the second GEMM; P1 second one (PASS 2: GO)
 // cs, rs      per-row scalars c_i and r_i (PASS 1: indexed by the resident row; PASS 2: streamed)
 // opart (B,S,N,D), rpart (B,S,N) partial outputs of slice blockIdx.y
+#define MS_TILE 4096  // floats per staged array tile (16 KiB): 128 channels x 32 columns
+
+// cooperative stage of one streamed tile: global -> registers (issued a tile ahead) -> LDS.
+// Written as macros over a plain register array: a lambda capturing the array sent it to scratch.
+#define MS_STAGE_LOAD(MT)                                                                     \
+  {                                                                                           \
+    const int j0s = (MT) * 32;                                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+      const int q = tid + 256 * u; /* float4 index inside a tile */                           \
+      /* channel-first arrays: row c = q / 8 (32 idx = 8 float4); padded to Np: in range */   \
+      const size_t ga = (size_t)(q >> 3) * Np + j0s + ((q & 7) << 2);                         \
+      sr[0][u] = *reinterpret_cast<const float4*>(Atb + ga);                                  \
+      if (PASS == 2) sr[NARR - 2][u] = *reinterpret_cast<const float4*>(At1b + ga);           \
+      /* point-major arrays: row = q / 32 (128 feat = 32 float4); rows past N clamp */        \
+      const size_t gp = (size_t)min(j0s + (q >> 5), N - 1) * MS_D + ((q & 31) << 2);          \
+      sr[1][u] = *reinterpret_cast<const float4*>(P0b + gp);                                  \
+      if (PASS == 2) sr[NARR - 1][u] = *reinterpret_cast<const float4*>(P1b + gp);            \
+    }                                                                                         \
+  }
+#define MS_STAGE_STORE(BUF)                                                                   \
+  {                                                                                           \
+    _Pragma("unroll") for (int a = 0; a < NARR; ++a)                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                         \
+            *reinterpret_cast<float4*>(&lds[BUF][a][(tid + 256 * u) << 2]) = sr[a][u];        \
+  }
+
 template <int PASS>
-__global__ __launch_bounds__(256) void pn_ms_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pn_ms_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const float* __restrict__ At,
     const float* __restrict__ At1, const float* __restrict__ P0, const float* __restrict__ P1,
     const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_,
     int N, int Np, int tiles_per_slice, float* __restrict__ opart, float* __restrict__ rpart) {
+  // LDS image of the streamed operands of one 32-index tile, double buffered and shared by the
+  // four waves of the block (they own different resident rows but stream the same tiles):
+  //   arr 0: At  tile [128 ch][32 idx]      (first GEMM, A operand)
+  //   arr 1: P0  tile [32 idx][128 feat]    (second GEMM, A operand)
+  //   arr 2/3 (PASS 2): At1 and P1 likewise
+  constexpr int NARR = PASS == 2 ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float lds[2][NARR][MS_TILE];
   const int b = blockIdx.z;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, h = lane >> 5;
-  const int i0 = (blockIdx.x * 4 + wave) * 32;  // resident block
-  if (i0 >= N) return;
-  const int S = gridDim.y, slice = blockIdx.y;
+  // grid.x = slice so that consecutive workgroups (round-robin over the 8 XCDs) differ in the
+  // SLICE: with S a multiple of 8 an XCD only ever streams 1/8 of the column range
+  const int i0 = (blockIdx.y * 4 + wave) * 32;  // resident block of this wave
+  const bool wave_on = i0 < N;                   // idle waves still help staging and barriers
+  const int S = gridDim.x, slice = blockIdx.x;
   const int ntiles = Np / 32;
   const int t_begin = slice * tiles_per_slice;
   const int t_end = min(ntiles, t_begin + tiles_per_slice);
   const float bsq = bsq_[b];
+  const float hinv = 0.5f / bsq;
   const size_t bN = (size_t)b * N;
   const float* __restrict__ Atb = At + (size_t)b * MS_D * Np;
   const float* __restrict__ At1b = PASS == 2 ? At1 + (size_t)b * MS_D * Np : nullptr;
@@ -88,71 +128,83 @@ __global__ __launch_bounds__(256) void pn_ms_kernel(
     for (int r = 0; r < 16; ++r) acc_o[fb][r] = 0.f;
   float rsum = 0.f;
 
+  float4 sr[NARR][4];
+  int cur = 0;
+  if (t_begin < t_end) {
+    MS_STAGE_LOAD(t_begin);
+    MS_STAGE_STORE(0);
+  }
+  __syncthreads();
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int j0 = mt * 32;
-    f32x16 s, t;
+    const bool has_next = mt + 1 < t_end;
+    if (has_next) MS_STAGE_LOAD(mt + 1);  // in flight while this tile is computed
+    if (wave_on) {
+      const float* __restrict__ lAt = lds[cur][0];
+      const float* __restrict__ lP0 = lds[cur][1];
+      const float* __restrict__ lAt1 = PASS == 2 ? lds[cur][2] : nullptr;
+      const float* __restrict__ lP1 = PASS == 2 ? lds[cur][3] : nullptr;
+      f32x16 s, t;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = 0.f;
-      t[r] = 0.f;
-    }
-#pragma unroll
-    for (int m0 = 0; m0 < MS_KS; m0 += 32) {
-      float av[32], av1[PASS == 2 ? 32 : 1];
-#pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        av[m] = Atb[(size_t)(2 * (m0 + m) + h) * Np + j0 + col];
-        if (PASS == 2) av1[m] = At1b[(size_t)(2 * (m0 + m) + h) * Np + j0 + col];
+      for (int r = 0; r < 16; ++r) {
+        s[r] = 0.f;
+        t[r] = 0.f;
       }
 #pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], br[m0 + m], s, 0, 0, 0);
-        if (PASS == 1) t = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], br1[m0 + m], t, 0, 0, 0);
-        if (PASS == 2) t = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], br[m0 + m], t, 0, 0, 0);
+      for (int m = 0; m < MS_KS; ++m) {
+        const float a0 = lAt[(2 * m + h) * 32 + col];
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br[m], s, 0, 0, 0);
+        if (PASS == 1) t = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br1[m], t, 0, 0, 0);
+        if (PASS == 2)
+          t = __builtin_amdgcn_mfma_f32_32x32x2f32(lAt1[(2 * m + h) * 32 + col], br[m], t, 0, 0, 0);
       }
-    }
-    // elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col]
-    float kv[16], gs[PASS == 0 ? 1 : 16];
-    float cst[PASS == 2 ? 16 : 1], rst[PASS == 2 ? 16 : 1];
-    if (PASS == 2) {
+      // elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col]
+      float kv[16], gs[PASS == 0 ? 1 : 16];
+      float cst[PASS == 2 ? 16 : 1], rst[PASS == 2 ? 16 : 1];
+      if (PASS == 2) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int jj = j0 + 8 * g + 4 * h;  // 4 consecutive streamed rows, may run past N
+        for (int g = 0; g < 4; ++g) {
+          const int jj = j0 + 8 * g + 4 * h;  // 4 consecutive streamed rows, may run past N
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int jc = min(jj + u, N - 1);
-          cst[4 * g + u] = cs[bN + jc];
-          rst[4 * g + u] = 1.0f / (rs[bN + jc] * bsq);
+          for (int u = 0; u < 4; ++u) {
+            const int jc = min(jj + u, N - 1);
+            cst[4 * g + u] = cs[bN + jc];
+            rst[4 * g + u] = 1.0f / (rs[bN + jc] * bsq);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        bool inside;
+        float k = ms_kernel_value(s[r], hinv, &inside);
+        if (j0 + row >= N) k = 0.f;
+        kv[r] = k;
+        if (PASS == 0) rsum += k;
+        if (PASS == 1) gs[r] = inside ? k * (t[r] - c_res) * rinv_res : 0.f;
+        if (PASS == 2) gs[r] = inside ? k * (t[r] - cst[r]) * rst[r] : 0.f;
+      }
+      // second GEMM: out[f][resident] += sum_streamed P[streamed][f] * w[streamed][resident];
+      // k-step m pairs the streamed indices row(m) of the two half-waves
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int lrow = (m & 3) + 8 * (m >> 2) + 4 * h;
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+          const float w = PASS == 0 ? kv[m] : gs[m];
+          acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lP0[lrow * MS_D + fb * 32 + col], w,
+                                                          acc_o[fb], 0, 0, 0);
+          if (PASS == 2)
+            acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lP1[lrow * MS_D + fb * 32 + col], kv[m],
+                                                            acc_o[fb], 0, 0, 0);
         }
       }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      bool inside;
-      float k = ms_kernel_value(s[r], bsq, &inside);
-      if (j0 + row >= N) k = 0.f;
-      kv[r] = k;
-      if (PASS == 0) rsum += k;
-      if (PASS == 1) gs[r] = inside ? k * (t[r] - c_res) * rinv_res : 0.f;
-      if (PASS == 2) gs[r] = inside ? k * (t[r] - cst[r]) * rst[r] : 0.f;
-    }
-    // second GEMM: out[f][resident] += sum_streamed P[streamed][f] * w[streamed][resident];
-    // k-step m pairs the streamed indices row(m) of the two half-waves
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int jrow = min(j0 + (m & 3) + 8 * (m >> 2) + 4 * h, N - 1);
-      const float* __restrict__ p0 = P0b + (size_t)jrow * MS_D + col;
-      const float* __restrict__ p1 = PASS == 2 ? P1b + (size_t)jrow * MS_D + col : nullptr;
-#pragma unroll
-      for (int fb = 0; fb < 4; ++fb) {
-        const float w = PASS == 0 ? kv[m] : gs[m];
-        acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[fb * 32], w, acc_o[fb], 0, 0, 0);
-        if (PASS == 2)
-          acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[fb * 32], kv[m], acc_o[fb], 0, 0, 0);
-      }
-    }
+    if (has_next) MS_STAGE_STORE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
+  if (!wave_on) return;
   // acc_o[fb]: D[f = fb*32 + (r&3)+8(r>>2)+4h][resident = col]
   const int ir = i0 + col;
   if (ir < N) {
@@ -259,13 +311,14 @@ __global__ void pn_ms_pack_kernel(const float* __restrict__ x, int N, int Np,
 
 static int ms_slices(int B, int N, int Np, int* tps) {
   const long long waves = (long long)B * pn_cdiv(N, 32);
-  int S = (int)(4096 / (waves > 0 ? waves : 1));
+  (void)waves;
   const int ntiles = Np / 32;
-  if (S > 16) S = 16;
-  if (S > ntiles) S = ntiles;
-  if (S < 1) S = 1;
+  // 8 or 16 slices (a multiple of the 8 XCDs, see pn_ms_kernel); tiny problems take fewer
+  int S = ntiles >= 64 ? 16 : (ntiles >= 16 ? 8 : 1);
   *tps = pn_cdiv(ntiles, S);
-  return pn_cdiv(ntiles, *tps);
+  // keep S itself (not cdiv(ntiles, tps)): trailing empty slices are harmless and preserve the
+  // slice -> XCD mapping
+  return S;
 }
 
 extern "C" int pn_meanshift_slices(int B, int N) {
@@ -298,7 +351,7 @@ extern "C" int pn_meanshift_iter_fwd_f32(const float* q, const float* x, const f
   const int Np = (int)pn_align_up(N, 64);
   int tps;
   const int S = ms_slices(B, N, Np, &tps);
-  dim3 grid(pn_cdiv(N, 128), S, B);
+  dim3 grid(S, pn_cdiv(N, 128), B);
   {
     PN_PROF("meanshift_fwd", stream);
     hipLaunchKernelGGL(pn_ms_kernel<0>, grid, dim3(256), 0, stream, q, nullptr, xt, nullptr, x,
@@ -332,7 +385,7 @@ extern "C" int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const 
   hipLaunchKernelGGL(pn_ms_prep_bwd_kernel, dim3(pn_cdiv(Np, 4), B), dim3(256), 0, stream, gy, y, q,
                      rsum, unorm, N, Np, gu, go, cs, qt, gut);
   PN_CHECK_LAUNCH();
-  dim3 grid(pn_cdiv(N, 128), S, B);
+  dim3 grid(S, pn_cdiv(N, 128), B);
   {
     PN_PROF("meanshift_bwd_rows", stream);
     hipLaunchKernelGGL(pn_ms_kernel<1>, grid, dim3(256), 0, stream, q, gu, xt, nullptr, x, nullptr,
