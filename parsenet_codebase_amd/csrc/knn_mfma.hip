@@ -114,18 +114,27 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     const float* __restrict__ xc, const float* __restrict__ xxc_, int Nc, int Ncp,
     int tiles_per_slice, float* __restrict__ tilemax, const float* __restrict__ tau,
     u64* __restrict__ lists, int* __restrict__ counts, int subcap) {
-  const int b = blockIdx.z;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int col = lane & 31, h = lane >> 5;
-  const int q0 = (blockIdx.x * 4 + wave) * (32 * QSETS);
-  if (q0 >= Nq) return;  // wave-uniform
+  // grid: (slices, query blocks, B): consecutive workgroups differ in the slice, so each of the
+  // 8 XCDs streams only its share of the candidates (kept in its private L2).
+  // The candidate tile [CP channels][32 candidates] (+ the 32 squared norms) is staged through
+  // LDS once per block, double buffered, and shared by the four waves (different queries).
   constexpr int CP = 2 * KSTEPS;
+  constexpr int TILE = CP * 32;            // floats
+  constexpr int NF4 = TILE / 4;            // float4 per tile
+  constexpr int PER = (NF4 + 255) / 256;   // float4 per thread
+  __shared__ __attribute__((aligned(16))) float lds[2][TILE + 32];
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, h = lane >> 5;
+  const int q0 = (blockIdx.y * 4 + wave) * (32 * QSETS);
+  const bool wave_on = q0 < Nq;
   const float* __restrict__ xqb = xq + (size_t)b * CP * Nqp;
   const float* __restrict__ xcb = xc + (size_t)b * CP * Ncp;
   const float* __restrict__ xxqb = xxq_ + (size_t)b * Nqp;
   const float* __restrict__ xxcb = xxc_ + (size_t)b * Ncp;
   const int ntiles = Ncp / 32;
-  const int S = gridDim.y, slice = blockIdx.y;
+  const int S = gridDim.x, slice = blockIdx.x;
   const int t_begin = slice * tiles_per_slice;
   const int t_end = min(ntiles, t_begin + tiles_per_slice);
   const int T16 = Ncp / 16;
@@ -148,87 +157,120 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     sub[s] = lists + ((((size_t)b * Nqp + qcl) * S + slice) * 2 + h) * (size_t)subcap;
   }
 
+  float4 sr[PER];
+  float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
+#define KM_STAGE_LOAD(MT)                                                              \
+  {                                                                                    \
+    const int j0s = (MT) * 32;                                                         \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                  \
+      const int q = tid + 256 * u; /* row c = q / 8, 4 candidates (q & 7) * 4 */       \
+      if (q < NF4)                                                                     \
+        sr[u] = *reinterpret_cast<const float4*>(xcb + (size_t)(q >> 3) * Ncp + j0s + ((q & 7) << 2)); \
+    }                                                                                  \
+    if (MODE != 2 && tid < 8) sx = *reinterpret_cast<const float4*>(xxcb + j0s + (tid << 2)); \
+  }
+#define KM_STAGE_STORE(BUF)                                                            \
+  {                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                  \
+      const int q = tid + 256 * u;                                                     \
+      if (q < NF4) *reinterpret_cast<float4*>(&lds[BUF][q << 2]) = sr[u];              \
+    }                                                                                  \
+    if (MODE != 2 && tid < 8) *reinterpret_cast<float4*>(&lds[BUF][TILE + (tid << 2)]) = sx; \
+  }
+  int cur = 0;
+  if (t_begin < t_end) {
+    KM_STAGE_LOAD(t_begin);
+    KM_STAGE_STORE(0);
+  }
+  __syncthreads();
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int j0 = mt * 32;
-    f32x16 acc[QSETS], accn[MODE == 1 ? QSETS : 1];
+    const bool has_next = mt + 1 < t_end;
+    if (has_next) KM_STAGE_LOAD(mt + 1);  // in flight while this tile is computed
+    // keep the scheduler from sinking the loads / hoisting the LDS stores across the compute:
+    // the stores (and their vmcnt wait) must come AFTER the MFMA work they overlap with
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_on) {
+      const float* __restrict__ lx = lds[cur];
+      f32x16 acc[QSETS], accn[MODE == 1 ? QSETS : 1];
 #pragma unroll
-    for (int s = 0; s < QSETS; ++s) {
+      for (int s = 0; s < QSETS; ++s) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-      if (MODE == 1) {
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+        if (MODE == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accn[s][r] = 0.f;
+          for (int r = 0; r < 16; ++r) accn[s][r] = 0.f;
+        }
       }
-    }
-    // A[i = lane&31][k = lane>>5]: candidate j0+col, channel 2m+h; streamed in chunks of at
-    // most 32 k-steps so that the operand window stays small for wide features
-    constexpr int KCH = KSTEPS < 32 ? KSTEPS : 32;
+      // A[i = lane&31][k = lane>>5]: candidate j0+col, channel 2m+h
 #pragma unroll
-    for (int m0 = 0; m0 < KSTEPS; m0 += KCH) {
-      float av[KCH];
-#pragma unroll
-      for (int m = 0; m < KCH; ++m) av[m] = xcb[(size_t)(2 * (m0 + m) + h) * Ncp + j0 + col];
-#pragma unroll
-      for (int m = 0; m < KCH; ++m) {
+      for (int m = 0; m < KSTEPS; ++m) {
+        const float a = lx[(2 * m + h) * 32 + col];
 #pragma unroll
         for (int s = 0; s < QSETS; ++s) {
-          if (MODE == 1 && m0 + m >= 2)
-            accn[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bq[s][m0 + m], accn[s], 0, 0, 0);
+          if (MODE == 1 && m >= 2)
+            accn[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[s][m], accn[s], 0, 0, 0);
           else
-            acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bq[s][m0 + m], acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[s][m], acc[s], 0, 0, 0);
         }
       }
-    }
-    // D[i][j]: lane holds column j = col (query), rows i = (r&3) + 8*(r>>2) + 4*h (candidates)
-    float xxj[16];
-    if (MODE != 2) {
+      // D[i][j]: lane holds column j = col (query), rows i = (r&3) + 8*(r>>2) + 4*h (candidates)
+      float xxj[16];
+      if (MODE != 2) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 t4 = *reinterpret_cast<const float4*>(&xxcb[j0 + 8 * g + 4 * h]);
-        xxj[4 * g + 0] = t4.x;
-        xxj[4 * g + 1] = t4.y;
-        xxj[4 * g + 2] = t4.z;
-        xxj[4 * g + 3] = t4.w;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < QSETS; ++s) {
-      float tm = -__builtin_inff();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v;
-        if (MODE == 0) {
-          // (-xx[j] - (-2*dot)) - xx[i]; 2*dot is exact, so the fma rounds once like the
-          // reference's subtraction
-          const float t = __builtin_fmaf(2.0f, acc[s][r], -xxj[r]);
-          v = __fsub_rn(t, xxq[s]);
-        } else if (MODE == 1) {
-          const float t = __builtin_fmaf(-2.0f, acc[s][r], xxj[r]);  // xx[j] - 2*dot_p
-          const float pp = __fadd_rn(t, xxq[s]);
-          const float pn = __builtin_fmaf(-2.0f, accn[s][r], 2.0f);  // 2 - 2*dot_n
-          v = -__fmul_rn(pp, __fadd_rn(1.0f, pn));
-        } else {
-          v = acc[s][r];
+        for (int g = 0; g < 4; ++g) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&lx[TILE + 8 * g + 4 * h]);
+          xxj[4 * g + 0] = t4.x;
+          xxj[4 * g + 1] = t4.y;
+          xxj[4 * g + 2] = t4.z;
+          xxj[4 * g + 3] = t4.w;
         }
-        const bool ok = (j0 + row) < Nc;
-        if (!COLLECT) {
-          tm = fmaxf(tm, ok ? v : -__builtin_inff());
-        } else {
-          if (ok && v >= tq[s]) {
-            // the key carries the PERMUTED index here; K4 rewrites it to the original one
-            if (mycnt[s] < subcap) sub[s][mycnt[s]] = knn_key(v, j0 + row);
-            ++mycnt[s];
+      }
+#pragma unroll
+      for (int s = 0; s < QSETS; ++s) {
+        float tm = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v;
+          if (MODE == 0) {
+            // (-xx[j] - (-2*dot)) - xx[i]; 2*dot is exact, so the fma rounds once like the
+            // reference's subtraction
+            const float t = __builtin_fmaf(2.0f, acc[s][r], -xxj[r]);
+            v = __fsub_rn(t, xxq[s]);
+          } else if (MODE == 1) {
+            const float t = __builtin_fmaf(-2.0f, acc[s][r], xxj[r]);  // xx[j] - 2*dot_p
+            const float pp = __fadd_rn(t, xxq[s]);
+            const float pn = __builtin_fmaf(-2.0f, accn[s][r], 2.0f);  // 2 - 2*dot_n
+            v = -__fmul_rn(pp, __fadd_rn(1.0f, pn));
+          } else {
+            v = acc[s][r];
+          }
+          const bool ok = (j0 + row) < Nc;
+          if (!COLLECT) {
+            tm = fmaxf(tm, ok ? v : -__builtin_inff());
+          } else {
+            if (ok && v >= tq[s]) {
+              // the key carries the PERMUTED index here; K4 rewrites it to the original one
+              if (mycnt[s] < subcap) sub[s][mycnt[s]] = knn_key(v, j0 + row);
+              ++mycnt[s];
+            }
           }
         }
-      }
-      if (!COLLECT) {
-        const int q = q0 + 32 * s + col;
-        if (q < Nqp) tilemax[((size_t)b * Nqp + q) * T16 + (2 * mt + h)] = tm;
+        if (!COLLECT) {
+          const int q = q0 + 32 * s + col;
+          if (q < Nqp) tilemax[((size_t)b * Nqp + q) * T16 + (2 * mt + h)] = tm;
+        }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) KM_STAGE_STORE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
-  if (COLLECT) {
+#undef KM_STAGE_LOAD
+#undef KM_STAGE_STORE
+  if (COLLECT && wave_on) {
 #pragma unroll
     for (int s = 0; s < QSETS; ++s) {
       const int q = q0 + 32 * s + col;
@@ -394,11 +436,13 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
     const long long waves_q = (long long)B * pn_cdiv(p.Nqp, 32 * p.qsets);
     int S = (int)(8192 / (waves_q > 0 ? waves_q : 1));
     const int ntiles = p.Ncp / 32;
+    if (S >= 8 && ntiles >= 64) S = 8;   // one slice per XCD (see pn_knn_mfma_kernel)
     if (S > 8) S = 8;
     if (S > ntiles) S = ntiles;
     if (S < 1) S = 1;
     p.tiles_per_slice = pn_cdiv(ntiles, S);
-    p.S = pn_cdiv(ntiles, p.tiles_per_slice);
+    if (S != 8) S = pn_cdiv(ntiles, p.tiles_per_slice);
+    p.S = S;
     // expected survivors per sub-list ~ 1.1-1.3 k / (2 S); leave generous head-room
     p.subcap = (int)pn_align_up(3 * k / (2 * p.S) + 16, 8);
     if (2 * p.S * p.subcap > KNN_CAP) p.subcap = KNN_CAP / (2 * p.S);
@@ -479,7 +523,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
                          q, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
   }
   PN_CHECK_LAUNCH();
-  dim3 grid(pn_cdiv(p.Nqp, 32 * p.qsets * 4), p.S, B);
+  dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
   for (int pass = 0; pass < 2; ++pass) {
     const bool collect = pass == 1;
     static const char* const pass_names[2][5] = {

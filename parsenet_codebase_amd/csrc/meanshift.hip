@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int j0 = mt * 32;
     const bool has_next = mt + 1 < t_end;
     if (has_next) MS_STAGE_LOAD(mt + 1);  // in flight while this tile is computed
+    // keep the scheduler from sinking the loads / hoisting the LDS stores across the compute:
+    // the stores (and their vmcnt wait) must come AFTER the MFMA work they overlap with
+    __builtin_amdgcn_sched_barrier(0);
     if (wave_on) {
       const float* __restrict__ lAt = lds[cur][0];
       const float* __restrict__ lP0 = lds[cur][1];
@@ -150,13 +153,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         s[r] = 0.f;
         t[r] = 0.f;
       }
+      // first GEMM, software pipelined by hand: the LDS reads of group g+1 are issued before the
+      // eight MFMAs of group g, so that a dependent MFMA chain never waits on an LDS round trip
+      {
+        float ac[8], an[8], ac1[PASS == 2 ? 8 : 1], an1[PASS == 2 ? 8 : 1];
 #pragma unroll
-      for (int m = 0; m < MS_KS; ++m) {
-        const float a0 = lAt[(2 * m + h) * 32 + col];
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br[m], s, 0, 0, 0);
-        if (PASS == 1) t = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, br1[m], t, 0, 0, 0);
-        if (PASS == 2)
-          t = __builtin_amdgcn_mfma_f32_32x32x2f32(lAt1[(2 * m + h) * 32 + col], br[m], t, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+          ac[u] = lAt[(2 * u + h) * 32 + col];
+          if (PASS == 2) ac1[u] = lAt1[(2 * u + h) * 32 + col];
+        }
+#pragma unroll
+        for (int g = 0; g < MS_KS / 8; ++g) {
+          if (g + 1 < MS_KS / 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              an[u] = lAt[(2 * (8 * (g + 1) + u) + h) * 32 + col];
+              if (PASS == 2) an1[u] = lAt1[(2 * (8 * (g + 1) + u) + h) * 32 + col];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int m = 8 * g + u;
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], br[m], s, 0, 0, 0);
+            if (PASS == 1) t = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], br1[m], t, 0, 0, 0);
+            if (PASS == 2) t = __builtin_amdgcn_mfma_f32_32x32x2f32(ac1[u], br[m], t, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            ac[u] = an[u];
+            if (PASS == 2) ac1[u] = an1[u];
+          }
+        }
       }
       // elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col]
       float kv[16], gs[PASS == 0 ? 1 : 16];
@@ -186,20 +214,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       // second GEMM: out[f][resident] += sum_streamed P[streamed][f] * w[streamed][resident];
       // k-step m pairs the streamed indices row(m) of the two half-waves
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int lrow = (m & 3) + 8 * (m >> 2) + 4 * h;
+      {
+        float pc[4], pn[4], pc1[PASS == 2 ? 4 : 1], pn1[PASS == 2 ? 4 : 1];
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
-          const float w = PASS == 0 ? kv[m] : gs[m];
-          acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lP0[lrow * MS_D + fb * 32 + col], w,
-                                                          acc_o[fb], 0, 0, 0);
-          if (PASS == 2)
-            acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lP1[lrow * MS_D + fb * 32 + col], kv[m],
-                                                            acc_o[fb], 0, 0, 0);
+          pc[fb] = lP0[(4 * h) * MS_D + fb * 32 + col];
+          if (PASS == 2) pc1[fb] = lP1[(4 * h) * MS_D + fb * 32 + col];
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          if (m + 1 < 16) {
+            const int lrow = ((m + 1) & 3) + 8 * ((m + 1) >> 2) + 4 * h;
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+              pn[fb] = lP0[lrow * MS_D + fb * 32 + col];
+              if (PASS == 2) pn1[fb] = lP1[lrow * MS_D + fb * 32 + col];
+            }
+          }
+#pragma unroll
+          for (int fb = 0; fb < 4; ++fb) {
+            const float w = PASS == 0 ? kv[m] : gs[m];
+            acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[fb], w, acc_o[fb], 0, 0, 0);
+            if (PASS == 2)
+              acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc1[fb], kv[m], acc_o[fb], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int fb = 0; fb < 4; ++fb) {
+            pc[fb] = pn[fb];
+            if (PASS == 2) pc1[fb] = pn1[fb];
+          }
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (has_next) MS_STAGE_STORE(cur ^ 1);
     __syncthreads();
     cur ^= 1;

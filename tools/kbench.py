@@ -44,6 +44,25 @@ def bench_chamfer():
               (B, Na, Nb, ms, 2 * 8.0 * B * Na * Nb / ms / 1e9))
 
 
+def bench_meanshift():
+    import numpy as np
+    from parsenet_codebase_amd.mean_shift import MeanShift
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    N = 10000
+    X = torch.nn.functional.normalize(torch.randn(N, 128, device=dev), dim=1)
+    ms = MeanShift()
+    b = torch.tensor(0.3, device=dev)
+
+    def fwd_bwd():
+        x = X.clone().requires_grad_(True)
+        y, _ = ms.mean_shift_(x, b, 10)
+        y.sum().backward()
+    t = timeit(fwd_bwd, warmup=1, iters=3)
+    print("meanshift N=%d 10 it fwd+bwd: %.2f ms  (%.1f TFLOP/s on 9 GEMM units/it)" %
+          (N, t, 10 * 9 * 2.0 * N * N * 128 / t / 1e9))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["knn", "chamfer"]
     for w in which:
