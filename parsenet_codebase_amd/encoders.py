@@ -17,6 +17,16 @@ from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
+def conv1x1(x, conv):
+    """nn.Conv1d(kernel_size=1) applied as a plain GEMM (rocBLAS) instead of a MIOpen convolution:
+    same arithmetic, no per-shape algorithm search (the fitting stage feeds a new point count for
+    every segment)."""
+    y = torch.matmul(conv.weight[:, :, 0], x)
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1)
+    return y
+
+
 def _edge_layer(cin2, cout, norm):
     # Sequential only to reproduce the reference's parameter names ("convN.0.weight"); the
     # forward pass feeds the weight to the fused kernel instead of calling it.
@@ -70,13 +80,13 @@ class DGCNNControlPoints(nn.Module):
             idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
-        x = self.conv5(torch.cat(feats, dim=1))
+        x = F.leaky_relu(self.bn5(conv1x1(torch.cat(feats, dim=1), self.conv5[0])), 0.2)
         if isinstance(weights, torch.Tensor):
             x = x * weights.reshape((1, 1, -1))
         x = F.adaptive_max_pool1d(x, 1)
-        x = F.relu(self.bn6(self.conv6(x)))
-        x = F.relu(self.bn7(self.conv7(x)))
-        x = self.tanh(self.conv8(x)[:, :, 0])
+        x = F.relu(self.bn6(conv1x1(x, self.conv6)))
+        x = F.relu(self.bn7(conv1x1(x, self.conv7)))
+        x = self.tanh(conv1x1(x, self.conv8)[:, :, 0])
         return x.view(batch_size, self.controlpoints * self.controlpoints, 3)
 
 
@@ -117,7 +127,7 @@ class DGCNNEncoderGn(nn.Module):
         x3 = graph.edge_conv_norm_max(x2, graph.knn_dilated(x2, k, k), self.conv3[0].weight, self.bn3, 0.2)
         x_features = torch.cat((x1, x2, x3), dim=1)
         # GroupNorm + ReLU + max over the points in one pass (norm and ReLU are monotone per channel)
-        x4 = group_norm_relu_max(self.mlp1(x_features), self.bnmlp1)
+        x4 = group_norm_relu_max(conv1x1(x_features, self.mlp1), self.bnmlp1)
         return x4, x_features
 
 
@@ -165,17 +175,17 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         ng = x.shape[1]
         w = self.conv1.weight[:, :, 0]
         glob = torch.addmm(self.conv1.bias, x, w[:, :ng].t())            # (B,512)
-        x = F.conv1d(first_layer_features, self.conv1.weight[:, ng:], None) + glob.unsqueeze(2)
+        x = torch.matmul(w[:, ng:], first_layer_features) + glob.unsqueeze(2)
         x = group_norm_relu(x, self.bn1)
-        x_all = group_norm_relu(self.conv2(x), self.bn2)
+        x_all = group_norm_relu(conv1x1(x, self.conv2), self.bn2)
         embedding = None
         primitives_log_prob = None
         if self.embedding:
-            x = group_norm_relu(self.mlp_seg_prob1(x_all), self.bn_seg_prob1)
-            embedding = self.mlp_seg_prob2(x)
+            x = group_norm_relu(conv1x1(x_all, self.mlp_seg_prob1), self.bn_seg_prob1)
+            embedding = conv1x1(x, self.mlp_seg_prob2)
         if self.primitives:
-            x = group_norm_relu(self.mlp_prim_prob1(x_all), self.bn_prim_prob1)
-            primitives_log_prob = self.logsoftmax(self.mlp_prim_prob2(x))
+            x = group_norm_relu(conv1x1(x_all, self.mlp_prim_prob1), self.bn_prim_prob1)
+            primitives_log_prob = self.logsoftmax(conv1x1(x, self.mlp_prim_prob2))
         if compute_loss:
             lab = labels.data.cpu().numpy() if torch.is_tensor(labels) else labels
             embed_loss = self.loss_function(embedding, lab)

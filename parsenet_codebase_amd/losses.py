@@ -38,9 +38,12 @@ class EmbeddingLoss:
                 per_label.append(np.random.choice(ids, num, replace=True))
             samples.append(np.stack(per_label, 0))            # (S_i, num)
 
-        # phase 2 (reference :85-123): random ordered segment pairs per shape
-        loss_diff = torch.zeros(1, device=dev)
+        # phase 2 (reference :85-123): random ordered segment pairs per shape; the RNG draws happen
+        # in the reference's order, the arithmetic of ALL pairs of ALL shapes is one batched
+        # expression (every shape samples the same number of points per segment when
+        # N // S + 1 >= 30, the usual case; otherwise shapes are grouped by sample count)
         only_one = 0
+        pair_sets = []          # (shape, pairs (P,2), normalization)
         for i in range(B):
             S = samples[i].shape[0]
             if S == 1:
@@ -53,23 +56,30 @@ class EmbeddingLoss:
                 k2 = np.random.choice(S, 1)[0]
                 if k1 != k2:
                     pairs.append((k1, k2))
-            normalization = len(pairs)
-            if normalization == 0:
-                continue
-            pairs = np.asarray(pairs)
-            sel = torch.from_numpy(samples[i]).to(dev)          # (S,num)
-            pred = out[i][sel]                                   # (S,num,D)
-            pa = torch.from_numpy(pairs[:, 0]).to(dev)
-            pb = torch.from_numpy(pairs[:, 1]).to(dev)
-            p1, p2 = pred[pa], pred[pb]                          # (P,num,D)
+            if pairs:
+                pair_sets.append((i, np.asarray(pairs), len(pairs)))
+        loss_diff = torch.zeros(1, device=dev)
+        by_num = {}
+        for i, pairs, norm in pair_sets:
+            by_num.setdefault(samples[i].shape[1], []).append((i, pairs, norm))
+        for num, group in by_num.items():
+            ia, ib, wts = [], [], []
+            for i, pairs, norm in group:
+                ia.append(i * N + samples[i][pairs[:, 0]])           # (P,num) flat point indices
+                ib.append(i * N + samples[i][pairs[:, 1]])
+                wts.append(np.full(len(pairs), 1.0 / (norm + 1e-8), dtype=np.float32))
+            ia = torch.from_numpy(np.concatenate(ia, 0)).to(dev)
+            ib = torch.from_numpy(np.concatenate(ib, 0)).to(dev)
+            wts = torch.from_numpy(np.concatenate(wts, 0)).to(dev)
+            flat = out.reshape(B * N, -1)
+            p1, p2 = flat[ia], flat[ib]                              # (P,num,D)
             anchor = p1.unsqueeze(2)
-            diff_pos = ((anchor - p1.unsqueeze(1)) ** 2).sum(3)  # (P,num,num)
+            diff_pos = ((anchor - p1.unsqueeze(1)) ** 2).sum(3)      # (P,num,num)
             diff_neg = ((anchor - p2.unsqueeze(1)) ** 2).sum(3)
             constraint = F.relu(diff_pos - diff_neg + self.margin)
             loss = constraint.sum((1, 2)) - torch.diagonal(constraint, dim1=1, dim2=2).sum(1)
             satisfied = ((constraint > 0).sum((1, 2)) + 1.0).to(loss.dtype)
-            loss_shape = (loss / satisfied.detach()).sum() / (normalization + 1e-8)
-            loss_diff = loss_diff + loss_shape
+            loss_diff = loss_diff + ((loss / satisfied.detach()) * wts).sum()
         return loss_diff / (B - only_one + 1e-8)
 
 
