@@ -52,28 +52,32 @@ __device__ static inline float ms_kernel_value(float s, float hinv, bool* inside
 // opart (B,S,N,D), rpart (B,S,N) partial outputs of slice blockIdx.y
 #define MS_TILE 4096  // floats per staged array tile (16 KiB): 128 channels x 32 columns
 
-// cooperative stage of one streamed tile: global -> registers (issued a tile ahead) -> LDS.
-// Written as macros over a plain register array: a lambda capturing the array sent it to scratch.
-#define MS_STAGE_LOAD(MT)                                                                     \
-  {                                                                                           \
-    const int j0s = (MT) * 32;                                                                \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
-      const int q = tid + 256 * u; /* float4 index inside a tile */                           \
-      /* channel-first arrays: row c = q / 8 (32 idx = 8 float4); padded to Np: in range */   \
-      const size_t ga = (size_t)(q >> 3) * Np + j0s + ((q & 7) << 2);                         \
-      sr[0][u] = *reinterpret_cast<const float4*>(Atb + ga);                                  \
-      if (PASS == 2) sr[NARR - 2][u] = *reinterpret_cast<const float4*>(At1b + ga);           \
-      /* point-major arrays: row = q / 32 (128 feat = 32 float4); rows past N clamp */        \
-      const size_t gp = (size_t)min(j0s + (q >> 5), N - 1) * MS_D + ((q & 31) << 2);          \
-      sr[1][u] = *reinterpret_cast<const float4*>(P0b + gp);                                  \
-      if (PASS == 2) sr[NARR - 1][u] = *reinterpret_cast<const float4*>(P1b + gp);            \
-    }                                                                                         \
-  }
-#define MS_STAGE_STORE(BUF)                                                                   \
-  {                                                                                           \
-    _Pragma("unroll") for (int a = 0; a < NARR; ++a)                                          \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                         \
-            *reinterpret_cast<float4*>(&lds[BUF][a][(tid + 256 * u) << 2]) = sr[a][u];        \
+// Cooperative stage of one streamed tile with the LDS DMA (global_load_lds, 16 bytes per lane:
+// one wave instruction moves 1 KiB from per-lane global addresses to a lane-linear LDS chunk).
+// No VGPRs are spent on staging and the copy of tile t+1 runs under the MFMAs of tile t; the
+// __syncthreads() that ends the tile waits for it (vmcnt) before anyone reads the buffer.
+typedef const __attribute__((address_space(1))) void* ms_gptr;
+typedef __attribute__((address_space(3))) void* ms_lptr;
+#define MS_GLDS16(G, L) __builtin_amdgcn_global_load_lds((ms_gptr)(G), (ms_lptr)(L), 16, 0, 0)
+#define MS_GLDS4(G, L) __builtin_amdgcn_global_load_lds((ms_gptr)(G), (ms_lptr)(L), 4, 0, 0)
+#define MS_STAGE(MT, BUF)                                                                       \
+  {                                                                                             \
+    const int j0s = (MT) * 32;                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
+      const int q = wave * 4 + u; /* 1 KiB chunk of the 16 KiB tile */                          \
+      /* channel-first tiles [128 ch][32 idx]: chunk q = rows 8q..8q+7 */                       \
+      const size_t ga = (size_t)(q * 8 + (lane >> 3)) * Np + j0s + ((lane & 7) << 2);           \
+      MS_GLDS16(Atb + ga, &lds[BUF][0][q * 256]);                                               \
+      if (PASS == 2) MS_GLDS16(At1b + ga, &lds[BUF][NARR - 2][q * 256]);                        \
+      /* point-major tiles [32 idx][128 feat]: chunk q = rows 2q, 2q+1; rows past N clamp */    \
+      const size_t gp = (size_t)min(j0s + q * 2 + (lane >> 5), N - 1) * MS_D + ((lane & 31) << 2); \
+      MS_GLDS16(P0b + gp, &lds[BUF][1][q * 256]);                                               \
+      if (PASS == 2) MS_GLDS16(P1b + gp, &lds[BUF][NARR - 1][q * 256]);                         \
+    }                                                                                           \
+    if (PASS == 2 && wave == 0) { /* per-row scalars c_i | r_i of the tile: 64 floats */        \
+      const int jc = min(j0s + (lane & 31), N - 1);                                             \
+      MS_GLDS4((lane < 32 ? cs : rs) + bN + jc, &lds_sc[BUF][0]);                               \
+    }                                                                                           \
   }
 
 template <int PASS>
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   //   arr 2/3 (PASS 2): At1 and P1 likewise
   constexpr int NARR = PASS == 2 ? 4 : 2;
   __shared__ __attribute__((aligned(16))) float lds[2][NARR][MS_TILE];
+  __shared__ __attribute__((aligned(16))) float lds_sc[2][64];
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -128,20 +133,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 16; ++r) acc_o[fb][r] = 0.f;
   float rsum = 0.f;
 
-  float4 sr[NARR][4];
   int cur = 0;
-  if (t_begin < t_end) {
-    MS_STAGE_LOAD(t_begin);
-    MS_STAGE_STORE(0);
-  }
+  if (t_begin < t_end) MS_STAGE(t_begin, 0);
   __syncthreads();
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int j0 = mt * 32;
     const bool has_next = mt + 1 < t_end;
-    if (has_next) MS_STAGE_LOAD(mt + 1);  // in flight while this tile is computed
-    // keep the scheduler from sinking the loads / hoisting the LDS stores across the compute:
-    // the stores (and their vmcnt wait) must come AFTER the MFMA work they overlap with
-    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) MS_STAGE(mt + 1, cur ^ 1);  // DMA in flight while this tile is computed
     if (wave_on) {
       const float* __restrict__ lAt = lds[cur][0];
       const float* __restrict__ lP0 = lds[cur][1];
@@ -192,12 +190,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (PASS == 2) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int jj = j0 + 8 * g + 4 * h;  // 4 consecutive streamed rows, may run past N
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int jc = min(jj + u, N - 1);
-            cst[4 * g + u] = cs[bN + jc];
-            rst[4 * g + u] = 1.0f / (rs[bN + jc] * bsq);
+            const int lr = 8 * g + 4 * h + u;  // streamed row inside the tile
+            cst[4 * g + u] = lds_sc[cur][lr];
+            rst[4 * g + u] = 1.0f / (lds_sc[cur][32 + lr] * bsq);
           }
         }
       }
@@ -247,8 +244,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) MS_STAGE_STORE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
