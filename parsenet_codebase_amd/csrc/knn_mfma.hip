@@ -120,8 +120,6 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
   // LDS once per block, double buffered, and shared by the four waves (different queries).
   constexpr int CP = 2 * KSTEPS;
   constexpr int TILE = CP * 32;            // floats
-  constexpr int NF4 = TILE / 4;            // float4 per tile
-  constexpr int PER = (NF4 + 255) / 256;   // float4 per thread
   __shared__ __attribute__((aligned(16))) float lds[2][TILE + 32];
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
@@ -157,39 +155,32 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     sub[s] = lists + ((((size_t)b * Nqp + qcl) * S + slice) * 2 + h) * (size_t)subcap;
   }
 
-  float4 sr[PER];
-  float4 sx = make_float4(0.f, 0.f, 0.f, 0.f);
-#define KM_STAGE_LOAD(MT)                                                              \
-  {                                                                                    \
-    const int j0s = (MT) * 32;                                                         \
-    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                  \
-      const int q = tid + 256 * u; /* row c = q / 8, 4 candidates (q & 7) * 4 */       \
-      if (q < NF4)                                                                     \
-        sr[u] = *reinterpret_cast<const float4*>(xcb + (size_t)(q >> 3) * Ncp + j0s + ((q & 7) << 2)); \
-    }                                                                                  \
-    if (MODE != 2 && tid < 8) sx = *reinterpret_cast<const float4*>(xxcb + j0s + (tid << 2)); \
-  }
-#define KM_STAGE_STORE(BUF)                                                            \
-  {                                                                                    \
-    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                  \
-      const int q = tid + 256 * u;                                                     \
-      if (q < NF4) *reinterpret_cast<float4*>(&lds[BUF][q << 2]) = sr[u];              \
-    }                                                                                  \
-    if (MODE != 2 && tid < 8) *reinterpret_cast<float4*>(&lds[BUF][TILE + (tid << 2)]) = sx; \
+  // stage with the LDS DMA: one wave instruction copies a 1 KiB chunk (8 channel rows x 32
+  // candidates) from per-lane global addresses into the lane-linear LDS image; no staging VGPRs
+  typedef const __attribute__((address_space(1))) void* km_gptr;
+  typedef __attribute__((address_space(3))) void* km_lptr;
+  constexpr int NCHUNK = (TILE + 255) / 256;
+#define KM_STAGE(MT, BUF)                                                                        \
+  {                                                                                              \
+    const int j0s = (MT) * 32;                                                                   \
+    _Pragma("unroll") for (int q = 0; q < NCHUNK; ++q) {                                         \
+      if ((q & 3) == wave) {                                                                     \
+        const int row = q * 8 + (lane >> 3);                                                     \
+        if (row < CP)                                                                            \
+          __builtin_amdgcn_global_load_lds((km_gptr)(xcb + (size_t)row * Ncp + j0s + ((lane & 7) << 2)), \
+                                           (km_lptr)(&lds[BUF][q * 256]), 16, 0, 0);             \
+      }                                                                                          \
+    }                                                                                            \
+    if (MODE != 2 && wave == 3 && lane < 32)                                                     \
+      __builtin_amdgcn_global_load_lds((km_gptr)(xxcb + j0s + lane), (km_lptr)(&lds[BUF][TILE]), 4, 0, 0); \
   }
   int cur = 0;
-  if (t_begin < t_end) {
-    KM_STAGE_LOAD(t_begin);
-    KM_STAGE_STORE(0);
-  }
+  if (t_begin < t_end) KM_STAGE(t_begin, 0);
   __syncthreads();
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int j0 = mt * 32;
     const bool has_next = mt + 1 < t_end;
-    if (has_next) KM_STAGE_LOAD(mt + 1);  // in flight while this tile is computed
-    // keep the scheduler from sinking the loads / hoisting the LDS stores across the compute:
-    // the stores (and their vmcnt wait) must come AFTER the MFMA work they overlap with
-    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) KM_STAGE(mt + 1, cur ^ 1);  // DMA in flight while this tile is computed
     if (wave_on) {
       const float* __restrict__ lx = lds[cur];
       f32x16 acc[QSETS], accn[MODE == 1 ? QSETS : 1];
@@ -263,13 +254,10 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) KM_STAGE_STORE(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
-#undef KM_STAGE_LOAD
-#undef KM_STAGE_STORE
+#undef KM_STAGE
   if (COLLECT && wave_on) {
 #pragma unroll
     for (int s = 0; s < QSETS; ++s) {
