@@ -81,7 +81,7 @@ typedef __attribute__((address_space(3))) void* ms_lptr;
   }
 
 template <int PASS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void pn_ms_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 0 ? 2 : 1))) void pn_ms_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const float* __restrict__ At,
     const float* __restrict__ At1, const float* __restrict__ P0, const float* __restrict__ P1,
     const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_,

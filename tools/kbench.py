@@ -34,6 +34,13 @@ def bench_knn():
         print("knn B=%d C=%d N=%d k=%d %s: %.3f ms  %.1f TFLOP/s" % (B, C, N, k, metric, ms, flops / ms / 1e9))
 
 
+def bench_knn64():
+    dev = torch.device("cuda:0")
+    x = torch.randn(4, 64, 10000, device=dev)
+    ms = timeit(lambda: kernels.knn(x, 80, "feature"))
+    print("knn64: %.3f ms" % ms)
+
+
 def bench_chamfer():
     dev = torch.device("cuda:0")
     for (B, Na, Nb) in [(1, 10000, 10000), (32, 1600, 700), (1, 900, 2000)]:
