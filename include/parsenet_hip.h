@@ -161,7 +161,9 @@ int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N
  *   bwd        : exact Group/BatchNorm gradient on every edge -> dPQ (B,N,2*Cout);
  *                t = gamma*gz, c1c2 fp32 [(per_sample?B:1)][groups][2] = group means of t and
  *                t*yhat over the edge activations; dense = 0 when the statistics were constants
- *                (eval-mode BatchNorm). */
+ *                (eval-mode BatchNorm).  The dense term is evaluated by transposing the kNN
+ *                graph (CSR by target point, built inside the call in `workspace`) and gathering
+ *                rows of Q; only the extreme edge of every (point, channel) uses an atomic. */
 int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma, int B,
                                int N, int k, int Cout, int groups, int per_sample, float* yext,
                                uint8_t* argk, float* s1, double* stats, void* stream);
@@ -175,10 +177,12 @@ int pn_edgeconv_bwd_prep_f32(const float* gout, const float* yext, const float* 
                              const float* rstd, const float* gamma, const float* beta, int B,
                              int N, int Cout, int groups, int per_sample, float slope, float* gz,
                              float* yhat, void* stream);
+size_t pn_edgeconv_bwd_workspace(int B, int N, int k);
 int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t, const float* s1,
                         const uint8_t* argk, const float* mean, const float* rstd,
                         const float* c1c2, int B, int N, int k, int Cout, int groups,
-                        int per_sample, int dense, float* dPQ, void* stream);
+                        int per_sample, int dense, float* dPQ, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- Chamfer nearest neighbour ---------------------------------------------------
  * Replaces the (M,N,3) broadcast + torch.min of src/utils.py:286-296 (chamfer_distance),

@@ -42,9 +42,10 @@ SIGNATURES = {
                                              c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "pn_edgeconv_bwd_prep_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "pn_edgeconv_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_edgeconv_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                    c_void_p]),
+                                    c_void_p, c_size_t, c_void_p]),
     "pn_dot_select_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pn_dot_select_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -538,20 +538,208 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_kernel(
   }
 }
 
+// ---- reverse kNN graph (CSR by target point) -----------------------------------------------
+// The dense part of the normalisation gradient needs, for every point j, the sum of Q[i] over
+// the edges (i -> j) that END in j.  Scattering 4*B*N*k*Cout bytes of fp32 atomics costs three
+// times the forward pass; instead the graph is transposed once per backward call (counting
+// sort with int atomics: 2 per edge) and the sum becomes a row gather like the forward.
+__global__ void pn_rev_count_kernel(const int64_t* __restrict__ idx, long long nedges, int N, int k,
+                                    int* __restrict__ deg) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nedges) return;
+  const long long b = e / ((long long)N * k);
+  atomicAdd(&deg[b * N + (int)idx[e]], 1);
+}
+
+// one block per item: exclusive scan of deg -> off (N+1 entries), cursor = copy of off
+__global__ __launch_bounds__(1024) void pn_rev_scan_kernel(const int* __restrict__ deg, int N,
+                                                           int* __restrict__ off,
+                                                           int* __restrict__ cursor) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int per = (N + 1023) / 1024;
+  const int lo = min(N, t * per), hi = min(N, lo + per);
+  const int* d = deg + (size_t)b * N;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += d[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;  // exclusive prefix of this thread's chunk
+  int* ob = off + (size_t)b * (N + 1);
+  int* cb = cursor + (size_t)b * N;
+  for (int i = lo; i < hi; ++i) {
+    ob[i] = run;
+    cb[i] = run;
+    run += d[i];
+  }
+  if (t == 1023) ob[N] = part[1023];
+}
+
+__global__ void pn_rev_fill_kernel(const int64_t* __restrict__ idx, long long nedges, int N, int k,
+                                   int* __restrict__ cursor, int* __restrict__ rev) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nedges) return;
+  const long long per = (long long)N * k;
+  const long long b = e / per;
+  const long long r = e - b * per;  // i*k + kk
+  const int pos = atomicAdd(&cursor[b * N + (int)idx[e]], 1);
+  rev[b * per + pos] = (int)(r / k);  // source point i
+}
+
+// dense term, one wave per target point j:
+//   dP[j,c] = -r*deg_j*(c1 + c2*r*(P[j,c]-mu)) - r^2*c2*sum_{(i->j)} Q[i,c]
+template <int COUT>
+__global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
+    const float* __restrict__ PQ, const int* __restrict__ off, const int* __restrict__ rev,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ c1c2,
+    int N, int k, int Cg, int per_sample, float* __restrict__ dPQ) {
+  constexpr int NCH = COUT <= 256 ? 1 : COUT / 256;
+  constexpr int LPR = COUT <= 256 ? COUT / 4 : 64;
+  constexpr int RPI = 64 / LPR;
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= N) return;
+  const int rg = lane / LPR, cl = lane - rg * LPR;
+  const int G = COUT / Cg;
+  const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * COUT;
+  const int* __restrict__ ob = off + (size_t)b * (N + 1);
+  const int* __restrict__ rb = rev + (size_t)b * N * k;
+  const int e0 = ob[j], e1 = ob[j + 1];
+  float4x acc[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[h].v[u] = 0.f;
+  for (int e = e0 + rg; e < e1; e += RPI) {
+    const int i = rb[e];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const float4x q = ld4(PQb + (size_t)i * 2 * COUT + COUT + (cl + h * 64) * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[h].v[u] += q.v[u];
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[h].v[u] += __shfl_xor(acc[h].v[u], o, 64);
+  if (rg == 0) {
+    const float deg = (float)(e1 - e0);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const int c0 = (cl + h * 64) * 4;
+      const float4x p = ld4(PQb + (size_t)j * 2 * COUT + c0);
+      float4x o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sidx = (per_sample ? b : 0) * G + (c0 + u) / Cg;
+        const float mu = mean[sidx], r = rstd[sidx];
+        const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
+        o.v[u] = -r * deg * (c1 + c2 * r * (p.v[u] - mu)) - r * r * c2 * acc[h].v[u];
+      }
+      st4(dPQ + ((size_t)b * N + j) * 2 * COUT + c0, o);
+    }
+  }
+}
+
+// per source point: dQ[i] (closed form) and the extreme edge's share of dP (sparse atomics)
+__global__ __launch_bounds__(256) void pn_edgeconv_bwd_point_kernel(
+    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ t,
+    const float* __restrict__ s1, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cout, int Cg,
+    int per_sample, float* __restrict__ dPQ) {
+  const int b = blockIdx.y;
+  const long long tix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= (long long)N * Cout) return;
+  const int i = (int)(tix / Cout), c = (int)(tix - (long long)i * Cout);
+  const int G = Cout / Cg;
+  const int sidx = (per_sample ? b : 0) * G + c / Cg;
+  const float mu = mean[sidx], r = rstd[sidx];
+  const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
+  const size_t o = ((size_t)b * N + i) * Cout + c;
+  const float tt = t[o];
+  const float fk = (float)k;
+  float* __restrict__ dPQb = dPQ + (size_t)b * N * 2 * Cout;
+  dPQb[(size_t)i * 2 * Cout + Cout + c] = r * (tt - fk * c1 - c2 * r * (s1[o] - fk * mu));
+  const int j = (int)idx[((size_t)b * N + i) * k + argk[o]];
+  atomicAdd(&dPQb[(size_t)j * 2 * Cout + c], r * tt);
+}
+
+extern "C" size_t pn_edgeconv_bwd_workspace(int B, int N, int k) {
+  return pn_align_up((size_t)B * N * 4, 256) * 2 + pn_align_up((size_t)B * (N + 1) * 4, 256) +
+         pn_align_up((size_t)B * N * k * 4, 256);
+}
+
 extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t,
                                    const float* s1, const uint8_t* argk, const float* mean,
                                    const float* rstd, const float* c1c2, int B, int N, int k,
                                    int Cout, int groups, int per_sample, int dense, float* dPQ,
-                                   void* stream_) {
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(PQ && idx && t && s1 && argk && mean && rstd && c1c2 && dPQ,
                "pn_edgeconv_bwd_f32: null pointer");
   PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_bwd_f32: groups=%d", groups);
-  PN_CHECK_HIP(hipMemsetAsync(dPQ, 0, (size_t)B * N * 2 * Cout * sizeof(float), stream));
-  PN_PROF("edgeconv_bwd", stream);
-  dim3 grid(pn_cdiv(N, 4), B);
-  hipLaunchKernelGGL(pn_edgeconv_bwd_kernel, grid, dim3(256), 0, stream, PQ, idx, t, s1, argk,
-                     mean, rstd, c1c2, N, k, Cout, Cout / groups, per_sample, dense, dPQ);
+  const int Cg = Cout / groups;
+  const bool fast = dense && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512);
+  if (!fast) {
+    // eval-mode BatchNorm (no dense term) and unusual widths: per-edge atomics
+    PN_CHECK_HIP(hipMemsetAsync(dPQ, 0, (size_t)B * N * 2 * Cout * sizeof(float), stream));
+    PN_PROF("edgeconv_bwd", stream);
+    dim3 grid(pn_cdiv(N, 4), B);
+    hipLaunchKernelGGL(pn_edgeconv_bwd_kernel, grid, dim3(256), 0, stream, PQ, idx, t, s1, argk,
+                       mean, rstd, c1c2, N, k, Cout, Cg, per_sample, dense, dPQ);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+  }
+  PN_CHECK_ARG(workspace && workspace_bytes >= pn_edgeconv_bwd_workspace(B, N, k),
+               "pn_edgeconv_bwd_f32: workspace too small");
+  char* w = (char*)workspace;
+  int* deg = (int*)w;
+  w += pn_align_up((size_t)B * N * 4, 256);
+  int* cursor = (int*)w;
+  w += pn_align_up((size_t)B * N * 4, 256);
+  int* off = (int*)w;
+  w += pn_align_up((size_t)B * (N + 1) * 4, 256);
+  int* rev = (int*)w;
+  const long long nedges = (long long)B * N * k;
+  PN_CHECK_HIP(hipMemsetAsync(deg, 0, (size_t)B * N * 4, stream));
+  {
+    PN_PROF("edgeconv_bwd_csr", stream);
+    hipLaunchKernelGGL(pn_rev_count_kernel, dim3(pn_cdiv(nedges, 256)), dim3(256), 0, stream, idx,
+                       nedges, N, k, deg);
+    hipLaunchKernelGGL(pn_rev_scan_kernel, dim3(B), dim3(1024), 0, stream, deg, N, off, cursor);
+    hipLaunchKernelGGL(pn_rev_fill_kernel, dim3(pn_cdiv(nedges, 256)), dim3(256), 0, stream, idx,
+                       nedges, N, k, cursor, rev);
+  }
+  PN_CHECK_LAUNCH();
+  {
+    PN_PROF("edgeconv_bwd", stream);
+    dim3 grid(pn_cdiv(N, 4), B);
+#define EC_BG(CO)                                                                               \
+  hipLaunchKernelGGL(pn_edgeconv_bwd_gather_kernel<CO>, grid, dim3(256), 0, stream, PQ, off, rev, \
+                     mean, rstd, c1c2, N, k, Cg, per_sample, dPQ)
+    if (Cout == 64)
+      EC_BG(64);
+    else if (Cout == 128)
+      EC_BG(128);
+    else if (Cout == 256)
+      EC_BG(256);
+    else
+      EC_BG(512);
+#undef EC_BG
+    dim3 g2(pn_cdiv((long long)N * Cout, 256), B);
+    hipLaunchKernelGGL(pn_edgeconv_bwd_point_kernel, g2, dim3(256), 0, stream, PQ, idx, t, s1, argk,
+                       mean, rstd, c1c2, N, k, Cout, Cg, per_sample, dPQ);
+  }
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -201,11 +201,14 @@ def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, den
     Cout = C2 // 2
     k = idx.shape[2]
     dPQ = torch.empty_like(PQ)
+    lib = _lib.load()
+    wsz = lib.pn_edgeconv_bwd_workspace(B, N, k)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=PQ.device)
     with torch.cuda.device(PQ.device):
-        rc = _lib.load().pn_edgeconv_bwd_f32(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk),
-                                             ptr(mean), ptr(rstd), ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout,
-                                             groups, int(per_sample), int(dense), ptr(dPQ),
-                                             current_stream(PQ.device))
+        rc = lib.pn_edgeconv_bwd_f32(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk), ptr(mean),
+                                     ptr(rstd), ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout, groups,
+                                     int(per_sample), int(dense), ptr(dPQ), ptr(ws), wsz,
+                                     current_stream(PQ.device))
     check(rc, "pn_edgeconv_bwd_f32")
     return dPQ
 
