@@ -150,7 +150,8 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
     wa, wb = w[:, :C], w[:, C:]
     # W [xj - xi ; xi] = Wa xj + (Wb - Wa) xi: one GEMM on points
     wcat = torch.cat([wa, wb - wa], 0)                     # (2Cout, C)
-    PQ = torch.matmul(x.transpose(1, 2), wcat.t())          # (B,N,2Cout)
+    # batched with stride 0 on the weight: no transposing copy of x (see encoders.weight_bmm)
+    PQ = torch.bmm(x.transpose(1, 2), wcat.t().unsqueeze(0).expand(B, -1, -1))   # (B,N,2Cout)
     if isinstance(norm, torch.nn.GroupNorm):
         out, _ = _EdgeConvNormMax.apply(PQ, idx, norm.weight, norm.bias, norm.num_groups, True, norm.eps,
                                         slope, None)

@@ -1,0 +1,20 @@
+"""Attribute torch-side kernels (copies, elementwise, reductions) of one workload step to
+tensor shapes: python tools/torchprof.py [cfg4|cfg5]."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from parsenet_codebase_amd import workloads
+
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+dev = torch.device("cuda:0")
+step = (workloads.ParsenetSegStep if which == "cfg4" else workloads.ParsenetE2EStep)(dev)
+for _ in range(2):
+    step.step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    step.step()
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45,
+                                                         max_name_column_width=40, max_shapes_column_width=70))
