@@ -77,13 +77,13 @@ int pn_dot_select_f32(const float* q, int Nq, const float* c, int Nc, int B, int
 /* ---- mean-shift iterations ----------------------------------------------------------
  * Replaces src/mean_shift.py:45-79 (mean_shift_, gaussian kernel) and the autograd graph the
  * reference keeps through it.  All tensors point-major (B,N,D) with D = 128; bsq (B) = b^2.
- *   slices   : number S of column slices the launch uses for (B,N) (sizes the scratch).
+ *   slices   : upper bound S of the column slices the launches use for (B,N) (sizes the scratch).
  *   pack     : x (B,N,D) -> xt (B,D,Np), Np = N rounded up to 64, zero padded.
  *   iter_fwd : y = normalise(q + ((K X) / rowsum(K) - q)), K = exp(clamp(-(2 - 2 q x^T)/b^2/2)).
  *              Scratch opart (B,S,N,D), rpart (B,S,N).  Saves rsum, unorm (B,N).
- *   iter_bwd : given gy = dL/dy: sum_s opart_q = dL/dq, sum_s opart_x = this iteration's
- *              contribution to dL/dx (recomputes K; nothing of size N x N is stored).
- *              Scratch gu, go (B,N,D), cs (B,N), qt, gut (B,D,Np), opart_q, opart_x (B,S,N,D). */
+ *   iter_bwd : given gy = dL/dy: gq = dL/dq (overwritten), gx += this iteration's contribution
+ *              to dL/dx (recomputes K; nothing of size N x N is stored).
+ *              Scratch gu, go (B,N,D), cs (B,2,N), qt, gut (B,D,Np), opart_q, opart_x (B,S,N,D). */
 int pn_meanshift_slices(int B, int N);
 int pn_meanshift_pack_f32(const float* x, int B, int N, int D, float* xt, void* stream);
 int pn_meanshift_iter_fwd_f32(const float* q, const float* x, const float* xt, const float* bsq,
@@ -93,7 +93,7 @@ int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const float* q, c
                               const float* xt, const float* rsum, const float* unorm,
                               const float* bsq, int B, int N, int D, float* gu, float* go,
                               float* cs, float* qt, float* gut, float* opart_q, float* opart_x,
-                              void* stream);
+                              float* gq, float* gx, void* stream);
 
 /* ---- GroupNorm (+ReLU) (+max over points) of the per-point heads -------------------------
  * Replaces torch GroupNorm -> ReLU (-> max over N) of src/PointNet.py:216-218, 274-283 on

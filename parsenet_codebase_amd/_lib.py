@@ -53,7 +53,7 @@ SIGNATURES = {
     "pn_meanshift_pack_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_iter_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "pn_meanshift_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 7 + [c_void_p]),
+    "pn_meanshift_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 9 + [c_void_p]),
     "pn_gn_rows_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "pn_gn_group_moments_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,

@@ -16,7 +16,8 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libparsenet_hip.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = [
+# PN_EXTRA_HIPCC_FLAGS: developer hook (e.g. "-DMS_TIMING" for the phase timers of meanshift.hip)
+FLAGS = os.environ.get("PN_EXTRA_HIPCC_FLAGS", "").split() + [
     "--offload-arch=gfx950",
     "-O3",
     "-std=c++17",

@@ -23,23 +23,21 @@
 //   gq_i  = sum_j gs_ij x_j                               (PASS 1, rows resident)
 //   gX_j += sum_i gs_ij q_i + sum_i K_ij go_i             (PASS 2, columns resident)
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MS_D 128
 #define MS_KS (MS_D / 2)  // k-steps of the 128-d dot products
 
-__device__ static inline float ms_kernel_value(float s, float hinv, bool* inside) {
-  // reference: dist = 2 - 2 s ; arg = -dist / b^2 / 2 ; clamp(+-75) ; exp.
-  // Evaluated as arg = -dist * (0.5 / b^2) (one rounding instead of the division's; <= 1 ulp of
-  // arg) and with the hardware exp2 (v_exp_f32, ~1e-7 relative): the two division/exp library
-  // sequences were a third of this kernel's time and the difference is far below the 1e-5 bar.
-  const float dist = __builtin_fmaf(-2.0f, s, 2.0f);
-  float arg = -dist * hinv;
-  *inside = (arg >= -75.0f) && (arg <= 75.0f);
-  arg = fminf(fmaxf(arg, -75.0f), 75.0f);
-  return __builtin_amdgcn_exp2f(arg * 1.4426950408889634f);
-}
+// Kernel value, reference: dist = 2 - 2 s ; arg = -dist / b^2 / 2 ; clamp(+-75) ; exp.
+// Evaluated as exp2(clamp(-dist * hl)) with hl = (0.5 / b^2) * log2(e) and the hardware exp2
+// (v_exp_f32, ~1e-7 relative): one rounding of the argument instead of the reference's two
+// divisions (<= 1-2 ulp of arg, i.e. <= |arg| * 1.2e-7 relative on K — far below the 1e-5
+// bar); the division/exp library sequences were a third of the kernel's time.
+#define MS_LOG2E 1.4426950408889634f
+#define MS_LIM2 (75.0f * MS_LOG2E)
 
 // PASS 0: forward          resident rows = Q,  streamed cols = X : out[f][row] += X[col][f] * K
 // PASS 1: backward, rows   resident rows = Q, GU; streamed cols = X : out += X[col][f] * gs
@@ -48,7 +46,7 @@ __device__ static inline float ms_kernel_value(float s, float hinv, bool* inside
 // R  (B,N,D)  point-major resident operand; R1 second resident operand (PASS 1: GU)
 // At (B,D,Np) channel-first padded streamed operand for S; At1 for T (PASS 2: GUt; PASS 1 reuses At)
 // P0 (B,N,D)  point-major streamed operand of the second GEMM; P1 second one (PASS 2: GO)
-// cs, rs      per-row scalars c_i and r_i (PASS 1: indexed by the resident row; PASS 2: streamed)
+// cs, rs      per-row scalars c_i and alpha_i = 1/(r_i b^2) (PASS 1: of the resident row; PASS 2: streamed)
 // opart (B,S,N,D), rpart (B,S,N) partial outputs of slice blockIdx.y
 #define MS_TILE 4096  // floats per staged array tile (16 KiB): 128 channels x 32 columns
 
@@ -60,28 +58,43 @@ typedef const __attribute__((address_space(1))) void* ms_gptr;
 typedef __attribute__((address_space(3))) void* ms_lptr;
 #define MS_GLDS16(G, L) __builtin_amdgcn_global_load_lds((ms_gptr)(G), (ms_lptr)(L), 16, 0, 0)
 #define MS_GLDS4(G, L) __builtin_amdgcn_global_load_lds((ms_gptr)(G), (ms_lptr)(L), 4, 0, 0)
-#define MS_STAGE(MT, BUF)                                                                       \
+#define MS_STAGE_PIECE(MT, BUF, U)                                                              \
   {                                                                                             \
     const int j0s = (MT) * 32;                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                             \
-      const int q = wave * 4 + u; /* 1 KiB chunk of the 16 KiB tile */                          \
-      /* channel-first tiles [128 ch][32 idx]: chunk q = rows 8q..8q+7 */                       \
-      const size_t ga = (size_t)(q * 8 + (lane >> 3)) * Np + j0s + ((lane & 7) << 2);           \
-      MS_GLDS16(Atb + ga, &lds[BUF][0][q * 256]);                                               \
-      if (PASS == 2) MS_GLDS16(At1b + ga, &lds[BUF][NARR - 2][q * 256]);                        \
-      /* point-major tiles [32 idx][128 feat]: chunk q = rows 2q, 2q+1; rows past N clamp */    \
-      const size_t gp = (size_t)min(j0s + q * 2 + (lane >> 5), N - 1) * MS_D + ((lane & 31) << 2); \
-      MS_GLDS16(P0b + gp, &lds[BUF][1][q * 256]);                                               \
-      if (PASS == 2) MS_GLDS16(P1b + gp, &lds[BUF][NARR - 1][q * 256]);                         \
-    }                                                                                           \
-    if (PASS == 2 && wave == 0) { /* per-row scalars c_i | r_i of the tile: 64 floats */        \
-      const int jc = min(j0s + (lane & 31), N - 1);                                             \
-      MS_GLDS4((lane < 32 ? cs : rs) + bN + jc, &lds_sc[BUF][0]);                               \
-    }                                                                                           \
+    const int q = wave * 4 + (U); /* 1 KiB chunk of the 16 KiB tile */                          \
+    /* channel-first tiles [128 ch][32 idx]: chunk q = rows 8q..8q+7 */                         \
+    const size_t ga = (size_t)(q * 8 + (lane >> 3)) * Np + j0s + ((lane & 7) << 2);             \
+    MS_GLDS16(Atb + ga, &lds[BUF][0][q * 256]);                                                 \
+    if (PASS == 2) MS_GLDS16(At1b + ga, &lds[BUF][NARR - 2][q * 256]);                          \
+    /* point-major tiles [32 idx][128 feat]: chunk q = rows 2q, 2q+1; rows past N clamp */      \
+    const size_t gp = (size_t)min(j0s + q * 2 + (lane >> 5), N - 1) * MS_D + ((lane & 31) << 2); \
+    MS_GLDS16(P0b + gp, &lds[BUF][1][q * 256]);                                                 \
+    if (PASS == 2) MS_GLDS16(P1b + gp, &lds[BUF][NARR - 1][q * 256]);                           \
+  }
+#define MS_STAGE_SCALARS(MT, BUF)                                                               \
+  if (PASS == 2 && wave == 0) { /* per-row scalars c_i | alpha_i of the tile: 64 floats */      \
+    const int jc = min((MT) * 32 + (lane & 31), N - 1);                                         \
+    MS_GLDS4((lane < 32 ? cs : rs) + bN + jc, &lds_sc[BUF][0]);                                 \
+  }
+#define MS_STAGE(MT, BUF)                                                                       \
+  {                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) MS_STAGE_PIECE(MT, BUF, u);                   \
+    MS_STAGE_SCALARS(MT, BUF);                                                                  \
   }
 
+#ifdef MS_TIMING
+// developer build only: per-phase shader-clock totals of wave 0 of workgroup (0,0,0)
+__device__ unsigned long long ms_dbg[3][8];
+extern "C" int pn_ms_debug_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ms_dbg), sizeof(ms_dbg));
+}
+#define MS_T(V) const unsigned long long V = __builtin_amdgcn_s_memtime()
+#else
+#define MS_T(V)
+#endif
+
 template <int PASS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 0 ? 2 : 1))) void pn_ms_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void pn_ms_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const float* __restrict__ At,
     const float* __restrict__ At1, const float* __restrict__ P0, const float* __restrict__ P1,
     const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_,
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
   const int t_begin = slice * tiles_per_slice;
   const int t_end = min(ntiles, t_begin + tiles_per_slice);
   const float bsq = bsq_[b];
-  const float hinv = 0.5f / bsq;
+  const float hl = (0.5f / bsq) * MS_LOG2E;
   const size_t bN = (size_t)b * N;
   const float* __restrict__ Atb = At + (size_t)b * MS_D * Np;
   const float* __restrict__ At1b = PASS == 2 ? At1 + (size_t)b * MS_D * Np : nullptr;
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
   float c_res = 0.f, rinv_res = 0.f;
   if (PASS == 1) {
     c_res = cs[bN + ires];
-    rinv_res = 1.0f / (rs[bN + ires] * bsq);
+    rinv_res = rs[bN + ires];
   }
   f32x16 acc_o[4];
 #pragma unroll
@@ -136,10 +149,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
   int cur = 0;
   if (t_begin < t_end) MS_STAGE(t_begin, 0);
   __syncthreads();
+#ifdef MS_TIMING
+  unsigned long long tg1 = 0, tew = 0, tg2 = 0, tbar = 0, tall = __builtin_amdgcn_s_memtime();
+#endif
   for (int mt = t_begin; mt < t_end; ++mt) {
+    MS_T(T0);
     const int j0 = mt * 32;
     const bool has_next = mt + 1 < t_end;
-    if (has_next) MS_STAGE(mt + 1, cur ^ 1);  // DMA in flight while this tile is computed
+    // The DMA of tile t+1 runs under the MFMAs of tile t.  Each global_load_lds costs its wave
+    // 60-180 issue cycles, so the pieces are spread over the MFMA groups of the first GEMM (one
+    // per 64-cycle MFMA shadow) instead of being issued back to back in front of them.
+    if (has_next && !wave_on) MS_STAGE(mt + 1, cur ^ 1);
     if (wave_on) {
       const float* __restrict__ lAt = lds[cur][0];
       const float* __restrict__ lP0 = lds[cur][1];
@@ -169,6 +189,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
               if (PASS == 2) an1[u] = lAt1[(2 * (8 * (g + 1) + u) + h) * 32 + col];
             }
           }
+          if (has_next) {
+            if ((g & 1) == 0) MS_STAGE_PIECE(mt + 1, cur ^ 1, g >> 1);
+            if (g == 1) MS_STAGE_SCALARS(mt + 1, cur ^ 1);
+          }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const int m = 8 * g + u;
@@ -184,6 +208,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
           }
         }
       }
+      MS_T(T1);
+#ifdef MS_TIMING
+      tg1 += T1 - T0;
+#endif
       // elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col]
       float kv[16], gs[PASS == 0 ? 1 : 16];
       float cst[PASS == 2 ? 16 : 1], rst[PASS == 2 ? 16 : 1];
@@ -194,21 +222,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
           for (int u = 0; u < 4; ++u) {
             const int lr = 8 * g + 4 * h + u;  // streamed row inside the tile
             cst[4 * g + u] = lds_sc[cur][lr];
-            rst[4 * g + u] = 1.0f / (lds_sc[cur][32 + lr] * bsq);
+            rst[4 * g + u] = lds_sc[cur][32 + lr];
           }
         }
       }
+      // Elementwise stage.  It is NOT interleaved with the MFMAs of the second GEMM: measured
+      // with the phase timers (MS_TIMING), fp32 MFMA and VALU work of a wave do not overlap on
+      // gfx950 — interleaving cost 7400 cycles per tile against 2400 + 4200 back to back — so
+      // the stage is kept short instead.
+      // ~10 VALU instructions per value: exp2 with log2(e) folded into the bandwidth factor,
+      // the clamp test as (clamped == unclamped), the padded-column test only in the last tile.
+#define MS_EW(R, TAIL)                                                                 \
+  {                                                                                    \
+    const float dist = __builtin_fmaf(-2.0f, s[R], 2.0f);                              \
+    const float a2 = -dist * hl;                                                       \
+    const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);                  \
+    float k = __builtin_amdgcn_exp2f(a2c);                                             \
+    if (TAIL && j0 + ((R) & 3) + 8 * ((R) >> 2) + 4 * h >= N) k = 0.f;                 \
+    kv[R] = k;                                                                         \
+    if (PASS == 0) rsum += k;                                                          \
+    if (PASS != 0) {                                                                   \
+      float g = PASS == 1 ? k * ((t[R] - c_res) * rinv_res)                            \
+                          : k * ((t[R] - cst[PASS == 2 ? (R) : 0]) * rst[PASS == 2 ? (R) : 0]); \
+      asm volatile("" : "+v"(g)); /* keep the select a v_cndmask, not a branch */        \
+      gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                                   \
+    }                                                                                  \
+  }
+      if (j0 + 32 > N) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        bool inside;
-        float k = ms_kernel_value(s[r], hinv, &inside);
-        if (j0 + row >= N) k = 0.f;
-        kv[r] = k;
-        if (PASS == 0) rsum += k;
-        if (PASS == 1) gs[r] = inside ? k * (t[r] - c_res) * rinv_res : 0.f;
-        if (PASS == 2) gs[r] = inside ? k * (t[r] - cst[r]) * rst[r] : 0.f;
+        for (int r = 0; r < 16; ++r) MS_EW(r, true);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) MS_EW(r, false);
       }
+      MS_T(T2);
+#ifdef MS_TIMING
+      tew += T2 - T1;
+#endif
       // second GEMM: out[f][resident] += sum_streamed P[streamed][f] * w[streamed][resident];
       // k-step m pairs the streamed indices row(m) of the two half-waves
       {
@@ -230,7 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
           }
 #pragma unroll
           for (int fb = 0; fb < 4; ++fb) {
-            const float w = PASS == 0 ? kv[m] : gs[m];
+            const float w = PASS == 0 ? kv[m] : gs[PASS == 0 ? 0 : m];
             acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[fb], w, acc_o[fb], 0, 0, 0);
             if (PASS == 2)
               acc_o[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc1[fb], kv[m], acc_o[fb], 0, 0, 0);
@@ -243,10 +293,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, PASS == 
           }
         }
       }
+#undef MS_EW
+#ifdef MS_TIMING
+      tg2 += __builtin_amdgcn_s_memtime() - T2;
+#endif
     }
+    MS_T(T3);
     __syncthreads();
+#ifdef MS_TIMING
+    tbar += __builtin_amdgcn_s_memtime() - T3;
+#endif
     cur ^= 1;
   }
+#ifdef MS_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    ms_dbg[PASS][0] = tg1;
+    ms_dbg[PASS][1] = tg2;
+    ms_dbg[PASS][2] = tbar;
+    ms_dbg[PASS][3] = __builtin_amdgcn_s_memtime() - tall;
+    ms_dbg[PASS][4] = t_end - t_begin;
+    ms_dbg[PASS][5] = tew;
+  }
+#endif
   if (!wave_on) return;
   // acc_o[fb]: D[f = fb*32 + (r&3)+8(r>>2)+4h][resident = col]
   const int ir = i0 + col;
@@ -300,9 +368,9 @@ __global__ __launch_bounds__(256) void pn_ms_combine_fwd_kernel(
 // also emits the channel-first padded copies Qt, GUt the column pass streams.
 __global__ __launch_bounds__(256) void pn_ms_prep_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ q,
-    const float* __restrict__ rsum, const float* __restrict__ unorm, int N, int Np,
-    float* __restrict__ gu, float* __restrict__ go, float* __restrict__ cs,
-    float* __restrict__ Qt, float* __restrict__ GUt) {
+    const float* __restrict__ rsum, const float* __restrict__ unorm, const float* __restrict__ bsq,
+    int N, int Np, float* __restrict__ gu, float* __restrict__ go, float* __restrict__ cs,
+    float* __restrict__ alpha, float* __restrict__ Qt, float* __restrict__ GUt) {
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -327,7 +395,10 @@ __global__ __launch_bounds__(256) void pn_ms_prep_bwd_kernel(
   gu[base + lane + 64] = u1;
   go[base + lane] = u0 / r;
   go[base + lane + 64] = u1 / r;
-  if (lane == 0) cs[(size_t)b * N + i] = c;
+  if (lane == 0) {
+    cs[(size_t)b * N + i] = c;
+    alpha[(size_t)b * N + i] = 1.0f / (r * bsq[b]);
+  }
   Qtb[(size_t)lane * Np + i] = q[base + lane];
   Qtb[(size_t)(lane + 64) * Np + i] = q[base + lane + 64];
   GUtb[(size_t)lane * Np + i] = u0;
@@ -352,21 +423,79 @@ __global__ void pn_ms_pack_kernel(const float* __restrict__ x, int N, int Np,
   }
 }
 
-static int ms_slices(int B, int N, int Np, int* tps) {
-  const long long waves = (long long)B * pn_cdiv(N, 32);
-  (void)waves;
+// backward epilogue: gq = sum_s opart_q (gradient w.r.t. the previous iterate), gx += sum_s opart_x
+__global__ __launch_bounds__(256) void pn_ms_combine_bwd_kernel(const float* __restrict__ opart_q,
+                                                                const float* __restrict__ opart_x,
+                                                                long long ND4, int S,
+                                                                float* __restrict__ gq,
+                                                                float* __restrict__ gx) {
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ND4) return;
+  const float4* pq = reinterpret_cast<const float4*>(opart_q) + (size_t)b * S * ND4 + e;
+  const float4* px = reinterpret_cast<const float4*>(opart_x) + (size_t)b * S * ND4 + e;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+  for (int s = 0; s < S; ++s) {
+    const float4 u = pq[(size_t)s * ND4], v = px[(size_t)s * ND4];
+    a.x += u.x, a.y += u.y, a.z += u.z, a.w += u.w;
+    c.x += v.x, c.y += v.y, c.z += v.z, c.w += v.w;
+  }
+  reinterpret_cast<float4*>(gq)[(size_t)b * ND4 + e] = a;
+  float4* g = reinterpret_cast<float4*>(gx) + (size_t)b * ND4 + e;
+  float4 o = *g;
+  o.x += c.x, o.y += c.y, o.z += c.z, o.w += c.w;
+  *g = o;
+}
+
+// Number of slices of the streamed range.  All workgroups of a launch take the same time, so
+// the grid is sized to fill an integral number of rounds over the chip's workgroup slots
+// (256 CUs x blocks_per_cu): 1264 blocks on 512 slots would idle half the chip in the third
+// round.  More slices cost partial-sum traffic (S x N x 512 B), hence the mild penalty.
+#define MS_BPC_FWD 2  // pn_ms_kernel<0>: two workgroups per CU (256 VGPRs, 64 KiB LDS)
+#define MS_BPC_BWD 1
+static int ms_slices(int B, int N, int Np, int blocks_per_cu, int* tps) {
   const int ntiles = Np / 32;
-  // 8 or 16 slices (a multiple of the 8 XCDs, see pn_ms_kernel); tiny problems take fewer
-  int S = ntiles >= 64 ? 16 : (ntiles >= 16 ? 8 : 1);
-  *tps = pn_cdiv(ntiles, S);
-  // keep S itself (not cdiv(ntiles, tps)): trailing empty slices are harmless and preserve the
-  // slice -> XCD mapping
-  return S;
+  const long long rowblocks = (long long)B * pn_cdiv(N, 128);
+  const long long slots = 256LL * blocks_per_cu;
+  if (ntiles < 16) {
+    *tps = ntiles;
+    return 1;
+  }
+  // developer override for tuning runs: PN_MS_SLICES="<fwd>,<bwd>"
+  if (const char* e = getenv("PN_MS_SLICES")) {
+    int sf = 0, sb = 0;
+    if (sscanf(e, "%d,%d", &sf, &sb) == 2) {
+      const int want = blocks_per_cu == MS_BPC_FWD ? sf : sb;
+      if (want >= 1 && want <= 32 && want <= ntiles) {
+        *tps = pn_cdiv(ntiles, want);
+        return want;
+      }
+    }
+  }
+  int best = 1;
+  double best_score = -1.0;
+  const int smax = ntiles / 8 < 32 ? ntiles / 8 : 32;  // at least 8 tiles per slice
+  for (int S = 1; S <= smax; ++S) {
+    const int t = pn_cdiv(ntiles, S);
+    if (pn_cdiv(ntiles, t) != S) continue;  // not a distinct split
+    const double rounds = (double)(rowblocks * S) / (double)slots;
+    const double eff = rounds / (double)(long long)(rounds + 0.999999);
+    // per-slice fixed cost (prologue/epilogue ~ 1.5 tiles) and partial-sum traffic
+    const double score = eff * (double)t / ((double)t + 1.5) - 0.002 * S;
+    if (score > best_score) {
+      best_score = score;
+      best = S;
+    }
+  }
+  *tps = pn_cdiv(ntiles, best);
+  return best;
 }
 
 extern "C" int pn_meanshift_slices(int B, int N) {
   int tps;
-  return ms_slices(B, N, (int)pn_align_up(N, 64), &tps);
+  const int Np = (int)pn_align_up(N, 64);
+  const int sf = ms_slices(B, N, Np, MS_BPC_FWD, &tps), sb = ms_slices(B, N, Np, MS_BPC_BWD, &tps);
+  return sf > sb ? sf : sb;
 }
 
 extern "C" int pn_meanshift_pack_f32(const float* x, int B, int N, int D, float* xt, void* stream) {
@@ -393,7 +522,7 @@ extern "C" int pn_meanshift_iter_fwd_f32(const float* q, const float* x, const f
   PN_CHECK_ARG(B > 0 && N > 0, "pn_meanshift_iter_fwd_f32: empty input");
   const int Np = (int)pn_align_up(N, 64);
   int tps;
-  const int S = ms_slices(B, N, Np, &tps);
+  const int S = ms_slices(B, N, Np, MS_BPC_FWD, &tps);
   dim3 grid(S, pn_cdiv(N, 128), B);
   {
     PN_PROF("meanshift_fwd", stream);
@@ -409,37 +538,42 @@ extern "C" int pn_meanshift_iter_fwd_f32(const float* q, const float* x, const f
 
 // Backward of one iteration.  gy (B,N,D) gradient w.r.t. the iterate produced by the forward
 // call with the same q/x/bsq; y, rsum, unorm its saved outputs.
-// Scratch: gu, go (B,N,D), cs (B,N), qt, gut (B,D,Np), opart_q, opart_x (B,S,N,D).
-// After the call sum_s opart_q is the gradient w.r.t. q and sum_s opart_x the contribution to
-// the gradient w.r.t. x (the caller reduces over s and accumulates across iterations).
+// Scratch: gu, go (B,N,D), cs (B,2,N), qt, gut (B,D,Np), opart_q, opart_x (B,S,N,D).
+// Outputs: gq (B,N,D) = gradient w.r.t. q (overwritten); gx (B,N,D) += gradient w.r.t. x.
 extern "C" int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const float* q,
                                          const float* x, const float* xt, const float* rsum,
                                          const float* unorm, const float* bsq, int B, int N, int D,
                                          float* gu, float* go, float* cs, float* qt, float* gut,
-                                         float* opart_q, float* opart_x, void* stream_) {
+                                         float* opart_q, float* opart_x, float* gq, float* gx,
+                                         void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(gy && y && q && x && xt && rsum && unorm && bsq && gu && go && cs && qt && gut &&
-                   opart_q && opart_x,
+                   opart_q && opart_x && gq && gx,
                "pn_meanshift_iter_bwd_f32: null pointer");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   const int Np = (int)pn_align_up(N, 64);
   int tps;
-  const int S = ms_slices(B, N, Np, &tps);
+  const int S = ms_slices(B, N, Np, MS_BPC_BWD, &tps);
+  float* alpha = cs + (size_t)B * N;
   hipLaunchKernelGGL(pn_ms_prep_bwd_kernel, dim3(pn_cdiv(Np, 4), B), dim3(256), 0, stream, gy, y, q,
-                     rsum, unorm, N, Np, gu, go, cs, qt, gut);
+                     rsum, unorm, bsq, N, Np, gu, go, cs, alpha, qt, gut);
   PN_CHECK_LAUNCH();
   dim3 grid(S, pn_cdiv(N, 128), B);
   {
     PN_PROF("meanshift_bwd_rows", stream);
     hipLaunchKernelGGL(pn_ms_kernel<1>, grid, dim3(256), 0, stream, q, gu, xt, nullptr, x, nullptr,
-                       cs, rsum, bsq, N, Np, tps, opart_q, nullptr);
+                       cs, alpha, bsq, N, Np, tps, opart_q, nullptr);
   }
   PN_CHECK_LAUNCH();
   {
     PN_PROF("meanshift_bwd_cols", stream);
     hipLaunchKernelGGL(pn_ms_kernel<2>, grid, dim3(256), 0, stream, x, nullptr, qt, gut, q, go, cs,
-                       rsum, bsq, N, Np, tps, opart_x, nullptr);
+                       alpha, bsq, N, Np, tps, opart_x, nullptr);
   }
+  PN_CHECK_LAUNCH();
+  const long long ND4 = (long long)N * MS_D / 4;
+  hipLaunchKernelGGL(pn_ms_combine_bwd_kernel, dim3(pn_cdiv(ND4, 256), B), dim3(256), 0, stream,
+                     opart_q, opart_x, ND4, S, gq, gx);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

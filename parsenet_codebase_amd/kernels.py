@@ -258,7 +258,7 @@ class MeanShiftWorkspace:
         if backward:
             self.gu = torch.empty((B, N, D), **f)
             self.go = torch.empty((B, N, D), **f)
-            self.cs = torch.empty((B, N), **f)
+            self.cs = torch.empty((B, 2, N), **f)
             self.qt = torch.empty((B, D, self.Np), **f)
             self.gut = torch.empty((B, D, self.Np), **f)
             self.opart_x = torch.empty((B, self.S, N, D), **f)
@@ -289,17 +289,19 @@ def meanshift_iter_fwd(q, x, xt, bsq, ws):
     return y, rsum, unorm
 
 
-def meanshift_iter_bwd(gy, y, q, x, xt, rsum, unorm, bsq, ws):
-    """Returns (dL/dq, contribution to dL/dx), both (B,N,D)."""
+def meanshift_iter_bwd(gy, y, q, x, xt, rsum, unorm, bsq, ws, gx):
+    """Returns dL/dq (B,N,D) and adds this iteration's contribution to dL/dx into ``gx``."""
     B, N, D = x.shape
     gy = _f32c(gy, "gy")
+    gq = torch.empty_like(x)
     with torch.cuda.device(x.device):
         rc = _lib.load().pn_meanshift_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(xt), ptr(rsum),
                                                    ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.go),
                                                    ptr(ws.cs), ptr(ws.qt), ptr(ws.gut), ptr(ws.opart),
-                                                   ptr(ws.opart_x), current_stream(x.device))
+                                                   ptr(ws.opart_x), ptr(gq), ptr(gx),
+                                                   current_stream(x.device))
     check(rc, "pn_meanshift_iter_bwd_f32")
-    return ws.opart.sum(1), ws.opart_x.sum(1)
+    return gq
 
 
 def sym3_eig(G):

@@ -44,10 +44,8 @@ class _MeanShiftIterations(torch.autograd.Function):
         gX = torch.zeros_like(x)
         g = gy.contiguous()
         for it in reversed(range(T)):
-            gq, gx = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it],
-                                          bsq, ws)
-            gX += gx
-            g = gq
+            g = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it], bsq,
+                                     ws, gX)
         gX += g  # the first iterate is X itself
         return gX, None, None
 
