@@ -36,6 +36,14 @@ def build_workload(name, device, rank):
             "workload": "cfg5: ParSeNet e2e (seg + mean-shift 10 it. + per-segment spline/primitive fit + "
                         "Chamfer/residual), 10k pts, batch 4 per GPU, fwd+bwd+allreduce+Adam",
             "batch_per_gpu": B, "points": N, "k": 80}
+    if name in ("cfg2", "cfg3"):
+        B, N = 32, 700
+        closed = name == "cfg3"
+        return workloads.SplineNetStep(device, closed=closed, batch=B, num_points=N, first_shape=rank * B), {
+            "workload": "%s: %s SplineNet (DGCNNControlPoints mode %d, k=10), 700-pt patches, batch 32 per GPU, "
+                        "one-sided Chamfer + permutation regression%s, fwd+bwd+allreduce+Adam"
+                        % (name, "closed" if closed else "open", int(closed), "" if closed else " + Laplacian"),
+            "batch_per_gpu": B, "points": N, "k": 10}
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -56,6 +64,8 @@ def kernel_roofline(step, nprof):
     table = {k: {"ms_total": v[0], "calls": v[1], "avg_ms": v[0] / max(v[1], 1)} for k, v in res.items()}
     dom = max(table, key=lambda k: table[k]["ms_total"])
     B, N, k = step.batch, step.num_points, 80
+    if not hasattr(step, "labels"):   # SplineNet steps: k = 10
+        k = 10
     avg_s = table[dom]["avg_ms"] * 1e-3
     # algorithmic work per launch (DESIGN.md / SURVEY.md §8d)
     if dom.startswith("knn_mfma_pass"):
@@ -97,6 +107,8 @@ def cpu_baseline(name):
     torch.manual_seed(0)
     np.random.seed(0)
     cores = torch.get_num_threads()
+    if name in ("cfg2", "cfg3"):
+        return cpu_baseline_splinenet(name, cores)
     model = R.PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True, num_primitives=10,
                                         loss_function=R.EmbeddingLoss(1.0).triplet_loss, mode=5,
                                         num_channels=6, nn_nb=80)
@@ -125,6 +137,47 @@ def cpu_baseline(name):
     best = min(times)
     return {"value": 1.0 / best, "unit": "shapes/s", "cores": cores, "kind": "port",
             "sample": "torch-CPU oracle (reference algorithm restated), %s, 1 shape x 10000 pts fwd+bwd, "
+                      "best of %d" % (name, len(times))}
+
+
+def oracle_splinenet_step(model, closed, points, control_points, nu, nv, loss_weight=0.9):
+    """The reference's SplineNet training step restated on the oracle (CPU): returns
+    (loss, cd, reg, lap, output).  Also used by tests/test_workloads_gpu.py as the checker."""
+    from oracle import ref_fitting as RF
+    B = points.shape[0]
+    out = model(points)
+    cd, _ = RF.spline_reconstruction_loss_one_sided(nu, nv, out, points, B, 20)
+    if closed:
+        reg, _ = RF.control_points_permute_closed_reg_loss(out, control_points, 20, 20)
+        return reg * loss_weight + cd * (1 - loss_weight), cd, reg, None, out
+    reg, perm = RF.control_points_permute_reg_loss(out, control_points, 20)
+    lap = RF.laplacian_loss(out.reshape(B, 20, 20, 3), perm)
+    return reg * loss_weight + (cd + lap) * (1 - loss_weight), cd, reg, lap, out
+
+
+def cpu_baseline_splinenet(name, cores):
+    import numpy as np
+    from oracle import ref_fitting as RF, ref_torch as R
+    from parsenet_codebase_amd import synthetic
+    closed = name == "cfg3"
+    B = 32
+    model = R.DGCNNControlPoints(20, 10, 1 if closed else 0)
+    nu, nv = RF.uniform_knot_bspline(20, 20, 3, 3, 30 if closed else 40)
+    nu, nv = torch.from_numpy(nu.astype(np.float32)), torch.from_numpy(nv.astype(np.float32))
+    pts, ctrl = synthetic.make_spline_patches(0, B, 700, 20, closed)
+    x = torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1)))
+    cp = torch.from_numpy(ctrl)
+    times = []
+    t_all = time.time()
+    for it in range(5):
+        t0 = time.time()
+        model.zero_grad()
+        oracle_splinenet_step(model, closed, x, cp, nu, nv)[0].backward()
+        times.append(time.time() - t0)
+        if time.time() - t_all > 20:
+            break
+    return {"value": B / min(times), "unit": "shapes/s", "cores": cores, "kind": "port",
+            "sample": "torch-CPU oracle (reference algorithm restated), %s, one batch of 32 x 700 pts fwd+bwd, "
                       "best of %d" % (name, len(times))}
 
 

@@ -86,3 +86,65 @@ class ParsenetE2EStep(ParsenetSegStep):
         self.opt.step()
         self.last_res = res_total
         return loss
+
+
+class _SplineCfg:
+    def __init__(self, batch_size, grid_size):
+        self.batch_size = batch_size
+        self.grid_size = grid_size
+
+
+class SplineNetStep:
+    """cfg2 (open, mode 0) / cfg3 (closed, mode 1): one SplineNet training step of
+    train_open_splines.py:140-186 / train_closed_control_points.py:141-176 — DGCNNControlPoints
+    (k = 10, training-mode BatchNorm) on 700-point patches, the predicted 20x20 grid evaluated on
+    the 40x40 (open) / 30x30 (closed) parameter lattice, one-sided Chamfer to the input points,
+    permutation regression (8 / 80 candidate orderings), Laplacian (open only);
+    loss = 0.9 reg + 0.1 (cd [+ lap]); backward, one gradient all-reduce, Adam (lr 1e-3)."""
+
+    def __init__(self, device, closed=False, batch=32, num_points=700, first_shape=0, seed=0, lr=1e-3,
+                 loss_weight=0.9):
+        from .bspline import uniform_knot_bspline
+        from .encoders import DGCNNControlPoints
+        torch.manual_seed(seed)
+        self.device = device
+        self.closed = closed
+        self.batch = batch
+        self.num_points = num_points
+        self.loss_weight = loss_weight
+        self.model = DGCNNControlPoints(20, num_points=10, mode=1 if closed else 0).to(device)
+        self.bucket = FlatGradBucket(self.model.parameters())
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
+        nu, nv = uniform_knot_bspline(20, 20, 3, 3, 30 if closed else 40)
+        self.nu = torch.from_numpy(nu.astype(np.float32)).to(device)
+        self.nv = torch.from_numpy(nv.astype(np.float32)).to(device)
+        pts, ctrl = synthetic.make_spline_patches(first_shape, batch, num_points, 20, closed)
+        self.points = torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1))).to(device)   # (B,3,P)
+        self.control_points = torch.from_numpy(ctrl).to(device)                                  # (B,20,20,3)
+        self.cfg = _SplineCfg(batch, 20)
+        self.last = None
+
+    def shapes_per_step(self):
+        return self.batch
+
+    def losses(self, output):
+        from . import spline_losses as SL
+        cd, _ = SL.spline_reconstruction_loss_one_sided(self.nu, self.nv, output, self.points, self.cfg)
+        if self.closed:
+            l_reg, _ = SL.control_points_permute_closed_reg_loss(output, self.control_points, 20, 20)
+            loss = l_reg * self.loss_weight + cd * (1 - self.loss_weight)
+            return loss, cd, l_reg, None
+        l_reg, permute_cp = SL.control_points_permute_reg_loss(output, self.control_points, 20)
+        lap = SL.laplacian_loss(output.reshape((self.batch, 20, 20, 3)), permute_cp, dist_type="l2")
+        loss = l_reg * self.loss_weight + (cd + lap) * (1 - self.loss_weight)
+        return loss, cd, l_reg, lap
+
+    def step(self):
+        self.bucket.zero()
+        output = self.model(self.points)
+        loss, cd, l_reg, lap = self.losses(output)
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        self.last = (cd, l_reg, lap)
+        return loss

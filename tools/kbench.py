@@ -70,6 +70,38 @@ def bench_meanshift():
           (N, t, 10 * 9 * 2.0 * N * N * 128 / t / 1e9))
 
 
+def bench_fitting():
+    """Per-shape cost of the clustering + fitting stage when the embedding HAS cluster structure
+    (what a trained network yields): embedding = noisy one-hot code of the ground-truth segment."""
+    import numpy as np
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.encoders import DGCNNControlPoints
+    from parsenet_codebase_amd.fitting import Evaluation
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    N = 10000
+    pts, nrm, lab, prim = synthetic.make_batch(0, 2, N)
+    ev = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1),
+                    open_path=DGCNNControlPoints(20, num_points=10, mode=0))
+    code = torch.nn.functional.normalize(torch.randn(32, 128), dim=1)
+    for b in range(2):
+        emb = code[torch.from_numpy(lab[b]).long()] + 0.01 * torch.randn(N, 128)
+        emb = torch.nn.functional.normalize(emb, dim=1).to(dev).unsqueeze(0).requires_grad_(True)
+        P = torch.from_numpy(pts[b:b + 1]).to(dev)
+        Nn = torch.from_numpy(nrm[b:b + 1]).to(dev)
+        logp = torch.log_softmax(torch.randn(1, 10, N, device=dev), 1)
+
+        def run():
+            res, extra = ev.fitting_loss(emb, P, Nn, lab[b:b + 1], prim[b:b + 1], logp, quantile=0.025,
+                                         iterations=10, lamb=0.1)
+            res[0].backward()
+            return res, extra
+        res, extra = run()
+        t = timeit(run, warmup=1, iters=3)
+        print("fitting shape %d: %d gt segments, %d predicted clusters, s-iou %.3f: %.1f ms fwd+bwd" %
+              (b, len(np.unique(lab[b])), len(np.unique(extra[1])), float(res[3]), t))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["knn", "chamfer"]
     for w in which:
