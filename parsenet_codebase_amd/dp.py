@@ -23,7 +23,10 @@ def init_from_env(backend=None):
             backend = "nccl" if device.type == "cuda" else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = device   # bind the RCCL communicator to this rank's GPU up front
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, device
 
 

@@ -14,6 +14,7 @@ import torch
 from scipy.optimize import linear_sum_assignment
 
 from . import kernels as K
+from ._lib import require_cuda
 from .bspline import sample_points_from_control_points_, uniform_knot_bspline
 from .chamfer import chamfer_distance_single_shape
 from .mean_shift import MeanShift
@@ -265,11 +266,25 @@ def project_to_plane(points, a, d):
     return projections + a.transpose(1, 0) * d
 
 
+def _knn_points_by_differences(points, k):
+    """k nearest neighbours of 3-D points from coordinate DIFFERENCES, (n,k) nearest first.
+    The kNN kernels use the reference's GEMM form |x|^2 + |y|^2 - 2 x.y (src/model.py:9-22), whose
+    rounding (~1e-7 absolute) reorders neighbours once spacings reach 1e-3 — which up-sampled
+    segments do; the reference's up-sampling and open3d's KD-tree work on differences, so these
+    two evaluation-only helpers do too (row blocks of 2048 on the GPU, n <= ~10^4)."""
+    require_cuda(points)
+    out = []
+    for s0 in range(0, points.shape[0], 2048):
+        d = ((points[s0:s0 + 2048].unsqueeze(1) - points.unsqueeze(0)) ** 2).sum(2)
+        out.append(torch.topk(d, k, 1, largest=False)[1])
+    return torch.cat(out, 0)
+
+
 def up_sample_points_torch(points, times=1):
     """src/fitting_utils.py:150-164: append the centroid of the 4 nearest neighbours of every
-    point (the kNN kernel replaces the N x N broadcast)."""
+    point."""
     for _ in range(times):
-        idx = K.knn(points.t().contiguous().unsqueeze(0), 5, "feature")[0]
+        idx = _knn_points_by_differences(points, 5)
         centers = torch.mean(points[idx[:, 1:]], 1)
         points = torch.cat([points, centers])
     return points
@@ -290,6 +305,48 @@ def up_sample_points_in_range(points, weights, a_min, a_max):
     return points[L], weights[L]
 
 
+def up_sample_points_torch_in_range(points, a_min, a_max):
+    """src/fitting_utils.py:222-237."""
+    N = points.shape[0]
+    if N > a_max:
+        L = np.random.choice(np.arange(N), a_max, replace=False)
+        return points[L]
+    while True:
+        points = up_sample_points_torch(points)
+        if points.shape[0] >= a_max:
+            break
+    L = np.random.choice(np.arange(points.shape[0]), a_max, replace=False)
+    return points[L]
+
+
+def remove_outliers(points, viz=False, nb_neighbors=20, std_ratio=0.50):
+    """src/fitting_utils.py:704-710.  The reference hands the segment to open3d 0.9.0's
+    ``remove_statistical_outlier(nb_neighbors=20, std_ratio=0.5)``; open3d is a third-party
+    dependency without source in the reference tree, so its published algorithm is restated:
+    mean distance of every point to its ``nb_neighbors`` nearest neighbours (the point itself
+    included, as its KD-tree search returns it), threshold = mean + std_ratio * std (Bessel) of
+    those means, keep 0 < mean < threshold; distances and statistics in float64 like open3d.
+    numpy (n,3) in -> numpy float64 (m,3) out (the reference's types); tensors stay tensors."""
+    as_numpy = isinstance(points, np.ndarray)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    P = torch.as_tensor(points, dtype=torch.float32, device=dev if as_numpy else None)
+    require_cuda(P)
+    n = P.shape[0]
+    k = min(nb_neighbors, n)
+    Pd = P.double()
+    idx = _knn_points_by_differences(Pd, k)                                    # (n,k), self first
+    dist = (Pd[idx] - Pd.unsqueeze(1)).norm(dim=2)                             # (n,k)
+    avg = dist.mean(1)
+    valid = avg > 0
+    nvalid = n                                      # every search returns >= 1 neighbour
+    cloud_mean = avg[valid].sum() / nvalid
+    sq = ((avg[valid] - cloud_mean) ** 2).sum()
+    std = torch.sqrt(sq / (nvalid - 1)) if nvalid > 1 else torch.zeros((), dtype=torch.float64, device=P.device)
+    keep = valid & (avg < cloud_mean + std_ratio * std)
+    out = (Pd if as_numpy else torch.as_tensor(points))[keep]
+    return out.cpu().numpy() if as_numpy else out
+
+
 # ---------------------------------------------------------------------------------------
 # SplineNet forward wrappers (src/primitive_forward.py:34-102, 347-415)
 # ---------------------------------------------------------------------------------------
@@ -304,8 +361,6 @@ def forward_pass_open_spline(input_points_, control_decoder, nu, nv, viz=False, 
                              if_optimize=True):
     """Standardise -> SplineNet (open, 20x20 grid) -> evaluate on (nu, nv) -> de-standardise.
     input_points_ (1,n,3), weights (n,1).  Returns (samples, samples) like the reference."""
-    if if_optimize:
-        raise NotImplementedError("if_optimize=True is the evaluation-only refit (SURVEY §8f rank 2)")
     nu, nv = nu.to(input_points_.device), nv.to(input_points_.device)
     with torch.no_grad():
         points_, scales, means, RS = standardize_points_torch(input_points_, weights)
@@ -315,6 +370,9 @@ def forward_pass_open_spline(input_points_, control_decoder, nu, nv, viz=False, 
     output = output.view(1, 400, 3)
     rec = torch.stack([_restore(reconstructed_points[b].clone(), scales[b], RS[b], means[b])
                        for b in range(batch_size)], 0)
+    if if_optimize:
+        ctrl = torch.stack([_restore(output[b], scales[b], RS[b], means[b]) for b in range(batch_size)], 0)
+        rec = optimize_open_spline_kronecker(rec, input_points_, ctrl, deform=True)
     return rec, rec
 
 
@@ -322,8 +380,6 @@ def forward_closed_splines(input_points_, control_decoder, nu, nv, viz=False, we
                            if_optimize=True):
     """Closed (u-periodic) variant: the first sample row is appended again (31 x 30 = 930 points).
     Returns (samples (1,930,3), None, samples)."""
-    if if_optimize and input_points_.shape[1] > 200:
-        raise NotImplementedError("if_optimize=True is the evaluation-only refit (SURVEY §8f rank 2)")
     batch_size = input_points_.shape[0]
     nu, nv = nu.to(input_points_.device), nv.to(input_points_.device)
     with torch.no_grad():
@@ -335,7 +391,93 @@ def forward_closed_splines(input_points_, control_decoder, nu, nv, viz=False, we
         tmp = _restore(reconstructed_points[b].clone(), scales[b], RS[b], means[b]).reshape((30, 30, 3))
         closed.append(torch.cat([tmp, tmp[0:1]], 0))
     rec = torch.stack(closed, 0).reshape((1, 930, 3))
+    if if_optimize and input_points_.shape[1] > 200:
+        # src/primitive_forward.py:389-410: the control grid is closed in u the same way
+        # (21 x 20) and restored to the input frame before the refit
+        ctrl = output.view(batch_size, 20, 20, 3)
+        ctrl = torch.cat([ctrl, ctrl[:, 0:1]], 1).reshape(batch_size, 21 * 20, 3)
+        ctrl = torch.stack([_restore(ctrl[b], scales[b], RS[b], means[b]) for b in range(batch_size)], 0)
+        rec = optimize_close_spline_kronecker(rec, input_points_, ctrl)
     return rec, None, rec
+
+
+# ---------------------------------------------------------------------------------------
+# evaluation-only LS refit of a predicted spline (src/primitive_forward.py:153-296)
+# ---------------------------------------------------------------------------------------
+def boundary_parameterization(grid_u):
+    """src/curve_utils.py:211-221: parameters of the four boundary curves of the unit square."""
+    u = np.arange(grid_u)
+    zeros, ones = np.zeros(grid_u), np.ones(grid_u)
+    parameters = [np.stack([zeros, u], 1),
+                  np.stack([np.arange(1, grid_u), np.zeros(grid_u - 1)], 1),
+                  np.stack([np.arange(1, grid_u), np.ones(grid_u - 1) * (grid_u - 1)], 1),
+                  np.stack([np.ones(grid_u - 2) * (grid_u - 1), np.arange(1, grid_u - 1)], 1)]
+    return np.concatenate(parameters, 0) / (grid_u - 1)
+
+
+def regular_parameterization(grid_u, grid_v):
+    """src/curve_utils.py:260-268."""
+    xv, yv = np.meshgrid(np.linspace(0, 1, grid_u), np.linspace(0, 1, grid_v))
+    return np.concatenate([xv.transpose().reshape(-1, 1), yv.transpose().reshape(-1, 1)], 1)
+
+
+def _refit_spline(control_points, size_u, size_v, input_points, up_range, subsample, new_cp_size,
+                  new_degree, boundary_grid):
+    """Shared body of the two optimize_*_spline_kronecker functions:
+    1600 parameters (random + boundary) -> samples of the PREDICTED degree-3 surface -> Hungarian
+    matching to up-sampled input points -> LS control grid (new_cp_size^2, a27) -> its 30 x 30
+    regular samples.  The surface evaluation replaces geomdl 5.2.9's ``evaluate_list`` by the
+    tensor-product basis it implements (sum_ij N_i(u) N_j(v) P_ij).  The reference's ARAP
+    deformation (deform=True) only rewrites a local variable that is never read again, so it has
+    no effect on the result and is not reproduced."""
+    from .approximation import fit_bezier_surface_fit_kronecker
+    from .bspline import basis_matrix, uniform_knots
+    dev = input_points.device
+    parameters = boundary_parameterization(boundary_grid)
+    parameters = np.concatenate([np.random.random((1600 - parameters.shape[0], 2)), parameters], 0)
+    ku, kv = uniform_knots(size_u, 3), uniform_knots(size_v, 3)
+    bu = torch.from_numpy(basis_matrix(parameters[:, 0], size_u, 3, ku)).to(dev)
+    bv = torch.from_numpy(basis_matrix(parameters[:, 1], size_v, 3, kv)).to(dev)
+    ctrl = control_points.reshape(size_u, size_v, 3).double()
+    samples = torch.einsum("ni,nj,ijc->nc", bu, bv, ctrl)                      # (1600,3) fp64
+    inp = up_sample_points_torch_in_range(input_points, up_range[0], up_range[1])
+    if subsample is not None:
+        L = np.random.choice(np.arange(inp.shape[0]), subsample, replace=False)
+        inp = inp[L]
+    inp = inp.double()
+    # (1600, M) fp64 on the GPU, from coordinate differences (the GEMM form of cdist loses the
+    # digits the assignment's near-ties depend on)
+    dist = torch.cdist(samples, inp, compute_mode="donot_use_mm_for_euclid_dist")
+    rids, cids = solve_dense(dist.cpu().numpy())
+    matched = inp[torch.from_numpy(np.asarray(cids)).to(dev)]
+    ku2, kv2 = uniform_knots(new_cp_size, new_degree), uniform_knots(new_cp_size, new_degree)
+    NU = torch.from_numpy(basis_matrix(parameters[:, 0], new_cp_size, new_degree, ku2)).to(dev)
+    NV = torch.from_numpy(basis_matrix(parameters[:, 1], new_cp_size, new_degree, kv2)).to(dev)
+    new_ctrl = fit_bezier_surface_fit_kronecker(matched, NU, NV)               # (cp,cp,3) fp64
+    reg = regular_parameterization(30, 30)
+    RU = torch.from_numpy(basis_matrix(reg[:, 0], new_cp_size, new_degree, ku2)).to(dev)
+    RV = torch.from_numpy(basis_matrix(reg[:, 1], new_cp_size, new_degree, kv2)).to(dev)
+    return torch.einsum("ni,nj,ijc->nc", RU, RV, new_ctrl).float()
+
+
+def optimize_open_spline_kronecker(reconstructed_points, input_points_, control_points, new_cp_size=10,
+                                   new_degree=2, deform=False):
+    """src/primitive_forward.py:229-296.  control_points (1,400,3) in the input frame;
+    returns the refitted surface's 30 x 30 samples (1,900,3)."""
+    pts = _refit_spline(control_points[0].detach(), 20, 20, input_points_[0].detach(), (1600, 2000), 1600,
+                        new_cp_size, new_degree, 20)
+    return pts.unsqueeze(0)
+
+
+def optimize_close_spline_kronecker(reconstructed_points, input_points_, control_points, new_cp_size=10,
+                                    new_degree=3, deform=True):
+    """src/primitive_forward.py:153-226.  control_points (1,420,3) (u-closed 21 x 20 grid);
+    returns 31 x 30 samples (1,930,3), first row repeated."""
+    pts = _refit_spline(control_points[0].detach(), 21, 20, input_points_[0].detach(), (2000, 2100), None,
+                        new_cp_size, new_degree, 30)
+    pts = pts.reshape((30, 30, 3))
+    pts = torch.cat([pts, pts[0:1]], 0).reshape((930, 3))
+    return pts.unsqueeze(0)
 
 
 def _load_splinenet(model_or_path, mode):
@@ -469,13 +611,23 @@ class FittingModule:
         return None
 
 
+def _mask_index(mask, device):
+    """Row indices selected by a boolean numpy mask, as a device tensor."""
+    return torch.from_numpy(np.nonzero(np.asarray(mask))[0]).to(device)
+
+
 def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=False, if_optimize=False,
                         if_visualize=False):
-    """src/primitive_forward.py:925-1047 (training mode): per matched segment pick the weight
-    column, keep every 2nd point (every 4th for analytic primitives), at most 4 splines per shape,
-    skip segments under 20 (splines: 100) points, dispatch on the ground-truth primitive type."""
-    if eval:
-        raise NotImplementedError("evaluation-mode fitting is SURVEY §8f rank 2")
+    """src/primitive_forward.py:925-1047.
+    Training mode: per matched segment pick the weight column, keep every 2nd point (every 4th for
+    analytic primitives), at most 4 splines per shape, skip segments under 20 (splines: 100)
+    points, dispatch on the ground-truth primitive type.
+    Evaluation mode: the segment's own points with its (hard) weights; spline segments have their
+    statistical outliers removed and are re-sampled to 1400-1800 (closed) / 1000-1500 (open)
+    points before the SplineNet; ``if_optimize`` adds the LS refit."""
+    if sample_points or if_visualize:
+        raise NotImplementedError("sample_points / if_visualize build open3d meshes for the viewer: out of "
+                                  "scope of the hot path (SURVEY section 8)")
     reconstructed_shape = []
     fitter.fitting.parameters = {}
     gt_points = {}
@@ -490,15 +642,19 @@ def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=Fal
         points, normals, labels, gpoints, segment_indices, part_index = d
         part_index, label_index = part_index
         labels = int(labels)
-        weight = weights[:, part_index:part_index + 1] + EPS
-        points, normals, weight = points[0::2], normals[0::2], weight[0::2]
-        if labels in [0, 2, 6, 7, 9, 8]:
-            spline_count += 1
-            if spline_count > 4:
-                skip(label_index)
-                continue
-        else:
+        Z = points.shape[0]
+        if not eval:
+            weight = weights[:, part_index:part_index + 1] + EPS
             points, normals, weight = points[0::2], normals[0::2], weight[0::2]
+            if labels in [0, 2, 6, 7, 9, 8]:
+                spline_count += 1
+                if spline_count > 4:
+                    skip(label_index)
+                    continue
+            else:
+                points, normals, weight = points[0::2], normals[0::2], weight[0::2]
+        else:
+            weight = weights[_mask_index(segment_indices, weights.device), part_index:part_index + 1] + EPS
         if points.shape[0] < 20:
             skip(label_index)
             continue
@@ -506,8 +662,13 @@ def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=Fal
             if points.shape[0] < 100:
                 skip(label_index)
                 continue
+            if eval:
+                Z = points.shape[0]
+                points = remove_outliers(points)
+                weight = weight[0:points.shape[0]]
+                points, weight = up_sample_points_in_range(points, weight, 1400, 1800)
             recon_points = fitter.forward_pass_closed_spline(points, weights=weight, ids=label_index,
-                                                             if_optimize=False)
+                                                             if_optimize=if_optimize and (Z > 200))
         elif labels == 1:
             recon_points = fitter.forward_pass_plane(points, normals, weight, ids=label_index)
         elif labels == 3:
@@ -520,8 +681,12 @@ def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=Fal
             if points.shape[0] < 100:
                 skip(label_index)
                 continue
+            if eval:
+                points = remove_outliers(points)
+                weight = weight[0:points.shape[0]]
+                points, weight = up_sample_points_in_range(points, weight, 1000, 1500)
             recon_points = fitter.forward_pass_open_spline(points, weights=weight, ids=label_index,
-                                                           if_optimize=False)
+                                                           if_optimize=if_optimize)
         else:
             raise ValueError("unknown primitive type %r" % (labels,))
         gt_points[label_index] = gpoints
@@ -674,8 +839,6 @@ class Evaluation:
         arrays; primitives_log_prob (B,10,N).  Returns ([Loss, geometric mean, spline mean, s_iou,
         p_iou], [parameters, cluster ids, weights]) of the last shape, like the reference (which
         is written for B = 1)."""
-        if eval:
-            raise NotImplementedError("evaluation-mode fitting is SURVEY §8f rank 2")
         batch_size = embedding.shape[0]
         embedding = torch.nn.functional.normalize(embedding, p=2, dim=2)
         prim_pred = torch.max(primitives_log_prob, 1)[1].data.cpu().numpy()
@@ -686,8 +849,17 @@ class Evaluation:
             center, bandwidth, cluster_ids = self.guard_mean_shift(embedding[b], quantile, iterations,
                                                                    kernel_type="gaussian")
             weights = center @ torch.transpose(embedding[b], 1, 0)
-            loss, parameters, _, rows, cols, distance = self.residual_train_mode(
-                points[b], normals[b], labels[b], cluster_ids, primitives[b], weights, bandwidth, lamb=lamb)
+            if not eval:
+                loss, parameters, _, rows, cols, distance = self.residual_train_mode(
+                    points[b], normals[b], labels[b], cluster_ids, primitives[b], weights, bandwidth, lamb=lamb)
+            else:
+                with torch.no_grad():
+                    loss, parameters, _ = self.residual_eval_mode(
+                        points[b], normals[b], labels[b], cluster_ids, primitives[b], prim_pred[b], weights,
+                        bandwidth, lamb=lamb, sample_points=False, if_optimize=False)
+                # in the eval mode the memberships are the hard selection
+                ids_np = cluster_ids.data.cpu().numpy()
+                weights = to_one_hot(ids_np, np.unique(ids_np).shape[0], device_id=points.device.index).T
             with torch.no_grad():
                 s_iou, p_iou, _, _ = SIOU_matched_segments(labels[b], cluster_ids.data.cpu().numpy(),
                                                            prim_pred[b], primitives[b], weights.T)
@@ -713,6 +885,44 @@ class Evaluation:
         distance = self.res_loss.residual_loss(gt_points, self.fitter.fitting.parameters)
         Loss = self.separate_losses(distance, gt_points, lamb=lamb)
         return Loss, self.fitter.fitting.parameters, None, rows, cols, distance
+
+    def residual_eval_mode(self, points, normals, labels, cluster_ids, primitives, pred_primitives, weights,
+                           bw, lamb=1.0, sample_points=False, if_optimize=False, if_visualize=False,
+                           epsilon=None):
+        """src/residual_utils.py:210-331: residual error with HARD memberships.  Every predicted
+        segment is fitted on its own points with the modal predicted primitive type (smallest on
+        ties, scipy.stats.mode), splines after outlier removal and re-sampling; distances are
+        reported with sqrt=True.  Returns (Loss, parameters, None); the mesh output of
+        ``sample_points`` / ``if_visualize`` is viewer code and not provided."""
+        if sample_points or if_visualize:
+            raise NotImplementedError("sample_points / if_visualize build open3d meshes for the viewer: out "
+                                      "of scope of the hot path (SURVEY section 8)")
+        if not isinstance(cluster_ids, np.ndarray):
+            cluster_ids = cluster_ids.data.cpu().numpy()
+        labels = np.asarray(labels)
+        pred_primitives = np.asarray(pred_primitives)
+        dev = points.device
+        rows, cols, unique_target, unique_pred = match(labels, cluster_ids)
+        data = []
+        for index, i in enumerate(unique_pred):
+            gt_indices_i = labels == cols[index]
+            pred_indices_i = cluster_ids == i
+            if (np.sum(gt_indices_i) == 0) or (np.sum(pred_indices_i) == 0):
+                continue
+            seg_type = int(np.bincount(pred_primitives[pred_indices_i].astype(np.int64)).argmax())
+            pi = _mask_index(pred_indices_i, dev)
+            gi = _mask_index(gt_indices_i, dev)
+            data.append([points[pi], normals[pi], seg_type, points[gi], pred_indices_i, (index, i)])
+        # hard memberships: one-hot of the cluster ids, pushed through the same normalisation and
+        # arg-max as the reference does (a fixed point for one-hot input, kept for fidelity)
+        w_first = to_one_hot(cluster_ids, np.unique(cluster_ids).shape[0], device_id=dev.index).T
+        w = torch.transpose(weights_normalize(w_first, float(bw)), 1, 0)
+        w = to_one_hot(torch.max(w, 1)[1], w.shape[1], device_id=dev.index)
+        gt_points, recon_points = fit_one_shape_torch(data, self.fitter, w, bw, eval=True,
+                                                      sample_points=False, if_optimize=if_optimize)
+        distance = self.res_loss.residual_loss(gt_points, self.fitter.fitting.parameters, sqrt=True)
+        Loss = self.separate_losses(distance, gt_points, lamb=lamb)
+        return Loss, self.fitter.fitting.parameters, None
 
     def separate_losses(self, distance, gt_points, lamb=1.0):
         Loss, geometric_loss, spline_loss = [], [], []

@@ -1,2 +1,3 @@
-"""src/residual_utils.py of the reference (end-to-end fitting loss, training mode)."""
+"""src/residual_utils.py of the reference (end-to-end fitting loss: training mode and
+evaluation mode with hard memberships)."""
 from parsenet_codebase_amd.fitting import Evaluation  # noqa: F401

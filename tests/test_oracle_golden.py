@@ -170,3 +170,31 @@ def test_end_to_end_fitting_loss():
     assert sorted(v[0] for v in params.values() if v is not None) == list(g["kinds"])
     assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 1e-4
     assert rel(emb.grad, g["grad_emb"]) < 1e-3
+
+
+def test_end_to_end_fitting_loss_eval_mode():
+    """fitting_loss(eval=True) -> residual_eval_mode of the reference (fixture e2e_eval.npz;
+    its remove_outliers step is the oracle's own restatement of open3d, see make_golden.py)."""
+    from oracle import ref_fitting as RF, ref_torch as R
+    from parsenet_codebase_amd import synthetic
+    from tests.golden.common import deterministic_init
+    g0, g = load("e2e"), load("e2e_eval")
+    pts, nrm, lab, prim = synthetic.make_shape(int(g0["shape_id"]), 3000, min_segments=4, max_segments=5)
+    open_net = deterministic_init(R.DGCNNControlPoints(20, num_points=10, mode=0)).eval()
+    closed_net = deterministic_init(R.DGCNNControlPoints(20, num_points=10, mode=1), salt=1).eval()
+    ev = RF.Evaluation(closed_net, open_net)
+    np.random.seed(2)
+    loss, (params, ids, w) = ev.fitting_loss(torch.from_numpy(g0["emb"]).unsqueeze(0),
+                                             torch.from_numpy(pts).unsqueeze(0), torch.from_numpy(nrm).unsqueeze(0),
+                                             lab[None], prim[None], quantile=0.025, iterations=10, lamb=0.1,
+                                             eval=True, primitives_log_prob=torch.from_numpy(g["logp"]))
+    assert np.array_equal(ids, g["cluster_ids"])
+    kinds = {int(k): v[0] for k, v in params.items() if v is not None}
+    assert sorted(kinds) == list(g["seg_ids"])
+    assert [kinds[k] for k in sorted(kinds)] == list(g["seg_kinds"])
+    for k in sorted(kinds):
+        if "recon_%d" % k in g.files:
+            assert rel(params[k][1], g["recon_%d" % k]) < 1e-4, k
+    assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 1e-4
+    assert abs(loss[1] - float(g["geo"])) / float(g["geo"]) < 1e-4
+    assert abs(loss[2] - float(g["spline"])) / float(g["spline"]) < 1e-4
