@@ -1,0 +1,415 @@
+"""Training loops around the hot path: the counterparts of
+  train_parsenet.py:142-285        segmentation-only   (3 micro-batches per step, patience 4)
+  train_parsenet_e2e.py:164-470    end to end          (5 micro-batches per step, patience 10,
+                                                        validation through fitting_loss(eval=True))
+  train_open_splines.py:136-260 / train_closed_control_points.py:132-250   SplineNets
+with the reference's call order, sub-sampling (numpy RNG), accumulation, Adam,
+ReduceLROnPlateau(factor 0.5), checkpoint-on-improvement and exception-skip behaviour.
+
+MI355X specifics: one process per GPU (``dp.init_from_env``); every rank draws its own shapes and
+the accumulated gradients meet in ONE flat-bucket all-reduce right before ``optimizer.step()``
+(the reference wraps the model in DataParallel instead).  Validation statistics are averaged
+over ranks so that every rank takes the same scheduler / checkpoint decision; rank 0 writes.
+
+The data source is an object with ``get_train()`` / ``get_val()`` generators yielding
+``(points, labels, normals, primitives)`` numpy batches like the reference's
+``dataset_segments.Dataset`` — ``SyntheticSegments`` (analytic shapes, no files) is the default
+because the ABC h5 files do not ship with the reference."""
+import os
+import traceback
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import dp, synthetic
+from .encoders import DGCNNControlPoints, PrimitivesEmbeddingDGCNGn
+from .losses import EmbeddingLoss, evaluate_miou, primitive_loss
+
+
+@dataclass
+class TrainConfig:
+    """The fields of the reference's read_config.Config that the loops use."""
+    model_path: str = "parsenet_{}"
+    pretrain_model_path: str = ""
+    preload_model: bool = False
+    normals: bool = True
+    num_train: int = 24
+    num_val: int = 8
+    num_test: int = 8
+    num_points: int = 10000
+    grid_size: int = 20
+    loss_weight: float = 0.9
+    epochs: int = 1
+    batch_size: int = 2
+    mode: int = 5
+    lr: float = 1e-2
+    patience: int = 4
+    out_dir: str = "logs/trained_models"
+    max_steps_per_epoch: int = 0       # 0 = derive from num_train like the reference
+
+    @classmethod
+    def from_file(cls, path):
+        """Reads the reference's config files (configs/*.yml: ``key = value`` under [train])."""
+        vals = {}
+        for line in open(path):
+            line = line.split("#", 1)[0].strip()
+            if "=" not in line or line.startswith("["):
+                continue
+            k, v = [t.strip() for t in line.split("=", 1)]
+            vals[k] = v.strip('"')
+        ren = {"num_epochs": "epochs"}
+        out = cls()
+        for k, v in vals.items():
+            k = ren.get(k, k)
+            if not hasattr(out, k):
+                continue
+            cur = getattr(out, k)
+            if isinstance(cur, bool):
+                setattr(out, k, v.lower() in ("true", "1", "yes"))
+            elif isinstance(cur, int):
+                setattr(out, k, int(float(v)))
+            elif isinstance(cur, float):
+                setattr(out, k, float(v))
+            else:
+                setattr(out, k, v)
+        return out
+
+
+class SyntheticSegments:
+    """Stand-in for dataset_segments.Dataset: endless generators of analytic shapes."""
+
+    def __init__(self, batch_size, num_train, num_val, num_points=10000, first_shape=0):
+        self.batch_size, self.num_train, self.num_val = batch_size, num_train, num_val
+        self.num_points, self.first = num_points, first_shape
+
+    def _gen(self, lo, count):
+        i = 0
+        while True:
+            ids = lo + (i % max(count // self.batch_size, 1)) * self.batch_size
+            pts, nrm, lab, prim = synthetic.make_batch(self.first + ids, self.batch_size, self.num_points)
+            yield pts, lab, nrm, prim
+            i += 1
+
+    def get_train(self, **_):
+        return self._gen(0, self.num_train)
+
+    def get_val(self, **_):
+        return self._gen(self.num_train, self.num_val)
+
+
+class ReduceLROnPlateau:
+    """mode "min", relative threshold 1e-4 — the arithmetic of torch's scheduler of that name
+    (the reference constructs it with factor 0.5, patience 4 / 10, min_lr 1e-4 / 3e-5)."""
+
+    def __init__(self, optimizer, factor=0.5, patience=4, min_lr=1e-4, threshold=1e-4):
+        self.opt, self.factor, self.patience, self.min_lr, self.threshold = optimizer, factor, patience, min_lr, threshold
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        metric = float(metric)
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            for g in self.opt.param_groups:
+                g["lr"] = max(g["lr"] * self.factor, self.min_lr)
+            self.bad = 0
+
+
+def _mean_over_ranks(value, device):
+    """Mean of a python float over ranks (nan-aware), so that every rank decides alike."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    ok = 0.0 if np.isnan(value) else 1.0
+    t = torch.tensor([0.0 if np.isnan(value) else float(value), ok], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return float(t[0] / t[1]) if float(t[1]) > 0 else float("nan")
+
+
+def _save(model, optimizer, cfg, name, rank):
+    if rank != 0:
+        return None
+    os.makedirs(cfg.out_dir, exist_ok=True)
+    path = os.path.join(cfg.out_dir, name + ".pth")
+    torch.save(model.state_dict(), path)
+    torch.save(optimizer.state_dict(), os.path.join(cfg.out_dir, name + "_optimizer.pth"))
+    return path
+
+
+def _subsample(arrays, keep, total):
+    """The reference's per-micro-batch random subset: np.arange(total) shuffled, first ``keep``."""
+    sel = np.arange(total)
+    np.random.shuffle(sel)
+    sel = sel[0:keep]
+    return [a[:, sel] for a in arrays]
+
+
+def _to_device(points, normals, primitives, device):
+    return (torch.from_numpy(points).to(device), torch.from_numpy(normals).to(device),
+            torch.from_numpy(primitives.astype(np.int64)).to(device))
+
+
+def _seg_forward(model, points, normals, labels, if_normals):
+    x = torch.cat([points, normals], 2) if if_normals else points
+    return model(x.permute(0, 2, 1).contiguous(), labels, True)
+
+
+def build_parsenet(cfg, device):
+    loss = EmbeddingLoss(margin=1.0, if_mean_shift=False)
+    model = PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True, num_primitives=10,
+                                      loss_function=loss.triplet_loss, mode=cfg.mode,
+                                      num_channels=6 if cfg.normals else 3).to(device)
+    if cfg.preload_model and cfg.pretrain_model_path:
+        state = torch.load(cfg.pretrain_model_path, map_location=device)
+        model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in state.items()})
+    return model
+
+
+def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000):
+    """train_parsenet.py:142-285.  Returns the per-epoch history (list of dicts)."""
+    rank, world, dev = dp.init_from_env()
+    device = device or dev
+    model = build_parsenet(cfg, device)
+    bucket = dp.FlatGradBucket(model.parameters())
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=4, min_lr=1e-4)
+    data = data or SyntheticSegments(cfg.batch_size, cfg.num_train, cfg.num_val, cfg.num_points,
+                                     first_shape=rank * (cfg.num_train + cfg.num_val))
+    train_it, val_it = data.get_train(), data.get_val()
+    name = cfg.model_path.format(cfg.mode)
+    prev_test_loss, history = 1e4, []
+    num_iter = 3     # gradient accumulation (train_parsenet.py:155)
+    steps = cfg.max_steps_per_epoch or cfg.num_train // cfg.batch_size
+    for e in range(cfg.epochs):
+        model.train()
+        tr = {"loss": [], "prim": [], "emb": [], "iou": []}
+        for _ in range(steps):
+            bucket.zero()
+            acc = {"loss": 0.0, "prim": 0.0, "emb": 0.0, "iou": 0.0}
+            for _ in range(num_iter):
+                points, labels, normals, primitives = next(train_it)
+                points, labels, normals, primitives = _subsample([points, labels, normals, primitives],
+                                                                 min(keep_points, points.shape[1]), points.shape[1])
+                pts, nrm, prim = _to_device(points, normals, primitives, device)
+                _, log_prob, embed_loss = _seg_forward(model, pts, nrm, labels, cfg.normals)
+                embed_loss = torch.mean(embed_loss)
+                p_loss = primitive_loss(log_prob, prim)
+                iou = evaluate_miou(prim.data.cpu().numpy(), log_prob.permute(0, 2, 1).data.cpu().numpy())
+                loss = embed_loss + p_loss
+                loss.backward()
+                acc["loss"] += loss.item() / num_iter
+                acc["prim"] += p_loss.item() / num_iter
+                acc["emb"] += embed_loss.item() / num_iter
+                acc["iou"] += iou / num_iter
+            bucket.all_reduce_mean()
+            optimizer.step()
+            for k in tr:
+                tr[k].append(acc[k])
+        model.eval()
+        te = {"loss": [], "prim": [], "emb": [], "iou": []}
+        for _ in range(max(cfg.num_test // cfg.batch_size - 1, 1)):
+            points, labels, normals, primitives = next(val_it)
+            points, labels, normals, primitives = _subsample([points, labels, normals, primitives],
+                                                             min(keep_points, points.shape[1]), points.shape[1])
+            pts, nrm, prim = _to_device(points, normals, primitives, device)
+            with torch.no_grad():
+                _, log_prob, embed_loss = _seg_forward(model, pts, nrm, labels, cfg.normals)
+                embed_loss = torch.mean(embed_loss)
+                p_loss = primitive_loss(log_prob, prim)
+            te["iou"].append(evaluate_miou(prim.data.cpu().numpy(), log_prob.permute(0, 2, 1).data.cpu().numpy()))
+            te["prim"].append(p_loss.item())
+            te["emb"].append(embed_loss.item())
+            te["loss"].append((embed_loss + p_loss).item())
+        test_emb = _mean_over_ranks(np.mean(te["emb"]), device)
+        rec = {"epoch": e, "lr": optimizer.param_groups[0]["lr"], "test_emb": test_emb, "saved": None}
+        rec.update({"train_" + k: float(np.mean(v)) for k, v in tr.items()})
+        rec.update({"test_" + k: float(np.mean(v)) for k, v in te.items()})
+        scheduler.step(test_emb)
+        if prev_test_loss > test_emb:
+            prev_test_loss = test_emb
+            rec["saved"] = _save(model, optimizer, cfg, name, rank)
+        if rank == 0:
+            log("Epoch: {}/{} => TrL:{:.4f}, TsL:{:.4f}, TrP:{:.4f}, TsP:{:.4f}, TrE:{:.4f}, TsE:{:.4f}, "
+                "TrI:{:.4f}, TsI:{:.4f}".format(e, cfg.epochs, rec["train_loss"], rec["test_loss"], rec["train_prim"],
+                                                rec["test_prim"], rec["train_emb"], rec["test_emb"],
+                                                rec["train_iou"], rec["test_iou"]))
+        history.append(rec)
+    return history
+
+
+def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, keep_train=7000, keep_val=8000):
+    """train_parsenet_e2e.py:164-470: batch 1 per micro-step, 5 micro-steps per optimizer step,
+    norm layers frozen (model.eval()), loss = triplet + NLL + residual (lamb 0.1); a fitting
+    exception skips the whole step ("mistake"); validation through fitting_loss(eval=True, lamb 1)
+    drives the scheduler (patience 10) and the checkpoint."""
+    from .fitting import Evaluation
+    rank, world, dev = dp.init_from_env()
+    device = device or dev
+    model = build_parsenet(cfg, device)
+    bucket = dp.FlatGradBucket(model.parameters())
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=10, min_lr=1e-4)
+    if evaluation is None:   # no pretrained SplineNets ship with the reference: frozen random init
+        evaluation = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1).to(device),
+                                open_path=DGCNNControlPoints(20, num_points=10, mode=0).to(device))
+    data = data or SyntheticSegments(1, cfg.num_train, cfg.num_val, cfg.num_points,
+                                     first_shape=rank * (cfg.num_train + cfg.num_val))
+    train_it, val_it = data.get_train(), data.get_val()
+    name = cfg.model_path.format(cfg.mode)
+    prev_test_loss, history = 1e4, []
+    lamb, num_iter = 0.1, 5
+    model.eval()      # no updates to the norm layers (train_parsenet_e2e.py:162)
+    steps = cfg.max_steps_per_epoch or cfg.num_train // num_iter
+    for e in range(cfg.epochs):
+        tr = {"loss": [], "prim": [], "emb": [], "res": [], "res_g": [], "res_s": [], "iou": [], "seg_iou": []}
+        skipped = 0
+        for _ in range(steps):
+            bucket.zero()
+            acc = {k: 0.0 for k in ("loss", "prim", "emb", "res", "iou", "seg_iou")}
+            res_g, res_s, mistake = [], [], False
+            for _ in range(num_iter):
+                points, labels, normals, primitives_ = next(train_it)
+                points, labels, normals, primitives_ = _subsample([points, labels, normals, primitives_],
+                                                                  min(keep_train, points.shape[1]), points.shape[1])
+                pts, nrm, prim = _to_device(points, normals, primitives_, device)
+                embedding, log_prob, embed_loss = _seg_forward(model, pts, nrm, labels, cfg.normals)
+                embed_loss = torch.mean(embed_loss)
+                p_loss = primitive_loss(log_prob, prim)
+                try:
+                    res_loss, _ = evaluation.fitting_loss(embedding.permute(0, 2, 1), pts, nrm, labels, primitives_,
+                                                          log_prob, quantile=0.025, iterations=10, lamb=lamb,
+                                                          eval=False)
+                except Exception:       # degenerate segment: the reference drops the step
+                    if rank == 0:
+                        log("exception in training: " + traceback.format_exc().splitlines()[-1])
+                    mistake = True
+                    break
+                s_iou, iou = res_loss[3:]
+                loss = embed_loss + p_loss + 1 * res_loss[0]
+                loss.backward()
+                acc["res"] += res_loss[0].item() / num_iter
+                if res_loss[1] is not None:
+                    res_g.append(res_loss[1])
+                if res_loss[2] is not None:
+                    res_s.append(res_loss[2])
+                acc["seg_iou"] += s_iou / num_iter
+                acc["loss"] += loss.item() / num_iter
+                acc["prim"] += p_loss.item() / num_iter
+                acc["iou"] += iou / num_iter
+                acc["emb"] += embed_loss.item() / num_iter
+            if world > 1:   # a skipped step must be skipped by every rank (the all-reduce is collective)
+                flag = torch.tensor([1.0 if mistake else 0.0], device=device)
+                dist.all_reduce(flag)
+                mistake = bool(flag.item() > 0)
+            if mistake:
+                skipped += 1
+                continue
+            bucket.all_reduce_mean()
+            optimizer.step()
+            for k in acc:
+                tr[k].append(acc[k])
+            tr["res_g"].append(float(np.mean(res_g)) if res_g else 1e-3)
+            tr["res_s"].append(float(np.mean(res_s)) if res_s else 9e-3)
+        te = {"loss": [], "prim": [], "emb": [], "res": [], "res_g": [], "res_s": [], "iou": [], "seg_iou": []}
+        for _ in range(max(cfg.num_test - 1, 1)):
+            points, labels, normals, primitives_ = next(val_it)
+            points, labels, normals, primitives_ = _subsample([points, labels, normals, primitives_],
+                                                              min(keep_val, points.shape[1]), points.shape[1])
+            pts, nrm, prim = _to_device(points, normals, primitives_, device)
+            with torch.no_grad():
+                embedding, log_prob, embed_loss = _seg_forward(model, pts, nrm, labels, cfg.normals)
+                try:
+                    res_loss, _ = evaluation.fitting_loss(embedding.permute(0, 2, 1), pts, nrm, labels, primitives_,
+                                                          log_prob, quantile=0.025, iterations=10, lamb=1.0,
+                                                          eval=True)
+                except Exception:
+                    if rank == 0:
+                        log("some exception while testing: " + traceback.format_exc().splitlines()[-1])
+                    continue
+                s_iou, iou = res_loss[3:]
+                embed_loss = torch.mean(embed_loss)
+                p_loss = primitive_loss(log_prob, prim)
+            te["res"].append(res_loss[0].item())
+            if res_loss[1] is not None:
+                te["res_g"].append(res_loss[1])
+            if res_loss[2] is not None:
+                te["res_s"].append(res_loss[2])
+            te["iou"].append(iou)
+            te["seg_iou"].append(s_iou)
+            te["prim"].append(p_loss.item())
+            te["emb"].append(embed_loss.item())
+            te["loss"].append((embed_loss + p_loss).item())
+        test_res = _mean_over_ranks(np.mean(te["res"]) if te["res"] else float("nan"), device)
+        rec = {"epoch": e, "lr": optimizer.param_groups[0]["lr"], "skipped_steps": skipped, "saved": None}
+        rec.update({"train_" + k: (float(np.mean(v)) if v else float("nan")) for k, v in tr.items()})
+        rec.update({"test_" + k: (float(np.mean(v)) if v else float("nan")) for k, v in te.items()})
+        rec["test_res"] = test_res
+        if not np.isnan(test_res):
+            scheduler.step(test_res)
+            if prev_test_loss > test_res:
+                prev_test_loss = test_res
+                rec["saved"] = _save(model, optimizer, cfg, name, rank)
+        if rank == 0:
+            log("Epoch: {}/{} => TrL:{:.4f}, TsL:{:.4f}, TrRes:{:.5f}, TsRes:{:.5f}, TrSIoU:{:.3f}, TsSIoU:{:.3f}, "
+                "skipped:{}".format(e, cfg.epochs, rec["train_loss"], rec["test_loss"], rec["train_res"],
+                                    rec["test_res"], rec["train_seg_iou"], rec["test_seg_iou"], skipped))
+        history.append(rec)
+    return history
+
+
+def train_splinenet(cfg, closed=False, device=None, log=print):
+    """train_open_splines.py:136-260 / train_closed_control_points.py:132-250 on synthetic
+    patches: random point count 400..1999 per step (open only, as in the reference; the closed
+    script feeds all points), loss as workloads.SplineNetStep, validation Chamfer drives
+    ReduceLROnPlateau(patience 10, min_lr 3e-5) and the checkpoint."""
+    from .workloads import SplineNetStep
+    rank, world, dev = dp.init_from_env()
+    device = device or dev
+    B = cfg.batch_size
+    step = SplineNetStep(device, closed=closed, batch=B, num_points=2000, first_shape=rank * 100000, lr=cfg.lr,
+                         loss_weight=cfg.loss_weight)
+    scheduler = ReduceLROnPlateau(step.opt, factor=0.5, patience=10, min_lr=3e-5)
+    name = cfg.model_path.format(int(closed))
+    steps = cfg.max_steps_per_epoch or cfg.num_train // B
+    prev, history = 1e8, []
+    shape_id = 0
+
+    def load(first):
+        pts, ctrl = synthetic.make_spline_patches(rank * 100000 + first, B, 2000, 20, closed)
+        return (torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1))).to(device),
+                torch.from_numpy(ctrl).to(device))
+    for e in range(cfg.epochs):
+        step.model.train()
+        tr = {"cd": [], "reg": [], "lap": []}
+        for _ in range(steps):
+            points, step.control_points = load(shape_id)
+            shape_id += B
+            n = 2000 if closed else int(700 + np.random.choice(np.arange(-300, 1300), 1)[0])
+            step.points = points[:, :, 0:n].contiguous()
+            step.step()
+            cd, reg, lap = step.last
+            tr["cd"].append(cd.item())
+            tr["reg"].append(reg.item())
+            tr["lap"].append(lap.item() if lap is not None else 0.0)
+        step.model.eval()
+        te = []
+        for v in range(max(cfg.num_test // B, 1)):
+            points, step.control_points = load(10 ** 6 + v * B)
+            step.points = points[:, :, 0:700].contiguous()
+            with torch.no_grad():
+                te.append(step.losses(step.model(step.points))[1].item())
+        test_cd = _mean_over_ranks(float(np.mean(te)), device)
+        scheduler.step(test_cd)
+        rec = {"epoch": e, "lr": step.opt.param_groups[0]["lr"], "test_cd": test_cd, "saved": None}
+        rec.update({"train_" + k: float(np.mean(v)) for k, v in tr.items()})
+        if prev > test_cd:
+            prev = test_cd
+            rec["saved"] = _save(step.model, step.opt, cfg, name, rank)
+        if rank == 0:
+            log("Epoch: {}/{} => train cd {:.5f} reg {:.5f} lap {:.5f}; test cd {:.5f}".format(
+                e, cfg.epochs, rec["train_cd"], rec["train_reg"], rec["train_lap"], test_cd))
+        history.append(rec)
+    return history
