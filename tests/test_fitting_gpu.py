@@ -207,3 +207,23 @@ def test_spline_losses(gpu):
     (l1g + l2g + l3g + l4g).backward()
     (l1r + l2r + l3r + l4r).backward()
     assert _rel(og.grad, orr.grad) < 1e-5
+
+
+def test_coverage_metrics_match_oracle(gpu):
+    """test.py:157-185: s-/p-coverage from per-point one-sided Chamfer distances (reduce=False)."""
+    from oracle import ref_torch as R
+    from parsenet_codebase_amd.metrics import continuous_labels, coverage_metrics
+    g = torch.Generator().manual_seed(3)
+    pts = torch.rand(4000, 3, generator=g) - 0.5
+    pred = pts[:3000] + 0.01 * torch.randn(3000, 3, generator=g)
+    got = coverage_metrics(pred.to(gpu), pts.to(gpu))
+    cd1 = R.chamfer_distance_single_shape(pred, pts, sqrt=True, one_side=True, reduce=False)
+    cd2 = R.chamfer_distance_single_shape(pts, pred, sqrt=True, one_side=True, reduce=False)
+    want = {"sk_1": (cd1 < 0.01).float().mean().item(), "sk_2": (cd1 < 0.02).float().mean().item(),
+            "sk": cd1.mean().item(), "pk_1": (cd2 < 0.01).float().mean().item(),
+            "pk_2": (cd2 < 0.02).float().mean().item(), "pk": cd2.mean().item()}
+    want["cd"] = (want["sk"] + want["pk"]) / 2
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 1e-5 * max(abs(v), 1e-3), (k, got[k], v)
+    lab = np.array([7, 7, 3, 9, 3])
+    assert np.array_equal(continuous_labels(lab), [1, 1, 0, 2, 0])
