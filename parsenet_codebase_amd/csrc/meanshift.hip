@@ -577,3 +577,5 @@ extern "C" int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const 
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
+
+#include "meanshift_x3.h"

@@ -1,0 +1,567 @@
+// Mean-shift iterations with fp32-grade products on the bf16 matrix cores ("bf16 x 3").
+//
+// Same mathematics, data flow and outputs as meanshift.hip; only the two GEMMs per tile change.
+// Every fp32 operand x is split without error into three bf16 pieces,
+//     x = xh + xm + xl,  xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)
+// (24 significand bits = 3 x 8; the residuals are exact in fp32), and a product x*y is
+// evaluated as  xh*yh + xh*ym + xm*yh + xm*ym + xh*yl + xl*yh  with fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16.  Each bf16 x bf16 product is exact in fp32; the dropped terms
+// (xm*yl, xl*ym, xl*yl) are below 2^-25 |x*y|, i.e. below the rounding of an fp32 product.  The
+// result is therefore an fp32 dot product with a different (tree) summation order — not a
+// reduced-precision one; tests/test_meanshift_gpu.py measures it against the fp64 oracle next
+// to the exact-fp32 path.  Six bf16 MFMAs (32 cycles each) replace eight fp32 MFMAs
+// (64 cycles each) per 32x32x16 block: 2.7x less matrix-pipe time, and bf16 MFMAs overlap with
+// the VALU work of the elementwise stage, which the fp32 ones do not.
+//
+// Streamed operands come pre-split from global memory as LDS images (one 24 KiB image per
+// 32-point tile and layout, written by pn_ms3_split_kernel, copied verbatim by the LDS DMA):
+//   P image [piece 3][row j 32][16 chunks of 8 channels]   chunk c stored at c ^ (j & 15)
+//   C image [piece 3][feature f 128][4 chunks of 8 points] chunk c stored at c ^ ((f >> 2) & 3)
+// The XOR swizzles make the ds_read_b128 operand fetches of both GEMMs bank-conflict free
+// (16-lane service groups, MI355X_MICROARCH.md section LDS).  In the C image the 32 points of a
+// tile are ordered as the D-layout of the first GEMM hands them to the second one: position
+// 16 t + 8 h + e holds point (e & 3) + 8 (2 t + (e >> 2)) + 4 h.
+// (included at the end of meanshift.hip: one translation unit, shared combine kernels)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define X3_IMG_U4 1536            // uint4 (16 B) units per 24 KiB tile image
+#define X3_PIECE_U4 512           // per piece
+
+typedef const __attribute__((address_space(1))) void* x3_gptr;
+typedef __attribute__((address_space(3))) void* x3_lptr;
+#define X3_GLDS16(G, L) __builtin_amdgcn_global_load_lds((x3_gptr)(G), (x3_lptr)(L), 16, 0, 0)
+
+// error-free split of two floats into three packed bf16 pairs (element 0 in the low half)
+struct X3Pieces {
+  uint32_t h, m, l;
+};
+__device__ static inline X3Pieces x3_split2(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 ph = __builtin_convertvector(v, bf16x2);
+  f32x2 r = {a - (float)ph[0], b - (float)ph[1]};
+  bf16x2 pm = __builtin_convertvector(r, bf16x2);
+  f32x2 r2 = {r[0] - (float)pm[0], r[1] - (float)pm[1]};
+  bf16x2 pl = __builtin_convertvector(r2, bf16x2);
+  X3Pieces o;
+  o.h = __builtin_bit_cast(uint32_t, ph);
+  o.m = __builtin_bit_cast(uint32_t, pm);
+  o.l = __builtin_bit_cast(uint32_t, pl);
+  return o;
+}
+#define X3_SPLIT_TO(A, B, VH, VM, VL, Q) \
+  {                                      \
+    const X3Pieces _p = x3_split2(A, B); \
+    VH[Q] = _p.h;                        \
+    VM[Q] = _p.m;                        \
+    VL[Q] = _p.l;                        \
+  }
+
+__device__ static inline bf16x8 x3_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// position p (0..31) of a tile's C image -> point index inside the tile
+__host__ __device__ static inline int x3_rho(int p) {
+  const int t = p >> 4, h = (p >> 3) & 1, e = p & 7;
+  return (e & 3) + 8 * (2 * t + (e >> 2)) + 4 * h;
+}
+
+// x (B,N,D) fp32 -> P and C images of every 32-point tile (rows >= N are zero).
+// One workgroup per tile; work item = one 16-byte chunk of each image.
+__global__ __launch_bounds__(256) void pn_ms3_split_kernel(const float* __restrict__ x, int N,
+                                                           int ntiles, u32x4* __restrict__ pimg,
+                                                           u32x4* __restrict__ cimg) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const float* __restrict__ xb = x + (size_t)b * N * MS_D;
+  u32x4* __restrict__ P = pimg + ((size_t)b * ntiles + tile) * X3_IMG_U4;
+  u32x4* __restrict__ C = cimg + ((size_t)b * ntiles + tile) * X3_IMG_U4;
+  const int j0 = tile * 32;
+  for (int it = threadIdx.x; it < 512; it += 256) {
+    if (pimg != nullptr) {  // P image: row j, chunk c = channels 8c..8c+7
+      const int j = it >> 4, c = it & 15;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (j0 + j < N) ? xb[(size_t)(j0 + j) * MS_D + 8 * c + e] : 0.f;
+      u32x4 h, m, l;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X3_SPLIT_TO(v[2 * q], v[2 * q + 1], h, m, l, q);
+      const int slot = j * 16 + (c ^ (j & 15));
+      P[slot] = h;
+      P[X3_PIECE_U4 + slot] = m;
+      P[2 * X3_PIECE_U4 + slot] = l;
+    }
+    if (cimg != nullptr) {  // C image: feature f, chunk c = positions 8c..8c+7 (points rho(8c+e))
+      const int f = it >> 2, c = it & 3;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = j0 + x3_rho(8 * c + e);
+        v[e] = j < N ? xb[(size_t)j * MS_D + f] : 0.f;
+      }
+      u32x4 h, m, l;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X3_SPLIT_TO(v[2 * q], v[2 * q + 1], h, m, l, q);
+      const int slot = f * 4 + (c ^ ((f >> 2) & 3));
+      C[slot] = h;
+      C[X3_PIECE_U4 + slot] = m;
+      C[2 * X3_PIECE_U4 + slot] = l;
+    }
+  }
+}
+
+// backward prologue, one wave per row (as pn_ms_prep_bwd_kernel, without the transposed copies):
+//   gu = (gy - y (y.gy)) / ||u|| ; c = gu . u (u = y ||u||) ; go = gu / r ; alpha = 1 / (r b^2)
+__global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
+    const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ rsum,
+    const float* __restrict__ unorm, const float* __restrict__ bsq, int N, float* __restrict__ gu,
+    float* __restrict__ go, float* __restrict__ cs, float* __restrict__ alpha) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= N) return;
+  const size_t base = ((size_t)b * N + i) * MS_D;
+  const float y0 = y[base + lane], y1 = y[base + lane + 64];
+  const float g0 = gy[base + lane], g1 = gy[base + lane + 64];
+  const float nn = unorm[(size_t)b * N + i], r = rsum[(size_t)b * N + i];
+  const float yg = pn_wave_sum(y0 * g0 + y1 * g1);
+  const float u0 = (g0 - y0 * yg) / nn, u1 = (g1 - y1 * yg) / nn;
+  const float c = pn_wave_sum(u0 * (y0 * nn) + u1 * (y1 * nn));
+  gu[base + lane] = u0;
+  gu[base + lane + 64] = u1;
+  go[base + lane] = u0 / r;
+  go[base + lane + 64] = u1 / r;
+  if (lane == 0) {
+    cs[(size_t)b * N + i] = c;
+    alpha[(size_t)b * N + i] = 1.0f / (r * bsq[b]);
+  }
+}
+
+// six-term product of two split operands into two accumulators (large and small terms apart)
+#define X3_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+
+// PASS 0 forward       resident rows Q;      streamed X:      out[f][i] += X[j][f] K
+// PASS 1 backward/rows resident rows Q, GU;  streamed X:      out[f][i] += X[j][f] gs
+// PASS 2 backward/cols resident cols X;      streamed Q, GU, GO: out[f][j] += Q[i][f] gs + GO[i][f] K
+//
+// R, R1       (B,N,D) fp32 resident operands (split in registers once per workgroup)
+// PA, PB      P images of the streamed operand(s) of the first GEMM (PB: GU, PASS 2 only)
+// CA, CB      C images of the streamed operand(s) of the second GEMM (CB: GO, PASS 2 only)
+// cs, rs      per-row c_i and alpha_i = 1/(r_i b^2): of the resident row (PASS 1) / streamed (PASS 2)
+// grid (slices, blocks of 128 resident indices, B), 256 threads: wave w owns 32 w .. 32 w + 31.
+// LDS: P images double buffered, C images single buffered (loaded under the first GEMM of the
+// same tile): 72 KiB (PASS 0/1), 144 KiB (PASS 2).
+template <int PASS>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void pn_ms3_kernel(
+    const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
+    const u32x4* __restrict__ PB, const u32x4* __restrict__ CA, const u32x4* __restrict__ CB,
+    const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_, int N,
+    int ntiles, int tiles_per_slice, float* __restrict__ opart, float* __restrict__ rpart) {
+  constexpr int NIMG = PASS == 2 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) u32x4 ldsP[2][NIMG][X3_IMG_U4];
+  __shared__ __attribute__((aligned(16))) u32x4 ldsC[NIMG][X3_IMG_U4];
+  __shared__ __attribute__((aligned(16))) float lds_sc[2][64];
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, h = lane >> 5;
+  const int i0 = (blockIdx.y * 4 + wave) * 32;
+  const bool wave_on = i0 < N;
+  const int S = gridDim.x, slice = blockIdx.x;
+  const int t_begin = slice * tiles_per_slice;
+  const int t_end = min(ntiles, t_begin + tiles_per_slice);
+  const float hl = (0.5f / bsq_[b]) * MS_LOG2E;
+  const size_t bN = (size_t)b * N;
+  const size_t boff = (size_t)b * ntiles * X3_IMG_U4;
+  const u32x4* __restrict__ PAb = PA + boff;
+  const u32x4* __restrict__ PBb = PASS == 2 ? PB + boff : nullptr;
+  const u32x4* __restrict__ CAb = CA + boff;
+  const u32x4* __restrict__ CBb = PASS == 2 ? CB + boff : nullptr;
+
+  // resident operand(s) as B operands of the first GEMM: k-step s = channels 16 s + 8 h + e
+  const int ires = min(i0 + col, N - 1);
+  bf16x8 qh[8], qm[8], ql[8];
+  bf16x8 uh[PASS == 1 ? 8 : 1], um[PASS == 1 ? 8 : 1], ul[PASS == 1 ? 8 : 1];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    {
+      const float* src = R + (bN + ires) * MS_D + 16 * s + 8 * h;
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 c = *reinterpret_cast<const float4*>(src + 4);
+      u32x4 vh, vm, vl;
+      X3_SPLIT_TO(a.x, a.y, vh, vm, vl, 0);
+      X3_SPLIT_TO(a.z, a.w, vh, vm, vl, 1);
+      X3_SPLIT_TO(c.x, c.y, vh, vm, vl, 2);
+      X3_SPLIT_TO(c.z, c.w, vh, vm, vl, 3);
+      qh[s] = x3_as_bf16(vh);
+      qm[s] = x3_as_bf16(vm);
+      ql[s] = x3_as_bf16(vl);
+    }
+    if (PASS == 1) {
+      const float* src = R1 + (bN + ires) * MS_D + 16 * s + 8 * h;
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 c = *reinterpret_cast<const float4*>(src + 4);
+      u32x4 vh, vm, vl;
+      X3_SPLIT_TO(a.x, a.y, vh, vm, vl, 0);
+      X3_SPLIT_TO(a.z, a.w, vh, vm, vl, 1);
+      X3_SPLIT_TO(c.x, c.y, vh, vm, vl, 2);
+      X3_SPLIT_TO(c.z, c.w, vh, vm, vl, 3);
+      uh[PASS == 1 ? s : 0] = x3_as_bf16(vh);
+      um[PASS == 1 ? s : 0] = x3_as_bf16(vm);
+      ul[PASS == 1 ? s : 0] = x3_as_bf16(vl);
+    }
+  }
+  float c_res = 0.f, a_res = 0.f;
+  if (PASS == 1) {
+    c_res = cs[bN + ires];
+    a_res = rs[bN + ires];
+  }
+  f32x16 acc_o[4];
+#pragma unroll
+  for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[fb][r] = 0.f;
+  float rsum = 0.f;
+
+  // a 24 KiB image = 24 chunks of 1 KiB: wave w copies chunks 6 w .. 6 w + 5 (64 lanes x 16 B)
+#define X3_STAGE(SRC, DST)                                                        \
+  {                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 6; ++u) {                               \
+      const int q = wave * 6 + u;                                                 \
+      X3_GLDS16((SRC) + q * 64 + lane, &(DST)[q * 64]);                           \
+    }                                                                             \
+  }
+#define X3_STAGE_P(MT, BUF)                                                       \
+  {                                                                               \
+    X3_STAGE(PAb + (size_t)(MT) * X3_IMG_U4, ldsP[BUF][0]);                       \
+    if (PASS == 2) {                                                              \
+      X3_STAGE(PBb + (size_t)(MT) * X3_IMG_U4, ldsP[BUF][NIMG - 1]);              \
+      if (wave == 0) { /* c_i | alpha_i of the 32 streamed rows */                \
+        const int jc = min((MT) * 32 + (lane & 31), N - 1);                       \
+        __builtin_amdgcn_global_load_lds((x3_gptr)((lane < 32 ? cs : rs) + bN + jc), \
+                                         (x3_lptr)&lds_sc[BUF][0], 4, 0, 0);      \
+      }                                                                           \
+    }                                                                             \
+  }
+  int cur = 0;
+  if (t_begin < t_end) X3_STAGE_P(t_begin, 0);
+#ifdef MS_TIMING
+  unsigned long long tb0 = 0, tdma = 0, tg1 = 0, tew = 0, tb1 = 0, tg2 = 0, tall = __builtin_amdgcn_s_memtime();
+#endif
+  for (int mt = t_begin; mt < t_end; ++mt) {
+    const int j0 = mt * 32;
+    MS_T(U0);
+    __syncthreads();  // P(mt) landed; every wave is done with the C images of tile mt - 1
+    MS_T(U1);
+    X3_STAGE(CAb + (size_t)mt * X3_IMG_U4, ldsC[0]);
+    if (PASS == 2) X3_STAGE(CBb + (size_t)mt * X3_IMG_U4, ldsC[NIMG - 1]);
+    if (mt + 1 < t_end) X3_STAGE_P(mt + 1, cur ^ 1);
+    MS_T(U2);
+    u32x4 wh[2], wm[2], wl[2];                                   // weights of the second GEMM
+    u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
+    if (wave_on) {
+      // ---- first GEMM: S[streamed][resident] (and T with the second operand) ----
+      f32x16 sa, sb, ta, tb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sa[r] = 0.f;
+        sb[r] = 0.f;
+        ta[r] = 0.f;
+        tb[r] = 0.f;
+      }
+      const u32x4* __restrict__ lp = ldsP[cur][0];
+      const u32x4* __restrict__ lp1 = ldsP[cur][NIMG - 1];
+      const int rowoff = col * 16, sw = col & 15;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int slot = rowoff + ((2 * s + h) ^ sw);
+        const bf16x8 ah = x3_as_bf16(lp[slot]);
+        const bf16x8 am = x3_as_bf16(lp[X3_PIECE_U4 + slot]);
+        const bf16x8 al = x3_as_bf16(lp[2 * X3_PIECE_U4 + slot]);
+        X3_MFMA(sb, al, qh[s]);
+        X3_MFMA(sa, am, qh[s]);
+        X3_MFMA(sb, ah, ql[s]);
+        X3_MFMA(sa, ah, qm[s]);
+        X3_MFMA(sb, am, qm[s]);
+        X3_MFMA(sa, ah, qh[s]);
+        if (PASS == 1) {  // T = X . GU: same streamed operand, second resident one
+          const int z = PASS == 1 ? s : 0;
+          X3_MFMA(tb, al, uh[z]);
+          X3_MFMA(ta, am, uh[z]);
+          X3_MFMA(tb, ah, ul[z]);
+          X3_MFMA(ta, ah, um[z]);
+          X3_MFMA(tb, am, um[z]);
+          X3_MFMA(ta, ah, uh[z]);
+        }
+        if (PASS == 2) {  // T = GU . X: second streamed operand, same resident one
+          const bf16x8 gh = x3_as_bf16(lp1[slot]);
+          const bf16x8 gm = x3_as_bf16(lp1[X3_PIECE_U4 + slot]);
+          const bf16x8 gl = x3_as_bf16(lp1[2 * X3_PIECE_U4 + slot]);
+          X3_MFMA(tb, gl, qh[s]);
+          X3_MFMA(ta, gm, qh[s]);
+          X3_MFMA(tb, gh, ql[s]);
+          X3_MFMA(ta, gh, qm[s]);
+          X3_MFMA(tb, gm, qm[s]);
+          X3_MFMA(ta, gh, qh[s]);
+        }
+      }
+      MS_T(U3);
+#ifdef MS_TIMING
+      tg1 += U3 - U2;
+#endif
+      // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col] ----
+      const bool tail = j0 + 32 > N;
+      float kv[16], gs[PASS == 0 ? 1 : 16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float sv = sa[r] + sb[r];
+        const float dist = __builtin_fmaf(-2.0f, sv, 2.0f);
+        const float a2 = -dist * hl;
+        const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);
+        float k = __builtin_amdgcn_exp2f(a2c);
+        if (tail && j0 + row >= N) k = 0.f;
+        kv[r] = k;
+        if (PASS == 0) rsum += k;
+        if (PASS != 0) {
+          const float tv = ta[r] + tb[r];
+          const float cc = PASS == 1 ? c_res : lds_sc[cur][row];
+          const float aa = PASS == 1 ? a_res : lds_sc[cur][32 + row];
+          float g = k * ((tv - cc) * aa);
+          asm volatile("" : "+v"(g));  // keep the select a v_cndmask, not a branch
+          gs[PASS == 0 ? 0 : r] = a2c == a2 ? g : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (PASS == 0) {
+            X3_SPLIT_TO(kv[8 * t + 2 * q], kv[8 * t + 2 * q + 1], wh[t], wm[t], wl[t], q);
+          } else {
+            const int e = PASS == 0 ? 0 : 8 * t + 2 * q;
+            X3_SPLIT_TO(gs[e], gs[e + (PASS == 0 ? 0 : 1)], wh[t], wm[t], wl[t], q);
+            if (PASS == 2) {
+              const int tt = PASS == 2 ? t : 0;
+              X3_SPLIT_TO(kv[8 * t + 2 * q], kv[8 * t + 2 * q + 1], vh[tt], vm[tt], vl[tt], q);
+            }
+          }
+        }
+#ifdef MS_TIMING
+      tew += __builtin_amdgcn_s_memtime() - U3;
+#endif
+    }
+    MS_T(U4);
+    __syncthreads();  // C(mt) landed
+    MS_T(U5);
+#ifdef MS_TIMING
+    tb0 += U1 - U0;
+    tdma += U2 - U1;
+    tb1 += U5 - U4;
+#endif
+    if (wave_on) {
+      // ---- second GEMM: out[f][resident] += sum_streamed C[f][streamed] w[streamed][resident];
+      //      k-step t = D registers 8t..8t+7 of the first GEMM ----
+      const u32x4* __restrict__ lc = ldsC[0];
+      const u32x4* __restrict__ lc1 = ldsC[NIMG - 1];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 bh = x3_as_bf16(wh[t]), bm = x3_as_bf16(wm[t]), bl = x3_as_bf16(wl[t]);
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+          const int f = fb * 32 + col;
+          const int slot = f * 4 + ((2 * t + h) ^ ((f >> 2) & 3));
+          const bf16x8 xh = x3_as_bf16(lc[slot]);
+          const bf16x8 xm = x3_as_bf16(lc[X3_PIECE_U4 + slot]);
+          const bf16x8 xl = x3_as_bf16(lc[2 * X3_PIECE_U4 + slot]);
+          X3_MFMA(acc_o[fb], xl, bh);
+          X3_MFMA(acc_o[fb], xh, bl);
+          X3_MFMA(acc_o[fb], xm, bm);
+          X3_MFMA(acc_o[fb], xm, bh);
+          X3_MFMA(acc_o[fb], xh, bm);
+          X3_MFMA(acc_o[fb], xh, bh);
+          if (PASS == 2) {
+            const int tt = PASS == 2 ? t : 0;
+            const bf16x8 kh = x3_as_bf16(vh[tt]), km = x3_as_bf16(vm[tt]), kl = x3_as_bf16(vl[tt]);
+            const bf16x8 oh = x3_as_bf16(lc1[slot]);
+            const bf16x8 om = x3_as_bf16(lc1[X3_PIECE_U4 + slot]);
+            const bf16x8 ol = x3_as_bf16(lc1[2 * X3_PIECE_U4 + slot]);
+            X3_MFMA(acc_o[fb], ol, kh);
+            X3_MFMA(acc_o[fb], oh, kl);
+            X3_MFMA(acc_o[fb], om, km);
+            X3_MFMA(acc_o[fb], om, kh);
+            X3_MFMA(acc_o[fb], oh, km);
+            X3_MFMA(acc_o[fb], oh, kh);
+          }
+        }
+      }
+    }
+#ifdef MS_TIMING
+    tg2 += __builtin_amdgcn_s_memtime() - U5;
+#endif
+    cur ^= 1;
+  }
+#ifdef MS_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    ms_dbg[PASS][0] = tg1;
+    ms_dbg[PASS][1] = tg2;
+    ms_dbg[PASS][2] = tb0;
+    ms_dbg[PASS][3] = __builtin_amdgcn_s_memtime() - tall;
+    ms_dbg[PASS][4] = t_end - t_begin;
+    ms_dbg[PASS][5] = tew;
+    ms_dbg[PASS][6] = tdma;
+    ms_dbg[PASS][7] = tb1;
+  }
+#endif
+  if (!wave_on) return;
+  const int ir = i0 + col;
+  if (ir < N) {
+    float* o = opart + (((size_t)b * S + slice) * N + ir) * MS_D;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(o + fb * 32 + 8 * g + 4 * h) =
+            make_float4(acc_o[fb][4 * g], acc_o[fb][4 * g + 1], acc_o[fb][4 * g + 2],
+                        acc_o[fb][4 * g + 3]);
+  }
+  if (PASS == 0) {
+    rsum += __shfl_xor(rsum, 32, 64);
+    if (h == 0 && ir < N) rpart[((size_t)b * S + slice) * N + ir] = rsum;
+  }
+}
+
+extern "C" size_t pn_meanshift_x3_image_bytes(int B, int N) {
+  const int Np = (int)pn_align_up(N, 64);
+  return (size_t)B * (Np / 32) * X3_IMG_U4 * 16;
+}
+
+// x (B,N,D) -> the two tile-image arrays (each pn_meanshift_x3_image_bytes(B,N) bytes)
+extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, void* pimg, void* cimg,
+                                         void* stream) {
+  PN_CHECK_ARG(x && pimg && cimg && B > 0 && N > 0, "pn_meanshift_x3_split_f32: bad arguments");
+  PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
+  const int ntiles = (int)pn_align_up(N, 64) / 32;
+  hipLaunchKernelGGL(pn_ms3_split_kernel, dim3(ntiles, B), dim3(256), 0, (hipStream_t)stream, x, N, ntiles,
+                     (u32x4*)pimg, (u32x4*)cimg);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
+  // fill whole rounds of the 256 x blocks_per_cu workgroup slots (forward: two 72 KiB workgroups
+  // per CU at <= 256 registers; backward: one)
+  const long long rowblocks = (long long)B * pn_cdiv(N, 128);
+  if (ntiles < 16) {
+    *tps = ntiles;
+    return 1;
+  }
+  int best = 1;
+  double best_score = -1.0;
+  const int smax = ntiles / 8 < 32 ? ntiles / 8 : 32;
+  for (int S = 1; S <= smax; ++S) {
+    const int t = pn_cdiv(ntiles, S);
+    if (pn_cdiv(ntiles, t) != S) continue;
+    const double rounds = (double)(rowblocks * S) / (256.0 * blocks_per_cu);
+    const double eff = rounds / (double)(long long)(rounds + 0.999999);
+    const double score = eff * (double)t / ((double)t + 1.5) - 0.002 * S;
+    if (score > best_score) {
+      best_score = score;
+      best = S;
+    }
+  }
+  *tps = pn_cdiv(ntiles, best);
+  return best;
+}
+
+// One forward iteration on the bf16 x 3 path: same contract as pn_meanshift_iter_fwd_f32 with the
+// images of x (pn_meanshift_x3_split_f32) in place of x / xt.
+extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* pimg, const void* cimg,
+                                            const float* bsq, int B, int N, int D, float* opart,
+                                            float* rpart, float* y, float* rsum, float* unorm,
+                                            void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(q && pimg && cimg && bsq && opart && rpart && y && rsum && unorm,
+               "pn_meanshift_x3_iter_fwd_f32: null pointer");
+  PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_meanshift_x3_iter_fwd_f32: empty input");
+  const int ntiles = (int)pn_align_up(N, 64) / 32;
+  int tps;
+  int S = x3_slices(B, N, ntiles, 2, &tps);
+  const int smax = pn_meanshift_slices(B, N);  // the scratch is sized for this many slices
+  if (S > smax) {
+    S = smax;
+    tps = pn_cdiv(ntiles, S);
+  }
+  dim3 grid(S, pn_cdiv(N, 128), B);
+  {
+    PN_PROF("meanshift_fwd", stream);
+    hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(256), 0, stream, q, nullptr, (const u32x4*)pimg,
+                       nullptr, (const u32x4*)cimg, nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart,
+                       rpart);
+  }
+  PN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pn_ms_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart,
+                     rpart, q, N, S, y, rsum, unorm);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// Backward of one iteration on the bf16 x 3 path: same contract as pn_meanshift_iter_bwd_f32 with
+// the images of x in place of (x, xt), and four scratch image arrays (each
+// pn_meanshift_x3_image_bytes(B,N) bytes) for the images of q, gu and go in place of (qt, gut).
+extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q,
+                                            const void* pimg_x, const void* cimg_x, const float* rsum,
+                                            const float* unorm, const float* bsq, int B, int N, int D,
+                                            float* gu, float* go, float* cs, void* pimg_q,
+                                            void* cimg_q, void* pimg_gu, void* cimg_go, float* opart_q,
+                                            float* opart_x, float* gq, float* gx, const float* x,
+                                            void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(gy && y && q && pimg_x && cimg_x && rsum && unorm && bsq && gu && go && cs && pimg_q &&
+                   cimg_q && pimg_gu && cimg_go && opart_q && opart_x && gq && gx && x,
+               "pn_meanshift_x3_iter_bwd_f32: null pointer");
+  PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
+  const int ntiles = (int)pn_align_up(N, 64) / 32;
+  int tps;
+  int S = x3_slices(B, N, ntiles, 1, &tps);
+  const int smax = pn_meanshift_slices(B, N);
+  if (S > smax) {
+    S = smax;
+    tps = pn_cdiv(ntiles, S);
+  }
+  float* alpha = cs + (size_t)B * N;
+  hipLaunchKernelGGL(pn_ms3_prep_bwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, gy, y, rsum,
+                     unorm, bsq, N, gu, go, cs, alpha);
+  PN_CHECK_LAUNCH();
+  dim3 sgrid(ntiles, B);
+  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, q, N, ntiles, (u32x4*)pimg_q,
+                     (u32x4*)cimg_q);
+  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, (const float*)gu, N, ntiles,
+                     (u32x4*)pimg_gu, (u32x4*)nullptr);
+  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, (const float*)go, N, ntiles,
+                     (u32x4*)nullptr, (u32x4*)cimg_go);
+  PN_CHECK_LAUNCH();
+  dim3 grid(S, pn_cdiv(N, 128), B);
+  {
+    PN_PROF("meanshift_bwd_rows", stream);
+    hipLaunchKernelGGL(pn_ms3_kernel<1>, grid, dim3(256), 0, stream, q, (const float*)gu,
+                       (const u32x4*)pimg_x, nullptr, (const u32x4*)cimg_x, nullptr, (const float*)cs,
+                       (const float*)alpha, bsq, N, ntiles, tps, opart_q, nullptr);
+  }
+  PN_CHECK_LAUNCH();
+  {
+    PN_PROF("meanshift_bwd_cols", stream);
+    hipLaunchKernelGGL(pn_ms3_kernel<2>, grid, dim3(256), 0, stream, x, nullptr, (const u32x4*)pimg_q,
+                       (const u32x4*)pimg_gu, (const u32x4*)cimg_q, (const u32x4*)cimg_go,
+                       (const float*)cs, (const float*)alpha, bsq, N, ntiles, tps, opart_x, nullptr);
+  }
+  PN_CHECK_LAUNCH();
+  const long long ND4 = (long long)N * MS_D / 4;
+  hipLaunchKernelGGL(pn_ms_combine_bwd_kernel, dim3(pn_cdiv(ND4, 256), B), dim3(256), 0, stream,
+                     opart_q, opart_x, ND4, S, gq, gx);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

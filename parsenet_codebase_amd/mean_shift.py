@@ -2,11 +2,18 @@
 kernels: bandwidth quantile and nearest-centre assignment through the matrix-core selection
 engine, iterations through the fused flash-style kernels with a recompute backward.  Same class,
 method names and return values as the reference."""
+import os
+
 import numpy as np
 import torch
 
 from . import kernels as K
 from ._lib import require_cuda
+
+
+# Arithmetic of the two GEMMs per tile: "bf16x3" (error-free 3-way bf16 split on the bf16 matrix
+# cores, fp32-grade) or "f32" (v_mfma_f32_32x32x2_f32, fma chains).  PARSENET_MS_ARITH overrides.
+ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 
 
 class _MeanShiftIterations(torch.autograd.Function):
@@ -21,12 +28,17 @@ class _MeanShiftIterations(torch.autograd.Function):
         ws = K.MeanShiftWorkspace(B, N, D, x.device)
         iterates, rsums, norms = [x], [], []
         q = x
+        x3 = K.meanshift_x3_split(x) if (ARITH == "bf16x3" and iterations > 0) else None
         for _ in range(iterations):
-            q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
+            if x3 is not None:
+                q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws)
+            else:
+                q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
             iterates.append(q)
             rsums.append(r)
             norms.append(n)
         ctx.iterations = iterations
+        ctx.x3 = x3
         ctx.save_for_backward(xt, bsq, *iterates, *rsums, *norms)
         return q if iterations > 0 else x.clone()
 
@@ -44,8 +56,12 @@ class _MeanShiftIterations(torch.autograd.Function):
         gX = torch.zeros_like(x)
         g = gy.contiguous()
         for it in reversed(range(T)):
-            g = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it], bsq,
-                                     ws, gX)
+            if ctx.x3 is not None:
+                g = K.meanshift_x3_iter_bwd(g, iterates[it + 1], iterates[it], x, ctx.x3, rsums[it], norms[it],
+                                            bsq, ws, gX)
+            else:
+                g = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it], bsq,
+                                         ws, gX)
         gX += g  # the first iterate is X itself
         return gX, None, None
 

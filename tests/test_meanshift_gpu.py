@@ -53,6 +53,54 @@ def test_iterations_forward_backward(gpu, N, iters):
     assert _rel(xg.grad, xr.grad) < 5e-5
 
 
+def test_bf16x3_products_are_fp32_grade(gpu):
+    """The bf16 x 3 matrix-core path against the fp64 evaluation of the reference formulas, next to
+    the exact-fp32 path: its error must be of the same size (it is an fp32 dot product in another
+    summation order, not a reduced-precision one)."""
+    from oracle import ref_torch as R
+    import parsenet_codebase_amd.mean_shift as MS
+    X, _ = _clustered(3001, 5, 7)
+    b = 0.35
+    y64, _ = R.MeanShift().mean_shift_(X.double(), torch.tensor(b, dtype=torch.float64), 5)
+    errs = {}
+    saved = MS.ARITH
+    try:
+        for mode in ("f32", "bf16x3"):
+            MS.ARITH = mode
+            y, _ = MS.MeanShift().mean_shift_(X.to(gpu), torch.tensor(b, device=gpu), 5)
+            errs[mode] = float((y.double().cpu() - y64).abs().max())
+    finally:
+        MS.ARITH = saved
+    assert errs["f32"] < 2e-6 and errs["bf16x3"] < 2e-6, errs
+    assert errs["bf16x3"] <= 2.0 * errs["f32"] + 1e-7, errs
+
+
+def test_bf16x3_backward_is_fp32_grade(gpu):
+    """Same for the gradient through 5 iterations (row and column passes)."""
+    from oracle import ref_torch as R
+    import parsenet_codebase_amd.mean_shift as MS
+    X, _ = _clustered(2000, 5, 9)
+    b = 0.35
+    w = torch.randn(2000, 128, generator=torch.Generator().manual_seed(1))
+    x64 = X.double().requires_grad_(True)
+    y64, _ = R.MeanShift().mean_shift_(x64, torch.tensor(b, dtype=torch.float64), 5)
+    (y64 * w.double()).sum().backward()
+    scale = float(x64.grad.abs().max())
+    errs = {}
+    saved = MS.ARITH
+    try:
+        for mode in ("f32", "bf16x3"):
+            MS.ARITH = mode
+            xg = X.to(gpu).requires_grad_(True)
+            y, _ = MS.MeanShift().mean_shift_(xg, torch.tensor(b, device=gpu), 5)
+            (y * w.to(gpu)).sum().backward()
+            errs[mode] = float((xg.grad.double().cpu() - x64.grad).abs().max()) / scale
+    finally:
+        MS.ARITH = saved
+    assert errs["f32"] < 2e-5 and errs["bf16x3"] < 2e-5, errs
+    assert errs["bf16x3"] <= 2.0 * errs["f32"] + 1e-6, errs
+
+
 def _canonical(labels):
     """Relabel by order of first occurrence: equal iff the partitions are equal."""
     labels = np.asarray(labels)

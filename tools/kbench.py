@@ -70,6 +70,21 @@ def bench_meanshift():
           (N, t, 10 * 9 * 2.0 * N * N * 128 / t / 1e9))
 
 
+def bench_meanshift_fwd():
+    import parsenet_codebase_amd.mean_shift as MS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    N = 10000
+    X = torch.nn.functional.normalize(torch.randn(N, 128, device=dev), dim=1)
+    b = torch.tensor(0.3, device=dev)
+    for mode in ("f32", "bf16x3"):
+        MS.ARITH = mode
+        with torch.no_grad():
+            t = timeit(lambda: MS.MeanShift().mean_shift_(X, b, 10), warmup=1, iters=3)
+        print("meanshift fwd only, %s: %.3f ms per iteration (%.1f TFLOP/s algorithmic)" %
+              (mode, t / 10, 2 * 2.0 * N * N * 128 / (t / 10) / 1e9))
+
+
 def bench_fitting():
     """Per-shape cost of the clustering + fitting stage when the embedding HAS cluster structure
     (what a trained network yields): embedding = noisy one-hot code of the ground-truth segment."""

@@ -18,7 +18,8 @@ buf = (ctypes.c_ulonglong * 24)()
 lib.pn_ms_debug_read.argtypes = [ctypes.c_void_p]
 print("rc", lib.pn_ms_debug_read(buf))
 for p in range(3):
-    g1, g2, bar, tot, nt, ew = [buf[p * 8 + i] for i in range(6)]
+    g1, g2, bar, tot, nt, ew, dma, bar1 = [buf[p * 8 + i] for i in range(8)]
     nt = max(nt, 1)
     print("PASS %d: tiles %d  per tile: G1 %.0f  EW %.0f  G2 %.0f  barrier %.0f  | loop total/tile %.0f (shader clocks)" %
-          (p, nt, g1 / nt, ew / nt, g2 / nt, bar / nt, tot / nt))
+          (p, nt, g1 / nt, ew / nt, g2 / nt, bar / nt, tot / nt) +
+          ("  [x3: dma issue %.0f  barrier B %.0f]" % (dma / nt, bar1 / nt) if dma else ""))
