@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PASS == 0 ?
     if (PASS != 0) {                                                                   \
       float g = PASS == 1 ? k * ((t[R] - c_res) * rinv_res)                            \
                           : k * ((t[R] - cst[PASS == 2 ? (R) : 0]) * rst[PASS == 2 ? (R) : 0]); \
-      asm volatile("" : "+v"(g)); /* keep the select a v_cndmask, not a branch */        \
+      asm("" : "+v"(g));          /* keep the select a v_cndmask, not a branch */        \
       gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                                   \
     }                                                                                  \
   }

@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
 // grid (slices, blocks of 128 resident indices, B), 256 threads: wave w owns 32 w .. 32 w + 31.
 // LDS: P images double buffered, C images single buffered (loaded under the first GEMM of the
 // same tile): 72 KiB (PASS 0/1), 144 KiB (PASS 2).
+#define X3_WAVES(PASS) ((PASS) == 0 ? 8 : 4)  // forward: 8 waves (2 per SIMD) share one LDS image
 template <int PASS>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64 * X3_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void pn_ms3_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
     const u32x4* __restrict__ PB, const u32x4* __restrict__ CA, const u32x4* __restrict__ CB,
@@ -167,7 +168,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, h = lane >> 5;
-  const int i0 = (blockIdx.y * 4 + wave) * 32;
+  constexpr int NW = X3_WAVES(PASS);
+  const int i0 = (blockIdx.y * NW + wave) * 32;
   const bool wave_on = i0 < N;
   const int S = gridDim.x, slice = blockIdx.x;
   const int t_begin = slice * tiles_per_slice;
@@ -225,11 +227,11 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
     for (int r = 0; r < 16; ++r) acc_o[fb][r] = 0.f;
   float rsum = 0.f;
 
-  // a 24 KiB image = 24 chunks of 1 KiB: wave w copies chunks 6 w .. 6 w + 5 (64 lanes x 16 B)
+  // a 24 KiB image = 24 chunks of 1 KiB (64 lanes x 16 B), dealt evenly to the NW waves
 #define X3_STAGE(SRC, DST)                                                        \
   {                                                                               \
-    _Pragma("unroll") for (int u = 0; u < 6; ++u) {                               \
-      const int q = wave * 6 + u;                                                 \
+    _Pragma("unroll") for (int u = 0; u < 24 / NW; ++u) {                         \
+      const int q = wave * (24 / NW) + u;                                         \
       X3_GLDS16((SRC) + q * 64 + lane, &(DST)[q * 64]);                           \
     }                                                                             \
   }
@@ -261,9 +263,9 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
     MS_T(U2);
     u32x4 wh[2], wm[2], wl[2];                                   // weights of the second GEMM
     u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
+    f32x16 sa, sb, ta, tb;
     if (wave_on) {
       // ---- first GEMM: S[streamed][resident] (and T with the second operand) ----
-      f32x16 sa, sb, ta, tb;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         sa[r] = 0.f;
@@ -307,54 +309,19 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
           X3_MFMA(ta, gh, qh[s]);
         }
       }
+      // large + small partial sums: one accumulator stays live across the barrier
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sa[r] += sb[r];
+        if (PASS != 0) ta[r] += tb[r];
+      }
       MS_T(U3);
 #ifdef MS_TIMING
       tg1 += U3 - U2;
 #endif
-      // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col] ----
-      const bool tail = j0 + 32 > N;
-      float kv[16], gs[PASS == 0 ? 1 : 16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float sv = sa[r] + sb[r];
-        const float dist = __builtin_fmaf(-2.0f, sv, 2.0f);
-        const float a2 = -dist * hl;
-        const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);
-        float k = __builtin_amdgcn_exp2f(a2c);
-        if (tail && j0 + row >= N) k = 0.f;
-        kv[r] = k;
-        if (PASS == 0) rsum += k;
-        if (PASS != 0) {
-          const float tv = ta[r] + tb[r];
-          const float cc = PASS == 1 ? c_res : lds_sc[cur][row];
-          const float aa = PASS == 1 ? a_res : lds_sc[cur][32 + row];
-          float g = k * ((tv - cc) * aa);
-          asm volatile("" : "+v"(g));  // keep the select a v_cndmask, not a branch
-          gs[PASS == 0 ? 0 : r] = a2c == a2 ? g : 0.f;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (PASS == 0) {
-            X3_SPLIT_TO(kv[8 * t + 2 * q], kv[8 * t + 2 * q + 1], wh[t], wm[t], wl[t], q);
-          } else {
-            const int e = PASS == 0 ? 0 : 8 * t + 2 * q;
-            X3_SPLIT_TO(gs[e], gs[e + (PASS == 0 ? 0 : 1)], wh[t], wm[t], wl[t], q);
-            if (PASS == 2) {
-              const int tt = PASS == 2 ? t : 0;
-              X3_SPLIT_TO(kv[8 * t + 2 * q], kv[8 * t + 2 * q + 1], vh[tt], vm[tt], vl[tt], q);
-            }
-          }
-        }
-#ifdef MS_TIMING
-      tew += __builtin_amdgcn_s_memtime() - U3;
-#endif
     }
     MS_T(U4);
-    __syncthreads();  // C(mt) landed
+    __syncthreads();  // C(mt) landed (issued before the first GEMM: the wait is short)
     MS_T(U5);
 #ifdef MS_TIMING
     tb0 += U1 - U0;
@@ -362,20 +329,92 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
     tb1 += U5 - U4;
 #endif
     if (wave_on) {
+      // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col], software
+      // pipelined with the second GEMM: k-step 0 of that GEMM only needs D registers 0..7, so
+      // the values 8..15 are processed between its MFMAs (bf16 MFMAs and VALU work overlap) ----
+      const bool tail = j0 + 32 > N;
+      float kv[16], gs[PASS == 0 ? 1 : 16];
+#define X3_EW(R)                                                                   \
+  {                                                                                \
+    const int row = ((R) & 3) + 8 * ((R) >> 2) + 4 * h;                            \
+    const float sv = sa[R];                                                        \
+    const float dist = __builtin_fmaf(-2.0f, sv, 2.0f);                            \
+    const float a2 = -dist * hl;                                                   \
+    const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);              \
+    float k = __builtin_amdgcn_exp2f(a2c);                                         \
+    if (tail && j0 + row >= N) k = 0.f;                                            \
+    kv[R] = k;                                                                     \
+    if (PASS == 0) rsum += k;                                                      \
+    if (PASS != 0) {                                                               \
+      const float tv = ta[R];                                                      \
+      const float cc = PASS == 1 ? c_res : lds_sc[cur][row];                       \
+      const float aa = PASS == 1 ? a_res : lds_sc[cur][32 + row];                  \
+      float g = k * ((tv - cc) * aa);                                              \
+      asm("" : "+v"(g));          /* keep the select a v_cndmask, not a branch */  \
+      gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                               \
+    }                                                                              \
+  }
+#define X3_SPLIT_W(T, Q)                                                                      \
+  {                                                                                           \
+    if (PASS == 0) {                                                                          \
+      X3_SPLIT_TO(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], wh[T], wm[T], wl[T], Q); \
+    } else {                                                                                  \
+      const int e = PASS == 0 ? 0 : 8 * (T) + 2 * (Q);                                        \
+      X3_SPLIT_TO(gs[e], gs[e + (PASS == 0 ? 0 : 1)], wh[T], wm[T], wl[T], Q);               \
+      if (PASS == 2) {                                                                        \
+        const int tt = PASS == 2 ? (T) : 0;                                                   \
+        X3_SPLIT_TO(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], vh[tt], vm[tt], vl[tt], Q); \
+      }                                                                                       \
+    }                                                                                         \
+  }
+      // (the forward pass runs two waves per SIMD in 256 registers: the other wave fills the
+      // matrix pipe during this stage, and the pipelining registers would spill)
+      constexpr bool PIPE = PASS != 0;
+#pragma unroll
+      for (int r = 0; r < (PIPE ? 8 : 16); ++r) X3_EW(r);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X3_SPLIT_W(0, q);
+      if (!PIPE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X3_SPLIT_W(1, q);
+      }
+      MS_T(U6);
+#ifdef MS_TIMING
+      tew += U6 - U5;
+#endif
       // ---- second GEMM: out[f][resident] += sum_streamed C[f][streamed] w[streamed][resident];
-      //      k-step t = D registers 8t..8t+7 of the first GEMM ----
+      //      k-step t = D registers 8t..8t+7 of the first GEMM.  Operands of the next (t, fb)
+      //      are fetched from LDS before the MFMAs of the current one. ----
       const u32x4* __restrict__ lc = ldsC[0];
       const u32x4* __restrict__ lc1 = ldsC[NIMG - 1];
+      u32x4 xc[3], oc[PASS == 2 ? 3 : 1], xn[3], on[PASS == 2 ? 3 : 1];
+#define X3_LOAD_C(DX, DO, T, FB)                                            \
+  {                                                                         \
+    const int f_ = (FB) * 32 + col;                                         \
+    const int slot_ = f_ * 4 + ((2 * (T) + h) ^ ((f_ >> 2) & 3));           \
+    DX[0] = lc[slot_];                                                      \
+    DX[1] = lc[X3_PIECE_U4 + slot_];                                        \
+    DX[2] = lc[2 * X3_PIECE_U4 + slot_];                                    \
+    if (PASS == 2) {                                                        \
+      DO[0] = lc1[slot_];                                                   \
+      DO[PASS == 2 ? 1 : 0] = lc1[X3_PIECE_U4 + slot_];                     \
+      DO[PASS == 2 ? 2 : 0] = lc1[2 * X3_PIECE_U4 + slot_];                 \
+    }                                                                       \
+  }
+      if (PIPE) X3_LOAD_C(xc, oc, 0, 0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const bf16x8 bh = x3_as_bf16(wh[t]), bm = x3_as_bf16(wm[t]), bl = x3_as_bf16(wl[t]);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
-          const int f = fb * 32 + col;
-          const int slot = f * 4 + ((2 * t + h) ^ ((f >> 2) & 3));
-          const bf16x8 xh = x3_as_bf16(lc[slot]);
-          const bf16x8 xm = x3_as_bf16(lc[X3_PIECE_U4 + slot]);
-          const bf16x8 xl = x3_as_bf16(lc[2 * X3_PIECE_U4 + slot]);
+          if (!PIPE) {
+            X3_LOAD_C(xc, oc, t, fb);
+          } else if (fb + 1 < 4) {
+            X3_LOAD_C(xn, on, t, fb + 1);
+          } else if (t == 0) {
+            X3_LOAD_C(xn, on, 1, 0);
+          }
+          const bf16x8 xh = x3_as_bf16(xc[0]), xm = x3_as_bf16(xc[1]), xl = x3_as_bf16(xc[2]);
           X3_MFMA(acc_o[fb], xl, bh);
           X3_MFMA(acc_o[fb], xh, bl);
           X3_MFMA(acc_o[fb], xm, bm);
@@ -385,9 +424,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
           if (PASS == 2) {
             const int tt = PASS == 2 ? t : 0;
             const bf16x8 kh = x3_as_bf16(vh[tt]), km = x3_as_bf16(vm[tt]), kl = x3_as_bf16(vl[tt]);
-            const bf16x8 oh = x3_as_bf16(lc1[slot]);
-            const bf16x8 om = x3_as_bf16(lc1[X3_PIECE_U4 + slot]);
-            const bf16x8 ol = x3_as_bf16(lc1[2 * X3_PIECE_U4 + slot]);
+            const bf16x8 oh = x3_as_bf16(oc[0]), om = x3_as_bf16(oc[PASS == 2 ? 1 : 0]),
+                         ol = x3_as_bf16(oc[PASS == 2 ? 2 : 0]);
             X3_MFMA(acc_o[fb], ol, kh);
             X3_MFMA(acc_o[fb], oh, kl);
             X3_MFMA(acc_o[fb], om, km);
@@ -395,8 +433,23 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
             X3_MFMA(acc_o[fb], oh, km);
             X3_MFMA(acc_o[fb], oh, kh);
           }
+          if (PIPE && t == 0) {  // second half of the elementwise stage, two values per block
+            X3_EW(8 + 2 * fb);
+            X3_EW(9 + 2 * fb);
+            X3_SPLIT_W(1, fb);
+          }
+          if (PIPE) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              xc[u] = xn[u];
+              if (PASS == 2) oc[PASS == 2 ? u : 0] = on[PASS == 2 ? u : 0];
+            }
+          }
         }
       }
+#undef X3_LOAD_C
+#undef X3_SPLIT_W
+#undef X3_EW
     }
 #ifdef MS_TIMING
     tg2 += __builtin_amdgcn_s_memtime() - U5;
@@ -451,12 +504,23 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 }
 
 static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
-  // fill whole rounds of the 256 x blocks_per_cu workgroup slots (forward: two 72 KiB workgroups
-  // per CU at <= 256 registers; backward: one)
-  const long long rowblocks = (long long)B * pn_cdiv(N, 128);
+  const int rows_per_block = blocks_per_cu == 2 ? 256 : 128;  // forward: 8-wave workgroups
+  // fill whole rounds of the 256 CUs (one workgroup per CU: the forward runs 8 waves of <= 256
+  // registers on one 72 KiB LDS image, the backward passes 4 waves of 512 registers)
+  const long long rowblocks = (long long)B * pn_cdiv(N, rows_per_block);
   if (ntiles < 16) {
     *tps = ntiles;
     return 1;
+  }
+  if (const char* e = getenv("PN_MS_SLICES")) {  // developer override: "<fwd>,<bwd>"
+    int sf = 0, sb = 0;
+    if (sscanf(e, "%d,%d", &sf, &sb) == 2) {
+      const int want = blocks_per_cu == 2 ? sf : sb;
+      if (want >= 1 && want <= 32 && want <= ntiles) {
+        *tps = pn_cdiv(ntiles, want);
+        return want;
+      }
+    }
   }
   int best = 1;
   double best_score = -1.0;
@@ -464,7 +528,7 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
   for (int S = 1; S <= smax; ++S) {
     const int t = pn_cdiv(ntiles, S);
     if (pn_cdiv(ntiles, t) != S) continue;
-    const double rounds = (double)(rowblocks * S) / (256.0 * blocks_per_cu);
+    const double rounds = (double)(rowblocks * S) / 256.0;  // one workgroup per CU either way
     const double eff = rounds / (double)(long long)(rounds + 0.999999);
     const double score = eff * (double)t / ((double)t + 1.5) - 0.002 * S;
     if (score > best_score) {
@@ -495,10 +559,10 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* pimg, co
     S = smax;
     tps = pn_cdiv(ntiles, S);
   }
-  dim3 grid(S, pn_cdiv(N, 128), B);
+  dim3 grid(S, pn_cdiv(N, 256), B);
   {
     PN_PROF("meanshift_fwd", stream);
-    hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(256), 0, stream, q, nullptr, (const u32x4*)pimg,
+    hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)pimg,
                        nullptr, (const u32x4*)cimg, nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart,
                        rpart);
   }
