@@ -192,9 +192,10 @@ def cpu_baseline_splinenet(name, cores):
                       "best of %d" % (name, len(times))}
 
 
-def _dtype_note():
+def _ms_arith():
     from parsenet_codebase_amd import mean_shift as _ms
-    return "f32" if _ms.ARITH != "bf16x3" else "f32 (mean-shift products: error-free bf16x3 split, fp32 accumulate)"
+    return ("fp32 via error-free bf16x3 operand split on the bf16 matrix cores, fp32 accumulate"
+            if _ms.ARITH == "bf16x3" else "fp32 matrix cores (v_mfma_f32_32x32x2_f32)")
 
 
 def main():
@@ -258,9 +259,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.workload != "cfg5" else _dtype_note(),
+            "dtype": "f32",
             "data": "synthetic",
-            "config": dict(cfg, parallelism="dp%d" % world, global_batch=step.shapes_per_step() * world),
+            "config": dict(cfg, parallelism="dp%d" % world, global_batch=step.shapes_per_step() * world,
+                           **({"meanshift_products": _ms_arith()} if args.workload == "cfg5" else {})),
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(table.items())},

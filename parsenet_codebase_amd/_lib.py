@@ -135,6 +135,16 @@ def require_cuda(*tensors):
                 % t.device)
 
 
+def h2d(array, device):
+    """Host array -> device tensor through pinned memory, stream-ordered (non_blocking).  A
+    pageable-memory copy makes the host wait for everything queued on the stream; the fitting
+    stage issues dozens of small index uploads per shape, each of which would drain the GPU."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def prof_enable(on=True):
     load().pn_prof_enable(1 if on else 0)
 

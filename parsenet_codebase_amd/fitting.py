@@ -14,7 +14,7 @@ import torch
 from scipy.optimize import linear_sum_assignment
 
 from . import kernels as K
-from ._lib import require_cuda
+from ._lib import h2d, require_cuda
 from .bspline import sample_points_from_control_points_, uniform_knot_bspline
 from .chamfer import chamfer_distance_single_shape
 from .mean_shift import MeanShift
@@ -162,7 +162,8 @@ def weights_normalize(weights, bw):
 def to_one_hot(target, maxx=50, device_id=0):
     """src/segment_utils.py:283-292."""
     if isinstance(target, np.ndarray):
-        target = torch.from_numpy(target.astype(np.int64)).cuda(device_id)
+        target = h2d(target.astype(np.int64), torch.device("cuda", device_id if device_id is not None else
+                                                          torch.cuda.current_device()))
     N = target.shape[0]
     one_hot = torch.zeros((N, maxx), device=target.device)
     return one_hot.scatter_(1, target.unsqueeze(1).long(), 1)
@@ -181,15 +182,27 @@ def solve_dense(cost):
     return linear_sum_assignment(cost)
 
 
+def _relaxed_iou_of_labels(pred_labels, target, max_clusters=50):
+    """relaxed_iou_fast(one_hot(pred), one_hot(target)) for two HOST label arrays, evaluated on
+    the host: the one-hot products are integer counts (exact in fp32), so the confusion matrix
+    from np.bincount followed by the same fp32 expression gives the reference's matrix bit for
+    bit — without uploading the labels, two launches and a synchronising download per call."""
+    p = np.asarray(pred_labels).astype(np.int64).ravel()
+    g = np.asarray(target).astype(np.int64).ravel()
+    if p.size and (p.min() < 0 or g.min() < 0 or p.max() >= max_clusters or g.max() >= max_clusters):
+        raise ValueError("labels must lie in [0, %d) (one-hot width of the reference)" % max_clusters)
+    dots = np.bincount(p * max_clusters + g, minlength=max_clusters * max_clusters)
+    dots = dots.reshape(max_clusters, max_clusters).astype(np.float32)
+    norms_p = dots.sum(1, keepdims=True, dtype=np.float32)
+    norms_g = dots.sum(0, keepdims=True, dtype=np.float32)
+    return dots / (norms_p + norms_g - dots + np.float32(1e-7))
+
+
 def match(target, pred_labels):
     """src/fitting_utils.py:362-376: Hungarian matching of predicted to ground-truth segments on
     the relaxed IoU of their one-hot encodings."""
-    dev = torch.cuda.current_device()
-    labels_one_hot = to_one_hot(target, device_id=dev)
-    cluster_ids_one_hot = to_one_hot(pred_labels, device_id=dev)
-    cost = relaxed_iou_fast(cluster_ids_one_hot.unsqueeze(0).float(), labels_one_hot.unsqueeze(0).float())
-    cost_ = 1.0 - cost.data.cpu().numpy()
-    rids, cids = solve_dense(cost_[0])
+    cost_ = 1.0 - _relaxed_iou_of_labels(pred_labels, target)
+    rids, cids = solve_dense(cost_)
     return rids, cids, np.unique(target), np.unique(pred_labels)
 
 
@@ -613,7 +626,7 @@ class FittingModule:
 
 def _mask_index(mask, device):
     """Row indices selected by a boolean numpy mask, as a device tensor."""
-    return torch.from_numpy(np.nonzero(np.asarray(mask))[0]).to(device)
+    return h2d(np.nonzero(np.asarray(mask))[0], device)
 
 
 def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=False, if_optimize=False,
@@ -786,10 +799,7 @@ def SIOU_matched_segments(target, pred_labels, primitives_pred, primitives, weig
     rewrites the primitive-id arrays in place; copies are used here.)"""
     primitives, primitives_pred = _merge_types(primitives), _merge_types(primitives_pred)
     dev = weights.device.index
-    labels_one_hot = to_one_hot(target, device_id=dev)
-    cluster_ids_one_hot = to_one_hot(pred_labels, device_id=dev)
-    cost = relaxed_iou_fast(cluster_ids_one_hot.unsqueeze(0).float(), labels_one_hot.unsqueeze(0).float())
-    rids, cids = solve_dense(1.0 - cost.data.cpu().numpy()[0])
+    rids, cids = solve_dense(1.0 - _relaxed_iou_of_labels(pred_labels, target))
     prim_hot = to_one_hot(primitives_pred, 10, dev).float()
     prim_pred = torch.max(torch.sum(prim_hot.unsqueeze(2) * weights.unsqueeze(1), 0), 0)[1].cpu().numpy()
     ious, prim_ok, pairs = [], [], []
@@ -827,7 +837,8 @@ class Evaluation:
         while True:
             _, center, bandwidth, cluster_ids = self.ms.mean_shift(embedding, 10000, quantile, iterations,
                                                                    kernel_type=kernel_type)
-            if torch.unique(cluster_ids).shape[0] > 49:
+            # labels index the centres: with <= 49 centres there cannot be more distinct labels
+            if center.shape[0] > 49 and torch.unique(cluster_ids).shape[0] > 49:
                 quantile *= 1.2
             else:
                 break
@@ -878,7 +889,7 @@ class Evaluation:
                 continue
             # modal ground-truth primitive type of the matched segment (smallest on ties)
             seg_type = int(np.bincount(primitives[gt_indices_i].astype(np.int64)).argmax())
-            gi = torch.from_numpy(np.nonzero(gt_indices_i)[0]).to(points.device)
+            gi = h2d(np.nonzero(gt_indices_i)[0], points.device)
             data.append([points, normals, seg_type, points[gi], None, (index, i)])
         w = torch.transpose(weights_normalize(weights, float(bw)), 1, 0)
         gt_points, recon_points = fit_one_shape_torch(data, self.fitter, w, bw, eval=False)
@@ -926,17 +937,20 @@ class Evaluation:
 
     def separate_losses(self, distance, gt_points, lamb=1.0):
         Loss, geometric_loss, spline_loss = [], [], []
-        for v in sorted(gt_points.keys()):
-            if gt_points[v] is None:
-                continue
-            if distance[v][1] > 1:
+        keys = [v for v in sorted(gt_points.keys()) if gt_points[v] is not None]
+        # one download for all segments instead of a synchronising comparison + .item() each
+        host = (torch.stack([distance[v][1].detach().reshape(()) for v in keys]).cpu().numpy()
+                if keys else np.zeros(0, np.float32))
+        for v, dv in zip(keys, host):
+            if dv > 1:
                 # most probably a degenerate case
                 distance[v][1] = torch.ones(1, device=distance[v][1].device)[0] * 0.1
+                dv = np.float32(0.1)
             if distance[v][0] in ["closed-spline", "open-spline"]:
-                spline_loss.append(distance[v][1].item())
+                spline_loss.append(float(dv))
                 Loss.append(distance[v][1] * lamb)
             else:
-                geometric_loss.append(distance[v][1].item())
+                geometric_loss.append(float(dv))
                 Loss.append(distance[v][1])
         Loss = torch.mean(torch.stack(Loss)) if Loss else torch.zeros(1, device="cuda")
         geometric_loss = np.mean(geometric_loss) if geometric_loss else None

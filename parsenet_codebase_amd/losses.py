@@ -1,6 +1,8 @@
 """Training losses of the segmentation network (src/segment_loss.py)."""
 import numpy as np
 import torch
+
+from ._lib import h2d
 import torch.nn.functional as F
 
 
@@ -68,9 +70,9 @@ class EmbeddingLoss:
                 ia.append(i * N + samples[i][pairs[:, 0]])           # (P,num) flat point indices
                 ib.append(i * N + samples[i][pairs[:, 1]])
                 wts.append(np.full(len(pairs), 1.0 / (norm + 1e-8), dtype=np.float32))
-            ia = torch.from_numpy(np.concatenate(ia, 0)).to(dev)
-            ib = torch.from_numpy(np.concatenate(ib, 0)).to(dev)
-            wts = torch.from_numpy(np.concatenate(wts, 0)).to(dev)
+            ia = h2d(np.concatenate(ia, 0), dev)
+            ib = h2d(np.concatenate(ib, 0), dev)
+            wts = h2d(np.concatenate(wts, 0), dev)
             flat = out.reshape(B * N, -1)
             p1, p2 = flat[ia], flat[ib]                              # (P,num,D)
             anchor = p1.unsqueeze(2)

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from ._lib import require_cuda
+from ._lib import h2d, require_cuda
 
 
 # Arithmetic of the two GEMMs per tile: "bf16x3" (error-free 3-way bf16 split on the bf16 matrix
@@ -128,7 +128,7 @@ class MeanShift:
         while True:
             _, center, bandwidth, cluster_ids = self.mean_shift(embedding, 5000, quantile, iterations,
                                                                 kernel_type=kernel_type)
-            if torch.unique(cluster_ids).shape[0] > 49:
+            if center.shape[0] > 49 and torch.unique(cluster_ids).shape[0] > 49:
                 quantile *= 2
             else:
                 break
@@ -154,7 +154,7 @@ class MeanShift:
         L = np.arange(N)
         np.random.shuffle(L)
         if num_samples < N:
-            X = X[torch.from_numpy(L[0:num_samples]).to(X.device)]
+            X = X[h2d(L[0:num_samples], X.device)]
         # with num_samples >= N every row is used: the statistic does not depend on the order
         Kq = int(quantile * num_samples)
         Xc = X.detach().contiguous().unsqueeze(0)
@@ -197,8 +197,8 @@ class MeanShift:
                 membership[s:s + 2048] = _first_argmax(X[s:s + 2048] @ centers.t(), 1)
         uniques, counts_ = np.unique(membership.cpu().numpy(), return_counts=True)
         num_mem_cluster = torch.zeros(N, device=X.device)
-        uq = torch.from_numpy(uniques).to(X.device)
-        num_mem_cluster[uq] = torch.from_numpy(counts_.astype(np.float32)).to(X.device)
+        uq = h2d(uniques, X.device)
+        num_mem_cluster[uq] = h2d(counts_.astype(np.float32), X.device)
         # neighbours (distance < b, not b^2, as in the reference) of the occupied centres only
         dist = 2.0 - 2.0 * centers[uq] @ centers.t()
         score = (dist < b).float() * num_mem_cluster.reshape(1, -1)

@@ -75,6 +75,35 @@ def test_bf16x3_products_are_fp32_grade(gpu):
     assert errs["bf16x3"] <= 2.0 * errs["f32"] + 1e-7, errs
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "f32"])
+def test_batched_and_tiny_inputs(gpu, arith):
+    """(B,N,D) batches with per-item bandwidths equal the per-item runs; N below one tile works."""
+    import parsenet_codebase_amd.mean_shift as MS
+    saved = MS.ARITH
+    MS.ARITH = arith
+    try:
+        Xa, _ = _clustered(333, 4, 3)
+        Xb, _ = _clustered(333, 3, 4)
+        Xs = torch.stack([Xa, Xb]).to(gpu).requires_grad_(True)
+        bw = torch.tensor([0.3, 0.45], device=gpu)
+        w = torch.randn(2, 333, 128, device=gpu)
+        y = MS.mean_shift_iterations(Xs, bw, 4)
+        (y * w).sum().backward()
+        for i, X in enumerate((Xa, Xb)):
+            xi = X.to(gpu).requires_grad_(True)
+            yi = MS.mean_shift_iterations(xi, bw[i], 4)
+            (yi * w[i]).sum().backward()
+            assert _rel(y[i], yi) < 1e-6
+            assert _rel(Xs.grad[i], xi.grad) < 1e-5
+        Xt, _ = _clustered(20, 2, 5)
+        from oracle import ref_torch as R
+        yr, _ = R.MeanShift().mean_shift_(Xt, torch.tensor(0.4), 3)
+        yt = MS.mean_shift_iterations(Xt.to(gpu), 0.4, 3)
+        assert _rel(yt, yr) < 1e-5
+    finally:
+        MS.ARITH = saved
+
+
 def test_bf16x3_backward_is_fp32_grade(gpu):
     """Same for the gradient through 5 iterations (row and column passes)."""
     from oracle import ref_torch as R

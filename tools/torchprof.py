@@ -16,5 +16,6 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step.step()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45,
-                                                         max_name_column_width=40, max_shapes_column_width=70))
+sort = sys.argv[2] if len(sys.argv) > 2 else "self_cuda_time_total"
+print(prof.key_averages(group_by_input_shape=(sort == "self_cuda_time_total")).table(
+    sort_by=sort, row_limit=45, max_name_column_width=40, max_shapes_column_width=70))
