@@ -844,21 +844,43 @@ class Evaluation:
                 break
         return center, bandwidth, cluster_ids
 
+    def prefetch_clustering(self, embedding_b, quantile, iterations):
+        """Queue the clustering of ONE shape (normalisation, bandwidth, mean-shift iterations) on
+        the current stream without a host synchronisation and return a handle for
+        ``fitting_loss(prefetched=[handle])``.  Lets a caller run shape b+1's iterations on a side
+        stream underneath the launch- and sync-bound fitting stage of shape b."""
+        emb = torch.nn.functional.normalize(embedding_b, p=2, dim=-1)
+        new_X, bw, flag = self.ms.shift_async(emb, 10000, quantile, iterations)
+        return {"emb": emb, "new_X": new_X, "bw": bw, "flag": flag}
+
+    def _clusters(self, emb_b, quantile, iterations, handle):
+        if handle is not None:
+            done = self.ms.finish(handle["emb"], handle["new_X"], handle["bw"], handle["flag"])
+            if done is not None:
+                _, center, bandwidth, cluster_ids = done
+                if not (center.shape[0] > 49 and torch.unique(cluster_ids).shape[0] > 49):
+                    return center, bandwidth, cluster_ids
+                quantile *= 1.2          # the guard's retry, on the synchronous path
+        return self.guard_mean_shift(emb_b, quantile, iterations, kernel_type="gaussian")
+
     def fitting_loss(self, embedding, points, normals, labels, primitives, primitives_log_prob,
-                     quantile=0.125, iterations=5, lamb=1.0, debug=False, eval=False):
+                     quantile=0.125, iterations=5, lamb=1.0, debug=False, eval=False, prefetched=None):
         """embedding (B,N,128), points/normals (B,N,3) tensors; labels, primitives (B,N) integer
         arrays; primitives_log_prob (B,10,N).  Returns ([Loss, geometric mean, spline mean, s_iou,
         p_iou], [parameters, cluster ids, weights]) of the last shape, like the reference (which
-        is written for B = 1)."""
+        is written for B = 1).  ``prefetched``: per-shape handles of ``prefetch_clustering``."""
         batch_size = embedding.shape[0]
-        embedding = torch.nn.functional.normalize(embedding, p=2, dim=2)
+        if prefetched is None:
+            embedding = torch.nn.functional.normalize(embedding, p=2, dim=2)
+        else:
+            embedding = [h["emb"] for h in prefetched]
         prim_pred = torch.max(primitives_log_prob, 1)[1].data.cpu().numpy()
         labels = np.asarray(labels)
         primitives = np.asarray(primitives)
         loss = parameters = cluster_ids = weights = None
         for b in range(batch_size):
-            center, bandwidth, cluster_ids = self.guard_mean_shift(embedding[b], quantile, iterations,
-                                                                   kernel_type="gaussian")
+            center, bandwidth, cluster_ids = self._clusters(embedding[b], quantile, iterations,
+                                                            prefetched[b] if prefetched is not None else None)
             weights = center @ torch.transpose(embedding[b], 1, 0)
             if not eval:
                 loss, parameters, _, rows, cols, distance = self.residual_train_mode(

@@ -109,6 +109,27 @@ class MeanShift:
         center = new_X[indices]
         return new_X, center, bw, new_labels
 
+    # -- the same in two stages, for callers that overlap shapes on two streams -------------
+    def shift_async(self, X, num_samples, quantile, iterations):
+        """Stage 1 of ``mean_shift`` (bandwidth + iterations) WITHOUT any host synchronisation, so
+        that it can be queued on a side stream while the host drives another shape's fitting
+        stage.  Returns (new_X, bw, flag); flag (0-dim tensor) > 0 means the bandwidth selection met
+        massive ties and the caller must use ``mean_shift`` instead (checked in ``finish``)."""
+        with torch.no_grad():
+            bw, flag = self.compute_bandwidth(X, num_samples, quantile, defer_flags=True)
+            bw = torch.clamp(bw, min=0.003)
+        new_X, _ = self.mean_shift_(X, b=bw, iterations=iterations)
+        return new_X, bw, flag
+
+    def finish(self, X, new_X, bw, flag=None):
+        """Stage 2: non-maximum suppression.  Returns (new_X, center, bw, labels) like
+        ``mean_shift``, or None if stage 1 has to be redone on the synchronous path."""
+        if flag is not None and int(flag) > 0:
+            return None
+        with torch.no_grad():
+            _, indices, new_labels = self.nms(new_X, X, b=bw)
+        return new_X, new_X[indices], bw, new_labels
+
     # -- src/mean_shift.py:45-79 ---------------------------------------------------------
     def mean_shift_(self, X, b, iterations=10, kernel_type="gaussian"):
         if kernel_type == "gaussian" and X.shape[-1] == 128:
@@ -146,9 +167,11 @@ class MeanShift:
         return self.kernel_between(X, X, "gaussian" if kernel_type == "gaussian" else "epa", bw)
 
     # -- src/mean_shift.py:115-137 -------------------------------------------------------
-    def compute_bandwidth(self, X, num_samples, quantile):
+    def compute_bandwidth(self, X, num_samples, quantile, defer_flags=False):
         """Mean over rows of the K-th smallest distance sqrt(2 - 2 x_i.x_j), K = int(quantile *
-        num_samples).  Consumes numpy's RNG exactly like the reference (one shuffle of N)."""
+        num_samples).  Consumes numpy's RNG exactly like the reference (one shuffle of N).
+        ``defer_flags``: do not look at the selection kernel's tie flags on the host (that is a
+        synchronisation); return (bw, number of flagged rows as a tensor) instead."""
         require_cuda(X)
         N = X.shape[0]
         L = np.arange(N)
@@ -162,6 +185,9 @@ class MeanShift:
         if res is not None:
             kth_dot, flags = res
             kth_dot = kth_dot[0]
+            if defer_flags:
+                kth = 2.0 - 2.0 * kth_dot
+                return torch.mean(torch.sqrt(torch.clamp(kth, min=1e-6))), (flags[0] != 0).sum()
             bad = torch.nonzero(flags[0]).flatten()
             if bad.numel() > 0:   # massively tied rows: redo those rows densely
                 d = X[bad] @ X.t()
@@ -172,7 +198,8 @@ class MeanShift:
             for s in range(0, X.shape[0], 2048):   # shapes outside the kernel's fast path
                 d = 2 - 2 * X[s:s + 2048] @ X.t()
                 kth[s:s + 2048] = torch.topk(d, Kq, dim=1, largest=False)[0][:, -1]
-        return torch.mean(torch.sqrt(torch.clamp(kth, min=1e-6)))
+        bw = torch.mean(torch.sqrt(torch.clamp(kth, min=1e-6)))
+        return (bw, torch.zeros((), dtype=torch.int64, device=X.device)) if defer_flags else bw
 
     # -- src/mean_shift.py:139-179 -------------------------------------------------------
     def nms(self, centers, X, b):

@@ -68,6 +68,11 @@ class ParsenetE2EStep(ParsenetSegStep):
         self.normals = torch.from_numpy(nrm).to(device)
         self.prim_np = prim
         self.last_res = None
+        # The clustering of shape b+1 (few large kernels) is queued on a side stream underneath the
+        # fitting stage of shape b (hundreds of tiny launches and the host synchronisations of the
+        # Hungarian matching): the reference processes one shape after the other.
+        self.overlap = True
+        self.side = torch.cuda.Stream(device=device)
 
     def step(self):
         self.bucket.zero()
@@ -75,10 +80,31 @@ class ParsenetE2EStep(ParsenetSegStep):
         loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
         emb = embedding.permute(0, 2, 1)
         res_total = 0
+        main = torch.cuda.current_stream(self.device)
+        handles, events = {}, {}
+
+        def prefetch(b):
+            self.side.wait_stream(main)            # the embedding (and everything before) is on main
+            with torch.cuda.stream(self.side):
+                h = self.evaluation.prefetch_clustering(emb[b], 0.025, 10)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            for t in h.values():                   # produced on the side stream, consumed on main
+                t.record_stream(main)
+            handles[b], events[b] = h, ev
+        if self.overlap:
+            prefetch(0)
         for b in range(self.batch):     # the fitting stage is per shape (reference: batch 1)
+            pre = None
+            if self.overlap:
+                if b + 1 < self.batch:
+                    prefetch(b + 1)
+                main.wait_event(events[b])
+                pre = [handles.pop(b)]
             res, _ = self.evaluation.fitting_loss(emb[b:b + 1], self.points[b:b + 1], self.normals[b:b + 1],
                                                   self.labels[b:b + 1], self.prim_np[b:b + 1],
-                                                  log_prob[b:b + 1], quantile=0.025, iterations=10, lamb=0.1)
+                                                  log_prob[b:b + 1], quantile=0.025, iterations=10, lamb=0.1,
+                                                  prefetched=pre)
             res_total = res_total + res[0]
         loss = loss + res_total / self.batch
         loss.backward()

@@ -67,3 +67,23 @@ def test_fitting_loss_forward_backward(gpu):
     assert float(gb.norm()) > 0
     cos = float(ga @ gb / (ga.norm() * gb.norm()))
     assert cos > 0.99, cos
+
+
+def test_side_stream_prefetch_equals_sequential(gpu):
+    """The end-to-end step with the clustering of shape b+1 prefetched on a side stream must give
+    the loss and the gradients of the strictly sequential step (same kernels, same RNG order)."""
+    from parsenet_codebase_amd.workloads import ParsenetE2EStep
+    outs = []
+    for overlap in (False, True):
+        np.random.seed(3)
+        torch.manual_seed(3)
+        step = ParsenetE2EStep(gpu, batch=3, num_points=2500, seed=4)
+        step.overlap = overlap
+        np.random.seed(11)
+        loss = step.step()
+        torch.cuda.synchronize()
+        outs.append((float(loss), step.bucket.flat.clone(), float(step.last_res)))
+    (l0, g0, r0), (l1, g1, r1) = outs
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    assert abs(r0 - r1) <= 1e-6 * max(abs(r0), 1e-12)
+    assert float((g0 - g1).abs().max()) <= 1e-5 * float(g0.abs().max())
