@@ -237,12 +237,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    roof, table = (None, {})
+    # The profiled steps contain the gradient all-reduce, a collective: EVERY rank runs them
+    # (only rank 0 keeps the per-kernel table), otherwise rank 0 would pair its all-reduce with
+    # the other ranks' barrier.
+    roof, table = kernel_roofline(step, args.profile_steps)
     cpu = None
-    if rank == 0:
-        roof, table = kernel_roofline(step, args.profile_steps)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.workload)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload)
     if world > 1:
         dist.barrier()
 
