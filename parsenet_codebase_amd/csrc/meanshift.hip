@@ -426,18 +426,21 @@ __global__ void pn_ms_pack_kernel(const float* __restrict__ x, int N, int Np,
 // backward epilogue: gq = sum_s opart_q (gradient w.r.t. the previous iterate), gx += sum_s opart_x
 __global__ __launch_bounds__(256) void pn_ms_combine_bwd_kernel(const float* __restrict__ opart_q,
                                                                 const float* __restrict__ opart_x,
-                                                                long long ND4, int S,
+                                                                long long ND4, int Sq, int Sx,
                                                                 float* __restrict__ gq,
                                                                 float* __restrict__ gx) {
   const int b = blockIdx.y;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ND4) return;
-  const float4* pq = reinterpret_cast<const float4*>(opart_q) + (size_t)b * S * ND4 + e;
-  const float4* px = reinterpret_cast<const float4*>(opart_x) + (size_t)b * S * ND4 + e;
+  const float4* pq = reinterpret_cast<const float4*>(opart_q) + (size_t)b * Sq * ND4 + e;
+  const float4* px = reinterpret_cast<const float4*>(opart_x) + (size_t)b * Sx * ND4 + e;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-  for (int s = 0; s < S; ++s) {
-    const float4 u = pq[(size_t)s * ND4], v = px[(size_t)s * ND4];
+  for (int s = 0; s < Sq; ++s) {
+    const float4 u = pq[(size_t)s * ND4];
     a.x += u.x, a.y += u.y, a.z += u.z, a.w += u.w;
+  }
+  for (int s = 0; s < Sx; ++s) {
+    const float4 v = px[(size_t)s * ND4];
     c.x += v.x, c.y += v.y, c.z += v.z, c.w += v.w;
   }
   reinterpret_cast<float4*>(gq)[(size_t)b * ND4 + e] = a;
@@ -573,7 +576,7 @@ extern "C" int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const 
   PN_CHECK_LAUNCH();
   const long long ND4 = (long long)N * MS_D / 4;
   hipLaunchKernelGGL(pn_ms_combine_bwd_kernel, dim3(pn_cdiv(ND4, 256), B), dim3(256), 0, stream,
-                     opart_q, opart_x, ND4, S, gq, gx);
+                     opart_q, opart_x, ND4, S, S, gq, gx);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

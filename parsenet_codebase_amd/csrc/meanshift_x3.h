@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
 // grid (slices, blocks of 128 resident indices, B), 256 threads: wave w owns 32 w .. 32 w + 31.
 // LDS: P images double buffered, C images single buffered (loaded under the first GEMM of the
 // same tile): 72 KiB (PASS 0/1), 144 KiB (PASS 2).
-#define X3_WAVES(PASS) ((PASS) == 0 ? 8 : 4)  // forward: 8 waves (2 per SIMD) share one LDS image
+#define X3_WAVES(PASS) ((PASS) == 1 ? 4 : 8)  // forward / column pass: 8 waves (2 per SIMD) share the LDS images
 template <int PASS>
 __global__ __launch_bounds__(64 * X3_WAVES(PASS))
-__attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void pn_ms3_kernel(
+__attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void pn_ms3_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
     const u32x4* __restrict__ PB, const u32x4* __restrict__ CA, const u32x4* __restrict__ CB,
     const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_, int N,
@@ -263,15 +263,22 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
     MS_T(U2);
     u32x4 wh[2], wm[2], wl[2];                                   // weights of the second GEMM
     u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
-    f32x16 sa, sb, ta, tb;
+    // two partial accumulators (small / large terms) per product where registers allow (row
+    // pass, one wave per SIMD); the 8-wave passes accumulate small-to-large into one
+    constexpr bool TWO_ACC = PASS == 1;
+    f32x16 sa, ta, sb_, tb_;
+#define sb (*(TWO_ACC ? &sb_ : &sa))
+#define tb (*(TWO_ACC ? &tb_ : &ta))
     if (wave_on) {
       // ---- first GEMM: S[streamed][resident] (and T with the second operand) ----
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         sa[r] = 0.f;
-        sb[r] = 0.f;
         ta[r] = 0.f;
-        tb[r] = 0.f;
+        if (TWO_ACC) {
+          sb_[r] = 0.f;
+          tb_[r] = 0.f;
+        }
       }
       const u32x4* __restrict__ lp = ldsP[cur][0];
       const u32x4* __restrict__ lp1 = ldsP[cur][NIMG - 1];
@@ -283,18 +290,18 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
         const bf16x8 am = x3_as_bf16(lp[X3_PIECE_U4 + slot]);
         const bf16x8 al = x3_as_bf16(lp[2 * X3_PIECE_U4 + slot]);
         X3_MFMA(sb, al, qh[s]);
-        X3_MFMA(sa, am, qh[s]);
         X3_MFMA(sb, ah, ql[s]);
-        X3_MFMA(sa, ah, qm[s]);
         X3_MFMA(sb, am, qm[s]);
+        X3_MFMA(sa, am, qh[s]);
+        X3_MFMA(sa, ah, qm[s]);
         X3_MFMA(sa, ah, qh[s]);
         if (PASS == 1) {  // T = X . GU: same streamed operand, second resident one
           const int z = PASS == 1 ? s : 0;
           X3_MFMA(tb, al, uh[z]);
-          X3_MFMA(ta, am, uh[z]);
           X3_MFMA(tb, ah, ul[z]);
-          X3_MFMA(ta, ah, um[z]);
           X3_MFMA(tb, am, um[z]);
+          X3_MFMA(ta, am, uh[z]);
+          X3_MFMA(ta, ah, um[z]);
           X3_MFMA(ta, ah, uh[z]);
         }
         if (PASS == 2) {  // T = GU . X: second streamed operand, same resident one
@@ -302,19 +309,23 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
           const bf16x8 gm = x3_as_bf16(lp1[X3_PIECE_U4 + slot]);
           const bf16x8 gl = x3_as_bf16(lp1[2 * X3_PIECE_U4 + slot]);
           X3_MFMA(tb, gl, qh[s]);
-          X3_MFMA(ta, gm, qh[s]);
           X3_MFMA(tb, gh, ql[s]);
-          X3_MFMA(ta, gh, qm[s]);
           X3_MFMA(tb, gm, qm[s]);
+          X3_MFMA(ta, gm, qh[s]);
+          X3_MFMA(ta, gh, qm[s]);
           X3_MFMA(ta, gh, qh[s]);
         }
       }
       // large + small partial sums: one accumulator stays live across the barrier
+      if (TWO_ACC) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sa[r] += sb[r];
-        if (PASS != 0) ta[r] += tb[r];
+        for (int r = 0; r < 16; ++r) {
+          sa[r] += sb_[r];
+          ta[r] += tb_[r];
+        }
       }
+#undef sb
+#undef tb
       MS_T(U3);
 #ifdef MS_TIMING
       tg1 += U3 - U2;
@@ -369,7 +380,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
   }
       // (the forward pass runs two waves per SIMD in 256 registers: the other wave fills the
       // matrix pipe during this stage, and the pipelining registers would spill)
-      constexpr bool PIPE = PASS != 0;
+      constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
+      constexpr bool PREFETCH = PASS == 1;  // operand double buffering (needs 12-24 registers)
 #pragma unroll
       for (int r = 0; r < (PIPE ? 8 : 16); ++r) X3_EW(r);
 #pragma unroll
@@ -401,13 +413,21 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
       DO[PASS == 2 ? 2 : 0] = lc1[2 * X3_PIECE_U4 + slot_];                 \
     }                                                                       \
   }
-      if (PIPE) X3_LOAD_C(xc, oc, 0, 0);
+      if (PREFETCH) X3_LOAD_C(xc, oc, 0, 0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (PIPE && !PREFETCH && t == 1) {
+          // 8-wave column pass: second half of the stage between the two k-steps (the other
+          // wave of the SIMD keeps the matrix pipe busy; interleaving would cost registers)
+#pragma unroll
+          for (int r = 8; r < 16; ++r) X3_EW(r);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) X3_SPLIT_W(1, q);
+        }
         const bf16x8 bh = x3_as_bf16(wh[t]), bm = x3_as_bf16(wm[t]), bl = x3_as_bf16(wl[t]);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
-          if (!PIPE) {
+          if (!PREFETCH) {
             X3_LOAD_C(xc, oc, t, fb);
           } else if (fb + 1 < 4) {
             X3_LOAD_C(xn, on, t, fb + 1);
@@ -433,12 +453,12 @@ __attribute__((amdgpu_waves_per_eu(PASS == 0 ? 2 : 1, PASS == 0 ? 2 : 1))) void 
             X3_MFMA(acc_o[fb], oh, km);
             X3_MFMA(acc_o[fb], oh, kh);
           }
-          if (PIPE && t == 0) {  // second half of the elementwise stage, two values per block
+          if (PREFETCH && t == 0) {  // second half of the elementwise stage, two values per block
             X3_EW(8 + 2 * fb);
             X3_EW(9 + 2 * fb);
             X3_SPLIT_W(1, fb);
           }
-          if (PIPE) {
+          if (PREFETCH) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               xc[u] = xn[u];
@@ -504,9 +524,10 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 }
 
 static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
-  const int rows_per_block = blocks_per_cu == 2 ? 256 : 128;  // forward: 8-wave workgroups
+  // blocks_per_cu == 2 selects the 8-wave workgroups (forward, column pass): 256 rows each
   // fill whole rounds of the 256 CUs (one workgroup per CU: the forward runs 8 waves of <= 256
   // registers on one 72 KiB LDS image, the backward passes 4 waves of 512 registers)
+  const int rows_per_block = blocks_per_cu == 2 ? 256 : 128;
   const long long rowblocks = (long long)B * pn_cdiv(N, rows_per_block);
   if (ntiles < 16) {
     *tps = ntiles;
@@ -589,12 +610,17 @@ extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, con
                "pn_meanshift_x3_iter_bwd_f32: null pointer");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   const int ntiles = (int)pn_align_up(N, 64) / 32;
-  int tps;
-  int S = x3_slices(B, N, ntiles, 1, &tps);
+  int tps, tps2;
   const int smax = pn_meanshift_slices(B, N);
+  int S = x3_slices(B, N, ntiles, 1, &tps);    // row pass: 4-wave workgroups
   if (S > smax) {
     S = smax;
     tps = pn_cdiv(ntiles, S);
+  }
+  int S2 = x3_slices(B, N, ntiles, 2, &tps2);  // column pass: 8-wave workgroups
+  if (S2 > smax) {
+    S2 = smax;
+    tps2 = pn_cdiv(ntiles, S2);
   }
   float* alpha = cs + (size_t)B * N;
   hipLaunchKernelGGL(pn_ms3_prep_bwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, gy, y, rsum,
@@ -618,14 +644,15 @@ extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, con
   PN_CHECK_LAUNCH();
   {
     PN_PROF("meanshift_bwd_cols", stream);
-    hipLaunchKernelGGL(pn_ms3_kernel<2>, grid, dim3(256), 0, stream, x, nullptr, (const u32x4*)pimg_q,
+    dim3 grid2(S2, pn_cdiv(N, 32 * X3_WAVES(2)), B);
+    hipLaunchKernelGGL(pn_ms3_kernel<2>, grid2, dim3(64 * X3_WAVES(2)), 0, stream, x, nullptr, (const u32x4*)pimg_q,
                        (const u32x4*)pimg_gu, (const u32x4*)cimg_q, (const u32x4*)cimg_go,
-                       (const float*)cs, (const float*)alpha, bsq, N, ntiles, tps, opart_x, nullptr);
+                       (const float*)cs, (const float*)alpha, bsq, N, ntiles, tps2, opart_x, nullptr);
   }
   PN_CHECK_LAUNCH();
   const long long ND4 = (long long)N * MS_D / 4;
   hipLaunchKernelGGL(pn_ms_combine_bwd_kernel, dim3(pn_cdiv(ND4, 256), B), dim3(256), 0, stream,
-                     opart_q, opart_x, ND4, S, gq, gx);
+                     opart_q, opart_x, ND4, S, S2, gq, gx);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
