@@ -105,6 +105,59 @@ __global__ void pn_knn_prep_kernel(const float* __restrict__ x, int C, int N, in
   xxp[(size_t)b * Np + jp] = acc;
 }
 
+// K0 for point-major sources (B,N,C) with a permutation (the mean-shift bandwidth / membership
+// queries: C = 128): the generic kernel above reads one 4-byte element per lane from 64 different
+// rows (250 us at N = 10 000).  Here a workgroup takes 64 output columns, reads their source rows
+// with 16-byte lanes along the row, turns the tile in LDS (row stride C + 1: conflict free) and
+// writes the channel-first rows 256 bytes at a time.  Norms stay a per-point fma chain in channel
+// order (their bits decide the ranking).
+__global__ __launch_bounds__(256) void pn_knn_prep_pm_kernel(const float* __restrict__ x, int C, int N,
+                                                            int Cp, int Np, KnnPerm perm,
+                                                            float* __restrict__ xp,
+                                                            float* __restrict__ xxp) {
+  extern __shared__ float prep_tile[];  // [64][C + 1]
+  const int b = blockIdx.y;
+  const int jp0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const float* xb = x + (size_t)b * C * N;
+  float* xpb = xp + (size_t)b * Cp * Np;
+  const int C4 = C >> 2, ld = C + 1;
+  for (int e = t; e < 64 * C4; e += 256) {
+    const int p = e / C4, q = e - p * C4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jp0 + p < N) v = *reinterpret_cast<const float4*>(xb + (size_t)knn_perm(perm, jp0 + p) * C + 4 * q);
+    float* d = prep_tile + p * ld + 4 * q;
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+    d[3] = v.w;
+  }
+  __syncthreads();
+  const int p = t & 63, part = t >> 6;
+  if (jp0 + p < Np) {
+    for (int c = part; c < Cp; c += 4) xpb[(size_t)c * Np + jp0 + p] = c < C ? prep_tile[p * ld + c] : 0.f;
+    if (part == 0) {
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float v = prep_tile[p * ld + c];
+        acc = __builtin_fmaf(v, v, acc);
+      }
+      xxp[(size_t)b * Np + jp0 + p] = acc;
+    }
+  }
+}
+
+static void knn_prep_launch(hipStream_t stream, const float* x, int B, int C, int N, int Cp, int Np, int mode,
+                            int point_major, KnnPerm perm, float* xp, float* xxp) {
+  if (point_major && mode != 1 && (C & 3) == 0 && C <= 224) {  // 64 x (C+1) floats of LDS
+    hipLaunchKernelGGL(pn_knn_prep_pm_kernel, dim3(pn_cdiv(Np, 64), B), dim3(256), 64 * (C + 1) * sizeof(float),
+                       stream, x, C, N, Cp, Np, perm, xp, xxp);
+  } else {
+    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(Np, 256), B), dim3(256), 0, stream, x, C, N, Cp, Np,
+                       mode, point_major, perm, xp, xxp);
+  }
+}
+
 // K1 / K3.  KSTEPS = Cp / 2 (MODE 1: 4 = two steps xyz + two steps normals), QSETS = number of
 // 32-query column blocks per wave.  Queries (xq, Nq valid of Nqp padded) and candidates
 // (xc, Nc of Ncp) may be the same array.
@@ -504,11 +557,8 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * Nq * 4, stream));
   {
     PN_PROF("knn_prep", stream);
-    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Ncp, 256), B), dim3(256), 0, stream, c,
-                       C, Nc, p.Cp, p.Ncp, mode, c_pm, perm_c, xc, xxc);
-    if (!self)
-      hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(p.Nqp, 256), B), dim3(256), 0, stream,
-                         q, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
+    knn_prep_launch(stream, c, B, C, Nc, p.Cp, p.Ncp, mode, c_pm, perm_c, xc, xxc);
+    if (!self) knn_prep_launch(stream, q, B, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
   }
   PN_CHECK_LAUNCH();
   dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
