@@ -161,12 +161,17 @@ static void knn_prep_launch(hipStream_t stream, const float* x, int B, int C, in
 // K1 / K3.  KSTEPS = Cp / 2 (MODE 1: 4 = two steps xyz + two steps normals), QSETS = number of
 // 32-query column blocks per wave.  Queries (xq, Nq valid of Nqp padded) and candidates
 // (xc, Nc of Ncp) may be the same array.
-template <int KSTEPS, int QSETS, int MODE, bool COLLECT>
+// KIND 0: tile maxima (pass 1); 1: collect survivors (pass 2); 2: single-pass arg-max (k = 1,
+// index only): every lane keeps the best key of its (query, slice, half) — value first, then the
+// smaller ORIGINAL candidate index — and writes it to lists[((b*Nqp+q)*S+slice)*2+h].
+template <int KSTEPS, int QSETS, int MODE, int KIND>
 __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
     const float* __restrict__ xc, const float* __restrict__ xxc_, int Nc, int Ncp,
     int tiles_per_slice, float* __restrict__ tilemax, const float* __restrict__ tau,
-    u64* __restrict__ lists, int* __restrict__ counts, int subcap) {
+    u64* __restrict__ lists, int* __restrict__ counts, int subcap, KnnPerm perm_c) {
+  constexpr bool COLLECT = KIND == 1;
+  constexpr bool ARGMAX = KIND == 2;
   // grid: (slices, query blocks, B): consecutive workgroups differ in the slice, so each of the
   // 8 XCDs streams only its share of the candidates (kept in its private L2).
   // The candidate tile [CP channels][32 candidates] (+ the 32 squared norms) is staged through
@@ -195,6 +200,8 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
   float xxq[QSETS], tq[QSETS];
   int mycnt[QSETS];
   u64* sub[QSETS];
+  int bestj[QSETS];
+  float bestv[QSETS];
 #pragma unroll
   for (int s = 0; s < QSETS; ++s) {
     const int q = q0 + 32 * s + col;
@@ -204,6 +211,8 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
     xxq[s] = xxqb[qcl];
     tq[s] = (COLLECT && q < Nq) ? tau[(size_t)b * Nqp + qcl] : __builtin_inff();
     mycnt[s] = 0;
+    bestj[s] = 0;
+    bestv[s] = -__builtin_inff();
     // sub-list of (query, slice, half): (((b*Nqp + q)*S + slice)*2 + h) * subcap
     sub[s] = lists + ((((size_t)b * Nqp + qcl) * S + slice) * 2 + h) * (size_t)subcap;
   }
@@ -291,7 +300,15 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
             v = acc[s][r];
           }
           const bool ok = (j0 + row) < Nc;
-          if (!COLLECT) {
+          if (ARGMAX) {
+            // candidates come in ORIGINAL order in this mode (identity permutation) and a lane
+            // visits its rows in increasing index order: a strict > keeps the smallest index
+            // among exact ties, which near-coincident mean-shift modes produce by the thousand
+            if (ok && v > bestv[s]) {
+              bestj[s] = j0 + row;
+              bestv[s] = v;
+            }
+          } else if (!COLLECT) {
             tm = fmaxf(tm, ok ? v : -__builtin_inff());
           } else {
             if (ok && v >= tq[s]) {
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
             }
           }
         }
-        if (!COLLECT) {
+        if (KIND == 0) {
           const int q = q0 + 32 * s + col;
           if (q < Nqp) tilemax[((size_t)b * Nqp + q) * T16 + (2 * mt + h)] = tm;
         }
@@ -318,6 +335,27 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
       if (q < Nqp) counts[(((size_t)b * Nqp + q) * S + slice) * 2 + h] = mycnt[s];
     }
   }
+  if (ARGMAX && wave_on) {
+#pragma unroll
+    for (int s = 0; s < QSETS; ++s) {
+      const int q = q0 + 32 * s + col;
+      if (q < Nqp)
+        lists[(((size_t)b * Nqp + q) * S + slice) * 2 + h] =
+            t_begin < t_end ? knn_key(bestv[s], knn_perm(perm_c, bestj[s])) : 0;
+    }
+  }
+}
+
+// arg-max epilogue: one thread per query, maximum of its 2 S partial keys
+__global__ void pn_knn_argmax_final_kernel(const u64* __restrict__ lists, int Nq, int Nqp, int S,
+                                           KnnPerm perm_q, int64_t* __restrict__ out_idx) {
+  const int b = blockIdx.y;
+  const int qp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qp >= Nq) return;
+  const u64* l = lists + ((size_t)b * Nqp + qp) * S * 2;
+  u64 best = 0;
+  for (int i = 0; i < 2 * S; ++i) best = l[i] > best ? l[i] : best;
+  out_idx[(size_t)b * Nq + knn_perm(perm_q, qp)] = knn_key_index(best);
 }
 
 // K2: one wave per query; the T = Ncp/16 tile maxima of the query are contiguous and live in
@@ -523,18 +561,20 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
 }
 
 template <int KSTEPS, int QSETS, int MODE>
-static void knn_mfma_launch_pass(bool collect, dim3 grid, hipStream_t stream, const float* xq,
+static void knn_mfma_launch_pass(int kind, dim3 grid, hipStream_t stream, const float* xq,
                                  const float* xxq, int Nq, int Nqp, const float* xc,
                                  const float* xxc, int Nc, int Ncp, int tps, float* tilemax,
-                                 const float* tau, u64* lists, int* cnt, int subcap) {
-  if (!collect)
-    hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, false>), grid, dim3(256), 0,
-                       stream, xq, xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau, lists, cnt,
-                       subcap);
-  else
-    hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, true>), grid, dim3(256), 0,
-                       stream, xq, xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau, lists, cnt,
-                       subcap);
+                                 const float* tau, u64* lists, int* cnt, int subcap, KnnPerm perm_c) {
+  if (kind == 0)
+    hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, 0>), grid, dim3(256), 0, stream, xq,
+                       xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau, lists, cnt, subcap, perm_c);
+  else if (kind == 1)
+    hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, 1>), grid, dim3(256), 0, stream, xq,
+                       xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau, lists, cnt, subcap, perm_c);
+  else if (MODE == 2)  // arg-max exists for the dot-product queries only
+    hipLaunchKernelGGL((pn_knn_mfma_kernel<KSTEPS, QSETS, MODE, (MODE == 2 ? 2 : 0)>), grid,
+                       dim3(256), 0, stream, xq, xxq, Nq, Nqp, xc, xxc, Nc, Ncp, tps, tilemax, tau,
+                       lists, cnt, subcap, perm_c);
 }
 
 // The shared engine.  self: queries use the candidates' permuted copy (kNN graph of one set).
@@ -551,7 +591,10 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   int* cnt = (int*)(base + w.cnt);
   int* flags = flags_out ? flags_out : (int*)(base + w.flags);
   u64* lists = (u64*)(base + w.lists);
-  const KnnPerm perm_c = knn_make_perm(Nc, false);
+  // k = 1 without the value (nearest-centre membership): one pass, no threshold, no lists, and
+  // no candidate permutation (it only serves the tile-maxima threshold)
+  const bool argmax = mode == 2 && k == 1 && out_val == nullptr && out_idx != nullptr && !self;
+  const KnnPerm perm_c = knn_make_perm(Nc, argmax);
   const KnnPerm perm_q = self ? perm_c : knn_make_perm(Nq, true);
 
   PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * Nq * 4, stream));
@@ -562,8 +605,8 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   }
   PN_CHECK_LAUNCH();
   dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
-  for (int pass = 0; pass < 2; ++pass) {
-    const bool collect = pass == 1;
+  for (int pass = 0; pass < (argmax ? 1 : 2); ++pass) {
+    const int collect = argmax ? 2 : pass;
     static const char* const pass_names[2][5] = {
         {"knn_mfma_pass1_c4", "knn_mfma_pass1_c64", "knn_mfma_pass1_wide", "knn_mfma_pass1_pn",
          "sel_mfma_pass1_dot"},
@@ -572,10 +615,10 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     const int fam =
         mode == 2 ? 4 : (mode == 1 ? 3 : (p.ksteps <= 4 ? 0 : (p.ksteps == 32 ? 1 : 2)));
     {
-      PN_PROF(pass_names[pass][fam], stream);
+      PN_PROF(argmax ? "sel_mfma_argmax_dot" : pass_names[pass][fam], stream);
 #define KM_GO(KS, QS, MD)                                                                        \
   knn_mfma_launch_pass<KS, QS, MD>(collect, grid, stream, xq, xxq, Nq, p.Nqp, xc, xxc, Nc, p.Ncp, \
-                                   p.tiles_per_slice, tilemax, tau, lists, cnt, p.subcap)
+                                   p.tiles_per_slice, tilemax, tau, lists, cnt, p.subcap, perm_c)
       if (mode == 1)
         KM_GO(4, 2, 1);
       else if (mode == 2 && p.ksteps == 2)
@@ -601,12 +644,19 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
 #undef KM_GO
     }
     PN_CHECK_LAUNCH();
-    if (!collect) {
+    if (collect == 0) {
       PN_PROF("knn_tau", stream);
       hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream,
                          tilemax, Nq, p.Nqp, p.Ncp / 16, k, tau);
       PN_CHECK_LAUNCH();
     }
+  }
+  if (argmax) {
+    PN_PROF("knn_final", stream);
+    hipLaunchKernelGGL(pn_knn_argmax_final_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, lists,
+                       Nq, p.Nqp, p.S, perm_q, out_idx);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
   }
   {
     PN_PROF("knn_final", stream);
