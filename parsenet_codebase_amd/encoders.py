@@ -90,7 +90,9 @@ class DGCNNControlPoints(nn.Module):
         x = F.leaky_relu(self.bn5(conv1x1(torch.cat(feats, dim=1), self.conv5[0])), 0.2)
         if isinstance(weights, torch.Tensor):
             x = x * weights.reshape((1, 1, -1))
-        x = F.adaptive_max_pool1d(x, 1)
+        # max over the points (F.adaptive_max_pool1d(x, 1) in the reference; torch's pooling kernel
+        # takes 0.5 ms on a 1024 x 5000 input, the reduction 20 us)
+        x = x.max(dim=2, keepdim=True)[0]
         x = F.relu(self.bn6(conv1x1(x, self.conv6)))
         x = F.relu(self.bn7(conv1x1(x, self.conv7)))
         x = self.tanh(conv1x1(x, self.conv8)[:, :, 0])
