@@ -1,0 +1,41 @@
+"""Operator census of one shape's clustering + fitting stage (fwd + bwd): python tools/fitprof.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from torch.profiler import profile, ProfilerActivity
+from parsenet_codebase_amd import synthetic
+from parsenet_codebase_amd.encoders import DGCNNControlPoints
+from parsenet_codebase_amd.fitting import Evaluation
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+N = 10000
+clustered = len(sys.argv) > 1 and sys.argv[1] == "clustered"
+pts, nrm, lab, prim = synthetic.make_batch(0, 1, N)
+ev = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1),
+                open_path=DGCNNControlPoints(20, num_points=10, mode=0))
+if clustered:
+    code = torch.nn.functional.normalize(torch.randn(32, 128), dim=1)
+    emb = code[torch.from_numpy(lab[0]).long()] + 0.01 * torch.randn(N, 128)
+else:
+    emb = torch.randn(N, 128)
+emb = torch.nn.functional.normalize(emb, dim=1).to(dev).unsqueeze(0).requires_grad_(True)
+P, Nn = torch.from_numpy(pts).to(dev), torch.from_numpy(nrm).to(dev)
+logp = torch.log_softmax(torch.randn(1, 10, N, device=dev), 1)
+
+
+def run():
+    res, extra = ev.fitting_loss(emb, P, Nn, lab, prim, logp, quantile=0.025, iterations=10, lamb=0.1)
+    res[0].backward()
+
+
+for _ in range(2):
+    run()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    run()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="count" if len(sys.argv) > 2 else "self_cuda_time_total", row_limit=40,
+                                max_name_column_width=50))
