@@ -34,6 +34,22 @@ def conv1x1(x, conv):
     return y
 
 
+def batch_norm_1d(x, bn):
+    """nn.BatchNorm1d applied to (B,C,N).  Evaluation mode is written out as the per-channel
+    affine map it is: torch routes F.batch_norm to MIOpen, which searches / compiles a kernel for
+    every new tensor shape — and the fitting stage feeds a different point count for every
+    segment (tens of milliseconds per first-seen size).  Training mode (fixed batch shapes) keeps
+    the library call, including the running-statistics update."""
+    if bn.training or bn.running_mean is None:
+        return bn(x)
+    scale = torch.rsqrt(bn.running_var + bn.eps)
+    shift = -bn.running_mean * scale
+    if bn.weight is not None:
+        scale = scale * bn.weight
+        shift = shift * bn.weight + bn.bias
+    return x * scale.view(1, -1, 1) + shift.view(1, -1, 1)
+
+
 def _edge_layer(cin2, cout, norm):
     # Sequential only to reproduce the reference's parameter names ("convN.0.weight"); the
     # forward pass feeds the weight to the fused kernel instead of calling it.
@@ -87,14 +103,14 @@ class DGCNNControlPoints(nn.Module):
             idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
-        x = F.leaky_relu(self.bn5(conv1x1(torch.cat(feats, dim=1), self.conv5[0])), 0.2)
+        x = F.leaky_relu(batch_norm_1d(conv1x1(torch.cat(feats, dim=1), self.conv5[0]), self.bn5), 0.2)
         if isinstance(weights, torch.Tensor):
             x = x * weights.reshape((1, 1, -1))
         # max over the points (F.adaptive_max_pool1d(x, 1) in the reference; torch's pooling kernel
         # takes 0.5 ms on a 1024 x 5000 input, the reduction 20 us)
         x = x.max(dim=2, keepdim=True)[0]
-        x = F.relu(self.bn6(conv1x1(x, self.conv6)))
-        x = F.relu(self.bn7(conv1x1(x, self.conv7)))
+        x = F.relu(batch_norm_1d(conv1x1(x, self.conv6), self.bn6))
+        x = F.relu(batch_norm_1d(conv1x1(x, self.conv7), self.bn7))
         x = self.tanh(conv1x1(x, self.conv8)[:, :, 0])
         return x.view(batch_size, self.controlpoints * self.controlpoints, 3)
 
