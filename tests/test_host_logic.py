@@ -199,3 +199,19 @@ mode = 5
     assert (c.num_train, c.num_test, c.epochs, c.batch_size, c.mode, c.patience) == (24000, 4000, 100, 1, 5, 8)
     assert c.lr == 1e-4 and c.loss_weight == 100.0 and c.normals is True
     assert c.model_path == "train_parsenet_e2e_{}" and c.pretrain_model_path == "parsenet_with_normals.pth"
+
+
+def test_host_iou_matrix_matches_one_hot_products_on_cpu():
+    """fitting._relaxed_iou_of_labels (host bincount form) == relaxed_iou_fast on one-hot
+    encodings (the reference's form), evaluated here with torch on the CPU: bit for bit."""
+    from parsenet_codebase_amd.fitting import _relaxed_iou_of_labels, relaxed_iou_fast
+    rng = np.random.RandomState(11)
+    for n, k in ((10000, 9), (5000, 49)):
+        gt = rng.randint(0, k, n)
+        pred = (gt + (rng.rand(n) < 0.3) * rng.randint(0, k, n)) % k
+        oh = lambda a: torch.zeros(n, 50).scatter_(1, torch.from_numpy(a).long().unsqueeze(1), 1)  # noqa: E731
+        want = relaxed_iou_fast(oh(pred).unsqueeze(0), oh(gt).unsqueeze(0))[0].numpy()
+        got = _relaxed_iou_of_labels(pred, gt)
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        _relaxed_iou_of_labels(np.array([0, 50]), np.array([0, 1]))
