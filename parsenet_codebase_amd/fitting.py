@@ -47,12 +47,6 @@ def _eigh_desc(G):
     return w.flip(-1), v.flip(-1)
 
 
-def _numerical_rank(sv, shape):
-    """numpy / torch.matrix_rank convention: #(s > max(m,n) * eps * s_max)."""
-    tol = sv.max() * max(shape) * EPS
-    return int((sv > tol).sum().item())
-
-
 class LeastSquares:
     """src/fitting_utils.py:32-65."""
 
@@ -65,9 +59,10 @@ class LeastSquares:
             sv, _ = _gram_spectrum(A)
         else:
             sv = torch.linalg.svdvals(A.detach().double())
-        if not bool(torch.isfinite(sv).all()):
+        sv_host = sv.cpu().numpy()       # one download decides finiteness and rank
+        if not np.isfinite(sv_host).all():
             raise RuntimeError("lstsq: non-finite entries in the design matrix")
-        if cols == _numerical_rank(sv, A.shape):
+        if cols == int((sv_host > sv_host.max() * max(A.shape) * EPS).sum()):
             Ad, Yd = A.double(), Y.double()
             if A.shape[0] == cols:     # square (the ridge system): solve it directly
                 x = torch.linalg.solve(Ad, Yd)
@@ -83,15 +78,21 @@ class LeastSquares:
 
 
 def best_lambda(A):
-    """src/fitting_utils.py:68-85."""
-    lamb = 1e-6
+    """src/fitting_utils.py:68-85: smallest lambda in {1e-6 * 10^i, i < 7} for which A + lambda I has
+    full numerical rank (torch.matrix_rank convention).  A is the symmetric Gram matrix of the
+    caller, so the singular values of A + lambda I are its eigenvalues shifted by lambda: one
+    eigen-decomposition (fp64 Jacobi kernel for 3 x 3) and one download replace the reference's up
+    to seven fp32 SVDs with a host synchronisation each.  Where lambda sits within fp32 noise of
+    the rank tolerance the reference's choice is decided by that noise (case
+    3); here it is decided by the exact spectrum."""
     cols = A.shape[0]
+    Ad = A.detach().double()
+    sym = 0.5 * (Ad + Ad.t())
+    ev = (K.sym3_eig(sym.unsqueeze(0))[0][0] if cols == 3 else torch.linalg.eigvalsh(sym).flip(-1)).cpu().numpy()
+    lamb = 1e-6
     for _ in range(7):
-        A_dash = A + lamb * torch.eye(cols, device=A.device)
-        # fp32 singular values, like torch.matrix_rank in the reference: when lambda is close
-        # to the rank tolerance the outcome is decided by fp32 noise there as well
-        sv = torch.linalg.svdvals(A_dash)
-        if cols == _numerical_rank(sv, A_dash.shape):
+        sv = np.abs(ev + lamb)
+        if cols == int((sv > sv.max() * cols * EPS).sum()):
             break
         lamb *= 10
     return lamb

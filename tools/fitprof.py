@@ -37,5 +37,5 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     run()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="count" if len(sys.argv) > 2 else "self_cuda_time_total", row_limit=40,
+print(prof.key_averages().table(sort_by=sys.argv[2] if len(sys.argv) > 2 else "self_cuda_time_total", row_limit=40,
                                 max_name_column_width=50))
