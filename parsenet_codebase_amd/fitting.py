@@ -33,11 +33,19 @@ def guard_sqrt(x, minimum=1e-5):
 # ---------------------------------------------------------------------------------------
 # small dense algebra
 # ---------------------------------------------------------------------------------------
+def _tall_gram(A, B=None):
+    """A^T B for tall-skinny operands (n x 3 or so) as a broadcast product + reduction.  A
+    library GEMM with a 3 x 3 output and n = 2 500..5 000 in the contraction runs on a single
+    workgroup (0.14 ms per call in fp64 — 8 % of a seven-segment shape's GPU time)."""
+    B = A if B is None else B
+    return (A.unsqueeze(2) * B.unsqueeze(1)).sum(0)
+
+
 def _gram_spectrum(A):
     """Singular values (descending, fp64) and right singular vectors (columns) of a tall (n,3)
     matrix from the eigen-decomposition of its fp64 Gram matrix (HIP Jacobi kernel)."""
     Ad = A.detach().double()
-    G = (Ad.t() @ Ad).unsqueeze(0)
+    G = _tall_gram(Ad).unsqueeze(0)
     evals, evecs = K.sym3_eig(G) if A.shape[1] == 3 else _eigh_desc(G)
     return torch.sqrt(torch.clamp(evals[0], min=0.0)), evecs[0]
 
@@ -67,13 +75,13 @@ class LeastSquares:
             if A.shape[0] == cols:     # square (the ridge system): solve it directly
                 x = torch.linalg.solve(Ad, Yd)
             else:
-                x = torch.linalg.solve(Ad.t() @ Ad, Ad.t() @ Yd)
+                x = torch.linalg.solve(_tall_gram(Ad), _tall_gram(Ad, Yd))
             return x.to(A.dtype)
-        AtA = A.transpose(1, 0) @ A
+        AtA = _tall_gram(A) if A.shape[0] > 8 * cols else A.transpose(1, 0) @ A
         with torch.no_grad():
             lamb = best_lambda(AtA)
         A_dash = AtA + lamb * torch.eye(cols, device=A.device)
-        Y_dash = A.transpose(1, 0) @ Y
+        Y_dash = _tall_gram(A, Y) if A.shape[0] > 8 * cols else A.transpose(1, 0) @ Y
         return self.lstsq(A_dash, Y_dash, 1)
 
 
