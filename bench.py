@@ -48,6 +48,24 @@ def build_workload(name, device, rank):
     raise SystemExit("unknown workload %r" % name)
 
 
+def pmc_traffic(kernel_name, arith):
+    """HBM-side bytes per launch of a mean-shift kernel from the committed PMC run of the same
+    launch configuration (profiles/: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH
+    doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
+    the file is not there — bench.py never profiles counters itself."""
+    import csv
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                      "r01_meanshift_x3_pmc.csv" if arith == "bf16x3" else "r01_meanshift_f32_pmc.csv")
+    idx = {"meanshift_fwd": 0, "meanshift_bwd_rows": 1, "meanshift_bwd_cols": 2}.get(kernel_name)
+    if idx is None or not os.path.exists(fn):
+        return None
+    want = ("pn_ms3_kernel<%d>" if arith == "bf16x3" else "pn_ms_kernel<%d>") % idx
+    vals = {r["counter"]: float(r["avg_per_launch"]) for r in csv.DictReader(open(fn)) if r["kernel"] == want}
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def kernel_roofline(step, nprof):
     """Average launch duration of every kernel family over ``nprof`` profiled steps (HIP events
     on the launch stream, recorded inside the C library), and the roofline entry of the
@@ -96,12 +114,13 @@ def kernel_roofline(step, nprof):
             # (fp32 accumulate): the roof for ALGORITHMIC fp32 FLOPs is the bf16 dense peak / 6
             peak = MFMA_BF16_PEAK_TFLOPS / 6.0
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": None, "avg_launch_ms": table[dom]["avg_ms"],
+                    "frac": ach / peak, "traffic": pmc_traffic(dom, "bf16x3"),
+                    "avg_launch_ms": table[dom]["avg_ms"],
                     "mfma": "v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)",
                     "executed_tflops": 6.0 * ach, "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, "f32"),
                     "avg_launch_ms": table[dom]["avg_ms"], "mfma": "v_mfma_f32_32x32x2_f32"}
     else:
         roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
