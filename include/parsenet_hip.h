@@ -100,23 +100,21 @@ int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const float* q, c
  * error into three bf16 pieces and each product is formed from the six significant piece
  * products with fp32 accumulation (an fp32 dot product in a different summation order).
  *   image_bytes : size of one tile-image array for (B,N).
- *   split       : x (B,N,D) -> pimg, cimg (pre-split, LDS-ready images of every 32-point tile).
- *   iter_fwd    : as pn_meanshift_iter_fwd_f32 with (pimg, cimg) of x in place of (x, xt).
- *   iter_bwd    : as pn_meanshift_iter_bwd_f32 with (pimg_x, cimg_x) in place of xt and four
- *                 scratch image arrays (images of q, gu, go) in place of (qt, gut); x itself is
- *                 still read as the resident operand of the column pass. */
+ *   split       : x (B,N,D) -> img (pre-split, LDS-ready image of every 32-point tile; both
+ *                 GEMMs read it, the second one through the hardware transpose read).
+ *   iter_fwd    : as pn_meanshift_iter_fwd_f32 with img_x in place of (x, xt).
+ *   iter_bwd    : as pn_meanshift_iter_bwd_f32 with img_x in place of xt and two scratch image
+ *                 arrays (images of q and gu) in place of (go, qt, gut). */
 size_t pn_meanshift_x3_image_bytes(int B, int N);
-int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, void* pimg, void* cimg,
-                              void* stream);
-int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* pimg, const void* cimg,
-                                 const float* bsq, int B, int N, int D, float* opart, float* rpart,
-                                 float* y, float* rsum, float* unorm, void* stream);
-int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q, const void* pimg_x,
-                                 const void* cimg_x, const float* rsum, const float* unorm,
-                                 const float* bsq, int B, int N, int D, float* gu, float* go,
-                                 float* cs, void* pimg_q, void* cimg_q, void* pimg_gu, void* cimg_go,
-                                 float* opart_q, float* opart_x, float* gq, float* gx, const float* x,
-                                 void* stream);
+int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, void* img, void* stream);
+int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, const float* bsq, int B, int N,
+                                 int D, float* opart, float* rpart, float* y, float* rsum,
+                                 float* unorm, void* stream);
+int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q, const float* x,
+                                 const void* img_x, const float* rsum, const float* unorm,
+                                 const float* bsq, int B, int N, int D, float* gu, float* cs,
+                                 void* img_q, void* img_gu, float* opart_q, float* opart_x, float* gq,
+                                 float* gx, void* stream);
 
 /* ---- GroupNorm (+ReLU) (+max over points) of the per-point heads -------------------------
  * Replaces torch GroupNorm -> ReLU (-> max over N) of src/PointNet.py:216-218, 274-283 on

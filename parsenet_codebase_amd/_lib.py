@@ -54,9 +54,9 @@ SIGNATURES = {
     "pn_meanshift_iter_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pn_meanshift_x3_image_bytes": (c_size_t, [c_int, c_int]),
-    "pn_meanshift_x3_split_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "pn_meanshift_x3_iter_fwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
-    "pn_meanshift_x3_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 12 + [c_void_p]),
+    "pn_meanshift_x3_split_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_meanshift_x3_iter_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "pn_meanshift_x3_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "pn_meanshift_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 9 + [c_void_p]),
     "pn_gn_rows_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),

@@ -13,20 +13,28 @@
 // (64 cycles each) per 32x32x16 block: 2.7x less matrix-pipe time, and bf16 MFMAs overlap with
 // the VALU work of the elementwise stage, which the fp32 ones do not.
 //
-// Streamed operands come pre-split from global memory as LDS images (one 24 KiB image per
-// 32-point tile and layout, written by pn_ms3_split_kernel, copied verbatim by the LDS DMA):
-//   P image [piece 3][row j 32][16 chunks of 8 channels]   chunk c stored at c ^ (j & 15)
-//   C image [piece 3][feature f 128][4 chunks of 8 points] chunk c stored at c ^ ((f >> 2) & 3)
-// The XOR swizzles make the ds_read_b128 operand fetches of both GEMMs bank-conflict free
-// (16-lane service groups, MI355X_MICROARCH.md section LDS).  In the C image the 32 points of a
-// tile are ordered as the D-layout of the first GEMM hands them to the second one: position
-// 16 t + 8 h + e holds point (e & 3) + 8 (2 t + (e >> 2)) + 4 h.
+// Streamed operands come pre-split from global memory as LDS images: one 24 KiB image per
+// 32-point tile, written by pn_ms3_split_kernel and copied verbatim by the LDS DMA:
+//   [piece 3][row j 32][16 chunks of 8 channels], chunk c of row j stored at c ^ swz(j),
+//   swz(j) = ((j & 3) << 2) | ((j >> 2) & 3).
+// The same image feeds both GEMMs.  The first one (contraction over channels) fetches its A
+// operand with ds_read_b128 (row = streamed point); the second one (contraction over the
+// streamed points) needs the transposed operand and gets it from the hardware transpose read
+// ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of 4 contiguous bf16
+// (row i>>2, columns 4(i&3)..) of a 4 x 16 block and receives column i of that block, i.e. 4
+// consecutive streamed points of one feature — exactly the 4-point runs in which the D layout
+// of the first GEMM hands the kernel values to the second (positions e, e+4 of a k-step are
+// points (e&3) + 8(2t + (e>>2)) + 4h).  The swizzle makes both access patterns bank-conflict
+// free (16-lane service groups of ds_read_b128; 4 rows x 4 chunks of the transpose read).
 // (included at the end of meanshift.hip: one translation unit, shared combine kernels)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* x3_lds_s16x4;
 
 #define X3_IMG_U4 1536            // uint4 (16 B) units per 24 KiB tile image
 #define X3_PIECE_U4 512           // per piece
@@ -62,61 +70,42 @@ __device__ static inline X3Pieces x3_split2(float a, float b) {
 
 __device__ static inline bf16x8 x3_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// position p (0..31) of a tile's C image -> point index inside the tile
-__host__ __device__ static inline int x3_rho(int p) {
-  const int t = p >> 4, h = (p >> 3) & 1, e = p & 7;
-  return (e & 3) + 8 * (2 * t + (e >> 2)) + 4 * h;
-}
+__host__ __device__ static inline int x3_swz(int j) { return ((j & 3) << 2) | ((j >> 2) & 3); }
 
-// x (B,N,D) fp32 -> P and C images of every 32-point tile (rows >= N are zero).
-// One workgroup per tile; work item = one 16-byte chunk of each image.
+// x (B,N,D) fp32 -> the image of every 32-point tile (rows >= N are zero).
+// One workgroup per tile; work item = one 16-byte chunk.
 __global__ __launch_bounds__(256) void pn_ms3_split_kernel(const float* __restrict__ x, int N,
-                                                           int ntiles, u32x4* __restrict__ pimg,
-                                                           u32x4* __restrict__ cimg) {
+                                                           int ntiles, u32x4* __restrict__ pimg) {
   const int b = blockIdx.y, tile = blockIdx.x;
   const float* __restrict__ xb = x + (size_t)b * N * MS_D;
   u32x4* __restrict__ P = pimg + ((size_t)b * ntiles + tile) * X3_IMG_U4;
-  u32x4* __restrict__ C = cimg + ((size_t)b * ntiles + tile) * X3_IMG_U4;
   const int j0 = tile * 32;
   for (int it = threadIdx.x; it < 512; it += 256) {
-    if (pimg != nullptr) {  // P image: row j, chunk c = channels 8c..8c+7
-      const int j = it >> 4, c = it & 15;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (j0 + j < N) ? xb[(size_t)(j0 + j) * MS_D + 8 * c + e] : 0.f;
-      u32x4 h, m, l;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) X3_SPLIT_TO(v[2 * q], v[2 * q + 1], h, m, l, q);
-      const int slot = j * 16 + (c ^ (j & 15));
-      P[slot] = h;
-      P[X3_PIECE_U4 + slot] = m;
-      P[2 * X3_PIECE_U4 + slot] = l;
+    const int j = it >> 4, c = it & 15;  // row j, chunk c = channels 8c..8c+7
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (j0 + j < N) {
+      const float* src = xb + (size_t)(j0 + j) * MS_D + 8 * c;
+      v0 = *reinterpret_cast<const float4*>(src);
+      v1 = *reinterpret_cast<const float4*>(src + 4);
     }
-    if (cimg != nullptr) {  // C image: feature f, chunk c = positions 8c..8c+7 (points rho(8c+e))
-      const int f = it >> 2, c = it & 3;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int j = j0 + x3_rho(8 * c + e);
-        v[e] = j < N ? xb[(size_t)j * MS_D + f] : 0.f;
-      }
-      u32x4 h, m, l;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) X3_SPLIT_TO(v[2 * q], v[2 * q + 1], h, m, l, q);
-      const int slot = f * 4 + (c ^ ((f >> 2) & 3));
-      C[slot] = h;
-      C[X3_PIECE_U4 + slot] = m;
-      C[2 * X3_PIECE_U4 + slot] = l;
-    }
+    u32x4 h, m, l;
+    X3_SPLIT_TO(v0.x, v0.y, h, m, l, 0);
+    X3_SPLIT_TO(v0.z, v0.w, h, m, l, 1);
+    X3_SPLIT_TO(v1.x, v1.y, h, m, l, 2);
+    X3_SPLIT_TO(v1.z, v1.w, h, m, l, 3);
+    const int slot = j * 16 + (c ^ x3_swz(j));
+    P[slot] = h;
+    P[X3_PIECE_U4 + slot] = m;
+    P[2 * X3_PIECE_U4 + slot] = l;
   }
 }
 
 // backward prologue, one wave per row (as pn_ms_prep_bwd_kernel, without the transposed copies):
-//   gu = (gy - y (y.gy)) / ||u|| ; c = gu . u (u = y ||u||) ; go = gu / r ; alpha = 1 / (r b^2)
+//   gu = (gy - y (y.gy)) / ||u|| ; c = gu . u (u = y ||u||) ; alpha = 1 / (r b^2)
 __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ rsum,
     const float* __restrict__ unorm, const float* __restrict__ bsq, int N, float* __restrict__ gu,
-    float* __restrict__ go, float* __restrict__ cs, float* __restrict__ alpha) {
+    float* __restrict__ cs, float* __restrict__ alpha) {
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -130,8 +119,6 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
   const float c = pn_wave_sum(u0 * (y0 * nn) + u1 * (y1 * nn));
   gu[base + lane] = u0;
   gu[base + lane + 64] = u1;
-  go[base + lane] = u0 / r;
-  go[base + lane + 64] = u1 / r;
   if (lane == 0) {
     cs[(size_t)b * N + i] = c;
     alpha[(size_t)b * N + i] = 1.0f / (r * bsq[b]);
@@ -143,26 +130,22 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
 
 // PASS 0 forward       resident rows Q;      streamed X:      out[f][i] += X[j][f] K
 // PASS 1 backward/rows resident rows Q, GU;  streamed X:      out[f][i] += X[j][f] gs
-// PASS 2 backward/cols resident cols X;      streamed Q, GU, GO: out[f][j] += Q[i][f] gs + GO[i][f] K
+// PASS 2 backward/cols resident cols X;      streamed Q, GU:  out[f][j] += Q[i][f] gs + GU[i][f] K / r_i
 //
 // R, R1       (B,N,D) fp32 resident operands (split in registers once per workgroup)
-// PA, PB      P images of the streamed operand(s) of the first GEMM (PB: GU, PASS 2 only)
-// CA, CB      C images of the streamed operand(s) of the second GEMM (CB: GO, PASS 2 only)
+// PA, PB      tile images of the streamed operand(s) (PB: GU, PASS 2 only); both GEMMs read them
 // cs, rs      per-row c_i and alpha_i = 1/(r_i b^2): of the resident row (PASS 1) / streamed (PASS 2)
 // grid (slices, blocks of 128 resident indices, B), 256 threads: wave w owns 32 w .. 32 w + 31.
-// LDS: P images double buffered, C images single buffered (loaded under the first GEMM of the
-// same tile): 72 KiB (PASS 0/1), 144 KiB (PASS 2).
+// LDS: images double buffered: 48 KiB (PASS 0/1), 96 KiB (PASS 2); one barrier per tile.
 #define X3_WAVES(PASS) ((PASS) == 1 ? 4 : 8)  // forward / column pass: 8 waves (2 per SIMD) share the LDS images
 template <int PASS>
 __global__ __launch_bounds__(64 * X3_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void pn_ms3_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
-    const u32x4* __restrict__ PB, const u32x4* __restrict__ CA, const u32x4* __restrict__ CB,
-    const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_, int N,
+    const u32x4* __restrict__ PB, const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_, int N,
     int ntiles, int tiles_per_slice, float* __restrict__ opart, float* __restrict__ rpart) {
   constexpr int NIMG = PASS == 2 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) u32x4 ldsP[2][NIMG][X3_IMG_U4];
-  __shared__ __attribute__((aligned(16))) u32x4 ldsC[NIMG][X3_IMG_U4];
   __shared__ __attribute__((aligned(16))) float lds_sc[2][64];
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
@@ -174,13 +157,12 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
   const int S = gridDim.x, slice = blockIdx.x;
   const int t_begin = slice * tiles_per_slice;
   const int t_end = min(ntiles, t_begin + tiles_per_slice);
-  const float hl = (0.5f / bsq_[b]) * MS_LOG2E;
+  const float bsqv = bsq_[b];
+  const float hl = (0.5f / bsqv) * MS_LOG2E;
   const size_t bN = (size_t)b * N;
   const size_t boff = (size_t)b * ntiles * X3_IMG_U4;
   const u32x4* __restrict__ PAb = PA + boff;
   const u32x4* __restrict__ PBb = PASS == 2 ? PB + boff : nullptr;
-  const u32x4* __restrict__ CAb = CA + boff;
-  const u32x4* __restrict__ CBb = PASS == 2 ? CB + boff : nullptr;
 
   // resident operand(s) as B operands of the first GEMM: k-step s = channels 16 s + 8 h + e
   const int ires = min(i0 + col, N - 1);
@@ -255,10 +237,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
   for (int mt = t_begin; mt < t_end; ++mt) {
     const int j0 = mt * 32;
     MS_T(U0);
-    __syncthreads();  // P(mt) landed; every wave is done with the C images of tile mt - 1
+    __syncthreads();  // image(s) of tile mt landed; every wave is done with tile mt - 1
     MS_T(U1);
-    X3_STAGE(CAb + (size_t)mt * X3_IMG_U4, ldsC[0]);
-    if (PASS == 2) X3_STAGE(CBb + (size_t)mt * X3_IMG_U4, ldsC[NIMG - 1]);
     if (mt + 1 < t_end) X3_STAGE_P(mt + 1, cur ^ 1);
     MS_T(U2);
     u32x4 wh[2], wm[2], wl[2];                                   // weights of the second GEMM
@@ -282,7 +262,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       }
       const u32x4* __restrict__ lp = ldsP[cur][0];
       const u32x4* __restrict__ lp1 = ldsP[cur][NIMG - 1];
-      const int rowoff = col * 16, sw = col & 15;
+      const int rowoff = col * 16, sw = x3_swz(col);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const int slot = rowoff + ((2 * s + h) ^ sw);
@@ -330,16 +310,11 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
 #ifdef MS_TIMING
       tg1 += U3 - U2;
 #endif
-    }
-    MS_T(U4);
-    __syncthreads();  // C(mt) landed (issued before the first GEMM: the wait is short)
-    MS_T(U5);
+      MS_T(U5);
 #ifdef MS_TIMING
-    tb0 += U1 - U0;
-    tdma += U2 - U1;
-    tb1 += U5 - U4;
+      tb0 += U1 - U0;
+      tdma += U2 - U1;
 #endif
-    if (wave_on) {
       // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col], software
       // pipelined with the second GEMM: k-step 0 of that GEMM only needs D registers 0..7, so
       // the values 8..15 are processed between its MFMAs (bf16 MFMAs and VALU work overlap) ----
@@ -360,6 +335,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       const float tv = ta[R];                                                      \
       const float cc = PASS == 1 ? c_res : lds_sc[cur][row];                       \
       const float aa = PASS == 1 ? a_res : lds_sc[cur][32 + row];                  \
+      if (PASS == 2) kv[R] = k * (aa * bsqv); /* weight of the GU term: K / r_i */ \
       float g = k * ((tv - cc) * aa);                                              \
       asm("" : "+v"(g));          /* keep the select a v_cndmask, not a branch */  \
       gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                               \
@@ -397,21 +373,30 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       // ---- second GEMM: out[f][resident] += sum_streamed C[f][streamed] w[streamed][resident];
       //      k-step t = D registers 8t..8t+7 of the first GEMM.  Operands of the next (t, fb)
       //      are fetched from LDS before the MFMAs of the current one. ----
-      const u32x4* __restrict__ lc = ldsC[0];
-      const u32x4* __restrict__ lc1 = ldsC[NIMG - 1];
+      // A operand of k-step t, feature block fb, piece p: two transpose reads (4 points each) of
+      // rows 16t + 4h + (0..3) and + 8, columns fb*32 + (lane & 31); lane i of a 16-lane group
+      // points at row (i >> 2), columns 4 (i & 3).. of its block
+      const char* lbase = reinterpret_cast<const char*>(ldsP[cur][0]);
+      const char* lbase1 = reinterpret_cast<const char*>(ldsP[cur][NIMG - 1]);
+      const int li = lane & 15, rb = 4 * h + (li >> 2), cb = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+      const int sz0 = (((li >> 2) & 3) << 2) | (h & 3), sz1 = (((li >> 2) & 3) << 2) | ((h + 2) & 3);
       u32x4 xc[3], oc[PASS == 2 ? 3 : 1], xn[3], on[PASS == 2 ? 3 : 1];
-#define X3_LOAD_C(DX, DO, T, FB)                                            \
-  {                                                                         \
-    const int f_ = (FB) * 32 + col;                                         \
-    const int slot_ = f_ * 4 + ((2 * (T) + h) ^ ((f_ >> 2) & 3));           \
-    DX[0] = lc[slot_];                                                      \
-    DX[1] = lc[X3_PIECE_U4 + slot_];                                        \
-    DX[2] = lc[2 * X3_PIECE_U4 + slot_];                                    \
-    if (PASS == 2) {                                                        \
-      DO[0] = lc1[slot_];                                                   \
-      DO[PASS == 2 ? 1 : 0] = lc1[X3_PIECE_U4 + slot_];                     \
-      DO[PASS == 2 ? 2 : 0] = lc1[2 * X3_PIECE_U4 + slot_];                 \
-    }                                                                       \
+#define X3_TR(BASE, P_, T, W, FB)                                                               \
+  __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_lds_s16x4)(                                        \
+      (BASE) + (P_) * (X3_PIECE_U4 * 16) + (16 * (T) + 8 * (W) + rb) * 256 +                    \
+      ((((FB) * 4 + (cb >> 3)) ^ ((W) ? sz1 : sz0)) << 4) + ((cb & 7) << 1)))
+#define X3_LOAD_C(DX, DO, T, FB)                                                                \
+  {                                                                                             \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                          \
+      const s16x4 lo_ = X3_TR(lbase, p_, T, 0, FB), hi_ = X3_TR(lbase, p_, T, 1, FB);           \
+      const s16x8 v_ = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);               \
+      DX[p_] = __builtin_bit_cast(u32x4, v_);                                                   \
+      if (PASS == 2) {                                                                          \
+        const s16x4 lo1_ = X3_TR(lbase1, p_, T, 0, FB), hi1_ = X3_TR(lbase1, p_, T, 1, FB);     \
+        const s16x8 w_ = __builtin_shufflevector(lo1_, hi1_, 0, 1, 2, 3, 4, 5, 6, 7);           \
+        DO[PASS == 2 ? p_ : 0] = __builtin_bit_cast(u32x4, w_);                                 \
+      }                                                                                         \
+    }                                                                                           \
   }
       if (PREFETCH) X3_LOAD_C(xc, oc, 0, 0);
 #pragma unroll
@@ -468,6 +453,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
         }
       }
 #undef X3_LOAD_C
+#undef X3_TR
 #undef X3_SPLIT_W
 #undef X3_EW
     }
@@ -511,14 +497,13 @@ extern "C" size_t pn_meanshift_x3_image_bytes(int B, int N) {
   return (size_t)B * (Np / 32) * X3_IMG_U4 * 16;
 }
 
-// x (B,N,D) -> the two tile-image arrays (each pn_meanshift_x3_image_bytes(B,N) bytes)
-extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, void* pimg, void* cimg,
-                                         void* stream) {
-  PN_CHECK_ARG(x && pimg && cimg && B > 0 && N > 0, "pn_meanshift_x3_split_f32: bad arguments");
+// x (B,N,D) -> its tile-image array (pn_meanshift_x3_image_bytes(B,N) bytes)
+extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, void* img, void* stream) {
+  PN_CHECK_ARG(x && img && B > 0 && N > 0, "pn_meanshift_x3_split_f32: bad arguments");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   const int ntiles = (int)pn_align_up(N, 64) / 32;
   hipLaunchKernelGGL(pn_ms3_split_kernel, dim3(ntiles, B), dim3(256), 0, (hipStream_t)stream, x, N, ntiles,
-                     (u32x4*)pimg, (u32x4*)cimg);
+                     (u32x4*)img);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -562,13 +547,12 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
 }
 
 // One forward iteration on the bf16 x 3 path: same contract as pn_meanshift_iter_fwd_f32 with the
-// images of x (pn_meanshift_x3_split_f32) in place of x / xt.
-extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* pimg, const void* cimg,
-                                            const float* bsq, int B, int N, int D, float* opart,
-                                            float* rpart, float* y, float* rsum, float* unorm,
-                                            void* stream_) {
+// tile images of x (pn_meanshift_x3_split_f32) in place of x / xt.
+extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, const float* bsq, int B,
+                                            int N, int D, float* opart, float* rpart, float* y,
+                                            float* rsum, float* unorm, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(q && pimg && cimg && bsq && opart && rpart && y && rsum && unorm,
+  PN_CHECK_ARG(q && img_x && bsq && opart && rpart && y && rsum && unorm,
                "pn_meanshift_x3_iter_fwd_f32: null pointer");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   PN_CHECK_ARG(B > 0 && N > 0, "pn_meanshift_x3_iter_fwd_f32: empty input");
@@ -583,9 +567,8 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* pimg, co
   dim3 grid(S, pn_cdiv(N, 256), B);
   {
     PN_PROF("meanshift_fwd", stream);
-    hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)pimg,
-                       nullptr, (const u32x4*)cimg, nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart,
-                       rpart);
+    hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)img_x,
+                       nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart, rpart);
   }
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart,
@@ -595,18 +578,18 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* pimg, co
 }
 
 // Backward of one iteration on the bf16 x 3 path: same contract as pn_meanshift_iter_bwd_f32 with
-// the images of x in place of (x, xt), and four scratch image arrays (each
-// pn_meanshift_x3_image_bytes(B,N) bytes) for the images of q, gu and go in place of (qt, gut).
+// the tile images of x in place of xt and two scratch image arrays (images of q and gu, each
+// pn_meanshift_x3_image_bytes(B,N) bytes) in place of (qt, gut).  x itself is still read as the
+// resident operand of the column pass; go is not needed (the column pass folds 1/r into K).
 extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q,
-                                            const void* pimg_x, const void* cimg_x, const float* rsum,
+                                            const float* x, const void* img_x, const float* rsum,
                                             const float* unorm, const float* bsq, int B, int N, int D,
-                                            float* gu, float* go, float* cs, void* pimg_q,
-                                            void* cimg_q, void* pimg_gu, void* cimg_go, float* opart_q,
-                                            float* opart_x, float* gq, float* gx, const float* x,
+                                            float* gu, float* cs, void* img_q, void* img_gu,
+                                            float* opart_q, float* opart_x, float* gq, float* gx,
                                             void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(gy && y && q && pimg_x && cimg_x && rsum && unorm && bsq && gu && go && cs && pimg_q &&
-                   cimg_q && pimg_gu && cimg_go && opart_q && opart_x && gq && gx && x,
+  PN_CHECK_ARG(gy && y && q && x && img_x && rsum && unorm && bsq && gu && cs && img_q && img_gu &&
+                   opart_q && opart_x && gq && gx,
                "pn_meanshift_x3_iter_bwd_f32: null pointer");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   const int ntiles = (int)pn_align_up(N, 64) / 32;
@@ -624,30 +607,27 @@ extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, con
   }
   float* alpha = cs + (size_t)B * N;
   hipLaunchKernelGGL(pn_ms3_prep_bwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, gy, y, rsum,
-                     unorm, bsq, N, gu, go, cs, alpha);
+                     unorm, bsq, N, gu, cs, alpha);
   PN_CHECK_LAUNCH();
   dim3 sgrid(ntiles, B);
-  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, q, N, ntiles, (u32x4*)pimg_q,
-                     (u32x4*)cimg_q);
+  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, q, N, ntiles, (u32x4*)img_q);
   hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, (const float*)gu, N, ntiles,
-                     (u32x4*)pimg_gu, (u32x4*)nullptr);
-  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, (const float*)go, N, ntiles,
-                     (u32x4*)nullptr, (u32x4*)cimg_go);
+                     (u32x4*)img_gu);
   PN_CHECK_LAUNCH();
-  dim3 grid(S, pn_cdiv(N, 128), B);
   {
     PN_PROF("meanshift_bwd_rows", stream);
-    hipLaunchKernelGGL(pn_ms3_kernel<1>, grid, dim3(256), 0, stream, q, (const float*)gu,
-                       (const u32x4*)pimg_x, nullptr, (const u32x4*)cimg_x, nullptr, (const float*)cs,
-                       (const float*)alpha, bsq, N, ntiles, tps, opart_q, nullptr);
+    dim3 grid(S, pn_cdiv(N, 32 * X3_WAVES(1)), B);
+    hipLaunchKernelGGL(pn_ms3_kernel<1>, grid, dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
+                       (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N,
+                       ntiles, tps, opart_q, nullptr);
   }
   PN_CHECK_LAUNCH();
   {
     PN_PROF("meanshift_bwd_cols", stream);
     dim3 grid2(S2, pn_cdiv(N, 32 * X3_WAVES(2)), B);
-    hipLaunchKernelGGL(pn_ms3_kernel<2>, grid2, dim3(64 * X3_WAVES(2)), 0, stream, x, nullptr, (const u32x4*)pimg_q,
-                       (const u32x4*)pimg_gu, (const u32x4*)cimg_q, (const u32x4*)cimg_go,
-                       (const float*)cs, (const float*)alpha, bsq, N, ntiles, tps2, opart_x, nullptr);
+    hipLaunchKernelGGL(pn_ms3_kernel<2>, grid2, dim3(64 * X3_WAVES(2)), 0, stream, x, nullptr,
+                       (const u32x4*)img_q, (const u32x4*)img_gu, (const float*)cs,
+                       (const float*)alpha, bsq, N, ntiles, tps2, opart_x, nullptr);
   }
   PN_CHECK_LAUNCH();
   const long long ND4 = (long long)N * MS_D / 4;

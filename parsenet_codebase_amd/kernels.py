@@ -277,34 +277,32 @@ def meanshift_pack(x):
 
 
 def meanshift_x3_split(x):
-    """x (B,N,128) -> (pimg, cimg): pre-split bf16 x 3 tile images for the matrix-core path."""
+    """x (B,N,128) -> pre-split bf16 x 3 tile images for the matrix-core path."""
     require_cuda(x)
     x = _f32c(x, "x")
     B, N, D = x.shape
     lib = _lib.load()
-    nbytes = lib.pn_meanshift_x3_image_bytes(B, N)
-    pimg = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    cimg = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    img = torch.empty(lib.pn_meanshift_x3_image_bytes(B, N), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.pn_meanshift_x3_split_f32(ptr(x), B, N, D, ptr(pimg), ptr(cimg), current_stream(x.device))
+        rc = lib.pn_meanshift_x3_split_f32(ptr(x), B, N, D, ptr(img), current_stream(x.device))
     check(rc, "pn_meanshift_x3_split_f32")
-    return pimg, cimg
+    return img
 
 
-def meanshift_x3_iter_fwd(q, x_images, bsq, ws):
+def meanshift_x3_iter_fwd(q, x_image, bsq, ws):
     B, N, D = q.shape
     y = torch.empty_like(q)
     rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
     unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
-        rc = _lib.load().pn_meanshift_x3_iter_fwd_f32(ptr(q), ptr(x_images[0]), ptr(x_images[1]), ptr(bsq), B, N, D,
-                                                      ptr(ws.opart), ptr(ws.rpart), ptr(y), ptr(rsum),
-                                                      ptr(unorm), current_stream(q.device))
+        rc = _lib.load().pn_meanshift_x3_iter_fwd_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
+                                                      ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
+                                                      current_stream(q.device))
     check(rc, "pn_meanshift_x3_iter_fwd_f32")
     return y, rsum, unorm
 
 
-def meanshift_x3_iter_bwd(gy, y, q, x, x_images, rsum, unorm, bsq, ws, gx):
+def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx):
     """bf16 x 3 counterpart of meanshift_iter_bwd: returns dL/dq, adds into ``gx``."""
     B, N, D = x.shape
     gy = _f32c(gy, "gy")
@@ -312,13 +310,12 @@ def meanshift_x3_iter_bwd(gy, y, q, x, x_images, rsum, unorm, bsq, ws, gx):
     lib = _lib.load()
     if getattr(ws, "x3_imgs", None) is None:
         nbytes = lib.pn_meanshift_x3_image_bytes(B, N)
-        ws.x3_imgs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(4)]
+        ws.x3_imgs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(2)]
     im = ws.x3_imgs
     with torch.cuda.device(x.device):
-        rc = lib.pn_meanshift_x3_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x_images[0]), ptr(x_images[1]),
-                                              ptr(rsum), ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.go),
-                                              ptr(ws.cs), ptr(im[0]), ptr(im[1]), ptr(im[2]), ptr(im[3]),
-                                              ptr(ws.opart), ptr(ws.opart_x), ptr(gq), ptr(gx), ptr(x),
+        rc = lib.pn_meanshift_x3_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(x_image), ptr(rsum),
+                                              ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.cs), ptr(im[0]),
+                                              ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq), ptr(gx),
                                               current_stream(x.device))
     check(rc, "pn_meanshift_x3_iter_bwd_f32")
     return gq
