@@ -247,7 +247,7 @@ class MeanShiftWorkspace:
     """Scratch buffers of the mean-shift kernels for one (B,N,D) problem, allocated once per
     mean_shift call and reused by every iteration."""
 
-    def __init__(self, B, N, D, device, backward=False):
+    def __init__(self, B, N, D, device, backward=False, exact_f32=True):
         lib = _lib.load()
         self.B, self.N, self.D = B, N, D
         self.Np = (N + 63) // 64 * 64
@@ -257,11 +257,12 @@ class MeanShiftWorkspace:
         self.rpart = torch.empty((B, self.S, N), **f)
         if backward:
             self.gu = torch.empty((B, N, D), **f)
-            self.go = torch.empty((B, N, D), **f)
             self.cs = torch.empty((B, 2, N), **f)
-            self.qt = torch.empty((B, D, self.Np), **f)
-            self.gut = torch.empty((B, D, self.Np), **f)
             self.opart_x = torch.empty((B, self.S, N, D), **f)
+            if exact_f32:   # the bf16 x 3 path needs neither go nor the channel-first copies
+                self.go = torch.empty((B, N, D), **f)
+                self.qt = torch.empty((B, D, self.Np), **f)
+                self.gut = torch.empty((B, D, self.Np), **f)
 
 
 def meanshift_pack(x):

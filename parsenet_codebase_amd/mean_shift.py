@@ -24,11 +24,12 @@ class _MeanShiftIterations(torch.autograd.Function):
     def forward(ctx, X, bsq, iterations):
         x = X.contiguous()
         B, N, D = x.shape
-        xt = K.meanshift_pack(x)
+        x3 = K.meanshift_x3_split(x) if (ARITH == "bf16x3" and iterations > 0) else None
+        # streamed copy of X: pre-split tile images (bf16 x 3) or channel-first fp32 (exact path)
+        xt = x3 if x3 is not None else K.meanshift_pack(x)
         ws = K.MeanShiftWorkspace(B, N, D, x.device)
         iterates, rsums, norms = [x], [], []
         q = x
-        x3 = K.meanshift_x3_split(x) if (ARITH == "bf16x3" and iterations > 0) else None
         for _ in range(iterations):
             if x3 is not None:
                 q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws)
@@ -52,7 +53,7 @@ class _MeanShiftIterations(torch.autograd.Function):
         norms = saved[3 + 2 * T:3 + 3 * T]
         x = iterates[0]
         B, N, D = x.shape
-        ws = K.MeanShiftWorkspace(B, N, D, x.device, backward=True)
+        ws = K.MeanShiftWorkspace(B, N, D, x.device, backward=True, exact_f32=ctx.x3 is None)
         gX = torch.zeros_like(x)
         g = gy.contiguous()
         for it in reversed(range(T)):
