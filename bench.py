@@ -269,7 +269,8 @@ def main():
     if rank == 0:
         shapes = step.shapes_per_step() * world * args.steps
         out = {
-            "metric": "shapes/sec fwd+bwd on 10k-pt clouds",
+            "metric": ("shapes/sec fwd+bwd on 10k-pt clouds" if args.workload in ("cfg4", "cfg5")
+                       else "shapes/sec fwd+bwd on 700-pt spline patches"),
             "value": shapes / elapsed,
             "unit": "shapes/s",
             "n_gpus": world,
