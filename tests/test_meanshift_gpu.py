@@ -130,6 +130,31 @@ def test_bf16x3_backward_is_fp32_grade(gpu):
     assert errs["bf16x3"] <= 2.0 * errs["f32"] + 1e-6, errs
 
 
+def test_full_size_consistency_of_the_two_arithmetics(gpu):
+    """N = 10 000 (the BASELINE size; the CPU oracle would need minutes and 3 x 400 MB per
+    iteration): the bf16 x 3 kernels and the exact-fp32 kernels are independent implementations
+    of the same iteration — they must agree on the iterates and on the gradient, rows must stay
+    unit vectors, and the gradient must be tangent to the sphere where the input is."""
+    import parsenet_codebase_amd.mean_shift as MS
+    X, _ = _clustered(10000, 9, 21)
+    w = torch.randn(10000, 128, generator=torch.Generator().manual_seed(2))
+    res = {}
+    saved = MS.ARITH
+    try:
+        for mode in ("f32", "bf16x3"):
+            MS.ARITH = mode
+            xg = X.to(gpu).requires_grad_(True)
+            y = MS.mean_shift_iterations(xg, 0.3, 10)
+            (y * w.to(gpu)).sum().backward()
+            res[mode] = (y.detach(), xg.grad.detach())
+    finally:
+        MS.ARITH = saved
+    (y0, g0), (y1, g1) = res["f32"], res["bf16x3"]
+    assert _rel(y1, y0) < 1e-5
+    assert _rel(g1, g0) < 1e-4
+    assert float((y1.norm(dim=1) - 1).abs().max()) < 1e-5
+
+
 def _canonical(labels):
     """Relabel by order of first occurrence: equal iff the partitions are equal."""
     labels = np.asarray(labels)
