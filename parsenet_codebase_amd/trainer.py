@@ -46,6 +46,7 @@ class TrainConfig:
     mode: int = 5
     lr: float = 1e-2
     patience: int = 4
+    dataset: str = ""                  # directory with {train,val,test}_data.npz|.h5 ("" = synthetic)
     out_dir: str = "logs/trained_models"
     max_steps_per_epoch: int = 0       # 0 = derive from num_train like the reference
 
@@ -99,6 +100,33 @@ class SyntheticSegments:
         return self._gen(self.num_train, self.num_val)
 
 
+def open_dataset(cfg, batch_size, rank=0, if_normal_noise=True, augment=False):
+    """The trainers' data source: the reference's schema from ``cfg.dataset`` (data.Dataset, with
+    the generator flags of the reference's scripts) or synthetic shapes."""
+    if not cfg.dataset:
+        return SyntheticSegments(batch_size, cfg.num_train, cfg.num_val, cfg.num_points,
+                                 first_shape=rank * (cfg.num_train + cfg.num_val))
+    from .data import Dataset
+
+    def path(split):
+        for ext in (".npz", ".h5"):
+            f = os.path.join(cfg.dataset, split + "_data" + ext)
+            if os.path.exists(f):
+                return f
+        raise FileNotFoundError("no %s_data.npz / .h5 under %s" % (split, cfg.dataset))
+    ds = Dataset(batch_size, train=path("train"), val=path("val"), train_size=cfg.num_train, val_size=cfg.num_val,
+                 normals=True, primitives=True)
+
+    class _Wrapped:     # bind the flags the reference's scripts pass (train_parsenet.py:104-107)
+        def get_train(self, **_):
+            return ds.get_train(randomize=True, augment=augment, align_canonical=True, anisotropic=False,
+                                if_normal_noise=if_normal_noise)
+
+        def get_val(self, **_):
+            return ds.get_val(align_canonical=True, anisotropic=False, if_normal_noise=if_normal_noise)
+    return _Wrapped()
+
+
 class ReduceLROnPlateau:
     """mode "min", relative threshold 1e-4 — the arithmetic of torch's scheduler of that name
     (the reference constructs it with factor 0.5, patience 4 / 10, min_lr 1e-4 / 3e-5)."""
@@ -148,7 +176,8 @@ def _subsample(arrays, keep, total):
 
 
 def _to_device(points, normals, primitives, device):
-    return (torch.from_numpy(points).to(device), torch.from_numpy(normals).to(device),
+    from ._lib import h2d
+    return (h2d(points.astype(np.float32, copy=False), device), h2d(normals.astype(np.float32, copy=False), device),
             torch.from_numpy(primitives.astype(np.int64)).to(device))
 
 
@@ -176,8 +205,7 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000):
     bucket = dp.FlatGradBucket(model.parameters())
     optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
     scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=4, min_lr=1e-4)
-    data = data or SyntheticSegments(cfg.batch_size, cfg.num_train, cfg.num_val, cfg.num_points,
-                                     first_shape=rank * (cfg.num_train + cfg.num_val))
+    data = data or open_dataset(cfg, cfg.batch_size, rank, augment=True)
     train_it, val_it = data.get_train(), data.get_val()
     name = cfg.model_path.format(cfg.mode)
     prev_test_loss, history = 1e4, []
@@ -255,8 +283,7 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
     if evaluation is None:   # no pretrained SplineNets ship with the reference: frozen random init
         evaluation = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1).to(device),
                                 open_path=DGCNNControlPoints(20, num_points=10, mode=0).to(device))
-    data = data or SyntheticSegments(1, cfg.num_train, cfg.num_val, cfg.num_points,
-                                     first_shape=rank * (cfg.num_train + cfg.num_val))
+    data = data or open_dataset(cfg, 1, rank, augment=False)
     train_it, val_it = data.get_train(), data.get_val()
     name = cfg.model_path.format(cfg.mode)
     prev_test_loss, history = 1e4, []

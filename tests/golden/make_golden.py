@@ -394,6 +394,53 @@ def main():
             arrays["recon_%d" % k] = params_e[k][1].detach().numpy().astype(np.float32)
     save("e2e_eval", **arrays)
 
+    # ---- data layer: the reference's generators and augmentation on synthetic arrays --------------
+    # dataset_segments.Dataset reads data/shapes/*.h5 through h5py (absent): a stand-in File object
+    # hands it the arrays below; everything recorded is the reference's own numpy arithmetic.
+    M, NP = 6, 400
+    shp = [synthetic.make_shape(40 + i, NP, min_segments=3, max_segments=4) for i in range(M)]
+    rngd = np.random.RandomState(9)
+    raw = {"points": np.stack([s_[0] for s_ in shp]) * 2.0 + rngd.uniform(-1, 1, (M, 1, 3)).astype(np.float32),
+           "normals": np.stack([s_[1] for s_ in shp]), "labels": np.stack([s_[2] for s_ in shp]),
+           "prim": np.stack([s_[3] for s_ in shp])}
+
+    class _File:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def get(self, key):
+            return raw[key].copy()
+    import src.dataset_segments as ref_ds
+    ref_ds.h5py = types.SimpleNamespace(File=_File)
+    out = {"raw_" + k: v for k, v in raw.items()}
+    ds = ref_ds.Dataset(2, M, M, M, normals=True, primitives=True)
+    np.random.seed(21)
+    gen = ds.get_train(randomize=True, augment=True, align_canonical=True, anisotropic=False, if_normal_noise=True)
+    for i in range(4):
+        pts_, lab_, nrm_, prm_ = next(gen)
+        out.update({"train%d_points" % i: np.array(pts_), "train%d_labels" % i: np.array(lab_),
+                    "train%d_normals" % i: np.array(nrm_), "train%d_prim" % i: np.array(prm_)})
+    ds = ref_ds.Dataset(3, M, M, M, normals=True, primitives=True)
+    np.random.seed(22)
+    gen = ds.get_val(align_canonical=True, anisotropic=True, if_normal_noise=True)
+    pts_, lab_, nrm_, prm_ = next(gen)
+    out.update(val_points=np.array(pts_), val_labels=np.array(lab_), val_normals=np.array(nrm_), val_prim=np.array(prm_))
+    np.random.seed(23)
+    pn_, nn_ = ds.normalize_points(raw["points"][1].copy(), raw["normals"][1].copy())
+    out.update(norm_points=pn_, norm_normals=nn_)
+    import src.augment_utils as ref_aug
+    np.random.seed(24)
+    out["aug_all"] = ref_aug.Augment().augment(raw["points"][:3].copy())
+    np.random.seed(25)
+    out["aug_rot"] = ref_aug.rotate_point_cloud(raw["points"][:2].copy())
+    save("data_layer", **out)
+
 
 if __name__ == "__main__":
     main()

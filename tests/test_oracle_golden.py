@@ -198,3 +198,38 @@ def test_end_to_end_fitting_loss_eval_mode():
     assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 1e-4
     assert abs(loss[1] - float(g["geo"])) / float(g["geo"]) < 1e-4
     assert abs(loss[2] - float(g["spline"])) / float(g["spline"]) < 1e-4
+
+
+def test_data_layer_matches_the_reference_generators(tmp_path):
+    """parsenet_codebase_amd.data (host logic) against batches produced by the
+    reference's dataset_segments.Dataset / augment_utils on the same arrays and numpy seed:
+    identical numpy arithmetic and RNG order -> equal to the last bit."""
+    from parsenet_codebase_amd import data as D
+    g = load("data_layer")
+    raw = {k: g["raw_" + k] for k in ("points", "normals", "labels", "prim")}
+    M = raw["points"].shape[0]
+    npz = tmp_path / "split.npz"
+    np.savez(npz, **raw)
+    ds = D.Dataset(2, train=str(npz), val=dict(raw), test=dict(raw), train_size=M, val_size=M, test_size=M,
+                   normals=True, primitives=True)
+    np.random.seed(21)
+    gen = ds.get_train(randomize=True, augment=True, align_canonical=True, anisotropic=False, if_normal_noise=True)
+    for i in range(4):
+        pts, lab, nrm, prm = next(gen)
+        assert np.array_equal(pts, g["train%d_points" % i]), i
+        assert np.array_equal(nrm, g["train%d_normals" % i]), i
+        assert np.array_equal(lab, g["train%d_labels" % i]) and np.array_equal(prm, g["train%d_prim" % i])
+    ds = D.Dataset(3, val=dict(raw), val_size=M, normals=True, primitives=True)
+    np.random.seed(22)
+    pts, lab, nrm, prm = next(ds.get_val(align_canonical=True, anisotropic=True, if_normal_noise=True))
+    assert np.array_equal(pts, g["val_points"]) and np.array_equal(nrm, g["val_normals"])
+    assert np.array_equal(lab, g["val_labels"]) and np.array_equal(prm, g["val_prim"])
+    np.random.seed(23)
+    pn, nn = D.normalize_points(raw["points"][1].copy(), raw["normals"][1].copy())
+    assert np.array_equal(pn, g["norm_points"]) and np.array_equal(nn, g["norm_normals"])
+    np.random.seed(24)
+    assert np.array_equal(D.Augment().augment(raw["points"][:3].copy()), g["aug_all"])
+    np.random.seed(25)
+    assert np.array_equal(D.rotate_point_cloud(raw["points"][:2].copy()), g["aug_rot"])
+    with pytest.raises(KeyError):
+        D.load_split({"points": raw["points"]})

@@ -53,3 +53,19 @@ def test_train_splinenet(gpu, tmp_path, closed):
     hist = train_splinenet(cfg, closed=closed, device=gpu, log=lambda s: None)
     assert len(hist) == 2 and all(np.isfinite(h["train_cd"]) and np.isfinite(h["test_cd"]) for h in hist)
     assert any(h["saved"] for h in hist)
+
+
+def test_train_parsenet_from_files(gpu, tmp_path):
+    """TrainConfig.dataset: the reference's four-array schema read from {train,val}_data.npz through
+    data.Dataset (shuffle, augmentation, normal noise, canonicalisation as the reference's script)."""
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.trainer import TrainConfig, train_parsenet
+    for split, first in (("train", 0), ("val", 50)):
+        pts, nrm, lab, prim = synthetic.make_batch(first, 4, 1500)
+        np.savez(tmp_path / (split + "_data.npz"), points=pts * 3.0 + 1.0, normals=nrm, labels=lab, prim=prim)
+    np.random.seed(5)
+    torch.manual_seed(5)
+    cfg = TrainConfig(num_train=4, num_val=4, num_test=4, num_points=1500, epochs=1, batch_size=2, lr=1e-3,
+                      out_dir=str(tmp_path / "out"), max_steps_per_epoch=1, dataset=str(tmp_path))
+    hist = train_parsenet(cfg, device=gpu, log=lambda s: None, keep_points=1200)
+    assert len(hist) == 1 and np.isfinite(hist[0]["train_loss"]) and np.isfinite(hist[0]["test_emb"])
