@@ -229,3 +229,104 @@ class Dataset:
     normalize_points = staticmethod(normalize_points)
     rotation_matrix_a_to_b = staticmethod(rotation_matrix_a_to_b)
     pca_numpy = staticmethod(pca_numpy)
+
+
+# ---------------------------------------------------------------------------------------
+# SplineNet patches: src/dataset.py:27-260 (DataSetControlPointsPoisson)
+# ---------------------------------------------------------------------------------------
+class generator_iter:
+    """dataset.py:13-24: lets a torch DataLoader pull from a generator."""
+
+    def __init__(self, generator, train_size):
+        self.generator, self.train_size = generator, train_size
+
+    def __len__(self):
+        return self.train_size
+
+    def __getitem__(self, idx):
+        return next(self.generator)
+
+
+class DataSetControlPointsPoisson:
+    """Points (M,P,3) sampled on spline patches + their control grids (M,u,v,3): shuffled once with
+    numpy seed 0, split by position (open: 50 000 / 10 000 / rest; closed: 28 000 / 3 000 / rest —
+    ``split_at`` overrides the positions for smaller sets), canonicalised per patch on the fly.
+    Generators yield [Points, None, controlpoints, scales, RS] like the reference."""
+
+    def __init__(self, path, batch_size, size_u=20, size_v=20, splits={}, closed=False, split_at=None):
+        self.path, self.batch_size, self.size_u, self.size_v = path, batch_size, size_u, size_v
+        self.train_size, self.val_size, self.test_size = splits["train"], splits["val"], splits["test"]
+        if isinstance(path, dict):
+            arrays = path
+        elif str(path).endswith(".npz"):
+            with np.load(path) as f:
+                arrays = {"points": f["points"], "controlpoints": f["controlpoints"]}
+        else:
+            try:
+                import h5py
+            except ImportError as e:  # pragma: no cover
+                raise ImportError("reading %s needs h5py; convert it to .npz (points, controlpoints)" % path) from e
+            with h5py.File(path, "r") as hf:
+                arrays = {"points": np.array(hf.get(name="points")), "controlpoints": np.array(hf.get(name="controlpoints"))}
+        points = arrays["points"].astype(np.float32)
+        control_points = arrays["controlpoints"].astype(np.float32)
+        np.random.seed(0)
+        order = np.arange(points.shape[0])
+        np.random.shuffle(order)
+        points, control_points = points[order], control_points[order]
+        a, b = split_at if split_at is not None else ((28000, 31000) if closed else (50000, 60000))
+        self.train_points, self.val_points, self.test_points = points[0:a], points[a:b], points[b:]
+        self.train_control_points = control_points[0:a]
+        self.val_control_points, self.test_control_points = control_points[a:b], control_points[b:]
+        self._augment = Augment()
+
+    rotation_matrix_a_to_b = staticmethod(rotation_matrix_a_to_b)
+    pca_numpy = staticmethod(pca_numpy)
+
+    def _batch(self, pts_all, cp_all, batch_id, align_canonical, anisotropic, if_augment, scale_iso=True):
+        Points, controlpoints, scales, RS = [], [], [], []
+        for i in range(self.batch_size):
+            points = pts_all[batch_id * self.batch_size + i]
+            mean = np.mean(points, 0)
+            points = points - mean
+            R = None
+            if align_canonical:
+                S, U = pca_numpy(points)
+                R = rotation_matrix_a_to_b(U[:, np.argmin(S)], np.array([1, 0, 0]))
+                points = (R @ points.T).T
+                RS.append(R)
+            if anisotropic:
+                std = np.abs(np.max(points, 0) - np.min(points, 0)).reshape((1, 3))
+                points = points / (std + EPS)
+            else:
+                std = np.max(np.max(points, 0) - np.min(points, 0))
+                if scale_iso:   # the reference's test loader leaves the points unscaled here
+                    points = points / std
+            scales.append(std)
+            Points.append(points)
+            cp = cp_all[batch_id * self.batch_size + i] - mean.reshape((1, 1, 3))
+            if align_canonical:
+                cp = np.reshape((R @ cp.reshape((self.size_u * self.size_v, 3)).T).T, (self.size_u, self.size_v, 3))
+            cp = cp / (std.reshape((1, 1, 3)) + EPS) if anisotropic else cp / std
+            controlpoints.append(cp)
+        controlpoints, Points = np.stack(controlpoints, 0), np.stack(Points, 0)
+        if if_augment:
+            Points = self._augment.augment(Points).astype(np.float32)
+        return [Points, None, controlpoints, scales, RS]
+
+    def load_train_data(self, if_regular_points=False, align_canonical=False, anisotropic=False, if_augment=False):
+        while True:
+            for batch_id in range(self.train_size // self.batch_size - 1):
+                yield self._batch(self.train_points, self.train_control_points, batch_id, align_canonical,
+                                  anisotropic, if_augment)
+
+    def load_val_data(self, if_regular_points=False, align_canonical=False, anisotropic=False, if_augment=False):
+        while True:
+            for batch_id in range(self.val_size // self.batch_size - 1):
+                yield self._batch(self.val_points, self.val_control_points, batch_id, align_canonical,
+                                  anisotropic, if_augment)
+
+    def load_test_data(self, if_regular_points=False, align_canonical=False, anisotropic=False, if_augment=False):
+        for batch_id in range(self.test_size // self.batch_size):
+            yield self._batch(self.test_points, self.test_control_points, batch_id, align_canonical, anisotropic,
+                              if_augment, scale_iso=False)   # dataset.py:238-239

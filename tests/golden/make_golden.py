@@ -439,6 +439,29 @@ def main():
     out["aug_all"] = ref_aug.Augment().augment(raw["points"][:3].copy())
     np.random.seed(25)
     out["aug_rot"] = ref_aug.rotate_point_cloud(raw["points"][:2].copy())
+    # SplineNet patches (src/dataset.py); the class slices at fixed positions (50 000 / 60 000), so the
+    # stand-in file holds 60 010 tiny patches of 16 points: only the batches drawn below matter
+    import src.dataset as ref_dsp
+    rngp = np.random.RandomState(31)
+    Mp = 60010
+    raw_p = {"points": rngp.uniform(-1, 1, (Mp, 16, 3)).astype(np.float32) * np.array([1.0, 0.6, 0.2], np.float32),
+             "controlpoints": rngp.uniform(-1, 1, (Mp, 3, 3, 3)).astype(np.float32)}
+
+    class _FileP(_File):
+        def get(self, name=None):
+            return raw_p[name].copy()
+    ref_dsp.h5py = types.SimpleNamespace(File=_FileP)
+    dsp = ref_dsp.DataSetControlPointsPoisson("x.h5", 2, size_u=3, size_v=3, splits={"train": 8, "val": 6, "test": 4})
+    np.random.seed(32)
+    b0 = next(dsp.load_train_data(align_canonical=True, anisotropic=True, if_augment=True))
+    np.random.seed(33)
+    b1 = next(dsp.load_val_data(align_canonical=True, anisotropic=False))
+    b2 = next(dsp.load_test_data(align_canonical=False, anisotropic=False))
+    sel = np.random.RandomState(0)  # the class reseeds numpy with 0 and shuffles: keep the rows it used
+    out.update(sp_seed=np.int32(31), sp_count=np.int32(Mp),
+               sp_train_points=b0[0], sp_train_cp=b0[2], sp_train_scales=np.stack(b0[3]), sp_train_RS=np.stack(b0[4]),
+               sp_val_points=b1[0], sp_val_cp=b1[2], sp_val_scales=np.array(b1[3]), sp_val_RS=np.stack(b1[4]),
+               sp_test_points=b2[0], sp_test_cp=b2[2], sp_test_scales=np.array(b2[3]))
     save("data_layer", **out)
 
 

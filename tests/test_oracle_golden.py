@@ -233,3 +233,27 @@ def test_data_layer_matches_the_reference_generators(tmp_path):
     assert np.array_equal(D.rotate_point_cloud(raw["points"][:2].copy()), g["aug_rot"])
     with pytest.raises(KeyError):
         D.load_split({"points": raw["points"]})
+
+
+def test_spline_patch_dataset_matches_the_reference():
+    """data.DataSetControlPointsPoisson against batches of the reference's class (src/dataset.py) on
+    the same stand-in arrays (regenerated here from the recorded seed) and numpy seeds."""
+    from parsenet_codebase_amd import data as D
+    g = load("data_layer")
+    rngp = np.random.RandomState(int(g["sp_seed"]))
+    Mp = int(g["sp_count"])
+    raw = {"points": rngp.uniform(-1, 1, (Mp, 16, 3)).astype(np.float32) * np.array([1.0, 0.6, 0.2], np.float32),
+           "controlpoints": rngp.uniform(-1, 1, (Mp, 3, 3, 3)).astype(np.float32)}
+    ds = D.DataSetControlPointsPoisson(raw, 2, size_u=3, size_v=3, splits={"train": 8, "val": 6, "test": 4})
+    np.random.seed(32)
+    b0 = next(ds.load_train_data(align_canonical=True, anisotropic=True, if_augment=True))
+    np.random.seed(33)
+    b1 = next(ds.load_val_data(align_canonical=True, anisotropic=False))
+    b2 = next(ds.load_test_data(align_canonical=False, anisotropic=False))
+    assert b0[1] is None
+    assert np.array_equal(b0[0], g["sp_train_points"]) and np.array_equal(b0[2], g["sp_train_cp"])
+    assert np.array_equal(np.stack(b0[3]), g["sp_train_scales"]) and np.array_equal(np.stack(b0[4]), g["sp_train_RS"])
+    assert np.array_equal(b1[0], g["sp_val_points"]) and np.array_equal(b1[2], g["sp_val_cp"])
+    assert np.array_equal(np.array(b1[3]), g["sp_val_scales"]) and np.array_equal(np.stack(b1[4]), g["sp_val_RS"])
+    assert np.array_equal(b2[0], g["sp_test_points"]) and np.array_equal(b2[2], g["sp_test_cp"])
+    assert np.array_equal(np.array(b2[3]), g["sp_test_scales"]) and b2[4] == []
