@@ -404,17 +404,36 @@ def train_splinenet(cfg, closed=False, device=None, log=print):
     prev, history = 1e8, []
     shape_id = 0
 
-    def load(first):
-        pts, ctrl = synthetic.make_spline_patches(rank * 100000 + first, B, 2000, 20, closed)
-        return (torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1))).to(device),
-                torch.from_numpy(ctrl).to(device))
+    files = None
+    if cfg.dataset:   # the reference's patch files (points, controlpoints), anisotropic canonicalisation
+        from .data import DataSetControlPointsPoisson
+        fn = None
+        for ext in (".npz", ".h5"):
+            cand = os.path.join(cfg.dataset, ("closed_splines" if closed else "open_splines") + ext)
+            fn = cand if os.path.exists(cand) else fn
+        if fn is None:
+            raise FileNotFoundError("no %s_splines.npz / .h5 under %s" % ("closed" if closed else "open", cfg.dataset))
+        ds = DataSetControlPointsPoisson(fn, B, splits={"train": cfg.num_train, "val": cfg.num_val,
+                                                        "test": cfg.num_test}, closed=closed,
+                                         split_at=getattr(cfg, "split_at", None))
+        files = (ds.load_train_data(anisotropic=True, align_canonical=True, if_augment=True),
+                 ds.load_val_data(anisotropic=True, align_canonical=True, if_augment=False))
+
+    def load(first, val=False):
+        if files is not None:
+            pts, _, ctrl, scales, _ = next(files[1 if val else 0])
+            step.scales = scales
+        else:
+            pts, ctrl = synthetic.make_spline_patches(rank * 100000 + first, B, 2000, 20, closed)
+        return (torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1)).astype(np.float32)).to(device),
+                torch.from_numpy(np.asarray(ctrl, dtype=np.float32)).to(device))
     for e in range(cfg.epochs):
         step.model.train()
         tr = {"cd": [], "reg": [], "lap": []}
         for _ in range(steps):
             points, step.control_points = load(shape_id)
             shape_id += B
-            n = 2000 if closed else int(700 + np.random.choice(np.arange(-300, 1300), 1)[0])
+            n = points.shape[2] if closed else int(700 + np.random.choice(np.arange(-300, 1300), 1)[0])
             step.points = points[:, :, 0:n].contiguous()
             step.step()
             cd, reg, lap = step.last
@@ -424,7 +443,7 @@ def train_splinenet(cfg, closed=False, device=None, log=print):
         step.model.eval()
         te = []
         for v in range(max(cfg.num_test // B, 1)):
-            points, step.control_points = load(10 ** 6 + v * B)
+            points, step.control_points = load(10 ** 6 + v * B, val=True)
             step.points = points[:, :, 0:700].contiguous()
             with torch.no_grad():
                 te.append(step.losses(step.model(step.points))[1].item())

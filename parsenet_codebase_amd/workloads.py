@@ -149,18 +149,28 @@ class SplineNetStep:
         self.control_points = torch.from_numpy(ctrl).to(device)                                  # (B,20,20,3)
         self.cfg = _SplineCfg(batch, 20)
         self.last = None
+        self.scales = None      # per-patch anisotropic scales of a file-backed loader (trainer)
 
     def shapes_per_step(self):
         return self.batch
 
     def losses(self, output):
         from . import spline_losses as SL
-        cd, _ = SL.spline_reconstruction_loss_one_sided(self.nu, self.nv, output, self.points, self.cfg)
+        points, control_points = self.points, self.control_points
+        if self.scales is not None:
+            # anisotropic canonicalisation: back to a common scale before the losses
+            # (train_open_splines.py:156-159, src/utils.py:361-390)
+            sc = torch.from_numpy(np.stack(self.scales, 0).astype(np.float32)).to(output.device).reshape((-1, 1, 3))
+            smax = torch.max(sc.reshape((-1, 3)), 1)[0]
+            output = output * sc / smax.reshape((-1, 1, 1))
+            points = points * sc.reshape((-1, 3, 1)) / smax.reshape((-1, 1, 1))
+            control_points = control_points * sc.reshape((-1, 1, 1, 3)) / smax.reshape((-1, 1, 1, 1))
+        cd, _ = SL.spline_reconstruction_loss_one_sided(self.nu, self.nv, output, points, self.cfg)
         if self.closed:
-            l_reg, _ = SL.control_points_permute_closed_reg_loss(output, self.control_points, 20, 20)
+            l_reg, _ = SL.control_points_permute_closed_reg_loss(output, control_points, 20, 20)
             loss = l_reg * self.loss_weight + cd * (1 - self.loss_weight)
             return loss, cd, l_reg, None
-        l_reg, permute_cp = SL.control_points_permute_reg_loss(output, self.control_points, 20)
+        l_reg, permute_cp = SL.control_points_permute_reg_loss(output, control_points, 20)
         lap = SL.laplacian_loss(output.reshape((self.batch, 20, 20, 3)), permute_cp, dist_type="l2")
         loss = l_reg * self.loss_weight + (cd + lap) * (1 - self.loss_weight)
         return loss, cd, l_reg, lap

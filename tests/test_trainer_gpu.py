@@ -69,3 +69,21 @@ def test_train_parsenet_from_files(gpu, tmp_path):
                       out_dir=str(tmp_path / "out"), max_steps_per_epoch=1, dataset=str(tmp_path))
     hist = train_parsenet(cfg, device=gpu, log=lambda s: None, keep_points=1200)
     assert len(hist) == 1 and np.isfinite(hist[0]["train_loss"]) and np.isfinite(hist[0]["test_emb"])
+
+
+def test_train_splinenet_from_files(gpu, tmp_path):
+    """File-backed SplineNet training: data.DataSetControlPointsPoisson (anisotropic canonicalisation,
+    augmentation) + the rescaling of outputs, points and control grids before the losses."""
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.trainer import TrainConfig, train_splinenet
+    pts, ctrl = synthetic.make_spline_patches(0, 24, 900, 20, closed=False)
+    np.savez(tmp_path / "open_splines.npz", points=pts * np.array([1.0, 0.7, 0.4], np.float32) + 0.3,
+             controlpoints=ctrl * np.array([1.0, 0.7, 0.4], np.float32) + 0.3)
+    cfg = TrainConfig(num_train=12, num_val=8, num_test=4, epochs=1, batch_size=4, lr=1e-3, loss_weight=0.9,
+                      out_dir=str(tmp_path / "out"), max_steps_per_epoch=2, model_path="splinenet_{}",
+                      dataset=str(tmp_path))
+    cfg.split_at = (12, 20)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    hist = train_splinenet(cfg, closed=False, device=gpu, log=lambda s: None)
+    assert len(hist) == 1 and np.isfinite(hist[0]["train_cd"]) and np.isfinite(hist[0]["test_cd"])
