@@ -320,7 +320,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       // the values 8..15 are processed between its MFMAs (bf16 MFMAs and VALU work overlap) ----
       const bool tail = j0 + 32 > N;
       float kv[16], gs[PASS == 0 ? 1 : 16];
-#define X3_EW(R)                                                                   \
+#define X3_EW_(R, MASKED)                                                          \
   {                                                                                \
     const int row = ((R) & 3) + 8 * ((R) >> 2) + 4 * h;                            \
     const float sv = sa[R];                                                        \
@@ -328,7 +328,9 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     const float a2 = -dist * hl;                                                   \
     const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);              \
     float k = __builtin_amdgcn_exp2f(a2c);                                         \
-    if (tail && j0 + row >= N) k = 0.f;                                            \
+    /* padded points have all-zero image rows: they add nothing in the second GEMM whatever \
+       their weight, so only the row sums of the forward pass need the mask */          \
+    if (PASS == 0 && (MASKED) && j0 + row >= N) k = 0.f;                           \
     kv[R] = k;                                                                     \
     if (PASS == 0) rsum += k;                                                      \
     if (PASS != 0) {                                                               \
@@ -341,6 +343,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                               \
     }                                                                              \
   }
+#define X3_EW(R) X3_EW_(R, false)
 #define X3_SPLIT_W(T, Q)                                                                      \
   {                                                                                           \
     if (PASS == 0) {                                                                          \
@@ -358,8 +361,13 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       // matrix pipe during this stage, and the pipelining registers would spill)
       constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
       constexpr bool PREFETCH = PASS == 1;  // operand double buffering (needs 12-24 registers)
+      if (PASS == 0 && tail) {  // only the last tile of the forward pass pays for the mask
 #pragma unroll
-      for (int r = 0; r < (PIPE ? 8 : 16); ++r) X3_EW(r);
+        for (int r = 0; r < 16; ++r) X3_EW_(r, true);
+      } else {
+#pragma unroll
+        for (int r = 0; r < (PIPE ? 8 : 16); ++r) X3_EW(r);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) X3_SPLIT_W(0, q);
       if (!PIPE) {
@@ -456,6 +464,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
 #undef X3_TR
 #undef X3_SPLIT_W
 #undef X3_EW
+#undef X3_EW_
     }
 #ifdef MS_TIMING
     tg2 += __builtin_amdgcn_s_memtime() - U5;
