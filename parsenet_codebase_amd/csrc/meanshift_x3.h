@@ -316,8 +316,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       tdma += U2 - U1;
 #endif
       // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col], software
-      // pipelined with the second GEMM: k-step 0 of that GEMM only needs D registers 0..7, so
-      // the values 8..15 are processed between its MFMAs (bf16 MFMAs and VALU work overlap) ----
+      // in two halves in the backward passes: k-step 0 of the second GEMM only needs D registers
+      // 0..7, so the values 8..15 are processed after it (fewer live registers) ----
       const bool tail = j0 + 32 > N;
       float kv[16], gs[PASS == 0 ? 1 : 16];
 #define X3_EW_(R, MASKED)                                                          \
@@ -360,7 +360,6 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       // (the forward pass runs two waves per SIMD in 256 registers: the other wave fills the
       // matrix pipe during this stage, and the pipelining registers would spill)
       constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
-      constexpr bool PREFETCH = PASS == 1;  // operand double buffering (needs 12-24 registers)
       if (PASS == 0 && tail) {  // only the last tile of the forward pass pays for the mask
 #pragma unroll
         for (int r = 0; r < 16; ++r) X3_EW_(r, true);
@@ -388,7 +387,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       const char* lbase1 = reinterpret_cast<const char*>(ldsP[cur][NIMG - 1]);
       const int li = lane & 15, rb = 4 * h + (li >> 2), cb = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
       const int sz0 = (((li >> 2) & 3) << 2) | (h & 3), sz1 = (((li >> 2) & 3) << 2) | ((h + 2) & 3);
-      u32x4 xc[3], oc[PASS == 2 ? 3 : 1], xn[3], on[PASS == 2 ? 3 : 1];
+      u32x4 xc[3], oc[PASS == 2 ? 3 : 1];
 #define X3_TR(BASE, P_, T, W, FB)                                                               \
   __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_lds_s16x4)(                                        \
       (BASE) + (P_) * (X3_PIECE_U4 * 16) + (16 * (T) + 8 * (W) + rb) * 256 +                    \
@@ -406,12 +405,11 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       }                                                                                         \
     }                                                                                           \
   }
-      if (PREFETCH) X3_LOAD_C(xc, oc, 0, 0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        if (PIPE && !PREFETCH && t == 1) {
-          // 8-wave column pass: second half of the stage between the two k-steps (the other
-          // wave of the SIMD keeps the matrix pipe busy; interleaving would cost registers)
+        if (PIPE && t == 1) {
+          // second half of the stage between the two k-steps (finer interleaving with the MFMAs
+          // was measured: it costs registers and gains nothing)
 #pragma unroll
           for (int r = 8; r < 16; ++r) X3_EW(r);
 #pragma unroll
@@ -420,13 +418,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
         const bf16x8 bh = x3_as_bf16(wh[t]), bm = x3_as_bf16(wm[t]), bl = x3_as_bf16(wl[t]);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
-          if (!PREFETCH) {
-            X3_LOAD_C(xc, oc, t, fb);
-          } else if (fb + 1 < 4) {
-            X3_LOAD_C(xn, on, t, fb + 1);
-          } else if (t == 0) {
-            X3_LOAD_C(xn, on, 1, 0);
-          }
+          X3_LOAD_C(xc, oc, t, fb);
           const bf16x8 xh = x3_as_bf16(xc[0]), xm = x3_as_bf16(xc[1]), xl = x3_as_bf16(xc[2]);
           X3_MFMA(acc_o[fb], xl, bh);
           X3_MFMA(acc_o[fb], xh, bl);
@@ -445,18 +437,6 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
             X3_MFMA(acc_o[fb], om, kh);
             X3_MFMA(acc_o[fb], oh, km);
             X3_MFMA(acc_o[fb], oh, kh);
-          }
-          if (PREFETCH && t == 0) {  // second half of the elementwise stage, two values per block
-            X3_EW(8 + 2 * fb);
-            X3_EW(9 + 2 * fb);
-            X3_SPLIT_W(1, fb);
-          }
-          if (PREFETCH) {
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              xc[u] = xn[u];
-              if (PASS == 2) oc[PASS == 2 ? u : 0] = on[PASS == 2 ? u : 0];
-            }
           }
         }
       }
