@@ -1,10 +1,3 @@
-"""src/guard.py of the reference: clamp-then-exp / clamp-then-sqrt (same numeric guards)."""
-import torch
-
-
-def guard_exp(x, max_value=75, min_value=-75):
-    return torch.exp(torch.clamp(x, max=max_value, min=min_value))
-
-
-def guard_sqrt(x, minimum=1e-5):
-    return torch.sqrt(torch.clamp(x, min=minimum))
+"""src/guard.py of the reference: the clamp-then-exp / clamp-then-sqrt guards, re-exported from
+the module that uses them."""
+from parsenet_codebase_amd.fitting import guard_exp, guard_sqrt  # noqa: F401
