@@ -21,6 +21,8 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
+ABI_VERSION = 2   # pn_abi_version() of the library these signatures describe
+
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
     "pn_abi_version": (c_int, []),
@@ -103,6 +105,10 @@ def load():
             raise HipExtensionError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    if lib.pn_abi_version() != ABI_VERSION:
+        raise HipExtensionError("%s has ABI version %d, this package binds version %d: rebuild it "
+                                "(python -m parsenet_codebase_amd.build)" % (LIB_PATH, lib.pn_abi_version(),
+                                                                              ABI_VERSION))
     _lib = lib
     return lib
 

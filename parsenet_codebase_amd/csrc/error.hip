@@ -13,4 +13,6 @@ void pn_set_error(const char* fmt, ...) {
 
 extern "C" const char* pn_last_error(void) { return g_err; }
 
-extern "C" int pn_abi_version(void) { return 1; }
+// 2: edge-conv backward takes a workspace, mean-shift backward reduces its partial sums itself,
+//    bf16 x 3 mean-shift entry points
+extern "C" int pn_abi_version(void) { return 2; }

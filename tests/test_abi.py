@@ -37,7 +37,7 @@ def test_ctypes_table_matches_header(lib_path):
     from parsenet_codebase_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.pn_abi_version() >= 1
+    assert lib.pn_abi_version() == _lib.ABI_VERSION
 
 
 def test_product_refuses_cpu_tensors(lib_path):
