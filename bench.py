@@ -95,7 +95,9 @@ def kernel_roofline(step, nprof):
         ach = flops / avg_s / 1e12
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                "avg_launch_ms": table[dom]["avg_ms"]}
+                "avg_launch_ms": table[dom]["avg_ms"], "mfma": "v_mfma_f32_32x32x2_f32",
+                # each of the two passes evaluates ALL N^2 distances: what the matrix cores execute
+                "executed_tflops": 2.0 * ach, "executed_peak_tflops": MFMA_F32_PEAK_TFLOPS}
     elif dom.startswith("edgeconv"):
         # fused edge-conv: read x-products (B,N,2Cout) + idx, write (B,N,Cout) x3 small outputs
         Cout = 64
