@@ -217,3 +217,32 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         else:
             embed_loss = torch.zeros(1, device=points.device)
         return embedding, primitives_log_prob, embed_loss
+
+
+class PrimitivesEmbeddingDGCNGne2e(PrimitivesEmbeddingDGCNGn):
+    """src/PointNet.py:292-380: the same network with the fitting loss evaluated inside
+    ``forward`` (no script of the reference instantiates it).  ``self.evaluation`` must be set to
+    an ``Evaluation`` object by the caller, like in the reference; the embedding loss is called
+    as ``loss_function(embedding, points (B,N,C), labels)``.  Same parameters and state_dict keys
+    as PrimitivesEmbeddingDGCNGn."""
+
+    evaluation = None
+
+    def forward(self, points, labels, primitives, quantile, debug, compute_loss=True):
+        loss_function, self.loss_function = self.loss_function, None
+        try:
+            embedding, primitives_log_prob, _ = super().forward(points, labels, compute_loss=False)
+        finally:
+            self.loss_function = loss_function
+        if compute_loss:
+            lab = labels.data.cpu().numpy() if torch.is_tensor(labels) else labels
+            embed_loss = self.loss_function(embedding, points.permute(0, 2, 1), lab)
+        else:
+            embed_loss = torch.zeros(1, device=points.device)
+        if self.evaluation is None:
+            raise RuntimeError("PrimitivesEmbeddingDGCNGne2e: set .evaluation (an Evaluation object) first")
+        normals = points[:, 3:, :].permute(0, 2, 1)
+        res_loss = self.evaluation.fitting_loss(embedding.permute(0, 2, 1), points.permute(0, 2, 1)[:, :, 0:3],
+                                                normals, labels, primitives, primitives_log_prob, quantile=0.025,
+                                                debug=False)
+        return res_loss, embedding, primitives_log_prob, embed_loss

@@ -1,6 +1,7 @@
 """src/PointNet.py of the reference (ParSeNet segmentation network) on the HIP kernels."""
 from parsenet_codebase_amd import graph as _graph
-from parsenet_codebase_amd.encoders import DGCNNEncoderGn, PrimitivesEmbeddingDGCNGn  # noqa: F401
+from parsenet_codebase_amd.encoders import (DGCNNEncoderGn, PrimitivesEmbeddingDGCNGn,  # noqa: F401
+                                            PrimitivesEmbeddingDGCNGne2e)
 
 
 def knn(x, k1, k2):
