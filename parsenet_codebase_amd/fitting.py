@@ -327,6 +327,60 @@ def up_sample_points_in_range(points, weights, a_min, a_max):
     return points[L], weights[L]
 
 
+def up_sample_points_torch_memory_efficient(points, times=1):
+    """src/fitting_utils.py:167-189: centroid of the 5 nearest neighbours INCLUDING the point."""
+    for _ in range(times):
+        idx = _knn_points_by_differences(points, 5)
+        points = torch.cat([points, torch.mean(points[idx], 1)])
+    return points
+
+
+def up_sample_points(points, times=1):
+    """src/fitting_utils.py:109-130: batched (B,3,N) -> (B,3,2^times N), centroid of the 3 nearest
+    (the point itself included)."""
+    pts = points.detach().permute(0, 2, 1)
+    for _ in range(times):
+        out = []
+        for b in range(pts.shape[0]):
+            idx = _knn_points_by_differences(pts[b], 3)
+            out.append(torch.cat([pts[b], torch.mean(pts[b][idx], 1)]))
+        pts = torch.stack(out, 0)
+    return pts.permute(0, 2, 1)
+
+
+def one_hot_normalization(weights):
+    """src/fitting_utils.py:328-333: rows -> one-hot of their arg-max."""
+    w = torch.as_tensor(weights)
+    return to_one_hot(torch.argmax(w, 1), w.shape[1], device_id=w.device.index if w.is_cuda else None).float()
+
+
+def pca_numpy(X):
+    S, U = np.linalg.eig(X.T @ X)
+    return S, U
+
+
+def reverse_all_transformation(point, mean, std, R):
+    """src/fitting_utils.py:601-606 (numpy): undo scale, rotation, centring."""
+    return (np.linalg.inv(R) @ (point * std.reshape((1, 3))).T).T + mean
+
+
+def reverse_all_transformations(points, means, stds, Rs):
+    return np.stack([reverse_all_transformation(points[i], means[i], stds[i], Rs[i]) for i in range(len(Rs))], 0)
+
+
+def project_to_point_cloud(points, surface):
+    """src/fitting_utils.py:637-643: nearest surface point of every point (arg-min of the squared
+    distance, smallest index on ties) through the Chamfer nearest-neighbour kernel instead of the
+    reference's (n, m, 3) broadcast.  numpy in -> numpy out, tensors stay tensors."""
+    as_numpy = isinstance(points, np.ndarray)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    P = torch.as_tensor(points, dtype=torch.float32, device=dev if as_numpy else None)
+    S = torch.as_tensor(surface, dtype=torch.float32, device=P.device)
+    _, idx, _, _ = K.chamfer_nn(P.unsqueeze(0), S.unsqueeze(0), True, False)
+    out = torch.as_tensor(surface, device=P.device)[idx[0]]
+    return out.cpu().numpy() if as_numpy else out
+
+
 def up_sample_points_torch_in_range(points, a_min, a_max):
     """src/fitting_utils.py:222-237."""
     N = points.shape[0]

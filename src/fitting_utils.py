@@ -5,6 +5,9 @@ from parsenet_codebase_amd.fitting import (EPS, CustomSVD, LeastSquares, best_la
                                            project_to_plane, relaxed_iou_fast,
                                            rotation_matrix_a_to_b, standardize_point_torch,
                                            standardize_points_torch, svd_grad_K, to_one_hot,
-                                           remove_outliers, up_sample_points_in_range,
-                                           up_sample_points_torch, up_sample_points_torch_in_range,
-                                           weights_normalize)
+                                           one_hot_normalization, pca_numpy, project_to_point_cloud,
+                                           remove_outliers, reverse_all_transformation,
+                                           reverse_all_transformations, up_sample_points,
+                                           up_sample_points_in_range, up_sample_points_torch,
+                                           up_sample_points_torch_in_range,
+                                           up_sample_points_torch_memory_efficient, weights_normalize)

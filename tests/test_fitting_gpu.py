@@ -267,3 +267,29 @@ def test_eval_helpers_edge_cases(gpu):
     p_g, w_g = up_sample_points_in_range(tiny.to(gpu), wt.to(gpu), 1000, 1500)
     assert tuple(p_g.shape) == (1500, 3) and torch.equal(w_g.cpu(), w_o)
     assert float((p_g.cpu() - p_o).abs().max()) < 1e-6
+
+
+def test_small_fitting_utils_helpers(gpu):
+    """The remaining non-viewer helpers of src/fitting_utils.py against their defining expressions."""
+    import src.fitting_utils as FU
+    g = torch.Generator().manual_seed(12)
+    pts = torch.rand(700, 3, generator=g)
+    surf = torch.rand(900, 3, generator=g)
+    want = surf[((pts.unsqueeze(1) - surf.unsqueeze(0)) ** 2).sum(2).argmin(1)]
+    assert torch.equal(FU.project_to_point_cloud(pts.to(gpu), surf.to(gpu)).cpu(), want)
+    assert np.array_equal(FU.project_to_point_cloud(pts.numpy(), surf.numpy()), want.numpy())
+    up = FU.up_sample_points_torch_memory_efficient(pts.to(gpu)).cpu()
+    d = ((pts.unsqueeze(1) - pts.unsqueeze(0)) ** 2).sum(2)
+    assert float((up[700:] - pts[d.topk(5, 1, largest=False)[1]].mean(1)).abs().max()) < 1e-6
+    upb = FU.up_sample_points(pts.t().unsqueeze(0).to(gpu)).cpu()
+    assert tuple(upb.shape) == (1, 3, 1400)
+    assert float((upb[0, :, 700:].t() - pts[d.topk(3, 1, largest=False)[1]].mean(1)).abs().max()) < 1e-6
+    w = torch.rand(50, 7, generator=g)
+    oh = FU.one_hot_normalization(w.to(gpu)).cpu()
+    assert torch.equal(oh.argmax(1), w.argmax(1)) and float(oh.sum()) == 50.0
+    R = np.linalg.qr(np.random.RandomState(1).randn(3, 3))[0]
+    x = np.random.RandomState(2).randn(40, 3)
+    mean, std = np.array([0.1, -0.2, 0.3]), np.array([[2.0, 0.5, 1.5]])
+    y = (R @ (x - mean).T).T / std
+    assert np.allclose(FU.reverse_all_transformation(y, mean, std, R), x, atol=1e-12)
+    assert np.allclose(FU.reverse_all_transformations(np.stack([y, y]), [mean, mean], [std, std], [R, R])[1], x)
