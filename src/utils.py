@@ -8,6 +8,12 @@ from parsenet_codebase_amd.chamfer import (chamfer_distance, chamfer_distance_on
 from parsenet_codebase_amd.fitting import rotation_matrix_a_to_b  # noqa: F401
 
 
+def get_rotation_matrix(theta):
+    """src/utils.py:19-23: rotation by theta about z (row-vector convention of the reference)."""
+    c, s_ = np.cos(theta), np.sin(theta)
+    return np.array([[c, s_, 0], [-s_, c, 0], [0, 0, 1]])
+
+
 def rescale_input_outputs(scales, output, points, control_points, batch_size):
     """src/utils.py:361-390: undo anisotropic scaling so that every axis is divided by the
     largest scale of its shape."""
