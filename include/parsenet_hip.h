@@ -116,6 +116,24 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
                                  void* img_q, void* img_gu, float* opart_q, float* opart_x, float* gq,
                                  float* gx, void* stream);
 
+/* ---- mean-shift, fp32-grade products on the fp16 matrix cores ("fp16 x 2") ---------------
+ * Same contract and outputs again; every operand is scaled by a power of two into the fp16
+ * range and split into two fp16 pieces, each product is formed from the three significant
+ * piece products with fp32 accumulation (error below that of an fp32 fma chain; see
+ * csrc/meanshift_h2.h for the scaling rules).  Rows of x and of the iterates must be unit
+ * vectors.  Entry points as the x3 ones; the backward takes ``rowsc`` (3 B N + B floats of
+ * scratch: per-row scalars and the per-shape maximum) in place of ``cs``. */
+size_t pn_meanshift_h2_image_bytes(int B, int N);
+int pn_meanshift_h2_split_f32(const float* x, int B, int N, int D, void* img, void* stream);
+int pn_meanshift_h2_iter_fwd_f32(const float* q, const void* img_x, const float* bsq, int B, int N,
+                                 int D, float* opart, float* rpart, float* y, float* rsum,
+                                 float* unorm, void* stream);
+int pn_meanshift_h2_iter_bwd_f32(const float* gy, const float* y, const float* q, const float* x,
+                                 const void* img_x, const float* rsum, const float* unorm,
+                                 const float* bsq, int B, int N, int D, float* gu, float* rowsc,
+                                 void* img_q, void* img_gu, float* opart_q, float* opart_x, float* gq,
+                                 float* gx, void* stream);
+
 /* ---- GroupNorm (+ReLU) (+max over points) of the per-point heads -------------------------
  * Replaces torch GroupNorm -> ReLU (-> max over N) of src/PointNet.py:216-218, 274-283 on
  * channel-first (B,C,N) tensors.  One block per (b,c) row.

@@ -582,3 +582,4 @@ extern "C" int pn_meanshift_iter_bwd_f32(const float* gy, const float* y, const 
 }
 
 #include "meanshift_x3.h"
+#include "meanshift_h2.h"

@@ -257,7 +257,7 @@ class MeanShiftWorkspace:
         self.rpart = torch.empty((B, self.S, N), **f)
         if backward:
             self.gu = torch.empty((B, N, D), **f)
-            self.cs = torch.empty((B, 2, N), **f)
+            self.cs = torch.empty(3 * B * N + B, **f)   # row scalars (+ the per-shape maximum of the fp16 path)
             self.opart_x = torch.empty((B, self.S, N, D), **f)
             if exact_f32:   # the bf16 x 3 path needs neither go nor the channel-first copies
                 self.go = torch.empty((B, N, D), **f)
@@ -319,6 +319,51 @@ def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx):
                                               ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq), ptr(gx),
                                               current_stream(x.device))
     check(rc, "pn_meanshift_x3_iter_bwd_f32")
+    return gq
+
+
+def meanshift_h2_split(x):
+    """x (B,N,128), unit rows -> pre-split fp16 x 2 tile images for the matrix-core path."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    B, N, D = x.shape
+    lib = _lib.load()
+    img = torch.empty(lib.pn_meanshift_h2_image_bytes(B, N), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.pn_meanshift_h2_split_f32(ptr(x), B, N, D, ptr(img), current_stream(x.device))
+    check(rc, "pn_meanshift_h2_split_f32")
+    return img
+
+
+def meanshift_h2_iter_fwd(q, x_image, bsq, ws):
+    B, N, D = q.shape
+    y = torch.empty_like(q)
+    rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
+    unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = _lib.load().pn_meanshift_h2_iter_fwd_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
+                                                      ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
+                                                      current_stream(q.device))
+    check(rc, "pn_meanshift_h2_iter_fwd_f32")
+    return y, rsum, unorm
+
+
+def meanshift_h2_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx):
+    """fp16 x 2 counterpart of meanshift_iter_bwd: returns dL/dq, adds into ``gx``."""
+    B, N, D = x.shape
+    gy = _f32c(gy, "gy")
+    gq = torch.empty_like(x)
+    lib = _lib.load()
+    if getattr(ws, "h2_imgs", None) is None:
+        nbytes = lib.pn_meanshift_h2_image_bytes(B, N)
+        ws.h2_imgs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(2)]
+    im = ws.h2_imgs
+    with torch.cuda.device(x.device):
+        rc = lib.pn_meanshift_h2_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(x_image), ptr(rsum),
+                                              ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.cs), ptr(im[0]),
+                                              ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq), ptr(gx),
+                                              current_stream(x.device))
+    check(rc, "pn_meanshift_h2_iter_bwd_f32")
     return gq
 
 

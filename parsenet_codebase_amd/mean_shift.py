@@ -11,9 +11,13 @@ from . import kernels as K
 from ._lib import h2d, require_cuda
 
 
-# Arithmetic of the two GEMMs per tile: "bf16x3" (error-free 3-way bf16 split on the bf16 matrix
-# cores, fp32-grade) or "f32" (v_mfma_f32_32x32x2_f32, fma chains).  PARSENET_MS_ARITH overrides.
-ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
+# Arithmetic of the two GEMMs per tile: "fp16x2" (scaled 2-way fp16 split, three piece products),
+# "bf16x3" (error-free 3-way bf16 split, six piece products) — both on the 16-bit matrix cores with
+# fp32 accumulation and errors below those of an fp32 GEMM — or "f32" (v_mfma_f32_32x32x2_f32,
+# exact fma chains).  PARSENET_MS_ARITH overrides.
+ARITH = os.environ.get("PARSENET_MS_ARITH", "fp16x2")
+_SPLIT = {"fp16x2": (K.meanshift_h2_split, K.meanshift_h2_iter_fwd, K.meanshift_h2_iter_bwd),
+          "bf16x3": (K.meanshift_x3_split, K.meanshift_x3_iter_fwd, K.meanshift_x3_iter_bwd)}
 
 
 class _MeanShiftIterations(torch.autograd.Function):
@@ -24,15 +28,18 @@ class _MeanShiftIterations(torch.autograd.Function):
     def forward(ctx, X, bsq, iterations):
         x = X.contiguous()
         B, N, D = x.shape
-        x3 = K.meanshift_x3_split(x) if (ARITH == "bf16x3" and iterations > 0) else None
-        # streamed copy of X: pre-split tile images (bf16 x 3) or channel-first fp32 (exact path)
+        if ARITH not in _SPLIT and ARITH != "f32":
+            raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
+        kern = _SPLIT.get(ARITH) if iterations > 0 else None
+        x3 = kern[0](x) if kern is not None else None
+        # streamed copy of X: pre-split tile images (16-bit pieces) or channel-first fp32 (exact path)
         xt = x3 if x3 is not None else K.meanshift_pack(x)
         ws = K.MeanShiftWorkspace(B, N, D, x.device)
         iterates, rsums, norms = [x], [], []
         q = x
         for _ in range(iterations):
             if x3 is not None:
-                q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws)
+                q, r, n = kern[1](q, x3, bsq, ws)
             else:
                 q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
             iterates.append(q)
@@ -40,6 +47,7 @@ class _MeanShiftIterations(torch.autograd.Function):
             norms.append(n)
         ctx.iterations = iterations
         ctx.x3 = x3
+        ctx.kern = kern
         ctx.save_for_backward(xt, bsq, *iterates, *rsums, *norms)
         return q if iterations > 0 else x.clone()
 
@@ -58,8 +66,7 @@ class _MeanShiftIterations(torch.autograd.Function):
         g = gy.contiguous()
         for it in reversed(range(T)):
             if ctx.x3 is not None:
-                g = K.meanshift_x3_iter_bwd(g, iterates[it + 1], iterates[it], x, ctx.x3, rsums[it], norms[it],
-                                            bsq, ws, gX)
+                g = ctx.kern[2](g, iterates[it + 1], iterates[it], x, ctx.x3, rsums[it], norms[it], bsq, ws, gX)
             else:
                 g = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it], bsq,
                                          ws, gX)

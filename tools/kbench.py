@@ -77,7 +77,7 @@ def bench_meanshift_fwd():
     N = 10000
     X = torch.nn.functional.normalize(torch.randn(N, 128, device=dev), dim=1)
     b = torch.tensor(0.3, device=dev)
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "fp16x2"):
         MS.ARITH = mode
         with torch.no_grad():
             t = timeit(lambda: MS.MeanShift().mean_shift_(X, b, 10), warmup=1, iters=3)
