@@ -19,7 +19,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense peak (v_mfma_f32_32x32x16_bf16)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense peak (v_mfma_f32_32x32x16_{bf16,f16})
 HBM_PEAK_GBS = 8000.0
 
 
@@ -54,12 +54,14 @@ def pmc_traffic(kernel_name, arith):
     doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
     the file is not there — bench.py never profiles counters itself."""
     import csv
-    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                      "r01_meanshift_x3_pmc.csv" if arith == "bf16x3" else "r01_meanshift_f32_pmc.csv")
+    files = {"fp16x2": ("r01_meanshift_h2_pmc.csv", "pn_msh_kernel<%d>"),
+             "bf16x3": ("r01_meanshift_x3_pmc.csv", "pn_ms3_kernel<%d>"),
+             "f32": ("r01_meanshift_f32_pmc.csv", "pn_ms_kernel<%d>")}
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", files[arith][0])
     idx = {"meanshift_fwd": 0, "meanshift_bwd_rows": 1, "meanshift_bwd_cols": 2}.get(kernel_name)
     if idx is None or not os.path.exists(fn):
         return None
-    want = ("pn_ms3_kernel<%d>" if arith == "bf16x3" else "pn_ms_kernel<%d>") % idx
+    want = files[arith][1] % idx
     vals = {r["counter"]: float(r["avg_per_launch"]) for r in csv.DictReader(open(fn)) if r["kernel"] == want}
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
@@ -111,15 +113,18 @@ def kernel_roofline(step, nprof):
         flops = units * 2.0 * N * N * 128
         ach = flops / avg_s / 1e12
         from parsenet_codebase_amd import mean_shift as _ms
-        if _ms.ARITH == "bf16x3":
-            # every fp32 product is formed from 6 bf16 piece products on the bf16 matrix cores
-            # (fp32 accumulate): the roof for ALGORITHMIC fp32 FLOPs is the bf16 dense peak / 6
-            peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+        if _ms.ARITH in ("bf16x3", "fp16x2"):
+            # every fp32 product is formed from 6 bf16 (3 fp16) piece products on the 16-bit matrix
+            # cores (fp32 accumulate): the roof for ALGORITHMIC fp32 FLOPs is the dense peak / 6 (/ 3)
+            pieces = 6.0 if _ms.ARITH == "bf16x3" else 3.0
+            peak = MFMA_BF16_PEAK_TFLOPS / pieces
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": pmc_traffic(dom, "bf16x3"),
+                    "frac": ach / peak, "traffic": pmc_traffic(dom, _ms.ARITH),
                     "avg_launch_ms": table[dom]["avg_ms"],
-                    "mfma": "v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)",
-                    "executed_tflops": 6.0 * ach, "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+                    "mfma": ("v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)"
+                             if _ms.ARITH == "bf16x3" else
+                             "v_mfma_f32_32x32x16_f16, 3 piece products per fp32 product (scaled fp16x2 split)"),
+                    "executed_tflops": pieces * ach, "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, "f32"),
@@ -215,8 +220,9 @@ def cpu_baseline_splinenet(name, cores):
 
 def _ms_arith():
     from parsenet_codebase_amd import mean_shift as _ms
-    return ("fp32 via error-free bf16x3 operand split on the bf16 matrix cores, fp32 accumulate"
-            if _ms.ARITH == "bf16x3" else "fp32 matrix cores (v_mfma_f32_32x32x2_f32)")
+    return {"fp16x2": "fp32 via scaled fp16x2 operand split on the fp16 matrix cores, fp32 accumulate",
+            "bf16x3": "fp32 via error-free bf16x3 operand split on the bf16 matrix cores, fp32 accumulate",
+            }.get(_ms.ARITH, "fp32 matrix cores (v_mfma_f32_32x32x2_f32)")
 
 
 def main():

@@ -445,10 +445,10 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
 #undef X3_SPLIT_W
 #undef X3_EW
 #undef X3_EW_
-    }
 #ifdef MS_TIMING
-    tg2 += __builtin_amdgcn_s_memtime() - U5;
+      tg2 += __builtin_amdgcn_s_memtime() - U6;
 #endif
+    }
     cur ^= 1;
   }
 #ifdef MS_TIMING

@@ -36,23 +36,25 @@ if not PMC_ONLY:
                                                 os.path.join(P, "r01_cfg5_kernel_stats.csv")), 2))
     print("cfg4 kernel ms/step", round(condense(os.path.join(R, "s4", "b_kernel_stats.csv"),
                                                 os.path.join(P, "r01_cfg4_kernel_stats.csv")), 2))
+# mean-shift kernel family of the counter runs: the default arithmetic (fp16 x 2)
+KERNEL, PMC_FILE = "pn_msh_kernel", "r01_meanshift_h2_pmc.csv"
 agg = collections.OrderedDict()
 for n in (1, 2, 3, 4):
     for r in csv.DictReader(open(os.path.join(R, "pmc%d" % n, "p_counter_collection.csv"))):
         k = r["Kernel_Name"]
-        if "pn_ms3_kernel" not in k:
+        if KERNEL not in k:
             continue
         a = agg.setdefault((k.split("(")[0].replace("void ", ""), r["Counter_Name"]), [0, 0.0])
         a[0] += 1
         a[1] += float(r["Counter_Value"])
-with open(os.path.join(P, "r01_meanshift_x3_pmc.csv"), "w", newline="") as f:
+with open(os.path.join(P, PMC_FILE), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "counter", "launches", "avg_per_launch"])
     for (k, c), (n, v) in sorted(agg.items()):
         w.writerow([k, c, n, round(v / n, 4)])
 g = lambda k, c: agg[(k, c)][1] / agg[(k, c)][0]   # noqa: E731
 for p_ in (0, 1, 2):
-    k = "pn_ms3_kernel<%d>" % p_
+    k = "%s<%d>" % (KERNEL, p_)
     print(k, "mfma busy/(4*wave cycles)", round(g(k, "SQ_VALU_MFMA_BUSY_CYCLES") / (4 * g(k, "SQ_WAVE_CYCLES")), 3),
           "FETCH MB", round(g(k, "FETCH_SIZE") / 1024, 1), "WRITE MB", round(g(k, "WRITE_SIZE") / 1024, 1),
           "LDS conflicts", g(k, "SQ_LDS_BANK_CONFLICT"))

@@ -68,6 +68,15 @@ def bench_meanshift():
     t = timeit(fwd_bwd, warmup=1, iters=3)
     print("meanshift N=%d 10 it fwd+bwd: %.2f ms  (%.1f TFLOP/s on 9 GEMM units/it)" %
           (N, t, 10 * 9 * 2.0 * N * N * 128 / t / 1e9))
+    from parsenet_codebase_amd import _lib
+    _lib.prof_enable(True)
+    _lib.prof_reset()
+    fwd_bwd()
+    torch.cuda.synchronize()
+    for name, (ms_, calls) in sorted(_lib.prof_results().items()):
+        if name.startswith("meanshift"):
+            print("  %-20s %.3f ms per launch (%d launches)" % (name, ms_ / calls, calls))
+    _lib.prof_enable(False)
 
 
 def bench_meanshift_fwd():

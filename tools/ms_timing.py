@@ -22,4 +22,4 @@ for p in range(3):
     nt = max(nt, 1)
     print("PASS %d: tiles %d  per tile: G1 %.0f  EW %.0f  G2 %.0f  barrier %.0f  | loop total/tile %.0f (shader clocks)" %
           (p, nt, g1 / nt, ew / nt, g2 / nt, bar / nt, tot / nt) +
-          ("  [x3: dma issue %.0f  barrier B %.0f]" % (dma / nt, bar1 / nt) if dma else ""))
+          ("  [dma issue %.0f  of the barrier: wait for the DMA %.0f]" % (dma / nt, bar1 / nt) if dma else ""))

@@ -5,7 +5,7 @@ set -x
 R=/root/repo/gpurun_out/r1b
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $R/pmc1 -o p -- python3 /root/repo/tools/kbench.py meanshift > $R/pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --kernel-trace --output-format csv -d $R/pmc1 -o p -- python3 /root/repo/tools/kbench.py meanshift > $R/pmc1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $R/pmc2 -o p -- python3 /root/repo/tools/kbench.py meanshift > $R/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/pmc3 -o p -- python3 /root/repo/tools/kbench.py meanshift > $R/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/pmc4 -o p -- python3 /root/repo/tools/kbench.py meanshift > $R/pmc4.log 2>&1
