@@ -121,8 +121,8 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
  * range and split into two fp16 pieces, each product is formed from the three significant
  * piece products with fp32 accumulation (error below that of an fp32 fma chain; see
  * csrc/meanshift_h2.h for the scaling rules).  Rows of x and of the iterates must be unit
- * vectors.  Entry points as the x3 ones; the backward takes ``rowsc`` (3 B N + B floats of
- * scratch: per-row scalars and the per-shape maximum) in place of ``cs``. */
+ * vectors.  Entry points as the x3 ones; the backward takes ``rowsc`` (3 B N + B ntiles floats of
+ * scratch, ntiles = 2 ceil(N / 64): per-row scalars and per-tile maxima) in place of ``cs``. */
 size_t pn_meanshift_h2_image_bytes(int B, int N);
 int pn_meanshift_h2_split_f32(const float* x, int B, int N, int D, void* img, void* stream);
 int pn_meanshift_h2_iter_fwd_f32(const float* q, const void* img_x, const float* bsq, int B, int N,

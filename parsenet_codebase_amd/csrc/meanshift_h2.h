@@ -19,8 +19,8 @@
 //                                       T' = gu'_i . x_j, c' = c_i ge_i, |T' - c'| < 2 sqrt(128)
 //   rho_i = alpha_i / ge_i              the row's gradient magnitude; the column pass contracts
 //                                       over rows, so their scales must share one power of two:
-//                                       sigma = 2^-E, rho_max sigma in [1/2,1) (atomic max in the
-//                                       prologue).  Rows more than 2^-24 below the largest one
+//                                       sigma = 2^-E, rho_max sigma in [1/2,1) (per-tile maxima from
+//                                       the prologue).  Rows more than 2^-24 below the largest one
 //                                       lose relative — not absolute — precision.
 // The scales are undone by exact power-of-two factors at the store (per lane in the row pass).
 // Values below 2^-24 after scaling flush to zero: an absolute error below 2^-36 of the
@@ -100,61 +100,69 @@ __global__ __launch_bounds__(256) void pn_msh_split_kernel(const float* __restri
   }
 }
 
-// backward prologue, one wave per row (rows N .. Np-1 of the images are written as zeros):
+// backward prologue, one workgroup per 32-row tile, one wave per row at a time (rows N .. Np-1 of
+// the images are written as zeros):
 //   gu = (gy - y (y.gy)) / ||u|| ; c = gu . u (u = y ||u||) ; alpha = 1 / (r b^2)
 //   ge = power of two normalising the row of gu ; rowsc = [c ge 2^-5 | rho = alpha / ge | ge]
-//   rhomax[b] = max_i bits(rho_i)
+//   rhotile[b][tile] = max over the tile's rows of rho (the column pass reduces these; no atomics:
+//   10 000 same-address atomic maxima serialise to ~100 us)
 //   img_q, img_gu: the tile images of q and of gu' = gu ge (each lane owns channels 2 lane, 2 lane + 1:
 //   one packed pair per piece, 4 bytes into chunk lane / 4)
 __global__ __launch_bounds__(256) void pn_msh_prep_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ q,
     const float* __restrict__ rsum, const float* __restrict__ unorm, const float* __restrict__ bsq, int N,
-    int ntiles, float* __restrict__ gu, float* __restrict__ rowsc, uint32_t* __restrict__ rhomax,
+    int ntiles, float* __restrict__ gu, float* __restrict__ rowsc, float* __restrict__ rhotile,
     uint32_t* __restrict__ img_q, uint32_t* __restrict__ img_gu) {
-  const int b = blockIdx.y;
+  __shared__ float wmax[4];
+  const int b = blockIdx.y, tile = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= ntiles * 32) return;
-  // word (4 bytes) of this lane inside the row's 256-byte image line, per piece
-  const int j = i & 31;
-  const size_t word = ((size_t)b * ntiles + (i >> 5)) * (H2_IMG_U4 * 4) +
-                      (size_t)(j * 16 + ((lane >> 2) ^ x3_swz(j))) * 4 + (lane & 3);
-  if (i >= N) {
-    img_q[word] = 0u;
-    img_q[word + H2_PIECE_U4 * 4] = 0u;
-    img_gu[word] = 0u;
-    img_gu[word + H2_PIECE_U4 * 4] = 0u;
-    return;
-  }
-  const size_t base = ((size_t)b * N + i) * MS_D + 2 * lane;
-  const float2 yv = *reinterpret_cast<const float2*>(y + base);
-  const float2 gv = *reinterpret_cast<const float2*>(gy + base);
-  const float2 qv = *reinterpret_cast<const float2*>(q + base);
-  const float nn = unorm[(size_t)b * N + i], r = rsum[(size_t)b * N + i];
-  const float yg = pn_wave_sum(yv.x * gv.x + yv.y * gv.y);
-  const float u0 = (gv.x - yv.x * yg) / nn, u1 = (gv.y - yv.y * yg) / nn;
-  const float c = pn_wave_sum(u0 * (yv.x * nn) + u1 * (yv.y * nn));
-  float mx = fmaxf(fabsf(u0), fabsf(u1));
+  const float ibsq = 1.0f / bsq[b];
+  float rmax = 0.f;
+  for (int j = wave; j < 32; j += 4) {
+    const int i = tile * 32 + j;
+    // word (4 bytes) of this lane inside the row's 256-byte image line, per piece
+    const size_t word = ((size_t)b * ntiles + tile) * (H2_IMG_U4 * 4) +
+                        (size_t)(j * 16 + ((lane >> 2) ^ x3_swz(j))) * 4 + (lane & 3);
+    if (i >= N) {
+      img_q[word] = 0u;
+      img_q[word + H2_PIECE_U4 * 4] = 0u;
+      img_gu[word] = 0u;
+      img_gu[word + H2_PIECE_U4 * 4] = 0u;
+      continue;
+    }
+    const size_t base = ((size_t)b * N + i) * MS_D + 2 * lane;
+    const float2 yv = *reinterpret_cast<const float2*>(y + base);
+    const float2 gv = *reinterpret_cast<const float2*>(gy + base);
+    const float2 qv = *reinterpret_cast<const float2*>(q + base);
+    const float nn = unorm[(size_t)b * N + i], r = rsum[(size_t)b * N + i];
+    const float yg = pn_wave_sum(yv.x * gv.x + yv.y * gv.y);
+    const float u0 = (gv.x - yv.x * yg) / nn, u1 = (gv.y - yv.y * yg) / nn;
+    const float c = pn_wave_sum(u0 * (yv.x * nn) + u1 * (yv.y * nn));
+    float mx = fmaxf(fabsf(u0), fabsf(u1));
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  *reinterpret_cast<float2*>(gu + base) = make_float2(u0, u1);
-  const float ge = h2_norm_scale(mx);
-  const H2Pieces pq = h2_split2(qv.x * H2_SX, qv.y * H2_SX);
-  const float gs = ge * H2_SX;
-  const H2Pieces pg = h2_split2(u0 * gs, u1 * gs);
-  img_q[word] = pq.h;
-  img_q[word + H2_PIECE_U4 * 4] = pq.m;
-  img_gu[word] = pg.h;
-  img_gu[word + H2_PIECE_U4 * 4] = pg.m;
-  if (lane == 0) {
-    const float alpha = 1.0f / (r * bsq[b]);
-    const float rho = alpha / ge;
-    float* rs = rowsc + (size_t)b * 3 * N;
-    rs[i] = c * ge * 0.03125f;
-    rs[N + i] = rho;
-    rs[2 * N + i] = ge;
-    if (rho > 0.f && rho < __builtin_inff()) atomicMax(rhomax + b, __builtin_bit_cast(uint32_t, rho));
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    *reinterpret_cast<float2*>(gu + base) = make_float2(u0, u1);
+    const float ge = h2_norm_scale(mx);
+    const H2Pieces pq = h2_split2(qv.x * H2_SX, qv.y * H2_SX);
+    const float gs = ge * H2_SX;
+    const H2Pieces pg = h2_split2(u0 * gs, u1 * gs);
+    img_q[word] = pq.h;
+    img_q[word + H2_PIECE_U4 * 4] = pq.m;
+    img_gu[word] = pg.h;
+    img_gu[word + H2_PIECE_U4 * 4] = pg.m;
+    const float rho = (ibsq / r) / ge;
+    if (lane == 0) {
+      float* rs = rowsc + (size_t)b * 3 * N;
+      rs[i] = c * ge * 0.03125f;
+      rs[N + i] = rho;
+      rs[2 * N + i] = ge;
+    }
+    if (rho > 0.f && rho < __builtin_inff()) rmax = fmaxf(rmax, rho);
   }
+  if (lane == 0) wmax[wave] = rmax;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    rhotile[(size_t)b * ntiles + tile] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
 #define H2_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
@@ -176,7 +184,7 @@ template <int PASS>
 __global__ __launch_bounds__(64 * H2_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) void pn_msh_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
-    const u32x4* __restrict__ PB, const float* __restrict__ rowsc, const uint32_t* __restrict__ rhomax,
+    const u32x4* __restrict__ PB, const float* __restrict__ rowsc, const float* __restrict__ rhotile,
     const float* __restrict__ bsq_, int N, int ntiles, int tiles_per_slice, float* __restrict__ opart,
     float* __restrict__ rpart) {
   constexpr int NIMG = PASS == 2 ? 2 : 1;
@@ -201,10 +209,15 @@ __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) voi
   const float* __restrict__ rs_c = PASS == 0 ? nullptr : rowsc + (size_t)b * 3 * N;
   const float* __restrict__ rs_rho = PASS == 0 ? nullptr : rs_c + N;
 
-  // global scale of the column pass: sigma = 2^(126 - E), 1 / sigma = 2^(E - 126)
+  // global scale of the column pass from the largest rho of the shape (maximum over the tile
+  // maxima of the prologue): sigma = 2^(126 - E), 1 / sigma = 2^(E - 126)
   float sigma = 1.f, isigma = 1.f;
   if (PASS == 2) {
-    int E = (int)(rhomax[b] >> 23 & 0xff);
+    float m = 0.f;
+    for (int t = lane; t < ntiles; t += 64) m = fmaxf(m, rhotile[(size_t)b * ntiles + t]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    int E = (int)(__builtin_bit_cast(uint32_t, m) >> 23 & 0xff);
     E = E < 1 ? 126 : (E > 252 ? 252 : E);
     sigma = __builtin_bit_cast(float, (uint32_t)(253 - E) << 23);
     isigma = __builtin_bit_cast(float, (uint32_t)(E + 1) << 23);
@@ -723,7 +736,7 @@ extern "C" int pn_meanshift_h2_iter_fwd_f32(const float* q, const void* img_x, c
 }
 
 // Backward of one iteration on the fp16 x 2 path: same contract as pn_meanshift_x3_iter_bwd_f32;
-// rowsc is a scratch of (3 B N + B) floats (row scalars and the per-shape maximum).
+// rowsc is a scratch of 3 B N + B ntiles floats, ntiles = 2 ceil(N / 64) (row scalars and per-tile maxima).
 extern "C" int pn_meanshift_h2_iter_bwd_f32(const float* gy, const float* y, const float* q,
                                             const float* x, const void* img_x, const float* rsum,
                                             const float* unorm, const float* bsq, int B, int N, int D,
@@ -748,16 +761,15 @@ extern "C" int pn_meanshift_h2_iter_bwd_f32(const float* gy, const float* y, con
     S2 = smax;
     tps2 = pn_cdiv(ntiles, S2);
   }
-  uint32_t* rhomax = reinterpret_cast<uint32_t*>(rowsc + (size_t)3 * B * N);
-  PN_CHECK_HIP(hipMemsetAsync(rhomax, 0, sizeof(uint32_t) * B, stream));
-  hipLaunchKernelGGL(pn_msh_prep_bwd_kernel, dim3(ntiles * 8, B), dim3(256), 0, stream, gy, y, q, rsum, unorm,
-                     bsq, N, ntiles, gu, rowsc, rhomax, (uint32_t*)img_q, (uint32_t*)img_gu);
+  float* rhotile = rowsc + (size_t)3 * B * N;
+  hipLaunchKernelGGL(pn_msh_prep_bwd_kernel, dim3(ntiles, B), dim3(256), 0, stream, gy, y, q, rsum, unorm, bsq,
+                     N, ntiles, gu, rowsc, rhotile, (uint32_t*)img_q, (uint32_t*)img_gu);
   PN_CHECK_LAUNCH();
   {
     PN_PROF("meanshift_bwd_rows", stream);
     dim3 grid(S, pn_cdiv(N, 32 * H2_WAVES(1)), B);
     hipLaunchKernelGGL(pn_msh_kernel<1>, grid, dim3(64 * H2_WAVES(1)), 0, stream, q, (const float*)gu,
-                       (const u32x4*)img_x, nullptr, (const float*)rowsc, (const uint32_t*)rhomax, bsq, N,
+                       (const u32x4*)img_x, nullptr, (const float*)rowsc, (const float*)rhotile, bsq, N,
                        ntiles, tps, opart_q, nullptr);
   }
   PN_CHECK_LAUNCH();
@@ -766,7 +778,7 @@ extern "C" int pn_meanshift_h2_iter_bwd_f32(const float* gy, const float* y, con
     dim3 grid2(S2, pn_cdiv(N, 32 * H2_WAVES(2)), B);
     hipLaunchKernelGGL(pn_msh_kernel<2>, grid2, dim3(64 * H2_WAVES(2)), 0, stream, x, nullptr,
                        (const u32x4*)img_q, (const u32x4*)img_gu, (const float*)rowsc,
-                       (const uint32_t*)rhomax, bsq, N, ntiles, tps2, opart_x, nullptr);
+                       (const float*)rhotile, bsq, N, ntiles, tps2, opart_x, nullptr);
   }
   PN_CHECK_LAUNCH();
   const long long ND4 = (long long)N * MS_D / 4;

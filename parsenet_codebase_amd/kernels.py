@@ -257,7 +257,8 @@ class MeanShiftWorkspace:
         self.rpart = torch.empty((B, self.S, N), **f)
         if backward:
             self.gu = torch.empty((B, N, D), **f)
-            self.cs = torch.empty(3 * B * N + B, **f)   # row scalars (+ the per-shape maximum of the fp16 path)
+            # row scalars (+ the per-tile maxima of the fp16 path)
+            self.cs = torch.empty(3 * B * N + B * (self.Np // 32), **f)
             self.opart_x = torch.empty((B, self.S, N, D), **f)
             if exact_f32:   # the bf16 x 3 path needs neither go nor the channel-first copies
                 self.go = torch.empty((B, N, D), **f)
