@@ -388,10 +388,7 @@ __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) voi
       }                                                                                       \
     }                                                                                         \
   }
-#ifndef H2_PIPE0
-#define H2_PIPE0 0
-#endif
-      constexpr bool PIPE = PASS != 0 || H2_PIPE0;      // elementwise stage in two halves around k-step 0
+      constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
       // (only the last tile of the forward pass pays for the mask)
 #define H2_EW_RANGE(LO, HI)                                                   \
   if (PASS == 0 && tail) {                                                    \
@@ -503,186 +500,6 @@ __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) voi
   }
 }
 
-// Forward pass, software pipelined inside each wave: the first GEMM of tile t+1 is issued
-// together with the elementwise stage of tile t, so that the VALU work runs in the shadow of
-// the matrix pipe (tools/ubench/mfma_valu_interleave.hip: up to ~6 VALU instructions hide under
-// each 32-cycle MFMA of the SAME wave, while VALU work of another wave does not overlap with
-// it at all, tools/ubench/mfma_valu_overlap.hip).  Three image buffers (tile t for the second
-// GEMM, t+1 for the first, t+2 in flight), one barrier per tile.
-#ifndef H2_FWD_PIPE
-#define H2_FWD_PIPE 0
-#endif
-#ifndef H2_FWD_WAVES
-#define H2_FWD_WAVES 4
-#endif
-__global__ __launch_bounds__(64 * H2_FWD_WAVES)
-__attribute__((amdgpu_waves_per_eu(H2_FWD_WAVES / 4, H2_FWD_WAVES / 4))) void pn_mshp_fwd_kernel(
-    const float* __restrict__ R, const u32x4* __restrict__ PA, const float* __restrict__ bsq_, int N,
-    int ntiles, int tiles_per_slice, float* __restrict__ opart, float* __restrict__ rpart) {
-  __shared__ __attribute__((aligned(16))) u32x4 ldsP[3][H2_IMG_U4];
-  const int b = blockIdx.z;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int col = lane & 31, h = lane >> 5;
-  constexpr int NW = H2_FWD_WAVES;
-  const int i0 = (blockIdx.y * NW + wave) * 32;
-  const bool wave_on = i0 < N;
-  const int S = gridDim.x, slice = blockIdx.x;
-  const int t_begin = slice * tiles_per_slice;
-  const int t_end = min(ntiles, t_begin + tiles_per_slice);
-  const float hl = (0.5f / bsq_[b]) * MS_LOG2E;
-  const size_t bN = (size_t)b * N;
-  const u32x4* __restrict__ PAb = PA + (size_t)b * ntiles * H2_IMG_U4;
-
-  const int ires = min(i0 + col, N - 1);
-  f16x8 qh[8], qm[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const float* src = R + (bN + ires) * MS_D + 16 * s + 8 * h;
-    const float4 a = *reinterpret_cast<const float4*>(src);
-    const float4 c = *reinterpret_cast<const float4*>(src + 4);
-    u32x4 vh, vm;
-    H2_SPLIT_TO(a.x * H2_SX, a.y * H2_SX, vh, vm, 0);
-    H2_SPLIT_TO(a.z * H2_SX, a.w * H2_SX, vh, vm, 1);
-    H2_SPLIT_TO(c.x * H2_SX, c.y * H2_SX, vh, vm, 2);
-    H2_SPLIT_TO(c.z * H2_SX, c.w * H2_SX, vh, vm, 3);
-    qh[s] = h2_as_f16(vh);
-    qm[s] = h2_as_f16(vm);
-  }
-  f32x16 acc_o[4];
-#pragma unroll
-  for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[fb][r] = 0.f;
-  float rsum = 0.f;
-
-#define HP_STAGE(MT, BUF)                                                                  \
-  {                                                                                        \
-    _Pragma("unroll") for (int u = 0; u < 16 / NW; ++u) {                                  \
-      const int q_ = wave * (16 / NW) + u;                                                 \
-      X3_GLDS16(PAb + (size_t)(MT) * H2_IMG_U4 + q_ * 64 + lane, &ldsP[BUF][q_ * 64]);     \
-    }                                                                                      \
-  }
-  const int rowoff = col * 16, sw = x3_swz(col);
-  // k-step s of the first GEMM of the image in buffer BUF into ACC
-#define HP_G1_STEP(ACC, BUF, s)                                         \
-  {                                                                     \
-    const int slot = rowoff + ((2 * (s) + h) ^ sw);                     \
-    const f16x8 ah = h2_as_f16(ldsP[BUF][slot]);                        \
-    const f16x8 am = h2_as_f16(ldsP[BUF][H2_PIECE_U4 + slot]);          \
-    H2_MFMA(ACC, am, qh[s]);                                            \
-    H2_MFMA(ACC, ah, qm[s]);                                            \
-    H2_MFMA(ACC, ah, qh[s]);                                            \
-  }
-  // elementwise stage of D register R_ of SA (tile at j0): k 2^14 into kv[R_]
-#define HP_EW(SA, R_, MASKED)                                                      \
-  {                                                                                \
-    const float dist = __builtin_fmaf(-2.0f * H2_ISX2, SA[R_], 2.0f);              \
-    const float a2c = __builtin_amdgcn_fmed3f(-dist * hl, -MS_LIM2, MS_LIM2);      \
-    float k = __builtin_amdgcn_exp2f(a2c + 14.0f);                                 \
-    if ((MASKED) && j0 + ((R_) & 3) + 8 * ((R_) >> 2) + 4 * h >= N) k = 0.f;       \
-    kv[R_] = k;                                                                    \
-    rsum += k;                                                                     \
-  }
-#define HP_SPLIT(T, Q) H2_SPLIT_TO(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], wh[T], wm[T], Q)
-  const int li = lane & 15, rb = 4 * h + (li >> 2), cb = 16 * ((lane >> 4) & 1) + 4 * (li & 3);
-  const int sz0 = (((li >> 2) & 3) << 2) | (h & 3), sz1 = (((li >> 2) & 3) << 2) | ((h + 2) & 3);
-#define HP_TR(BASE, P_, T, W, FB)                                                               \
-  __builtin_amdgcn_ds_read_tr16_b64_v4i16((x3_lds_s16x4)(                                        \
-      (BASE) + (P_) * (H2_PIECE_U4 * 16) + (16 * (T) + 8 * (W) + rb) * 256 +                    \
-      ((((FB) * 4 + (cb >> 3)) ^ ((W) ? sz1 : sz0)) << 4) + ((cb & 7) << 1)))
-  // k-step T of the second GEMM of the image in buffer BUF
-#define HP_G2_STEP(BUF, T)                                                                      \
-  {                                                                                             \
-    const char* lbase = reinterpret_cast<const char*>(ldsP[BUF]);                               \
-    const f16x8 bh = h2_as_f16(wh[T]), bm = h2_as_f16(wm[T]);                                   \
-    _Pragma("unroll") for (int fb = 0; fb < 4; ++fb) {                                          \
-      u32x4 xc[2];                                                                              \
-      _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                        \
-        const s16x4 lo_ = HP_TR(lbase, p_, T, 0, fb), hi_ = HP_TR(lbase, p_, T, 1, fb);         \
-        const s16x8 v_ = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);             \
-        xc[p_] = __builtin_bit_cast(u32x4, v_);                                                 \
-      }                                                                                         \
-      const f16x8 xh = h2_as_f16(xc[0]), xm = h2_as_f16(xc[1]);                                 \
-      H2_MFMA(acc_o[fb], xm, bh);                                                               \
-      H2_MFMA(acc_o[fb], xh, bm);                                                               \
-      H2_MFMA(acc_o[fb], xh, bh);                                                               \
-    }                                                                                           \
-  }
-  // tile mt (buffer BI, first-GEMM result SA): [first GEMM of tile mt+1 into SB from buffer B1,
-  // interleaved with] the elementwise stage, then the second GEMM
-#define HP_TILE(SA, SB, BI, B1, NEXT, MASKED)                                      \
-  {                                                                                \
-    float kv[16];                                                                  \
-    u32x4 wh[2], wm[2];                                                            \
-    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                \
-      if (NEXT) HP_G1_STEP(SB, B1, s);                                             \
-      HP_EW(SA, 2 * s, MASKED);                                                    \
-      HP_EW(SA, 2 * s + 1, MASKED);                                                \
-      HP_SPLIT(s >> 2, s & 3);                                                     \
-    }                                                                              \
-    HP_G2_STEP(BI, 0);                                                             \
-    HP_G2_STEP(BI, 1);                                                             \
-  }
-
-  f32x16 sa, sb;
-  if (t_begin < t_end) {
-    HP_STAGE(t_begin, 0);
-    if (t_begin + 1 < t_end) HP_STAGE(t_begin + 1, 1);
-    __syncthreads();
-    if (wave_on) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) HP_G1_STEP(sa, 0, s);
-    }
-  }
-  int bi = 0;
-  for (int mt = t_begin; mt < t_end; ++mt) {
-    const int j0 = mt * 32;
-    const int b1 = bi == 2 ? 0 : bi + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-    if (mt > t_begin) __syncthreads();  // tile mt + 1 landed; every wave is done with tile mt - 1
-    if (mt + 2 < t_end) HP_STAGE(mt + 2, b2);
-    if (wave_on) {
-      const bool tail = j0 + 32 > N;
-      if (mt + 1 < t_end) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sb[r] = 0.f;
-        if (!tail) {
-          HP_TILE(sa, sb, bi, b1, true, false);
-        } else {
-          HP_TILE(sa, sb, bi, b1, true, true);
-        }
-        sa = sb;
-      } else {
-        HP_TILE(sa, sb, bi, b1, false, true);
-      }
-    }
-    bi = b1;
-  }
-#undef HP_TILE
-#undef HP_G2_STEP
-#undef HP_TR
-#undef HP_SPLIT
-#undef HP_EW
-#undef HP_G1_STEP
-#undef HP_STAGE
-  if (!wave_on) return;
-  const int ir = i0 + col;
-  if (ir < N) {
-    float* o = opart + (((size_t)b * S + slice) * N + ir) * MS_D;
-#pragma unroll
-    for (int fb = 0; fb < 4; ++fb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(o + fb * 32 + 8 * g + 4 * h) =
-            make_float4(acc_o[fb][4 * g] * 0x1p-26f, acc_o[fb][4 * g + 1] * 0x1p-26f,
-                        acc_o[fb][4 * g + 2] * 0x1p-26f, acc_o[fb][4 * g + 3] * 0x1p-26f);
-  }
-  rsum += __shfl_xor(rsum, 32, 64);
-  if (h == 0 && ir < N) rpart[((size_t)b * S + slice) * N + ir] = rsum * 0x1p-14f;
-}
-
 extern "C" size_t pn_meanshift_h2_image_bytes(int B, int N) {
   const int Np = (int)pn_align_up(N, 64);
   return (size_t)B * (Np / 32) * H2_IMG_U4 * 16;
@@ -711,22 +528,17 @@ extern "C" int pn_meanshift_h2_iter_fwd_f32(const float* q, const void* img_x, c
   PN_CHECK_ARG(B > 0 && N > 0, "pn_meanshift_h2_iter_fwd_f32: empty input");
   const int ntiles = (int)pn_align_up(N, 64) / 32;
   int tps;
-  const int fwd_waves = H2_FWD_PIPE ? H2_FWD_WAVES : 8;
-  int S = x3_slices(B, N, ntiles, fwd_waves == 8 ? 2 : 1, &tps);
+  int S = x3_slices(B, N, ntiles, 2, &tps);
   const int smax = pn_meanshift_slices(B, N);  // the scratch is sized for this many slices
   if (S > smax) {
     S = smax;
     tps = pn_cdiv(ntiles, S);
   }
-  dim3 grid(S, pn_cdiv(N, 32 * fwd_waves), B);
+  dim3 grid(S, pn_cdiv(N, 256), B);
   {
     PN_PROF("meanshift_fwd", stream);
-    if (H2_FWD_PIPE)
-      hipLaunchKernelGGL(pn_mshp_fwd_kernel, grid, dim3(64 * fwd_waves), 0, stream, q, (const u32x4*)img_x, bsq,
-                         N, ntiles, tps, opart, rpart);
-    else
-      hipLaunchKernelGGL(pn_msh_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)img_x,
-                         nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart, rpart);
+    hipLaunchKernelGGL(pn_msh_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)img_x,
+                       nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart, rpart);
   }
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart,
