@@ -116,6 +116,16 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
                                  void* img_q, void* img_gu, float* opart_q, float* opart_x, float* gq,
                                  float* gx, void* stream);
 
+/* ---- K-th largest dot product between unit vectors, fp16 x 2 matrix-core passes -----------
+ * The bandwidth statistic of src/mean_shift.py:125-137 only needs the VALUE of the K-th nearest
+ * neighbour (to 1e-5 after averaging): same engine as pn_dot_select_f32(out_val), with both
+ * distance passes on the fp16 matrix cores (scaled fp16 x 2 split, |error| ~1e-7 on the dot
+ * products).  q (B,Nq,128) unit rows; img_c = pn_meanshift_h2_split_f32 of the candidates
+ * (B,Nc,128); workspace as pn_dot_select_workspace(B,128,Nq,Nc,k,1); flags as pn_dot_select_f32. */
+int pn_dot_kth_unit_h2_f32(const float* q, int Nq, const void* img_c, int Nc, int B, int D, int k,
+                           float* out_val, int* flags, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ---- mean-shift, fp32-grade products on the fp16 matrix cores ("fp16 x 2") ---------------
  * Same contract and outputs again; every operand is scaled by a power of two into the fp16
  * range and split into two fp16 pieces, each product is formed from the three significant

@@ -38,6 +38,7 @@
 //            v = -(p * (1 + n))                                     (PointNet.py:41-59)
 //   MODE 2:  v = dot(q_i, c_j)     (mean_shift.py: 2 - 2*dot is a decreasing, exact map)
 #include "knn_common.h"
+#include "split_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -662,6 +663,180 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     PN_PROF("knn_final", stream);
     hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists,
                        cnt, Nq, p.Nqp, k, p.S, p.subcap, perm_q, perm_c, out_idx, out_val, flags);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ---- K-th largest dot product between unit vectors on the fp16 matrix cores ----------------
+// The bandwidth statistic of mean-shift (src/mean_shift.py:125-137) needs the VALUE of the K-th
+// nearest neighbour of every point, averaged over the points, to 1e-5 — not its identity.  The two
+// passes of the engine above (tile maxima, collect) are matrix-core bound at the fp32 MFMA rate;
+// here they evaluate the dot products with the scaled fp16 x 2 split of meanshift_h2.h (three
+// 32-cycle MFMAs per 16 channels instead of eight 64-cycle ones; |error| <= ~1e-7 on dot products
+// of unit vectors, far below the tolerance of the statistic and of the same size as the error of
+// an fp32 GEMM).  Candidates come as the tile images of pn_meanshift_h2_split_f32, queries as fp32
+// rows split in registers; tile maxima, thresholds, survivor lists and the final selection are
+// those of the exact engine (natural candidate order: identity permutation).
+// KIND 0: tile maxima; 1: collect survivors.  grid (slices, blocks of 256 queries, B), 512 threads.
+template <int KIND>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pn_dotsel_h2_kernel(
+    const float* __restrict__ Q, int Nq, int Nqp, const u32x4* __restrict__ PC, int Nc, int Ncp,
+    int tiles_per_slice, float* __restrict__ tilemax, const float* __restrict__ tau,
+    u64* __restrict__ lists, int* __restrict__ counts, int subcap) {
+  __shared__ __attribute__((aligned(16))) u32x4 ldsP[2][H2_IMG_U4];
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, h = lane >> 5;
+  const int q0 = (blockIdx.y * 8 + wave) * 32;
+  const bool wave_on = q0 < Nq;
+  const int ntiles = Ncp / 32;
+  const int S = gridDim.x, slice = blockIdx.x;
+  const int t_begin = slice * tiles_per_slice;
+  const int t_end = min(ntiles, t_begin + tiles_per_slice);
+  const int T16 = Ncp / 16;
+  const u32x4* __restrict__ PCb = PC + (size_t)b * ntiles * H2_IMG_U4;
+
+  // resident queries as B operands: k-step s = channels 16 s + 8 h + e
+  const int q = q0 + col;
+  const int qcl = q < Nq ? q : Nq - 1;
+  f16x8 qh[8], qm[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float* src = Q + ((size_t)b * Nq + qcl) * 128 + 16 * s + 8 * h;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 c = *reinterpret_cast<const float4*>(src + 4);
+    u32x4 vh, vm;
+    H2_SPLIT_TO(a.x * H2_SX, a.y * H2_SX, vh, vm, 0);
+    H2_SPLIT_TO(a.z * H2_SX, a.w * H2_SX, vh, vm, 1);
+    H2_SPLIT_TO(c.x * H2_SX, c.y * H2_SX, vh, vm, 2);
+    H2_SPLIT_TO(c.z * H2_SX, c.w * H2_SX, vh, vm, 3);
+    qh[s] = h2_as_f16(vh);
+    qm[s] = h2_as_f16(vm);
+  }
+  const float tq = (KIND == 1 && q < Nq) ? tau[(size_t)b * Nqp + qcl] : __builtin_inff();
+  int mycnt = 0;
+  u64* sub = lists + ((((size_t)b * Nqp + qcl) * S + slice) * 2 + h) * (size_t)subcap;
+
+#define DS_STAGE(MT, BUF)                                                                  \
+  {                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                        \
+      const int c_ = wave * 2 + u;                                                         \
+      X3_GLDS16(PCb + (size_t)(MT) * H2_IMG_U4 + c_ * 64 + lane, &ldsP[BUF][c_ * 64]);     \
+    }                                                                                      \
+  }
+  int cur = 0;
+  if (t_begin < t_end) DS_STAGE(t_begin, 0);
+  const int rowoff = col * 16, sw = x3_swz(col);
+  for (int mt = t_begin; mt < t_end; ++mt) {
+    const int j0 = mt * 32;
+    __syncthreads();  // image of tile mt landed; every wave is done with tile mt - 1
+    if (mt + 1 < t_end) DS_STAGE(mt + 1, cur ^ 1);
+    if (wave_on) {
+      f32x16 sa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+      const u32x4* __restrict__ lp = ldsP[cur];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int slot = rowoff + ((2 * s + h) ^ sw);
+        const f16x8 ah = h2_as_f16(lp[slot]);
+        const f16x8 am = h2_as_f16(lp[H2_PIECE_U4 + slot]);
+        H2_MFMA(sa, am, qh[s]);
+        H2_MFMA(sa, ah, qm[s]);
+        H2_MFMA(sa, ah, qh[s]);
+      }
+      // D[candidate = (r&3) + 8(r>>2) + 4h][query = col]
+      const bool tail = j0 + 32 > Nc;
+      if (KIND == 0) {
+        float tm = -__builtin_inff();
+        if (!tail) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sa[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tm = fmaxf(tm, j0 + (r & 3) + 8 * (r >> 2) + 4 * h < Nc ? sa[r] : -__builtin_inff());
+        }
+        if (q < Nqp) tilemax[((size_t)b * Nqp + q) * T16 + (2 * mt + h)] = tm * H2_ISX2;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = sa[r] * H2_ISX2;
+          if (j0 + row < Nc && v >= tq) {
+            if (mycnt < subcap) sub[mycnt] = knn_key(v, j0 + row);
+            ++mycnt;
+          }
+        }
+      }
+    }
+    cur ^= 1;
+  }
+#undef DS_STAGE
+  if (KIND == 1 && wave_on && q < Nqp) counts[(((size_t)b * Nqp + q) * S + slice) * 2 + h] = mycnt;
+}
+
+extern "C" int pn_dot_kth_unit_h2_f32(const float* q, int Nq, const void* img_c, int Nc, int B, int D,
+                                      int k, float* out_val, int* flags, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(q && img_c && out_val && flags, "pn_dot_kth_unit_h2_f32: null pointer");
+  PN_CHECK_ARG(D == 128, "pn_dot_kth_unit_h2_f32: embedding size %d unsupported (built for 128)", D);
+  PN_CHECK_ARG(B > 0 && Nq > 0 && Nc > 0 && k >= 1 && k <= Nc,
+               "pn_dot_kth_unit_h2_f32: bad sizes (B=%d Nq=%d Nc=%d k=%d)", B, Nq, Nc, k);
+  const KnnPlan p = knn_mfma_plan(2, B, D, Nq, Nc, k, true);
+  if (!p.fast) {
+    pn_set_error("pn_dot_kth_unit_h2_f32: shape outside the fast path (Nc/16 >= 2k, k <= %d)", KNN_CAP / 2);
+    return PN_ERR_UNSUPPORTED;
+  }
+  const KnnWs w = knn_mfma_ws(p, B, D, Nq, k, false, false);
+  PN_CHECK_ARG(workspace && workspace_bytes >= w.total, "pn_dot_kth_unit_h2_f32: workspace too small");
+  char* base = (char*)workspace;
+  float* tilemax = (float*)(base + w.tilemax);
+  float* tau = (float*)(base + w.tau);
+  int* cnt = (int*)(base + w.cnt);
+  u64* lists = (u64*)(base + w.lists);
+  const KnnPerm ident_q = knn_make_perm(Nq, true), ident_c = knn_make_perm(Nc, true);
+  PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * Nq * 4, stream));
+  // rows Nq .. Nqp-1 of tilemax / counts are never read (the tau and final kernels stop at Nq).
+  // Workgroups hold 256 queries (one per CU): fewer, longer slices than the exact engine's plan so
+  // that the grid fits one round of the 256 CUs; the sub-lists grow accordingly, inside the same
+  // allocation.
+  const int ntiles = p.Ncp / 32;
+  const long long rowblocks = (long long)B * pn_cdiv(Nq, 256);
+  int S = p.S;
+  if (rowblocks * S > 256 && rowblocks <= 256) S = (int)(256 / rowblocks);
+  S = S < 1 ? 1 : S;
+  const int tps = pn_cdiv(ntiles, S);
+  S = pn_cdiv(ntiles, tps);
+  int subcap = (int)pn_align_up(3 * k / (2 * S) + 16, 8);
+  if (2 * S * subcap > 2 * p.S * p.subcap) subcap = (2 * p.S * p.subcap) / (2 * S);
+  if (2 * S * subcap > KNN_CAP) subcap = KNN_CAP / (2 * S);
+  dim3 grid(S, pn_cdiv(Nq, 256), B);
+  {
+    PN_PROF("sel_h2_pass1_dot", stream);
+    hipLaunchKernelGGL(pn_dotsel_h2_kernel<0>, grid, dim3(512), 0, stream, q, Nq, p.Nqp, (const u32x4*)img_c,
+                       Nc, p.Ncp, tps, tilemax, (const float*)tau, lists, cnt, subcap);
+  }
+  PN_CHECK_LAUNCH();
+  {
+    PN_PROF("knn_tau", stream);
+    hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, tilemax, Nq, p.Nqp,
+                       p.Ncp / 16, k, tau);
+  }
+  PN_CHECK_LAUNCH();
+  {
+    PN_PROF("sel_h2_pass2_dot", stream);
+    hipLaunchKernelGGL(pn_dotsel_h2_kernel<1>, grid, dim3(512), 0, stream, q, Nq, p.Nqp, (const u32x4*)img_c,
+                       Nc, p.Ncp, tps, tilemax, (const float*)tau, lists, cnt, subcap);
+  }
+  PN_CHECK_LAUNCH();
+  {
+    PN_PROF("knn_final", stream);
+    hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                       p.Nqp, k, S, subcap, ident_q, ident_c, (int64_t*)nullptr, out_val, flags);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;

@@ -31,35 +31,7 @@
 // hand-over are those of meanshift_x3.h.
 // (included at the end of meanshift.hip, after meanshift_x3.h)
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-#define H2_IMG_U4 1024            // uint4 (16 B) units per 16 KiB tile image
-#define H2_PIECE_U4 512           // per piece
-#define H2_SX 4096.0f             // 2^12: unit rows
-#define H2_ISX2 0x1p-24f          // 1 / H2_SX^2
-
-struct H2Pieces {
-  uint32_t h, m;
-};
-__device__ static inline H2Pieces h2_split2(float a, float b) {
-  f32x2 v = {a, b};
-  f16x2 ph = __builtin_convertvector(v, f16x2);
-  f32x2 r = {a - (float)ph[0], b - (float)ph[1]};
-  f16x2 pm = __builtin_convertvector(r, f16x2);
-  H2Pieces o;
-  o.h = __builtin_bit_cast(uint32_t, ph);
-  o.m = __builtin_bit_cast(uint32_t, pm);
-  return o;
-}
-#define H2_SPLIT_TO(A, B, VH, VM, Q)     \
-  {                                      \
-    const H2Pieces _p = h2_split2(A, B); \
-    VH[Q] = _p.h;                        \
-    VM[Q] = _p.m;                        \
-  }
-
-__device__ static inline f16x8 h2_as_f16(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+#include "split_common.h"
 
 // 2^-(e+1) for a positive float with exponent e (value in [2^e, 2^(e+1))): the power of two that
 // brings it into [1/2, 1), limited to 2^+-100 (so that products with it stay finite; rows that
@@ -164,8 +136,6 @@ __global__ __launch_bounds__(256) void pn_msh_prep_bwd_kernel(
   if (threadIdx.x == 0)
     rhotile[(size_t)b * ntiles + tile] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
-
-#define H2_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)
 
 // PASS 0 forward       resident rows Q;      streamed X:      out[f][i] += X[j][f] K
 // PASS 1 backward/rows resident rows Q, GU;  streamed X:      out[f][i] += X[j][f] gs

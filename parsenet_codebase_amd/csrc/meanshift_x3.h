@@ -28,20 +28,10 @@
 // free (16-lane service groups of ds_read_b128; 4 rows x 4 chunks of the transpose read).
 // (included at the end of meanshift.hip: one translation unit, shared combine kernels)
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4* x3_lds_s16x4;
+#include "split_common.h"
 
 #define X3_IMG_U4 1536            // uint4 (16 B) units per 24 KiB tile image
 #define X3_PIECE_U4 512           // per piece
-
-typedef const __attribute__((address_space(1))) void* x3_gptr;
-typedef __attribute__((address_space(3))) void* x3_lptr;
-#define X3_GLDS16(G, L) __builtin_amdgcn_global_load_lds((x3_gptr)(G), (x3_lptr)(L), 16, 0, 0)
 
 // error-free split of two floats into three packed bf16 pairs (element 0 in the low half)
 struct X3Pieces {
@@ -69,8 +59,6 @@ __device__ static inline X3Pieces x3_split2(float a, float b) {
   }
 
 __device__ static inline bf16x8 x3_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
-__host__ __device__ static inline int x3_swz(int j) { return ((j & 3) << 2) | ((j >> 2) & 3); }
 
 // x (B,N,D) fp32 -> the image of every 32-point tile (rows >= N are zero).
 // One workgroup per tile; work item = one 16-byte chunk.

@@ -1,0 +1,52 @@
+// Operand-split helpers shared by the 16-bit matrix-core kernels (meanshift_x3.h, meanshift_h2.h,
+// the fp16 x 2 selection pass of knn_mfma.hip): vector typedefs, the LDS-DMA wrapper, the chunk
+// swizzle of the tile images and the scaled two-piece fp16 split.
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* x3_lds_s16x4;
+
+typedef const __attribute__((address_space(1))) void* x3_gptr;
+typedef __attribute__((address_space(3))) void* x3_lptr;
+#define X3_GLDS16(G, L) __builtin_amdgcn_global_load_lds((x3_gptr)(G), (x3_lptr)(L), 16, 0, 0)
+
+// chunk swizzle of the tile images: chunk c (8 channels) of row j is stored at c ^ x3_swz(j)
+__host__ __device__ static inline int x3_swz(int j) { return ((j & 3) << 2) | ((j >> 2) & 3); }
+
+// ---- fp16 x 2 (meanshift_h2.h has the scaling rules) ----
+#define H2_IMG_U4 1024            // uint4 (16 B) units per 16 KiB tile image
+#define H2_PIECE_U4 512           // per piece
+#define H2_SX 4096.0f             // 2^12: unit rows
+#define H2_ISX2 0x1p-24f          // 1 / H2_SX^2
+
+struct H2Pieces {
+  uint32_t h, m;
+};
+__device__ static inline H2Pieces h2_split2(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 ph = __builtin_convertvector(v, f16x2);
+  f32x2 r = {a - (float)ph[0], b - (float)ph[1]};
+  f16x2 pm = __builtin_convertvector(r, f16x2);
+  H2Pieces o;
+  o.h = __builtin_bit_cast(uint32_t, ph);
+  o.m = __builtin_bit_cast(uint32_t, pm);
+  return o;
+}
+#define H2_SPLIT_TO(A, B, VH, VM, Q)     \
+  {                                      \
+    const H2Pieces _p = h2_split2(A, B); \
+    VH[Q] = _p.h;                        \
+    VM[Q] = _p.m;                        \
+  }
+
+__device__ static inline f16x8 h2_as_f16(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+
+#define H2_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0)

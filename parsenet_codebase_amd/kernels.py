@@ -243,6 +243,28 @@ def dot_select(q, c, k, want_value):
     return out, flags
 
 
+def dot_kth_unit(q, c_image, Nc, k):
+    """K-th largest dot product between the unit rows of q (B,Nq,128) and the candidates whose
+    fp16 x 2 tile images are ``c_image`` (meanshift_h2_split): (values (B,Nq), flags) with the
+    distance passes on the fp16 matrix cores (|error| ~1e-7), or None outside the fast path."""
+    require_cuda(q)
+    q = _f32c(q, "q")
+    B, Nq, C = q.shape
+    lib = _lib.load()
+    wsz = lib.pn_dot_select_workspace(B, C, Nq, int(Nc), int(k), 1)
+    if wsz == 0 or C != 128:
+        return None
+    dev = q.device
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    flags = torch.empty((B, Nq), dtype=torch.int32, device=dev)
+    out = torch.empty((B, Nq), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn_dot_kth_unit_h2_f32(ptr(q), Nq, ptr(c_image), int(Nc), B, C, int(k), ptr(out), ptr(flags),
+                                        ptr(ws), wsz, current_stream(dev))
+    check(rc, "pn_dot_kth_unit_h2_f32")
+    return out, flags
+
+
 class MeanShiftWorkspace:
     """Scratch buffers of the mean-shift kernels for one (B,N,D) problem, allocated once per
     mean_shift call and reused by every iteration."""

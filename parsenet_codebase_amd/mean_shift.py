@@ -189,7 +189,14 @@ class MeanShift:
         # with num_samples >= N every row is used: the statistic does not depend on the order
         Kq = int(quantile * num_samples)
         Xc = X.detach().contiguous().unsqueeze(0)
-        res = K.dot_select(Xc, Xc, Kq, want_value=True) if 1 <= Kq <= Xc.shape[1] else None
+        res = None
+        if 1 <= Kq <= Xc.shape[1]:
+            if ARITH == "fp16x2" and Xc.shape[2] == 128:
+                # the statistic is a mean of K-th distances compared at 1e-5: both distance passes
+                # on the fp16 matrix cores (values to ~1e-7), same selection engine
+                res = K.dot_kth_unit(Xc, K.meanshift_h2_split(Xc), Xc.shape[1], Kq)
+            if res is None:
+                res = K.dot_select(Xc, Xc, Kq, want_value=True)
         if res is not None:
             kth_dot, flags = res
             kth_dot = kth_dot[0]

@@ -257,3 +257,24 @@ def test_full_mean_shift_partition(gpu):
     assert cg.shape == cr.shape
     assert np.array_equal(_canonical(lg.cpu().numpy()), _canonical(lr.numpy()))
     assert np.array_equal(_canonical(lr.numpy()), _canonical(lab.numpy()))
+
+
+@pytest.mark.parametrize("N,k", [(3000, 75), (10000, 250), (777, 19)])
+def test_kth_dot_on_the_fp16_cores(gpu, N, k):
+    """The bandwidth pass on the fp16 matrix cores: the K-th largest dot product of every row within
+    6e-7 of the fp64 value (the C oracle's fp32 fma chains are themselves ~5e-7 away from it; the
+    two agree to 1.5e-6), no row flagged on tie-free data."""
+    from oracle import cbind
+    from parsenet_codebase_amd import kernels
+    X, _ = _clustered(N, 6, 31 + N)
+    Xg = X.to(gpu).unsqueeze(0)
+    res = kernels.dot_kth_unit(Xg, kernels.meanshift_h2_split(Xg), N, k)
+    assert res is not None
+    val, flags = res
+    assert int(flags.sum()) == 0
+    got = val[0].cpu().numpy()
+    assert np.abs(got - cbind.kth_largest_dot(X.numpy(), k)).max() < 1.5e-6
+    if N <= 3000:
+        x64 = X.numpy().astype(np.float64)
+        truth = -np.partition(-(x64 @ x64.T), k - 1, axis=1)[:, k - 1]
+        assert np.abs(got - truth).max() < 6e-7
