@@ -33,7 +33,12 @@ struct H2Pieces {
 __device__ static inline H2Pieces h2_split2(float a, float b) {
   f32x2 v = {a, b};
   f16x2 ph = __builtin_convertvector(v, f16x2);
-  f32x2 r = {a - (float)ph[0], b - (float)ph[1]};
+  // a - float(h) (exact) as ONE v_fma_mix_f32 that reads the fp16 half in place, instead of
+  // v_cvt_f32_f16 + v_sub_f32: fma(half, -1.0f, a); op_sel picks the half, op_sel_hi marks src0 as fp16
+  const uint32_t hb = __builtin_bit_cast(uint32_t, ph);
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hb), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hb), "v"(b));
   f16x2 pm = __builtin_convertvector(r, f16x2);
   H2Pieces o;
   o.h = __builtin_bit_cast(uint32_t, ph);
