@@ -7,6 +7,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float mfma_loop(int iters, float seed) {
+#ifdef MFMA_PRIO
+  __builtin_amdgcn_s_setprio(MFMA_PRIO);
+#endif
   f32x16 acc[2];
   for (int c = 0; c < 2; ++c)
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
@@ -33,6 +36,9 @@ __device__ __forceinline__ float mfma_loop(int iters, float seed) {
 // 4: v_cvt_pk_f16_f32 (+ v_cvt_f32_f16)
 template <int KIND>
 __device__ __forceinline__ float valu_loop(int iters, float seed) {
+#ifdef VALU_PRIO
+  __builtin_amdgcn_s_setprio(VALU_PRIO);
+#endif
   float v[8];
   for (int i = 0; i < 8; ++i) v[i] = seed + i;
   for (int i = 0; i < iters; ++i) {
