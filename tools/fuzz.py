@@ -67,21 +67,31 @@ while time.time() - t0 < budget:
     for g_, w_ in zip(ga, wa):
         assert np.array_equal(g_.cpu().numpy(), w_), ("chamfer", Na, Nb)
     n["chamfer"] += 1
-    # mean-shift: the two arithmetics agree
+    # mean-shift: the three arithmetics agree (random sizes, bandwidths, gradient scales)
     Nm = int(rng.randint(5, 1200))
     X = torch.nn.functional.normalize(torch.randn(Nm, 128), dim=1)
-    bw = float(rng.uniform(0.15, 0.6))
-    w = torch.randn(Nm, 128)
+    bw = float(rng.uniform(0.1, 0.9))
+    w = torch.randn(Nm, 128) * float(10.0 ** rng.uniform(-6, 6))
     its = int(rng.randint(1, 5))
     out = {}
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", "bf16x3", "fp16x2"):
         MS.ARITH = mode
         xg = X.to(dev).requires_grad_(True)
         y = MS.mean_shift_iterations(xg, bw, its)
         (y * w.to(dev)).sum().backward()
         out[mode] = (y.detach(), xg.grad.detach())
-    dy = float((out["f32"][0] - out["bf16x3"][0]).abs().max())
-    dg = float((out["f32"][1] - out["bf16x3"][1]).abs().max() / (out["f32"][1].abs().max() + 1e-30))
-    assert dy < 2e-6 and dg < 1e-4, ("meanshift", Nm, bw, its, dy, dg)
+    for mode in ("bf16x3", "fp16x2"):
+        dy = float((out["f32"][0] - out[mode][0]).abs().max())
+        dg = float((out["f32"][1] - out[mode][1]).abs().max() / (out["f32"][1].abs().max() + 1e-30))
+        assert dy < 2e-6 and dg < 1e-4, ("meanshift", mode, Nm, bw, its, dy, dg)
+    # bandwidth statistic on the fp16 cores against the exact engine
+    if Nm >= 700:
+        MS.ARITH = "fp16x2"
+        np.random.seed(1)
+        b1 = float(MS.MeanShift().compute_bandwidth(X.to(dev), 10000, 0.002))
+        MS.ARITH = "f32"
+        np.random.seed(1)
+        b0 = float(MS.MeanShift().compute_bandwidth(X.to(dev), 10000, 0.002))
+        assert abs(b1 - b0) <= 1e-6 * abs(b0), ("bandwidth", Nm, b0, b1)
     n["ms"] += 1
 print("fuzz ok", n, "in %.0f s" % (time.time() - t0))
