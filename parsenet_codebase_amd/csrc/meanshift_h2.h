@@ -12,10 +12,10 @@
 //
 // fp16 has a 5-bit exponent, so every operand is brought into range by a power of two (exact):
 //   unit rows (X, the iterates)         x 2^12                                (|.| <= 4096)
-//   kernel values k in [0,1]            x 2^14
+//   kernel values k in [0,1]            x 2^14   (exp2 of the shifted argument)
 //   gu rows (backward)                  x ge_i 2^12, ge_i = 2^-e_i the row's own power of two
 //                                       (max_c |gu_ic| ge_i in [1/2,1))
-//   backward weights                    k (T' - c') 2^9 [x rho_i sigma in the column pass],
+//   backward weights                    (k 2^14) (T' - c') 2^-5 [x rho_i sigma in the column pass],
 //                                       T' = gu'_i . x_j, c' = c_i ge_i, |T' - c'| < 2 sqrt(128)
 //   rho_i = alpha_i / ge_i              the row's gradient magnitude; the column pass contracts
 //                                       over rows, so their scales must share one power of two:
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void pn_msh_split_kernel(const float* __restri
 // backward prologue, one workgroup per 32-row tile, one wave per row at a time (rows N .. Np-1 of
 // the images are written as zeros):
 //   gu = (gy - y (y.gy)) / ||u|| ; c = gu . u (u = y ||u||) ; alpha = 1 / (r b^2)
-//   ge = power of two normalising the row of gu ; rowsc = [c ge 2^9 | rho = alpha / ge | ge]
+//   ge = power of two normalising the row of gu ; rowsc = [c ge 2^-5 | rho = alpha / ge | ge]
 //   rhotile[b][tile] = max over the tile's rows of rho (the column pass reduces these; no atomics:
 //   10 000 same-address atomic maxima serialise to ~100 us)
 //   img_q, img_gu: the tile images of q and of gu' = gu ge (each lane owns channels 2 lane, 2 lane + 1:
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void pn_msh_prep_bwd_kernel(
     const float rho = (ibsq / r) / ge;
     if (lane == 0) {
       float* rs = rowsc + (size_t)b * 3 * N;
-      rs[i] = c * ge * 512.0f;
+      rs[i] = c * ge * 0.03125f;
       rs[N + i] = rho;
       rs[2 * N + i] = ge;
     }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void pn_msh_prep_bwd_kernel(
 //
 // R, R1       (B,N,D) fp32 resident operands (scaled and split in registers once per workgroup)
 // PA, PB      tile images of the streamed operand(s) (PB: GU', PASS 2 only); both GEMMs read them
-// rowsc       (B,3,N): c_i ge_i 2^9 | rho_i | ge_i — of the resident row (PASS 1) / streamed (PASS 2)
+// rowsc       (B,3,N): c_i ge_i 2^-5 | rho_i | ge_i — of the resident row (PASS 1) / streamed (PASS 2)
 // grid (slices, blocks of 32 NW resident indices, B), 64 NW threads: wave w owns 32 w .. 32 w + 31.
 // LDS: images double buffered: 32 KiB (PASS 0/1), 64 KiB (PASS 2); one barrier per tile.
 #define H2_WAVES(PASS) ((PASS) == 1 ? H2_ROW_WAVES : 8)
@@ -171,8 +171,7 @@ __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) voi
   const int t_begin = slice * tiles_per_slice;
   const int t_end = min(ntiles, t_begin + tiles_per_slice);
   const float bsqv = bsq_[b];
-  const float hl2 = (1.0f / bsqv) * MS_LOG2E, hl2s = hl2 * H2_ISX2;   // exponent = (S - 1) hl2
-  const float cb9 = bsqv * 512.0f;                                    // b^2 2^9 (column pass)
+  const float hl = (0.5f / bsqv) * MS_LOG2E;
   const size_t bN = (size_t)b * N;
   const size_t boff = (size_t)b * ntiles * H2_IMG_U4;
   const u32x4* __restrict__ PAb = PA + boff;
@@ -319,34 +318,37 @@ __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) voi
       tdma += U2 - U1;
 #endif
       // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col] ----
-      //   S = sa 2^-24;  k = exp2(clamp((S - 1) / b^2 log2 e));  weights: forward k 2^14,
-      //   backward k (T' - c') 2^9 [rho sigma]
+      //   S = sa 2^-24;  k 2^14 = exp2(a2c + 14);  backward weight = k 2^14 (T' - c') 2^-5
       const bool tail = j0 + 32 > N;
       float kv[16], gs[PASS == 0 ? 1 : 16];
 #define H2_EW_(R, MASKED)                                                          \
   {                                                                                \
     const int row = ((R) & 3) + 8 * ((R) >> 2) + 4 * h;                            \
-    /* exponent (S - 1) / b^2 in log2 units with ONE rounding: S = sa 2^-24 */     \
-    const float a2 = __builtin_fmaf(sa[R], hl2s, -hl2);                            \
-    float k = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2)); \
+    const float sv = sa[R];                                                        \
+    const float dist = __builtin_fmaf(-2.0f * H2_ISX2, sv, 2.0f);                  \
+    const float a2 = -dist * hl;                                                   \
+    const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);              \
+    float k = __builtin_amdgcn_exp2f(a2c + 14.0f);                                 \
     if (PASS == 0 && (MASKED) && j0 + row >= N) k = 0.f;                           \
     kv[R] = k;                                                                     \
     if (PASS == 0) rsum += k;                                                      \
-    /* (the reference zeroes the gradient where the clamp is active: with unit rows only the     \
-       lower one can be, and there k <= e^-75 — the weight flushes to zero in the fp16 split) */ \
-    if (PASS == 1) gs[PASS == 1 ? (R) : 0] = k * __builtin_fmaf(ta[R], 0x1p-15f, -c_res); \
-    if (PASS == 2) {                                                               \
-      const float ka = k * (lds_sc[cur][32 + row] * sigma);   /* k rho_i sigma */  \
-      gs[PASS == 2 ? (R) : 0] = ka * __builtin_fmaf(ta[R], 0x1p-15f, -lds_sc[cur][row]); \
-      kv[R] = ka * cb9;                                       /* weight of the GU' term */ \
+    if (PASS != 0) {                                                               \
+      const float cc = PASS == 1 ? c_res : lds_sc[cur][row];                       \
+      float g = k * __builtin_fmaf(ta[R], 0x1p-29f, -cc);                          \
+      if (PASS == 2) {                                                             \
+        const float aa = lds_sc[cur][32 + row] * sigma;                            \
+        g *= aa;                                                                   \
+        kv[R] = k * (aa * (bsqv * 0x1p-5f)); /* weight of the GU' term */          \
+      }                                                                            \
+      asm("" : "+v"(g));          /* keep the select a v_cndmask, not a branch */  \
+      gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                               \
     }                                                                              \
   }
 #define H2_EW(R) H2_EW_(R, false)
 #define H2_SPLIT_W(T, Q)                                                                      \
   {                                                                                           \
     if (PASS == 0) {                                                                          \
-      const f32x2 k2 = f32x2{kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1]} * 16384.0f;   \
-      H2_SPLIT_TO(k2[0], k2[1], wh[T], wm[T], Q);                                             \
+      H2_SPLIT_TO(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], wh[T], wm[T], Q);        \
     } else {                                                                                  \
       const int e = PASS == 0 ? 0 : 8 * (T) + 2 * (Q);                                        \
       H2_SPLIT_TO(gs[e], gs[e + (PASS == 0 ? 0 : 1)], wh[T], wm[T], Q);                      \
@@ -464,7 +466,7 @@ __attribute__((amdgpu_waves_per_eu(H2_WAVES(PASS) / 4, H2_WAVES(PASS) / 4))) voi
   }
   if (PASS == 0) {
     rsum += __shfl_xor(rsum, 32, 64);
-    if (h == 0 && ir < N) rpart[((size_t)b * S + slice) * N + ir] = rsum;
+    if (h == 0 && ir < N) rpart[((size_t)b * S + slice) * N + ir] = rsum * 0x1p-14f;
   }
 }
 
