@@ -237,10 +237,10 @@ class MeanShift:
             membership = torch.empty(N, dtype=torch.int64, device=X.device)
             for s in range(0, N, 2048):
                 membership[s:s + 2048] = _first_argmax(X[s:s + 2048] @ centers.t(), 1)
-        uniques, counts_ = np.unique(membership.cpu().numpy(), return_counts=True)
-        num_mem_cluster = torch.zeros(N, device=X.device)
-        uq = h2d(uniques, X.device)
-        num_mem_cluster[uq] = h2d(counts_.astype(np.float32), X.device)
+        # members per centre and the occupied centres in ascending order (np.unique + return_counts of
+        # the reference) without leaving the device
+        num_mem_cluster = torch.bincount(membership, minlength=N).to(torch.float32)
+        uq = torch.nonzero(num_mem_cluster).flatten()
         # neighbours (distance < b, not b^2, as in the reference) of the occupied centres only
         dist = 2.0 - 2.0 * centers[uq] @ centers.t()
         score = (dist < b).float() * num_mem_cluster.reshape(1, -1)
