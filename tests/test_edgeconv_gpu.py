@@ -60,6 +60,8 @@ def _norm(kind, Cout, groups):
     ("bn", 1, 256, 512, 40, 10, 0, True),
     ("bn", 2, 64, 128, 90, 10, 0, False),
     ("gn", 1, 5, 40, 60, 6, 4, True),      # generic-width kernel
+    ("gn", 2, 6, 64, 10000, 12, 2, True),  # BASELINE point count: transposed graph through the LDS histograms
+    ("gn", 1, 3, 64, 16500, 4, 2, True),   # more points than LDS counters: global-atomic counting sort
 ])
 def test_edge_conv_norm_max_fwd_bwd(gpu, kind, B, C, Cout, N, k, groups, train):
     from oracle import ref_torch as R
