@@ -56,7 +56,9 @@ struct PnProfScope {
   PnProfScope(const char* name, hipStream_t st) : s(st) { pn_prof_begin(name, st, &token); }
   ~PnProfScope() { pn_prof_end(s, token); }
 };
-#define PN_PROF(name, stream) PnProfScope _pn_prof_scope_##__LINE__(name, stream)
+#define PN_CAT2(a, b) a##b
+#define PN_CAT(a, b) PN_CAT2(a, b)
+#define PN_PROF(name, stream) PnProfScope PN_CAT(_pn_prof_scope_, __LINE__)(name, stream)
 
 static inline size_t pn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int pn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -913,11 +913,13 @@ class Evaluation:
         ``fitting_loss(prefetched=[handle])``.  Lets a caller run shape b+1's iterations on a side
         stream underneath the launch- and sync-bound fitting stage of shape b."""
         emb = torch.nn.functional.normalize(embedding_b, p=2, dim=-1)
+        if emb.shape[0] > 10000:      # the bandwidth would depend on the shuffle: synchronous path
+            return {"emb": emb, "new_X": None, "bw": None, "flag": None}
         new_X, bw, flag = self.ms.shift_async(emb, 10000, quantile, iterations)
         return {"emb": emb, "new_X": new_X, "bw": bw, "flag": flag}
 
     def _clusters(self, emb_b, quantile, iterations, handle):
-        if handle is not None:
+        if handle is not None and handle["new_X"] is not None:
             done = self.ms.finish(handle["emb"], handle["new_X"], handle["bw"], handle["flag"])
             if done is not None:
                 _, center, bandwidth, cluster_ids = done

@@ -11,11 +11,14 @@ from . import kernels as K
 from ._lib import h2d, require_cuda
 
 
-# Arithmetic of the two GEMMs per tile: "fp16x2" (scaled 2-way fp16 split, three piece products),
-# "bf16x3" (error-free 3-way bf16 split, six piece products) — both on the 16-bit matrix cores with
-# fp32 accumulation and errors below those of an fp32 GEMM — or "f32" (v_mfma_f32_32x32x2_f32,
-# exact fma chains).  PARSENET_MS_ARITH overrides.
-ARITH = os.environ.get("PARSENET_MS_ARITH", "fp16x2")
+# Arithmetic of the two GEMMs per tile.  Default "bf16x3": every fp32 operand is split WITHOUT
+# error into three bf16 pieces (3 x 8 = 24 significand bits) and the six piece products above
+# 2^-25 relative size are accumulated in fp32 on the bf16 matrix cores — an fp32 dot product in
+# another summation order, i.e. the reference's precision.  "f32": v_mfma_f32_32x32x2_f32, exact
+# fma chains.  "fp16x2" (opt-in): scaled 2-way fp16 split, three piece products, 22 significand
+# bits per operand — NARROWER than fp32; faster, never the default, and bench.py labels it.
+# PARSENET_MS_ARITH overrides.
+ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 _SPLIT = {"fp16x2": (K.meanshift_h2_split, K.meanshift_h2_iter_fwd, K.meanshift_h2_iter_bwd),
           "bf16x3": (K.meanshift_x3_split, K.meanshift_x3_iter_fwd, K.meanshift_x3_iter_bwd)}
 
@@ -123,17 +126,25 @@ class MeanShift:
         that it can be queued on a side stream while the host drives another shape's fitting
         stage.  Returns (new_X, bw, flag); flag (0-dim tensor) > 0 means the bandwidth selection met
         massive ties and the caller must use ``mean_shift`` instead (checked in ``finish``)."""
+        if num_samples < X.shape[0]:
+            raise ValueError("shift_async needs num_samples >= N: the bandwidth then does not depend on the "
+                             "shuffle, which is what lets ``finish`` draw it at the reference's place in "
+                             "numpy's RNG stream")
         with torch.no_grad():
-            bw, flag = self.compute_bandwidth(X, num_samples, quantile, defer_flags=True)
+            bw, flag = self.compute_bandwidth(X, num_samples, quantile, defer_flags=True, defer_shuffle=True)
             bw = torch.clamp(bw, min=0.003)
         new_X, _ = self.mean_shift_(X, b=bw, iterations=iterations)
         return new_X, bw, flag
 
     def finish(self, X, new_X, bw, flag=None):
         """Stage 2: non-maximum suppression.  Returns (new_X, center, bw, labels) like
-        ``mean_shift``, or None if stage 1 has to be redone on the synchronous path."""
+        ``mean_shift``, or None if stage 1 has to be redone on the synchronous path.  The shuffle
+        that ``mean_shift`` owes numpy's RNG (src/mean_shift.py:121-122) is drawn HERE, i.e. when the
+        caller turns to this shape — shape by shape like the reference, however early stage 1 was
+        queued; a redo on the synchronous path draws its own."""
         if flag is not None and int(flag) > 0:
             return None
+        np.random.shuffle(np.arange(X.shape[0]))
         with torch.no_grad():
             _, indices, new_labels = self.nms(new_X, X, b=bw)
         return new_X, new_X[indices], bw, new_labels
@@ -175,7 +186,7 @@ class MeanShift:
         return self.kernel_between(X, X, "gaussian" if kernel_type == "gaussian" else "epa", bw)
 
     # -- src/mean_shift.py:115-137 -------------------------------------------------------
-    def compute_bandwidth(self, X, num_samples, quantile, defer_flags=False):
+    def compute_bandwidth(self, X, num_samples, quantile, defer_flags=False, defer_shuffle=False):
         """Mean over rows of the K-th smallest distance sqrt(2 - 2 x_i.x_j), K = int(quantile *
         num_samples).  Consumes numpy's RNG exactly like the reference (one shuffle of N).
         ``defer_flags``: do not look at the selection kernel's tie flags on the host (that is a
@@ -183,7 +194,8 @@ class MeanShift:
         require_cuda(X)
         N = X.shape[0]
         L = np.arange(N)
-        np.random.shuffle(L)
+        if not (defer_shuffle and num_samples >= N):   # see ``finish``
+            np.random.shuffle(L)
         if num_samples < N:
             X = X[h2d(L[0:num_samples], X.device)]
         # with num_samples >= N every row is used: the statistic does not depend on the order

@@ -78,6 +78,43 @@ class TrainConfig:
         return out
 
 
+def model_name(cfg, kind):
+    """The checkpoint stem the reference's scripts build from ``model_path``:
+    segmentation / e2e (train_parsenet.py:28-35, train_parsenet_e2e.py:30-37) fill
+    (batch_size, lr, num_train, num_test, loss_weight, mode); the SplineNet scripts
+    (train_open_splines.py:33-42, train_closed_control_points.py:29-38) fill
+    (mode, num_points, loss_weight, batch_size, lr, num_train, num_test, loss_weight).
+    ``str.format`` ignores surplus positional arguments, so templates with fewer fields work too."""
+    if kind == "spline":
+        args = (cfg.mode, cfg.num_points, cfg.loss_weight, cfg.batch_size, cfg.lr, cfg.num_train, cfg.num_test,
+                cfg.loss_weight)
+    else:
+        args = (cfg.batch_size, cfg.lr, cfg.num_train, cfg.num_test, cfg.loss_weight, cfg.mode)
+    return cfg.model_path.format(*args)
+
+
+def sync_module_from_rank0(*modules):
+    """Every rank must hold ONE set of weights (the reference's DataParallel replicates rank 0's
+    module each step, train_parsenet.py:90-91): broadcast all parameters and buffers from rank 0
+    as one flat fp32 collective (plus one per other dtype).  No-op on a single rank."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    tensors = []
+    for m in modules:
+        tensors += [p.data for p in m.parameters()] + [b.data for b in m.buffers()]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=0)
+        o = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[o:o + n].view_as(t))
+            o += n
+
+
 class SyntheticSegments:
     """Stand-in for dataset_segments.Dataset: endless generators of analytic shapes."""
 
@@ -202,12 +239,13 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000):
     rank, world, dev = dp.init_from_env()
     device = device or dev
     model = build_parsenet(cfg, device)
+    sync_module_from_rank0(model)
     bucket = dp.FlatGradBucket(model.parameters())
     optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
     scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=4, min_lr=1e-4)
     data = data or open_dataset(cfg, cfg.batch_size, rank, augment=True)
     train_it, val_it = data.get_train(), data.get_val()
-    name = cfg.model_path.format(cfg.mode)
+    name = model_name(cfg, "seg")
     prev_test_loss, history = 1e4, []
     num_iter = 3     # gradient accumulation (train_parsenet.py:155)
     steps = cfg.max_steps_per_epoch or cfg.num_train // cfg.batch_size
@@ -268,7 +306,7 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000):
     return history
 
 
-def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, keep_train=7000, keep_val=8000):
+def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, keep_train=8000, keep_val=8000):
     """train_parsenet_e2e.py:164-470: batch 1 per micro-step, 5 micro-steps per optimizer step,
     norm layers frozen (model.eval()), loss = triplet + NLL + residual (lamb 0.1); a fitting
     exception skips the whole step ("mistake"); validation through fitting_loss(eval=True, lamb 1)
@@ -277,15 +315,17 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
     rank, world, dev = dp.init_from_env()
     device = device or dev
     model = build_parsenet(cfg, device)
-    bucket = dp.FlatGradBucket(model.parameters())
-    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
-    scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=10, min_lr=1e-4)
     if evaluation is None:   # no pretrained SplineNets ship with the reference: frozen random init
         evaluation = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1).to(device),
                                 open_path=DGCNNControlPoints(20, num_points=10, mode=0).to(device))
+    # one set of weights on every rank, the frozen SplineNets included
+    sync_module_from_rank0(model, evaluation.fitter.closed_control_decoder, evaluation.fitter.open_control_decoder)
+    bucket = dp.FlatGradBucket(model.parameters())
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=10, min_lr=1e-4)
     data = data or open_dataset(cfg, 1, rank, augment=False)
     train_it, val_it = data.get_train(), data.get_val()
-    name = cfg.model_path.format(cfg.mode)
+    name = model_name(cfg, "seg")
     prev_test_loss, history = 1e4, []
     lamb, num_iter = 0.1, 5
     model.eval()      # no updates to the norm layers (train_parsenet_e2e.py:162)
@@ -399,7 +439,8 @@ def train_splinenet(cfg, closed=False, device=None, log=print):
     step = SplineNetStep(device, closed=closed, batch=B, num_points=2000, first_shape=rank * 100000, lr=cfg.lr,
                          loss_weight=cfg.loss_weight)
     scheduler = ReduceLROnPlateau(step.opt, factor=0.5, patience=10, min_lr=3e-5)
-    name = cfg.model_path.format(int(closed))
+    sync_module_from_rank0(step.model)
+    name = model_name(cfg, "spline")
     steps = cfg.max_steps_per_epoch or cfg.num_train // B
     prev, history = 1e8, []
     shape_id = 0
@@ -408,9 +449,11 @@ def train_splinenet(cfg, closed=False, device=None, log=print):
     if cfg.dataset:   # the reference's patch files (points, controlpoints), anisotropic canonicalisation
         from .data import DataSetControlPointsPoisson
         fn = None
+        if os.path.isfile(cfg.dataset):     # the reference's configs name the file itself
+            fn = cfg.dataset
         for ext in (".npz", ".h5"):
             cand = os.path.join(cfg.dataset, ("closed_splines" if closed else "open_splines") + ext)
-            fn = cand if os.path.exists(cand) else fn
+            fn = cand if (fn is None and os.path.exists(cand)) else fn
         if fn is None:
             raise FileNotFoundError("no %s_splines.npz / .h5 under %s" % ("closed" if closed else "open", cfg.dataset))
         ds = DataSetControlPointsPoisson(fn, B, splits={"train": cfg.num_train, "val": cfg.num_val,

@@ -143,8 +143,38 @@ def _worker(rank, world, port, out):
     m = _mean_over_ranks(1.0 + rank, dev)                   # (1 + 2) / 2
     n = _mean_over_ranks(float("nan") if rank == 0 else 4.0, dev)
     ok = ok and abs(m - 1.5) < 1e-12 and abs(n - 4.0) < 1e-12
+    # one set of weights on every rank (the reference's DataParallel): rank-dependent init, then
+    # sync_module_from_rank0 -> all ranks equal rank 0's parameters AND buffers
+    from parsenet_codebase_amd.trainer import sync_module_from_rank0
+    torch.manual_seed(500 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    net[1].running_mean.add_(rank + 1.0)
+    sync_module_from_rank0(net)
+    state = torch.cat([t.reshape(-1).double() for t in list(net.parameters()) + list(net.buffers())])
+    both = [torch.zeros_like(state) for _ in range(w)]
+    dist.all_gather(both, state)
+    ok = ok and torch.equal(both[0], both[1]) and float(net[1].running_mean[0]) == 1.0
     out[rank] = bool(ok)
     dist.destroy_process_group()
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher environment starts two ranks as children
+    (torch.distributed.run) and rank 0 reports the world size it observed."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["world_size_observed"] == 2
+    # a launcher that started another number of ranks than --gpus is an error, not a warning
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                       capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0
 
 
 def test_flat_gradient_bucket_allreduce_gloo_world2():
@@ -199,6 +229,24 @@ mode = 5
     assert (c.num_train, c.num_test, c.epochs, c.batch_size, c.mode, c.patience) == (24000, 4000, 100, 1, 5, 8)
     assert c.lr == 1e-4 and c.loss_weight == 100.0 and c.normals is True
     assert c.model_path == "train_parsenet_e2e_{}" and c.pretrain_model_path == "parsenet_with_normals.pth"
+
+
+def test_checkpoint_names_of_the_reference_config_templates():
+    """The ``model_path`` templates of the reference's configs/*.yml carry 6 (segmentation, e2e) or 8
+    (SplineNet) fields, filled as its scripts do (train_parsenet.py:28-35, train_open_splines.py:33-42)."""
+    from parsenet_codebase_amd.trainer import TrainConfig, model_name
+    c = TrainConfig(batch_size=2, lr=0.01, num_train=24000, num_test=4000, loss_weight=100.0, mode=5)
+    c.model_path = "train_parsenet_{}_lr_{}_trsz_{}_tsz_{}_wght_{}_mode_{}"
+    assert model_name(c, "seg") == "train_parsenet_2_lr_0.01_trsz_24000_tsz_4000_wght_100.0_mode_5"
+    c.model_path = "train_parsenet_e2e_{}_lr_{}_trsz_{}_tsz_{}_wght_{}_mode_{}"
+    assert model_name(c, "seg").startswith("train_parsenet_e2e_2_lr_0.01_")
+    s = TrainConfig(batch_size=36, lr=0.001, num_train=3200, num_test=3000, loss_weight=0.9, mode=0, num_points=700)
+    s.model_path = "temp_{}_{}_{}_bt_{}_lr_{}_trsz_{}_tsz_{}_wght_{}"
+    assert model_name(s, "spline") == "temp_0_700_0.9_bt_36_lr_0.001_trsz_3200_tsz_3000_wght_0.9"
+    s.model_path = "train_closed_spline_{}_{}_{}_bt_{}_lr_{}_trsz_{}_tsz_{}_wght_{}"
+    assert model_name(s, "spline").startswith("train_closed_spline_0_700_0.9_bt_36_")
+    s.model_path = "one_field_{}"
+    assert model_name(s, "spline") == "one_field_0" and model_name(s, "seg") == "one_field_36"
 
 
 def test_host_iou_matrix_matches_one_hot_products_on_cpu():

@@ -43,12 +43,46 @@ def bench_knn64():
 
 def bench_chamfer():
     dev = torch.device("cuda:0")
-    for (B, Na, Nb) in [(1, 10000, 10000), (32, 1600, 700), (1, 900, 2000)]:
+    for (B, Na, Nb) in [(1, 10000, 10000), (32, 1600, 700), (1, 900, 2000), (8, 900, 1200)]:
         a = torch.rand(B, Na, 3, device=dev)
         b = torch.rand(B, Nb, 3, device=dev)
         ms = timeit(lambda: kernels.chamfer_nn(a, b))
-        print("chamfer B=%d %dx%d: %.3f ms  %.2f TFLOP/s (8 flop/pair, both sides)" %
-              (B, Na, Nb, ms, 2 * 8.0 * B * Na * Nb / ms / 1e9))
+        # roof of this kernel: fp32 VALU issue.  8 arithmetic instructions per pair (3 sub, 3 mul,
+        # 2 add, unfused like the reference's elementwise path); 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+        pairs = 2.0 * B * Na * Nb
+        print("chamfer B=%d %dx%d: %.3f ms  %.2f TFLOP/s (8 flop/pair, both sides) = %.1f %% of the 78.6 Tinstr/s "
+              "VALU issue roof; %.1f GB/s of algorithmic HBM bytes" %
+              (B, Na, Nb, ms, 8.0 * pairs / ms / 1e9, 100 * 8.0 * pairs / ms / 1e9 / 78.6,
+               (12.0 * B * (Na + Nb) + 12.0 * B * (Na + Nb)) / ms / 1e6))
+
+
+def bench_edge():
+    """The API form of get_graph_feature (src/PointNet.py:72-103): cat(x_j - x_i, x_i) materialised,
+    and the fused gather-reduce the networks use instead.  Algorithmic bytes per SURVEY 8(d)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for (B, N, k, C) in [(4, 10000, 80, 64), (4, 10000, 80, 6), (32, 700, 10, 64)]:
+        xt = torch.randn(B, N, C, device=dev)
+        idx = torch.randint(0, N, (B, N, k), device=dev, dtype=torch.int64)
+        ms = timeit(lambda: kernels.edge_feature_fwd(xt, idx))
+        nbytes = 4.0 * B * N * C + 8.0 * B * N * k + 4.0 * B * N * k * 2 * C
+        print("edge_feature_fwd B=%d N=%d k=%d C=%d: %.3f ms  %.2f GB algorithmic -> %.0f GB/s (%.1f %% of 8 TB/s)"
+              % (B, N, k, C, ms, nbytes / 1e9, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
+        g = torch.randn(B, N, k, 2 * C, device=dev)
+        ms = timeit(lambda: kernels.edge_feature_bwd(g, idx))
+        nb = 4.0 * B * N * C + 8.0 * B * N * k + 4.0 * B * N * k * 2 * C
+        print("edge_feature_bwd B=%d N=%d k=%d C=%d: %.3f ms  -> %.0f GB/s" % (B, N, k, C, ms, nb / ms / 1e6))
+    # real kNN graph (spatially coherent neighbours) for the fused kernel
+    B, N, k, Cout = 4, 10000, 80, 64
+    x = torch.randn(B, 64, N, device=dev)
+    idx = kernels.knn(x, k, "feature")
+    PQ = torch.randn(B, N, 2 * Cout, device=dev)
+    gamma = torch.ones(Cout, device=dev)
+    ms = timeit(lambda: kernels.edgeconv_reduce_fwd(PQ, idx, gamma, 2, True))
+    gathered = 4.0 * B * N * k * Cout
+    hbm = 4.0 * B * N * 2 * Cout + 8.0 * B * N * k + 9.0 * B * N * Cout
+    print("edgeconv_reduce_fwd B=%d N=%d k=%d Cout=%d: %.3f ms  gathered rows %.0f GB/s (L2), HBM-algorithmic %.0f GB/s"
+          % (B, N, k, Cout, ms, gathered / ms / 1e6, hbm / ms / 1e6))
 
 
 def bench_meanshift():
