@@ -245,6 +245,80 @@ int pn_chamfer_nn_f32(const float* a, const float* b, int B, int Na, int Nb, flo
                       int64_t* argA, float* minB, int64_t* argB, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Ragged batch: item i is a[offA[i] .. offA[i+1]) against b[offB[i] .. offB[i+1]) of two
+ * concatenated clouds (totalA / totalB rows; offsets: B+1 device ints; maxA / maxB = largest item,
+ * used to size the grid).  Outputs are concatenated like the inputs, indices are local to the
+ * item.  Used for the spline segments of a step (src/primitives.py:204-206: 900 | 930 samples
+ * against a different number of ground-truth points per segment) in ONE launch per direction. */
+size_t pn_chamfer_nn_ragged_workspace(int totalA, int totalB);
+int pn_chamfer_nn_ragged_f32(const float* a, const int* offA, int totalA, int maxA, const float* b,
+                             const int* offB, int totalB, int maxB, int B, float* minA,
+                             int64_t* argA, float* minB, int64_t* argB, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* ---- batched per-segment fitting (pn_weighted_moments, pn_small_lstsq,
+ *      pn_bspline_eval) ------------------------------------------------------------------
+ * Replace the serial per-segment Python loop of src/primitive_forward.py:925-1047
+ * (fit_one_shape_torch), the four fits :708-843 (Fit.fit_{plane,sphere,cylinder,cone}_torch),
+ * src/fitting_utils.py:32-85 (LeastSquares.lstsq, best_lambda), :385-455 (CustomSVD and its
+ * custom backward), src/primitives.py:58-206 (ComputePrimitiveDistance) and the per-segment
+ * loop of src/residual_utils.py:154-208 — for ALL analytic segments of ALL shapes of a step.
+ *
+ * Segment table (device int32 arrays of S entries): seg_shape = shape index b, seg_row = row of
+ * the membership matrix W (B,Cp,N) holding the segment's soft weights, seg_type = 0 plane,
+ * 1 sphere, 2 cylinder, 3 cone, seg_rows = number of fitted points (rank tolerance).  The fit
+ * uses the points stride*j of the shape (fit_one_shape_torch keeps every 4th point for
+ * analytic primitives) with weight W[b,row,stride*j] + eps.
+ *
+ *   pn_weighted_moments_f64   partial (S, pn_weighted_moments_chunks(), pn_weighted_moments_count())
+ *                             fp64: sums of w^e * monomial(p, n), e <= 3, degree <= 3 (table in
+ *                             csrc/fit_math.h) — everything the four fits need, one pass.
+ *   pn_primitive_fit_f64      (the "pn_small_lstsq" of the survey, fused with the 3x3
+ *                             eigen-decomposition) moments -> params (S,16) fp64 and the Jacobian
+ *                             jac (S,16,64) = d params / d moments; 3x3 Jacobi, normal equations,
+ *                             torch.matrix_rank-style rank test and the 1e-6*10^i ridge search on the
+ *                             device.  params: plane a(3),d | sphere c(3),r | cylinder axis(3),c(3),r |
+ *                             cone apex(3),axis(3),theta; slot 15 = ridge lambda used.  status bits:
+ *                             1 = non-finite / no full-rank system (the reference raises),
+ *                             2 = null cone (cond > 1e5: zero cone, no gradient), 4 = NaN residual.
+ *   pn_cone_angle_f64         second pass of fit_cone_torch: theta (params slot 6), its Jacobian
+ *                             row, and cone_direct (S) = factor of the direct path d theta / d w_i.
+ *   pn_primitive_residual_f32 mean (squared, or guard_sqrt'ed if sqrt_flag) distance of the
+ *                             ground-truth points gt_idx[gt_off[s] .. gt_off[s+1]) (indices into
+ *                             the shape's points) to the primitive: dist (S) fp32, and
+ *                             dparam (S,16) fp64 = d dist / d params.
+ *   pn_weighted_moments_bwd_f32  gW (B,Cp,N) fp32 (zero-initialised by the caller) receives
+ *                             d loss / d W at the fitted points given g_dist (S) = d loss / d dist. */
+int pn_weighted_moments_chunks(void);
+int pn_weighted_moments_count(void);
+int pn_weighted_moments_f64(const float* P, const float* Nrm, const float* W, int B, int N, int Cp,
+                            int stride, float eps, const int* seg_shape, const int* seg_row, int S,
+                            double* partial, void* stream);
+int pn_primitive_fit_f64(const double* partial, const int* seg_type, const int* seg_rows, int S,
+                         double* params, double* jac, int* status, void* stream);
+int pn_cone_angle_f64(const float* P, const float* W, int B, int N, int Cp, int stride, float eps,
+                      const int* seg_shape, const int* seg_row, const int* seg_type,
+                      const int* status, int S, double* params, double* jac, double* cone_direct,
+                      void* stream);
+int pn_primitive_residual_f32(const float* P, int B, int N, const int* seg_shape, const int* seg_type,
+                              const int* gt_off, const int* gt_idx, int S, const double* params,
+                              int sqrt_flag, float* dist, double* dparam, int* status, void* stream);
+int pn_weighted_moments_bwd_f32(const float* P, const float* Nrm, const float* W, int B, int N, int Cp,
+                                int stride, float eps, const int* seg_shape, const int* seg_row,
+                                const int* seg_type, int S, const float* g_dist, const double* dparam,
+                                const double* jac, const double* params, const double* cone_direct,
+                                float* gW, void* stream);
+
+/* B-spline surface evaluation, src/fitting_utils.py:609-622 sample_points_from_control_points_:
+ * out[s,u,v,:] = A_s (sum_ij nu[u,i] nv[v,j] ctrl[s,i,j,:]) + t_s with nu (gu,cu), nv (gv,cv),
+ * ctrl (S,cu,cv,3); affine (S,3,4) = [A_s | t_s] or NULL (the de-standardisation of
+ * src/primitive_forward.py:60-72 folded in); wrap = 1 appends the first u-row again (closed
+ * splines, :377-385): out (S,(gu+wrap)*gv,3).  _bwd: gctrl (S,cu,cv,3) from gout. */
+int pn_bspline_eval_f32(const float* nu, const float* nv, const float* ctrl, const float* affine, int S,
+                        int gu, int gv, int cu, int cv, int wrap, float* out, void* stream);
+int pn_bspline_eval_bwd_f32(const float* nu, const float* nv, const float* gout, const float* affine,
+                            int S, int gu, int gv, int cu, int cv, int wrap, float* gctrl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

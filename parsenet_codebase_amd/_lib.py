@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 4   # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 5   # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -82,6 +82,25 @@ SIGNATURES = {
     "pn_chamfer_nn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_chamfer_nn_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_chamfer_nn_ragged_workspace": (c_size_t, [c_int, c_int]),
+    "pn_chamfer_nn_ragged_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_weighted_moments_chunks": (c_int, []),
+    "pn_weighted_moments_count": (c_int, []),
+    "pn_weighted_moments_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pn_primitive_fit_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_cone_angle_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_primitive_residual_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_weighted_moments_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_bspline_eval_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p, c_void_p]),
+    "pn_bspline_eval_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

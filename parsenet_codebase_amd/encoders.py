@@ -105,7 +105,9 @@ class DGCNNControlPoints(nn.Module):
             feats.append(x)
         x = F.leaky_relu(batch_norm_1d(conv1x1(torch.cat(feats, dim=1), self.conv5[0]), self.bn5), 0.2)
         if isinstance(weights, torch.Tensor):
-            x = x * weights.reshape((1, 1, -1))
+            # the reference reshapes to (1,1,-1) (one segment per call); a (B,n) matrix weights
+            # every item of a batch of segments with its own memberships
+            x = x * weights.reshape((batch_size if weights.numel() == batch_size * x.shape[2] else 1, 1, -1))
         # max over the points (F.adaptive_max_pool1d(x, 1) in the reference; torch's pooling kernel
         # takes 0.5 ms on a 1024 x 5000 input, the reduction 20 us)
         x = x.max(dim=2, keepdim=True)[0]

@@ -894,6 +894,12 @@ class Evaluation:
             for p in net.parameters():
                 p.requires_grad = False
         self.ms = MeanShift()
+        # batched training path (fitting_batch.py): length of the padded list of occupied centres
+        # in the non-maximum suppression (adapted from the previous call, no synchronisation), and
+        # counters for bench.py's ``segments_per_shape``
+        self.batched = True
+        self.occupied_cap = 1024
+        self.stats = {"shapes": 0, "clusters": 0, "fitted": 0}
 
     def guard_mean_shift(self, embedding, quantile, iterations, kernel_type="gaussian"):
         """Re-run with a 1.2x larger quantile while more than 49 clusters come out."""
@@ -934,6 +940,9 @@ class Evaluation:
         arrays; primitives_log_prob (B,10,N).  Returns ([Loss, geometric mean, spline mean, s_iou,
         p_iou], [parameters, cluster ids, weights]) of the last shape, like the reference (which
         is written for B = 1).  ``prefetched``: per-shape handles of ``prefetch_clustering``."""
+        if self.batched and not eval and prefetched is None and not debug:
+            return self.fitting_losses(embedding, points, normals, labels, primitives, primitives_log_prob,
+                                       quantile=quantile, iterations=iterations, lamb=lamb)[-1]
         batch_size = embedding.shape[0]
         if prefetched is None:
             embedding = torch.nn.functional.normalize(embedding, p=2, dim=2)
@@ -963,6 +972,17 @@ class Evaluation:
                                                            prim_pred[b], primitives[b], weights.T)
             loss = loss + [s_iou, p_iou]
         return loss, [parameters, cluster_ids.data.cpu().numpy(), weights]
+
+    def fitting_losses(self, embedding, points, normals, labels, primitives, primitives_log_prob,
+                       quantile=0.125, iterations=5, lamb=1.0):
+        """Training-mode ``fitting_loss`` of EVERY shape of the batch (the reference's function
+        returns the last shape's): a list of ([Loss, geometric mean, spline mean, s_iou, p_iou],
+        [parameters, cluster ids, weights]), computed stage by stage over all shapes and segments
+        (fitting_batch.py) instead of shape by shape and segment by segment."""
+        from .fitting_batch import fitting_losses_train
+        require_cuda(embedding, points, normals)
+        return fitting_losses_train(self, embedding, points, normals, labels, primitives, primitives_log_prob,
+                                    quantile, iterations, lamb)
 
     def residual_train_mode(self, points, normals, labels, cluster_ids, primitives, weights, bw, lamb=1.0):
         if not isinstance(cluster_ids, np.ndarray):

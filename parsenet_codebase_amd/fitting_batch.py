@@ -1,0 +1,503 @@
+"""The training-mode fitting stage of a whole batch of shapes in a few dozen launches.
+
+Same arithmetic and decisions as the per-segment functions of ``fitting.py`` — which follow
+src/residual_utils.py:86-208 (Evaluation.fitting_loss / residual_train_mode / separate_losses),
+src/primitive_forward.py:925-1047 (fit_one_shape_torch), :708-843 (Fit.fit_*_torch), :34-102 /
+:347-415 (SplineNet forward wrappers), src/fitting_utils.py:306-325 (weights_normalize), :493-553
+(standardize_point_torch), src/mean_shift.py:19-179 and src/primitives.py:18-206 — but organised
+by STAGE over all shapes and segments instead of by shape and segment:
+
+  clustering   bandwidths, mean-shift iterations and non-maximum suppression of all shapes as
+               batched launches with static shapes (occupied centres / cluster centres are
+               padded lists, no torch.unique / nonzero), ONE download (labels, counts, flags);
+  host         Hungarian matching and the segment table of every shape (what the reference also
+               does on the host), ONE packed upload;
+  primitives   csrc/fitbatch.hip: weighted moments -> fits -> cone pass -> residuals, 4 launches
+               forward and 1 backward for every plane / sphere / cylinder / cone of the step;
+  splines      standardisation of all spline segments as batched tensor expressions (ONE
+               download of the 3x3 covariances: the minor axis is taken from LAPACK geev on the
+               host like the reference, whose sign convention fixes the canonical frame), ONE
+               SplineNet forward per net over its segments, B-spline evaluation with the
+               de-standardisation folded in, ONE ragged Chamfer launch per direction;
+  loss         per-shape means, ONE download (distances, fit status, predicted types).
+
+The reference's serial path costs ~250 launches and ~10 host synchronisations per segment; this
+one ~60 launches per shape and 3 synchronisations per step."""
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import mean_shift as MSM
+from ._lib import h2d
+
+EPS = float(np.finfo(np.float32).eps)
+SPLINE_TYPES = (0, 2, 6, 7, 9, 8)
+CLOSED_TYPES = (0, 9, 6, 7)
+OPEN_TYPES = (2, 8)
+PRIM_CODE = {1: K.PRIM_PLANE, 5: K.PRIM_SPHERE, 4: K.PRIM_CYLINDER, 3: K.PRIM_CONE}
+PRIM_NAME = {K.PRIM_PLANE: "plane", K.PRIM_SPHERE: "sphere", K.PRIM_CYLINDER: "cylinder", K.PRIM_CONE: "cone"}
+CMAX = 64          # padded list of cluster centres (the guard retries above 49 anyway)
+
+
+# -------------------------------------------------------------------------------------------
+# clustering
+# -------------------------------------------------------------------------------------------
+def bandwidth_batch(X, quantile, num_samples=10000):
+    """MeanShift.compute_bandwidth (src/mean_shift.py:115-137) for every shape of X (B,N,128):
+    (bw (B,) clamped at 0.003, flagged rows per shape (B,)) or None outside the selection
+    kernel's fast path.  Needs num_samples >= N (every row is used, the shuffle is immaterial;
+    the caller still draws it from numpy's RNG)."""
+    B, N, D = X.shape
+    Kq = int(quantile * num_samples)
+    if N > num_samples or not (1 <= Kq <= N):
+        return None
+    Xc = X.detach().contiguous()
+    res = None
+    if MSM.ARITH == "fp16x2" and D == 128:
+        res = K.dot_kth_unit(Xc, K.meanshift_h2_split(Xc), N, Kq)
+    if res is None:
+        res = K.dot_select(Xc, Xc, Kq, want_value=True)
+    if res is None:
+        return None
+    kth_dot, flags = res
+    kth = 2.0 - 2.0 * kth_dot
+    bw = torch.mean(torch.sqrt(torch.clamp(kth, min=1e-6)), 1)
+    return torch.clamp(bw, min=0.003), (flags != 0).sum(1)
+
+
+def _padded_true_indices(mask, cap):
+    """For every row of a (B,N) boolean mask the ascending indices of its True entries, padded
+    (with indices of False entries) to ``cap`` columns, and the number of True entries."""
+    order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)
+    return order[:, :cap], mask.sum(1)
+
+
+def nms_batch(new_X, X, bw, occupied_cap):
+    """MeanShift.nms (src/mean_shift.py:139-179) for all shapes with static shapes.
+    new_X, X (B,N,128) detached, bw (B,).  Returns a dict of device tensors:
+      labels (B,N) int64, cid (B,CMAX) int64 ascending centre ids (padded), ncl (B,), nocc (B,)
+      number of occupied centres (must be <= occupied_cap), nflag (B,) rows the selection kernel
+      flagged (massive ties).  None outside the kernel's fast path."""
+    B, N, D = X.shape
+    res = K.dot_select(X, new_X, 1, want_value=False)
+    if res is None:
+        return None
+    idx, flags = res
+    membership = idx[:, :, 0]
+    counts = torch.zeros((B, N), dtype=torch.float32, device=X.device)
+    counts.scatter_add_(1, membership, torch.ones((B, N), dtype=torch.float32, device=X.device))
+    U = min(int(occupied_cap), N)
+    uq, nocc = _padded_true_indices(counts > 0, U)
+    rowvalid = torch.arange(U, device=X.device).unsqueeze(0) < nocc.unsqueeze(1)
+    Cu = torch.gather(new_X, 1, uq.unsqueeze(2).expand(-1, -1, D))
+    dist = 2.0 - 2.0 * torch.bmm(Cu, new_X.transpose(1, 2))                     # (B,U,N)
+    score = (dist < bw.reshape(B, 1, 1)).float() * counts.unsqueeze(1)
+    best = MSM._first_argmax(score, 2)                                         # (B,U)
+    hits = torch.zeros((B, N), dtype=torch.float32, device=X.device)
+    hits.scatter_add_(1, best, rowvalid.float())
+    cid, ncl = _padded_true_indices(hits > 0, CMAX)
+    cvalid = torch.arange(cid.shape[1], device=X.device).unsqueeze(0) < ncl.unsqueeze(1)
+    Csel = torch.gather(new_X, 1, cid.unsqueeze(2).expand(-1, -1, D))
+    sc = torch.bmm(Csel, X.transpose(1, 2))                                     # (B,CMAX,N)
+    sc = torch.where(cvalid.unsqueeze(2), sc, torch.full_like(sc, float("-inf")))
+    labels = MSM._first_argmax(sc, 1)
+    return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc, "nflag": (flags != 0).sum(1)}
+
+
+# -------------------------------------------------------------------------------------------
+# memberships
+# -------------------------------------------------------------------------------------------
+def weights_normalize_batch(Wraw, bw, ncl):
+    """fitting_utils.weights_normalize (src/fitting_utils.py:306-325) on padded (B,Cp,N) centre /
+    point dot products: rows >= ncl[b] are padding and come out as zeros."""
+    B, Cp, N = Wraw.shape
+    rowmask = (torch.arange(Cp, device=Wraw.device).unsqueeze(0) < ncl.unsqueeze(1)).unsqueeze(2)
+    x = Wraw / (bw.reshape(B, 1, 1) ** 2) / 2
+    prob = torch.exp(torch.clamp(x, max=75, min=-75))
+    prob = torch.where(rowmask, prob, torch.zeros_like(prob))
+    prob = prob / torch.sum(prob, 1, keepdim=True)
+    shifted = prob - torch.min(prob, 2, keepdim=True)[0]
+    shifted = shifted / (torch.max(shifted, 2, keepdim=True)[0] + EPS)
+    return torch.where((ncl > 1).reshape(B, 1, 1), shifted, prob)
+
+
+# -------------------------------------------------------------------------------------------
+# analytic primitives
+# -------------------------------------------------------------------------------------------
+class _PrimitiveFitLoss(torch.autograd.Function):
+    """Wn (B,Cp,N) normalised memberships -> mean residual distance of every analytic segment.
+    Forward: moments, fits, cone pass, residuals (4 launches); backward: one launch."""
+
+    @staticmethod
+    def forward(ctx, Wn, P, Nrm, tab, stride, sqrt_flag):
+        Wn = Wn.contiguous()
+        partial = K.weighted_moments(P, Nrm, Wn, tab["shape"], tab["row"], stride, EPS)
+        params, jac, status = K.primitive_fit(partial, tab["type"], tab["rows"])
+        cone_direct = K.cone_angle(P, Wn, tab["shape"], tab["row"], tab["type"], status, params, jac, stride, EPS)
+        dist, dparam = K.primitive_residual(P, tab["shape"], tab["type"], tab["gt_off"], tab["gt_idx"], params,
+                                            status, sqrt_flag)
+        ctx.save_for_backward(Wn, P, Nrm, params, jac, dparam, cone_direct)
+        ctx.tab, ctx.stride = tab, stride
+        ctx.mark_non_differentiable(params, status)
+        return dist, params, status
+
+    @staticmethod
+    def backward(ctx, g_dist, _gp, _gs):
+        Wn, P, Nrm, params, jac, dparam, cone_direct = ctx.saved_tensors
+        tab = ctx.tab
+        gW = K.weighted_moments_bwd(P, Nrm, Wn, tab["shape"], tab["row"], tab["type"], g_dist.contiguous(), dparam,
+                                    jac, params, cone_direct, ctx.stride, EPS)
+        return gW, None, None, None, None, None
+
+
+# -------------------------------------------------------------------------------------------
+# splines
+# -------------------------------------------------------------------------------------------
+class _BSplineEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ctrl, nu, nv, affine, wrap):
+        ctx.save_for_backward(nu, nv, affine)
+        ctx.wrap, ctx.cu, ctx.cv = wrap, ctrl.shape[1], ctrl.shape[2]
+        return K.bspline_eval(nu, nv, ctrl, affine, wrap)
+
+    @staticmethod
+    def backward(ctx, gout):
+        nu, nv, affine = ctx.saved_tensors
+        return K.bspline_eval_bwd(nu, nv, gout.contiguous(), affine, ctx.cu, ctx.cv, ctx.wrap), None, None, None, None
+
+
+class _RaggedChamfer(torch.autograd.Function):
+    """chamfer_distance_single_shape (src/utils.py:326-358, two-sided, squared, reduced) of S
+    (prediction, ground truth) pairs of different sizes: pred (TA,3) concatenated predictions
+    (differentiable), gt (TB,3) concatenated targets -> (S,) values
+    (mean_i min_j + mean_j min_i) / 2.  The kernel's minima are the reference's values bit for
+    bit; the backward routes each minimum to its pair of points."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, off_a, off_b, item_a, item_b, cnt_a, cnt_b, max_a, max_b):
+        minA, argA, minB, argB = K.chamfer_nn_ragged(pred.detach(), off_a, max_a, gt, off_b, max_b)
+        S = cnt_a.shape[0]
+        sa = torch.zeros(S, dtype=torch.float32, device=pred.device).index_add_(0, item_a, minA)
+        sb = torch.zeros(S, dtype=torch.float32, device=pred.device).index_add_(0, item_b, minB)
+        ctx.save_for_backward(pred, gt, argA, argB, off_a, off_b, item_a, item_b, cnt_a, cnt_b)
+        return (sa / cnt_a + sb / cnt_b) / 2.0
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, argA, argB, off_a, off_b, item_a, item_b, cnt_a, cnt_b = ctx.saved_tensors
+        ga = (g / cnt_a)[item_a]                       # d/d minA_i = g_s / (2 nA): the 2 of the square cancels
+        gb = (g / cnt_b)[item_b]
+        nb = gt[argA + off_b[item_a].long()]
+        gpred = (pred - nb) * ga.unsqueeze(1)
+        ja = argB + off_a[item_b].long()
+        gpred.index_add_(0, ja, (pred[ja] - gt) * gb.unsqueeze(1))
+        return gpred, None, None, None, None, None, None, None, None, None
+
+
+def _host_minor_axis_rotation(cov):
+    """standardize_point_torch's host step (src/fitting_utils.py:532-540): eigenvectors of the 3x3
+    covariance from LAPACK geev (its sign convention decides the canonical frame), minor axis
+    rotated to +x.  cov (3,3) float32 CPU tensor -> R (3,3) float32 numpy."""
+    from .fitting import rotation_matrix_a_to_b
+    w, v = torch.linalg.eig(cov)
+    U = v.real
+    smallest_ev = U[:, torch.min(w.real, 0)[1]].numpy()
+    return rotation_matrix_a_to_b(smallest_ev, np.array([1, 0, 0])).astype(np.float32)
+
+
+def standardize_segments(P2, w):
+    """standardize_point_torch (src/fitting_utils.py:512-553) for S segments at once.
+    P2 (S,n,3) sub-sampled points of each segment's shape, w (S,n) memberships (+EPS).
+    Returns (points (S,n,3), std (S,3), mean (S,3), R (S,3,3)); one download (covariances)."""
+    S, n, _ = P2.shape
+    with torch.no_grad():
+        hi = w > 0.8
+        cnt = hi.sum(1, keepdim=True)
+        kf = n // 4 if n >= 7500 else n // 2
+        top = torch.topk(w, kf, dim=1)[1]
+        fb = torch.zeros_like(hi).scatter_(1, top, torch.ones_like(top, dtype=torch.bool))
+        sel = torch.where(cnt < 400, fb, hi)
+        self_ = sel.float()
+        wsel = w * self_
+        mean = (P2 * wsel.unsqueeze(2)).sum(1) / (wsel.sum(1, keepdim=True) + EPS)
+        Pc = P2 - mean.unsqueeze(1)
+        cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
+        cov_h = cov.cpu()                                        # host step of the reference
+        R = torch.from_numpy(np.stack([_host_minor_axis_rotation(cov_h[s]) for s in range(S)], 0))
+        R = R.pin_memory().to(P2.device, non_blocking=True)
+        Pr = torch.bmm(Pc, R.transpose(1, 2))
+        wp = Pr * w.unsqueeze(2)
+        big = torch.full_like(wp, float("inf"))
+        selx = sel.unsqueeze(2)
+        std = torch.abs(torch.where(selx, wp, -big).max(1)[0] - torch.where(selx, wp, big).min(1)[0])
+        pts = Pr / (std.unsqueeze(1) + EPS)
+    return pts, std, mean, R
+
+
+# -------------------------------------------------------------------------------------------
+# host side: matching and the segment table
+# -------------------------------------------------------------------------------------------
+def build_segment_table(labels, primitives, cluster_ids, N):
+    """What residual_train_mode + fit_one_shape_torch decide on the host for ONE shape
+    (src/residual_utils.py:154-200, src/primitive_forward.py:938-1020): Hungarian matching, the
+    ground-truth segment of every predicted cluster, its modal primitive type, the sub-sampling
+    and minimum-size rules, at most 4 splines.  Returns (segments, match) where a segment is a dict
+    {row, key, type, kind ('prim' | 'open' | 'closed'), gt (indices)} in the order the reference
+    fits them, and match = (rids, cids, confusion) for the metrics."""
+    from .fitting import _relaxed_iou_of_labels, solve_dense
+    iou = _relaxed_iou_of_labels(cluster_ids, labels)
+    rids, cids = solve_dense(1.0 - iou)
+    unique_pred = np.unique(cluster_ids)
+    gcount = np.bincount(np.asarray(labels).astype(np.int64), minlength=50)
+    n2 = (N + 1) // 2
+    n4 = (n2 + 1) // 2
+    segs, spline_count = [], 0
+    for index, i in enumerate(unique_pred):
+        if gcount[cids[i]] == 0:
+            continue
+        gi = np.nonzero(labels == cids[i])[0]
+        seg_type = int(np.bincount(primitives[gi].astype(np.int64)).argmax())
+        if seg_type in SPLINE_TYPES:
+            spline_count += 1
+            if spline_count > 4 or n2 < 20:
+                continue
+            if n2 < 100:
+                continue
+            kind = "closed" if seg_type in CLOSED_TYPES else "open"
+        elif seg_type in PRIM_CODE:
+            if n4 < 20:
+                continue
+            kind = "prim"
+        else:
+            raise ValueError("unknown primitive type %r" % (seg_type,))
+        segs.append({"row": index, "key": int(i), "type": seg_type, "kind": kind, "gt": gi})
+    return segs, (rids, cids, unique_pred, gcount)
+
+
+def siou_matched_segments_fast(labels, cluster_ids, prim_pred_per_cluster, primitives, rids, cids):
+    """segment_utils.SIOU_matched_segments (src/segment_utils.py:139-187) from the confusion matrix
+    instead of one boolean mask pair per match: identical values."""
+    from .fitting import _merge_types
+    prim = _merge_types(primitives)
+    p = np.asarray(cluster_ids).astype(np.int64)
+    g = np.asarray(labels).astype(np.int64)
+    conf = np.bincount(p * 50 + g, minlength=2500).reshape(50, 50)
+    np_, ng = conf.sum(1), conf.sum(0)
+    _, first = np.unique(g, return_index=True)
+    first_of = dict(zip(np.unique(g).tolist(), first.tolist()))
+    ious, ok, pairs = [], [], []
+    for r, c in zip(rids, cids):
+        if ng[c] == 0 or np_[r] == 0 or ng[c] < 100:
+            continue
+        inter = conf[r, c]
+        ious.append(inter / ((np_[r] + ng[c] - inter) + 1e-8))
+        gt_type = prim[first_of[int(c)]]
+        ok.append(gt_type == prim_pred_per_cluster[r])
+        pairs.append([gt_type, prim_pred_per_cluster[r]])
+    return (np.mean(ious) if ious else float("nan"), np.mean(ok) if ok else float("nan"), [[rids, cids]], pairs)
+
+
+# -------------------------------------------------------------------------------------------
+# the stage
+# -------------------------------------------------------------------------------------------
+def fitting_losses_train(ev, embedding, points, normals, labels, primitives, primitives_log_prob, quantile,
+                         iterations, lamb):
+    """Training-mode Evaluation.fitting_loss for every shape of the batch.  Returns a list (one
+    entry per shape) of ([Loss, geometric mean, spline mean, s_iou, p_iou], [parameters, cluster
+    ids, weights]) exactly as the reference's call with that single shape would.
+    ``ev``: the owning fitting.Evaluation (SplineNets, mean-shift object, slow-path helpers)."""
+    B, N, D = embedding.shape
+    dev = embedding.device
+    labels, primitives = np.asarray(labels), np.asarray(primitives)
+    emb = torch.nn.functional.normalize(embedding, p=2, dim=2)
+    fitter = ev.fitter
+
+    # ---- clustering, all shapes ---------------------------------------------------------
+    state = None
+    cap_used = ev.occupied_cap
+    with torch.no_grad():
+        bwres = bandwidth_batch(emb, quantile)
+    if bwres is not None and D == 128:
+        bw, bwflag = bwres
+        new_X = MSM.mean_shift_iterations(emb, bw, iterations)
+        with torch.no_grad():
+            state = nms_batch(new_X.detach(), emb.detach(), bw, cap_used)
+    with torch.no_grad():
+        # SIOU_matched_segments merges the predicted types before the per-cluster vote
+        # (src/segment_utils.py:152-161: 0, 6, 7 -> 9; 8 -> 2)
+        lut = torch.tensor([9, 1, 2, 3, 4, 5, 9, 9, 2, 9], dtype=torch.int64, device=dev)
+        prim_pred = lut[torch.max(primitives_log_prob, 1)[1]]
+    if state is not None:
+        pack = torch.cat([state["labels"].reshape(-1), state["cid"].reshape(-1), state["ncl"], state["nocc"],
+                          state["nflag"], bwflag]).to(torch.int32).cpu().numpy()   # sync 1
+        o = 0
+        lab_h = pack[o:o + B * N].reshape(B, N); o += B * N
+        cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
+        ncl_h, nocc_h, nflag_h, bwflag_h = [pack[o + k * B:o + (k + 1) * B] for k in range(4)]
+        ev.occupied_cap = int(min(N, max(256, 1 << int(np.ceil(np.log2(2 * max(int(nocc_h.max()), 1)))))))
+    centers, bws, cluster_ids = [], [], []
+    for b in range(B):
+        # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122)
+        fast = (state is not None and nflag_h[b] == 0 and bwflag_h[b] == 0 and nocc_h[b] <= cap_used
+                and ncl_h[b] <= CMAX)
+        if fast:
+            np.random.shuffle(np.arange(N))
+        if fast and ncl_h[b] <= 49:
+            centers.append(new_X[b][state["cid"][b, :int(ncl_h[b])]])
+            bws.append(bw[b])
+            cluster_ids.append(lab_h[b].astype(np.int64))
+        else:
+            # tie-flagged selection rows, more occupied centres than the padded list holds, or the
+            # guard's retry above 49 clusters: this shape alone on the synchronous path
+            q = quantile * 1.2 if (fast and ncl_h[b] > 49) else quantile
+            c, bwb, ids = ev.guard_mean_shift(emb[b], q, iterations, kernel_type="gaussian")
+            centers.append(c)
+            bws.append(bwb.reshape(()))
+            cluster_ids.append(ids.cpu().numpy().astype(np.int64))
+    ncl_list = [int(c.shape[0]) for c in centers]
+    Cp = max(ncl_list)
+    cen = torch.stack([torch.nn.functional.pad(c, (0, 0, 0, Cp - c.shape[0])) for c in centers], 0)   # (B,Cp,D)
+    bwt = torch.stack(bws).detach()
+    ncl_t = h2d(np.asarray(ncl_list, dtype=np.int64), dev)
+    Wraw = torch.bmm(cen, emb.transpose(1, 2))                                   # (B,Cp,N)
+    Wn = weights_normalize_batch(Wraw, bwt, ncl_t)
+
+    # ---- host: matching + segment tables -------------------------------------------------
+    tables, matches = [], []
+    for b in range(B):
+        segs, m = build_segment_table(labels[b], primitives[b], cluster_ids[b], N)
+        tables.append(segs)
+        matches.append(m)
+    prim_segs = [(b, s) for b in range(B) for s in tables[b] if s["kind"] == "prim"]
+    spl_segs = [(b, s) for b in range(B) for s in tables[b] if s["kind"] != "prim"]
+    spl_segs.sort(key=lambda t: t[1]["kind"] != "open")       # open first, then closed (stable)
+    n_open = sum(1 for _, s in spl_segs if s["kind"] == "open")
+    all_segs = prim_segs + spl_segs
+    S_p, S_s = len(prim_segs), len(spl_segs)
+
+    # one packed upload of every integer table
+    parts, where = [], {}
+
+    def add(name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)
+        where[name] = (sum(p.size for p in parts), a.size)
+        parts.append(a)
+    gt_lists = [s["gt"] for _, s in all_segs]
+    gt_off = np.concatenate([[0], np.cumsum([g.size for g in gt_lists])]) if all_segs else np.zeros(1)
+    add("seg_shape", [b for b, _ in all_segs])
+    add("seg_row", [s["row"] for _, s in all_segs])
+    add("seg_type", [PRIM_CODE.get(s["type"], 0) for _, s in all_segs])
+    add("seg_rows", [((N + 1) // 2 + 1) // 2] * len(all_segs))
+    add("gt_off", gt_off)
+    add("gt_idx", np.concatenate(gt_lists) if all_segs else np.zeros(0))
+    add("gt_flat", np.concatenate([g + b * N for (b, _), g in zip(all_segs, gt_lists)]) if all_segs else np.zeros(0))
+    if S_s:
+        na = [900 if s["kind"] == "open" else 930 for _, s in spl_segs]
+        nb = [g.size for g in gt_lists[S_p:]]
+        add("off_a", np.concatenate([[0], np.cumsum(na)]))
+        add("off_b", np.concatenate([[0], np.cumsum(nb)]))
+        add("item_a", np.repeat(np.arange(S_s), na))
+        add("item_b", np.repeat(np.arange(S_s), nb))
+    dev_tab = h2d(np.concatenate(parts) if parts else np.zeros(1, np.int32), dev)
+    T = {k: dev_tab[o:o + n] for k, (o, n) in where.items()}
+
+    dists = []
+    params_p = status = None
+    # ---- analytic primitives ------------------------------------------------------------
+    if S_p:
+        tab = {"shape": T["seg_shape"][:S_p], "row": T["seg_row"][:S_p], "type": T["seg_type"][:S_p],
+               "rows": T["seg_rows"][:S_p], "gt_off": T["gt_off"][:S_p + 1], "gt_idx": T["gt_idx"]}
+        d_p, params_p, status = _PrimitiveFitLoss.apply(Wn, points, normals, tab, 4, False)
+        dists.append(d_p)
+    # ---- splines ------------------------------------------------------------------------
+    recs = []
+    if S_s:
+        sb = T["seg_shape"][S_p:].long()
+        sr = T["seg_row"][S_p:].long()
+        P2 = points[:, 0::2].detach()[sb]                                    # (S_s,n2,3)
+        w2 = Wn[:, :, 0::2][sb, sr] + EPS                                     # (S_s,n2), differentiable
+        pts_std, std, mean, R = standardize_segments(P2, w2.detach())          # sync 2
+        affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
+        nu, nv = fitter.nu.to(dev), fitter.nv.to(dev)
+        pieces = []
+        for lo, hi, net, wrap in ((0, n_open, fitter.open_control_decoder, False),
+                                  (n_open, S_s, fitter.closed_control_decoder, True)):
+            if hi > lo:
+                ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
+                rec = _BSplineEval.apply(ctrl.reshape(hi - lo, 20, 20, 3), nu, nv, affine[lo:hi], wrap)
+                pieces.append(rec.reshape(-1, 3))
+                recs += [rec[k:k + 1] for k in range(hi - lo)]
+        pred = torch.cat(pieces, 0)
+        gt_cloud = points.reshape(B * N, 3)[T["gt_flat"][int(gt_off[S_p]):].long()]
+        cnt_a = h2d(np.asarray(na, dtype=np.float32), dev)
+        cnt_b = h2d(np.asarray(nb, dtype=np.float32), dev)
+        d_s = _RaggedChamfer.apply(pred, gt_cloud, T["off_a"], T["off_b"], T["item_a"].long(), T["item_b"].long(),
+                                   cnt_a, cnt_b, max(na), max(nb))
+        dists.append(d_s)
+
+    # ---- losses, metrics, ONE download ----------------------------------------------------
+    S_all = S_p + S_s
+    with torch.no_grad():
+        hot = torch.nn.functional.one_hot(prim_pred, 10).to(Wraw.dtype).transpose(1, 2)      # (B,10,N)
+        ptype = torch.max(torch.bmm(hot, Wraw.detach().transpose(1, 2)), 1)[1]               # (B,Cp)
+    if S_all:
+        d_all = torch.cat(dists)
+        scale = h2d(np.asarray([lamb if s["kind"] != "prim" else 1.0 for _, s in all_segs], dtype=np.float32), dev)
+        d_used = torch.where(d_all.detach() > 1, torch.full_like(d_all, 0.1), d_all)   # degenerate case -> constant
+        cnt_shape = np.bincount([b for b, _ in all_segs], minlength=B).astype(np.float32)
+        loss_b = torch.zeros(B, dtype=torch.float32, device=dev).index_add_(0, T["seg_shape"].long(), d_used * scale)
+        loss_b = loss_b / h2d(np.maximum(cnt_shape, 1.0), dev)
+        tail = [d_all.detach().double()]
+        if S_p:
+            tail.append(status.double())
+        host = torch.cat(tail + [ptype.reshape(-1).double()]).cpu().numpy()                    # sync 3
+        d_h = host[:S_all]
+        st_h = host[S_all:S_all + S_p].astype(np.int64) if S_p else np.zeros(0, np.int64)
+        ptype_h = host[S_all + S_p:].astype(np.int64).reshape(B, Cp)
+        if (st_h & 5).any():
+            bad = int(np.nonzero(st_h & 5)[0][0])
+            raise RuntimeError("fitting: %s in segment %d of shape %d" % (
+                "non-finite design matrix / no full-rank ridge system (lstsq)" if st_h[bad] & 1 else
+                "NaN residual distance", prim_segs[bad][1]["key"], prim_segs[bad][0]))
+    else:
+        loss_b = torch.zeros(B, dtype=torch.float32, device=dev)
+        d_h = np.zeros(0)
+        ptype_h = ptype.cpu().numpy()
+    pf = params_p.float() if S_p else None
+
+    out = []
+    for b in range(B):
+        parameters, geo, spl = {}, [], []
+        for k, (bb, s) in enumerate(all_segs):
+            if bb != b:
+                continue
+            dv = 0.1 if d_h[k] > 1 else d_h[k]
+            if s["kind"] == "prim":
+                code, p = PRIM_CODE[s["type"]], pf[k]
+                if code == K.PRIM_PLANE:
+                    parameters[s["key"]] = ["plane", p[0:3].reshape(3, 1), p[3]]
+                elif code == K.PRIM_SPHERE:
+                    parameters[s["key"]] = ["sphere", p[0:3].reshape(1, 3), p[3]]
+                elif code == K.PRIM_CYLINDER:
+                    parameters[s["key"]] = ["cylinder", p[0:3].reshape(3, 1), p[3:6].reshape(1, 3), p[6]]
+                else:
+                    parameters[s["key"]] = ["cone", p[0:3].reshape(1, 3), p[3:6].reshape(3, 1), p[6:7]]
+                geo.append(float(dv))
+            else:
+                parameters[s["key"]] = ["open-spline" if s["kind"] == "open" else "closed-spline", recs[k - S_p]]
+                spl.append(float(dv))
+        fitted = {s["key"] for bb, s in all_segs if bb == b}
+        for i in matches[b][2]:              # skipped segments are recorded as None like the reference
+            if int(i) not in fitted and matches[b][3][matches[b][1][i]] > 0:
+                parameters[int(i)] = None
+        nseg = sum(1 for bb, _ in all_segs if bb == b)
+        Loss = loss_b[b] if nseg else torch.zeros(1, device=dev)
+        rids, cids = matches[b][0], matches[b][1]
+        s_iou, p_iou, _, _ = siou_matched_segments_fast(labels[b], cluster_ids[b], ptype_h[b], primitives[b],
+                                                         rids, cids)
+        ev.stats["shapes"] += 1
+        ev.stats["clusters"] += ncl_list[b]
+        ev.stats["fitted"] += nseg
+        out.append(([Loss, float(np.mean(geo)) if geo else None, float(np.mean(spl)) if spl else None, s_iou, p_iou],
+                    [parameters, cluster_ids[b], Wraw[b, :ncl_list[b]]]))
+    return out

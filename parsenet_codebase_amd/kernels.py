@@ -431,3 +431,156 @@ def sym3_eig(G):
         rc = _lib.load().pn_sym3_eig_f64(ptr(G), M, ptr(evals), ptr(evecs), current_stream(G.device))
     check(rc, "pn_sym3_eig_f64")
     return evals, evecs
+
+
+def _i32c(t, name):
+    if t.dtype != torch.int32:
+        raise TypeError("%s must be int32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def chamfer_nn_ragged(a, off_a, max_a, b, off_b, max_b, side_a=True, side_b=True):
+    """Ragged batch of nearest-neighbour searches: item i is a[off_a[i]:off_a[i+1]] against
+    b[off_b[i]:off_b[i+1]] (a (TA,3), b (TB,3) fp32; offsets (B+1,) int32 on the GPU; max_* the
+    largest item sizes, known to the host).  Returns (minA (TA,), argA (TA,), minB (TB,), argB (TB,))
+    with indices local to the item; sides not requested are None."""
+    require_cuda(a, b, off_a, off_b)
+    a = _f32c(a, "a")
+    b = _f32c(b, "b")
+    off_a, off_b = _i32c(off_a, "off_a"), _i32c(off_b, "off_b")
+    TA, TB = a.shape[0], b.shape[0]
+    B = off_a.shape[0] - 1
+    if B < 1 or off_b.shape[0] != B + 1 or TA == 0 or TB == 0:
+        raise ValueError("chamfer_nn_ragged: empty batch")
+    lib = _lib.load()
+    dev = a.device
+    minA = argA = minB = argB = None
+    if side_a:
+        minA = torch.empty(TA, dtype=torch.float32, device=dev)
+        argA = torch.empty(TA, dtype=torch.int64, device=dev)
+    if side_b:
+        minB = torch.empty(TB, dtype=torch.float32, device=dev)
+        argB = torch.empty(TB, dtype=torch.int64, device=dev)
+    wsz = lib.pn_chamfer_nn_ragged_workspace(TA, TB)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn_chamfer_nn_ragged_f32(ptr(a), ptr(off_a), TA, int(max_a), ptr(b), ptr(off_b), TB, int(max_b),
+                                          B, ptr(minA), ptr(argA), ptr(minB), ptr(argB), ptr(ws), wsz,
+                                          current_stream(dev))
+    check(rc, "pn_chamfer_nn_ragged_f32")
+    return minA, argA, minB, argB
+
+
+# ---- batched primitive fits (csrc/fitbatch.hip) ---------------------------------------------
+PRIM_PLANE, PRIM_SPHERE, PRIM_CYLINDER, PRIM_CONE = 0, 1, 2, 3
+FIT_NPAR = 16
+
+
+def weighted_moments(P, Nrm, W, seg_shape, seg_row, stride, eps):
+    """P, Nrm (B,N,3), W (B,Cp,N) fp32; seg_* (S,) int32 -> partial moment sums (S, chunks, 64) fp64."""
+    require_cuda(P, Nrm, W, seg_shape, seg_row)
+    P, Nrm, W = _f32c(P, "P"), _f32c(Nrm, "Nrm"), _f32c(W, "W")
+    B, N, _ = P.shape
+    Cp = W.shape[1]
+    S = seg_shape.shape[0]
+    lib = _lib.load()
+    partial = torch.empty((S, lib.pn_weighted_moments_chunks(), lib.pn_weighted_moments_count()),
+                          dtype=torch.float64, device=P.device)
+    with torch.cuda.device(P.device):
+        rc = lib.pn_weighted_moments_f64(ptr(P), ptr(Nrm), ptr(W), B, N, Cp, int(stride), float(eps),
+                                         ptr(_i32c(seg_shape, "seg_shape")), ptr(_i32c(seg_row, "seg_row")), S,
+                                         ptr(partial), current_stream(P.device))
+    check(rc, "pn_weighted_moments_f64")
+    return partial
+
+
+def primitive_fit(partial, seg_type, seg_rows):
+    """partial (S,chunks,64) fp64 -> params (S,16) fp64, jac (S,16,64) fp64, status (S,) int32."""
+    require_cuda(partial, seg_type, seg_rows)
+    S = partial.shape[0]
+    dev = partial.device
+    params = torch.empty((S, FIT_NPAR), dtype=torch.float64, device=dev)
+    jac = torch.empty((S, FIT_NPAR, partial.shape[2]), dtype=torch.float64, device=dev)
+    status = torch.empty(S, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_primitive_fit_f64(ptr(partial.contiguous()), ptr(_i32c(seg_type, "seg_type")),
+                                              ptr(_i32c(seg_rows, "seg_rows")), S, ptr(params), ptr(jac),
+                                              ptr(status), current_stream(dev))
+    check(rc, "pn_primitive_fit_f64")
+    return params, jac, status
+
+
+def cone_angle(P, W, seg_shape, seg_row, seg_type, status, params, jac, stride, eps):
+    """Second pass of the cone fit; updates params[:,6] and jac[:,6,:] in place, returns cone_direct (S,)."""
+    B, N, _ = P.shape
+    S = seg_shape.shape[0]
+    cone_direct = torch.empty(S, dtype=torch.float64, device=P.device)
+    with torch.cuda.device(P.device):
+        rc = _lib.load().pn_cone_angle_f64(ptr(P), ptr(W), B, N, W.shape[1], int(stride), float(eps),
+                                           ptr(seg_shape), ptr(seg_row), ptr(seg_type), ptr(status), S,
+                                           ptr(params), ptr(jac), ptr(cone_direct), current_stream(P.device))
+    check(rc, "pn_cone_angle_f64")
+    return cone_direct
+
+
+def primitive_residual(P, seg_shape, seg_type, gt_off, gt_idx, params, status, sqrt_flag=False):
+    """Mean residual of the ground-truth points of every segment: dist (S,) fp32, dparam (S,16) fp64."""
+    require_cuda(P, gt_off, gt_idx, params)
+    B, N, _ = P.shape
+    S = seg_shape.shape[0]
+    dist = torch.empty(S, dtype=torch.float32, device=P.device)
+    dparam = torch.zeros((S, FIT_NPAR), dtype=torch.float64, device=P.device)
+    with torch.cuda.device(P.device):
+        rc = _lib.load().pn_primitive_residual_f32(ptr(_f32c(P, "P")), B, N, ptr(seg_shape), ptr(seg_type),
+                                                   ptr(_i32c(gt_off, "gt_off")), ptr(_i32c(gt_idx, "gt_idx")), S,
+                                                   ptr(params), int(bool(sqrt_flag)), ptr(dist), ptr(dparam),
+                                                   ptr(status), current_stream(P.device))
+    check(rc, "pn_primitive_residual_f32")
+    return dist, dparam
+
+
+def weighted_moments_bwd(P, Nrm, W, seg_shape, seg_row, seg_type, g_dist, dparam, jac, params, cone_direct,
+                         stride, eps):
+    """d loss / d W (B,Cp,N) fp32 of the batched fits given g_dist (S,) = d loss / d dist."""
+    B, N, _ = P.shape
+    S = seg_shape.shape[0]
+    gW = torch.zeros_like(W)
+    with torch.cuda.device(P.device):
+        rc = _lib.load().pn_weighted_moments_bwd_f32(ptr(P), ptr(Nrm), ptr(W), B, N, W.shape[1], int(stride),
+                                                     float(eps), ptr(seg_shape), ptr(seg_row), ptr(seg_type), S,
+                                                     ptr(_f32c(g_dist, "g_dist")), ptr(dparam), ptr(jac),
+                                                     ptr(params), ptr(cone_direct), ptr(gW),
+                                                     current_stream(P.device))
+    check(rc, "pn_weighted_moments_bwd_f32")
+    return gW
+
+
+def bspline_eval(nu, nv, ctrl, affine=None, wrap=False):
+    """ctrl (S,cu,cv,3), nu (gu,cu), nv (gv,cv) fp32 -> (S,(gu+wrap)*gv,3); affine (S,3,4) optional."""
+    require_cuda(nu, nv, ctrl, affine)
+    nu, nv, ctrl = _f32c(nu, "nu"), _f32c(nv, "nv"), _f32c(ctrl, "ctrl")
+    S, cu, cv, _ = ctrl.shape
+    gu, gv = nu.shape[0], nv.shape[0]
+    if affine is not None:
+        affine = _f32c(affine, "affine")
+    out = torch.empty((S, (gu + int(wrap)) * gv, 3), dtype=torch.float32, device=ctrl.device)
+    with torch.cuda.device(ctrl.device):
+        rc = _lib.load().pn_bspline_eval_f32(ptr(nu), ptr(nv), ptr(ctrl), ptr(affine), S, gu, gv, cu, cv, int(wrap),
+                                             ptr(out), current_stream(ctrl.device))
+    check(rc, "pn_bspline_eval_f32")
+    return out
+
+
+def bspline_eval_bwd(nu, nv, gout, affine, cu, cv, wrap=False):
+    require_cuda(nu, nv, gout, affine)
+    nu, nv, gout = _f32c(nu, "nu"), _f32c(nv, "nv"), _f32c(gout, "gout")
+    S = gout.shape[0]
+    gu, gv = nu.shape[0], nv.shape[0]
+    if affine is not None:
+        affine = _f32c(affine, "affine")
+    gctrl = torch.empty((S, cu, cv, 3), dtype=torch.float32, device=gout.device)
+    with torch.cuda.device(gout.device):
+        rc = _lib.load().pn_bspline_eval_bwd_f32(ptr(nu), ptr(nv), ptr(gout), ptr(affine), S, gu, gv, cu, cv,
+                                                 int(wrap), ptr(gctrl), current_stream(gout.device))
+    check(rc, "pn_bspline_eval_bwd_f32")
+    return gctrl

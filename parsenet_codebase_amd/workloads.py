@@ -54,10 +54,23 @@ class ParsenetE2EStep(ParsenetSegStep):
     backward through everything, one gradient all-reduce, Adam.  The SplineNets are frozen
     random-init DGCNNControlPoints (no pretrained weights ship with the reference)."""
 
-    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-4):
-        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr)
+    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-4,
+                 pretrain_steps=0):
+        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr=1e-2)
         from .encoders import DGCNNControlPoints
         from .fitting import Evaluation
+        # The reference starts end-to-end training from a segmentation network pre-trained by
+        # train_parsenet.py (train_parsenet_e2e.py:82-84 loads parsenet_with_normals.pth); no
+        # checkpoint ships with it, so the stand-in is a fixed number of deterministic
+        # segmentation-only steps (triplet + NLL, Adam 1e-2, train-mode norms) on this batch: the
+        # embedding then HAS cluster structure and every shape goes through matching, primitive
+        # fits and SplineNets from the first timed step on.
+        self.pretrain_steps = int(pretrain_steps)
+        if self.pretrain_steps:
+            np.random.seed(4321 + first_shape)
+            for _ in range(self.pretrain_steps):
+                ParsenetSegStep.step(self)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
         torch.manual_seed(seed + 1)
         open_net = DGCNNControlPoints(20, num_points=10, mode=0)
         closed_net = DGCNNControlPoints(20, num_points=10, mode=1)
@@ -71,9 +84,15 @@ class ParsenetE2EStep(ParsenetSegStep):
         # The clustering of shape b+1 (few large kernels) is queued on a side stream underneath the
         # fitting stage of shape b (hundreds of tiny launches and the host synchronisations of the
         # Hungarian matching): the reference processes one shape after the other.
-        self.overlap = True
+        self.batched = True       # stage-wise over the whole batch (fitting_batch.py); False: shape by shape
+        self.overlap = True       # (shape-by-shape mode) clustering of shape b+1 on a side stream
         self.side = torch.cuda.Stream(device=device)
         self._warmed = False
+
+    def segments_per_shape(self):
+        st = self.evaluation.stats
+        n = max(st["shapes"], 1)
+        return {"clusters": st["clusters"] / n, "fitted": st["fitted"] / n}
 
     def warm_paths(self):
         """One pass of the clustering + fitting stage (forward and backward) on an embedding that HAS
@@ -88,17 +107,25 @@ class ParsenetE2EStep(ParsenetSegStep):
         g = torch.Generator().manual_seed(12345)
         code = torch.nn.functional.normalize(torch.randn(64, 128, generator=g), dim=1).to(self.device)
         log_prob = torch.log_softmax(torch.randn(self.batch, 10, self.num_points, generator=g), 1).to(self.device)
+        stats = dict(self.evaluation.stats)
+        embs = []
         for b in range(self.batch):
             lab = torch.from_numpy(np.asarray(self.labels[b]).astype(np.int64) % 64).to(self.device)
             emb = code[lab] + 0.01 * torch.randn(self.num_points, 128, generator=g).to(self.device)
-            emb = torch.nn.functional.normalize(emb, dim=1).unsqueeze(0).requires_grad_(True)
-            res, _ = self.evaluation.fitting_loss(emb, self.points[b:b + 1], self.normals[b:b + 1],
-                                                  self.labels[b:b + 1], self.prim_np[b:b + 1],
-                                                  log_prob[b:b + 1], quantile=0.025, iterations=10, lamb=0.1)
-            if torch.is_tensor(res[0]) and res[0].requires_grad:
-                res[0].backward()
+            embs.append(torch.nn.functional.normalize(emb, dim=1))
+        emb = torch.stack(embs, 0).requires_grad_(True)
+        self.evaluation.batched = self.batched
+        res = self.evaluation.fitting_losses(emb, self.points, self.normals, self.labels, self.prim_np, log_prob,
+                                             quantile=0.025, iterations=10, lamb=0.1) if self.batched else [
+            self.evaluation.fitting_loss(emb[b:b + 1], self.points[b:b + 1], self.normals[b:b + 1],
+                                         self.labels[b:b + 1], self.prim_np[b:b + 1], log_prob[b:b + 1],
+                                         quantile=0.025, iterations=10, lamb=0.1) for b in range(self.batch)]
+        tot = sum(r[0][0].sum() for r in res)
+        if torch.is_tensor(tot) and tot.requires_grad:
+            tot.backward()
         torch.cuda.synchronize(self.device)
         np.random.set_state(state)
+        self.evaluation.stats.update(stats)
         self._warmed = True
 
     def step(self):
@@ -109,6 +136,17 @@ class ParsenetE2EStep(ParsenetSegStep):
         loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
         emb = embedding.permute(0, 2, 1)
         res_total = 0
+        self.evaluation.batched = self.batched
+        if self.batched:
+            res = self.evaluation.fitting_losses(emb, self.points, self.normals, self.labels, self.prim_np, log_prob,
+                                                 quantile=0.025, iterations=10, lamb=0.1)
+            res_total = sum(r[0][0].sum() for r in res)
+            loss = loss + res_total / self.batch
+            loss.backward()
+            self.bucket.all_reduce_mean()
+            self.opt.step()
+            self.last_res = res_total
+            return loss
         main = torch.cuda.current_stream(self.device)
         handles, events = {}, {}
 

@@ -1,0 +1,200 @@
+"""GPU: the batched (stage-wise) training-mode fitting path of fitting_batch.py / csrc/fitbatch.hip
+against the per-segment path of fitting.py (itself held to the oracle and the reference fixtures
+by test_fitting_gpu.py / test_golden_gpu.py / test_e2e_gpu.py) and against the oracle directly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EPS = float(np.finfo(np.float32).eps)
+
+
+def _structured_batch(gpu, B, N, seeds, noise=0.01):
+    from parsenet_codebase_amd import synthetic
+    pts, nrm, lab, prim = [], [], [], []
+    for s in seeds:
+        p, n, l, t = synthetic.make_shape(s, N)
+        pts.append(p); nrm.append(n); lab.append(l); prim.append(t)
+    g = torch.Generator().manual_seed(99)
+    code = torch.nn.functional.normalize(torch.randn(32, 128, generator=g), dim=1)
+    emb = torch.stack([torch.nn.functional.normalize(
+        code[torch.from_numpy(lab[b]).long()] + noise * torch.randn(N, 128, generator=g), dim=1) for b in range(B)])
+    logp = torch.log_softmax(torch.randn(B, 10, N, generator=g), 1)
+    return (torch.from_numpy(np.stack(pts)).to(gpu), torch.from_numpy(np.stack(nrm)).to(gpu), np.stack(lab),
+            np.stack(prim), emb.to(gpu), logp.to(gpu))
+
+
+def _evaluation(gpu, seed=0):
+    from parsenet_codebase_amd.encoders import DGCNNControlPoints
+    from parsenet_codebase_amd.fitting import Evaluation
+    torch.manual_seed(seed)
+    return Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1),
+                      open_path=DGCNNControlPoints(20, num_points=10, mode=0))
+
+
+@pytest.mark.parametrize("N", [3000, 10000])
+def test_batched_stage_equals_shape_by_shape(gpu, N):
+    """Loss, per-kind means, metrics, cluster ids and d loss / d embedding of the stage-wise path
+    equal the reference-ordered shape-by-shape, segment-by-segment path."""
+    torch.cuda.set_device(gpu)
+    B = 3
+    P, Nn, lab, prim, emb, logp = _structured_batch(gpu, B, N, (3, 8, 21))
+    ev = _evaluation(gpu)
+    outs = {}
+    for mode in ("sequential", "batched"):
+        ev.batched = mode == "batched"
+        e = emb.clone().requires_grad_(True)
+        np.random.seed(5)
+        if ev.batched:
+            res = ev.fitting_losses(e, P, Nn, lab, prim, logp, quantile=0.025, iterations=10, lamb=0.1)
+        else:
+            res = [ev.fitting_loss(e[b:b + 1], P[b:b + 1], Nn[b:b + 1], lab[b:b + 1], prim[b:b + 1], logp[b:b + 1],
+                                   quantile=0.025, iterations=10, lamb=0.1) for b in range(B)]
+        sum(r[0][0].sum() for r in res).backward()
+        outs[mode] = (res, e.grad.clone(), np.random.get_state()[2])
+    (rs, gs, ps), (rb, gb, pb) = outs["sequential"], outs["batched"]
+    assert ps == pb                                   # numpy's RNG stream advanced identically
+    for b in range(B):
+        ls, lb = rs[b][0], rb[b][0]
+        assert np.array_equal(rs[b][1][1], rb[b][1][1])                       # cluster ids
+        assert abs(float(ls[0]) - float(lb[0])) < 2e-5 * abs(float(ls[0])) + 1e-9, (b, float(ls[0]), float(lb[0]))
+        for k in (1, 2, 3, 4):
+            assert (ls[k] is None) == (lb[k] is None)
+            if ls[k] is not None:
+                assert abs(ls[k] - lb[k]) < 2e-5 * abs(ls[k]) + 1e-9, (b, k, ls[k], lb[k])
+        ks, kb = rs[b][1][0], rb[b][1][0]
+        assert sorted(ks) == sorted(kb)
+        for key in ks:
+            assert (ks[key] is None) == (kb[key] is None)
+            if ks[key] is not None:
+                assert ks[key][0] == kb[key][0]
+        assert torch.allclose(rs[b][1][2], rb[b][1][2], atol=1e-6)
+    scale = float(gs.abs().max())
+    assert float((gs - gb).abs().max()) < 5e-4 * scale, float((gs - gb).abs().max()) / scale
+    cos = float((gs.double().flatten() @ gb.double().flatten()) / (gs.double().norm() * gb.double().norm()))
+    assert cos > 0.99999, cos
+
+
+def test_primitive_kernels_against_the_oracle(gpu):
+    """csrc/fitbatch.hip end to end on the GPU (moments -> fit -> cone pass -> residual -> adjoint)
+    for one segment of each kind, against the oracle's Fit.fit_*_torch + distance in fp64."""
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd import kernels as K
+    from parsenet_codebase_amd.fitting_batch import _PrimitiveFitLoss
+    from tests.test_fit_math_host import make_segment, oracle, align_sign
+    torch.cuda.set_device(gpu)
+    kinds = ["plane", "sphere", "cylinder", "cone"]
+    n = 2400
+    segs = [make_segment(k, 11 + i, n=n) for i, k in enumerate(kinds)]
+    # one "shape" per segment: points / normals at stride 4 of a (B, 4n, 3) cloud, weights in row 1
+    B, N = len(kinds), 4 * n
+    P = torch.zeros(B, N, 3)
+    Nn = torch.zeros(B, N, 3)
+    W = torch.zeros(B, 3, N)
+    gts = []
+    for b, (p, nn, w, gt) in enumerate(segs):
+        P[b, 0::4] = torch.from_numpy(p)
+        Nn[b, 0::4] = torch.from_numpy(nn)
+        W[b, 1, 0::4] = torch.from_numpy(w - np.float32(EPS))
+        P[b, 1::4][:gt.shape[0]] = torch.from_numpy(gt)                       # ground-truth points elsewhere
+        gts.append(1 + 4 * np.arange(gt.shape[0]))
+    i32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device=gpu)   # noqa: E731
+    tab = {"shape": i32(range(B)), "row": i32([1] * B), "type": i32([0, 1, 2, 3]), "rows": i32([n] * B),
+           "gt_off": i32(np.concatenate([[0], np.cumsum([g.size for g in gts])])), "gt_idx": i32(np.concatenate(gts))}
+    Wg = W.to(gpu).requires_grad_(True)
+    dist, params, status = _PrimitiveFitLoss.apply(Wg, P.to(gpu), Nn.to(gpu), tab, 4, False)
+    assert status.cpu().tolist() == [0, 0, 0, 0]
+    dist.sum().backward()
+    for b, kind in enumerate(kinds):
+        p, nn, w, gt = segs[b]
+        w_eff = (torch.from_numpy(w - np.float32(EPS)) + np.float32(EPS)).numpy()    # what the kernel sees
+        ref_p, ref_d, ref_g = oracle(kind, p, nn, w_eff, P[b, gts[b]].numpy(), torch.float64)
+        mine = align_sign(kind, params[b, :len(ref_p)].cpu().numpy(), ref_p)
+        if kind == "cylinder":
+            assert np.abs(mine[:3] - ref_p[:3]).max() < 1e-7 and abs(mine[6] - ref_p[6]) < 1e-5 * ref_p[6]
+            assert abs(float(dist[b]) - ref_d) < 1e-4 * ref_d
+            assert np.abs(Wg.grad[b, 1, 0::4].cpu().numpy() - ref_g).max() < 1e-3 * np.abs(ref_g).max()
+            continue
+        tol = 2e-6 if kind == "cone" else 1e-9
+        assert np.abs(mine - ref_p).max() < tol * max(1.0, np.abs(ref_p).max()), (kind, mine, ref_p)
+        assert abs(float(dist[b]) - ref_d) < 5e-6 * ref_d
+        g = Wg.grad[b, 1, 0::4].cpu().numpy()
+        assert np.abs(g - ref_g).max() < 1e-4 * np.abs(ref_g).max(), (kind, np.abs(g - ref_g).max() / np.abs(ref_g).max())
+    assert float(Wg.grad[:, 0].abs().max()) == 0 and float(Wg.grad[:, 1, 1::4].abs().max()) == 0
+
+
+def test_static_nms_equals_the_dynamic_one(gpu):
+    from parsenet_codebase_amd.fitting_batch import bandwidth_batch, nms_batch
+    from parsenet_codebase_amd.mean_shift import MeanShift, mean_shift_iterations
+    torch.cuda.set_device(gpu)
+    B, N = 3, 4000
+    _, _, lab, _, emb, _ = _structured_batch(gpu, B, N, (1, 2, 5), noise=0.03)
+    bw, flag = bandwidth_batch(emb, 0.025)
+    ms = MeanShift()
+    for b in range(B):
+        np.random.seed(0)
+        ref = torch.clamp(ms.compute_bandwidth(emb[b], 10000, 0.025), min=0.003)
+        assert abs(float(bw[b]) - float(ref)) <= 1e-6 * float(ref)
+    new_X = mean_shift_iterations(emb, bw, 10)
+    st = nms_batch(new_X, emb, bw, 512)
+    for b in range(B):
+        _, ids, labels = ms.nms(new_X[b], emb[b], bw[b])
+        n = int(st["ncl"][b])
+        assert n == ids.shape[0] and torch.equal(st["cid"][b, :n], ids)
+        assert torch.equal(st["labels"][b], labels)
+        assert int(st["nocc"][b]) <= 512 and int(st["nflag"][b]) == 0
+
+
+def test_ragged_chamfer_and_bspline_kernels(gpu):
+    from parsenet_codebase_amd import kernels as K
+    from parsenet_codebase_amd.bspline import evaluate_surface, uniform_knot_bspline
+    from parsenet_codebase_amd.fitting_batch import _BSplineEval, _RaggedChamfer
+    torch.cuda.set_device(gpu)
+    g = torch.Generator().manual_seed(3)
+    na, nb = [900, 930, 900, 17], [1200, 333, 4096, 5]
+    A = [torch.rand(n, 3, generator=g) for n in na]
+    Bc = [torch.rand(n, 3, generator=g) for n in nb]
+    off = lambda c: torch.tensor(np.concatenate([[0], np.cumsum(c)]), dtype=torch.int32, device=gpu)   # noqa: E731
+    minA, argA, minB, argB = K.chamfer_nn_ragged(torch.cat(A).to(gpu), off(na), max(na), torch.cat(Bc).to(gpu),
+                                                 off(nb), max(nb))
+    oa = ob = 0
+    for a, b in zip(A, Bc):
+        m1, i1, m2, i2 = K.chamfer_nn(a.unsqueeze(0).to(gpu), b.unsqueeze(0).to(gpu))
+        d = ((a.unsqueeze(1) - b.unsqueeze(0)) ** 2)
+        dd = (d[..., 0] + d[..., 1]) + d[..., 2]
+        assert torch.equal(minA[oa:oa + len(a)].cpu(), dd.min(1)[0]) and torch.equal(m1[0].cpu(), dd.min(1)[0])
+        assert torch.equal(argA[oa:oa + len(a)], i1[0]) and torch.equal(argB[ob:ob + len(b)], i2[0])
+        assert torch.equal(minB[ob:ob + len(b)].cpu(), dd.min(0)[0])
+        oa += len(a); ob += len(b)
+    # autograd form against the per-pair API
+    from parsenet_codebase_amd.chamfer import chamfer_distance_single_shape
+    pred = torch.cat(A).to(gpu).requires_grad_(True)
+    item = lambda c: torch.tensor(np.repeat(np.arange(len(c)), c), device=gpu)   # noqa: E731
+    cnt = lambda c: torch.tensor(c, dtype=torch.float32, device=gpu)            # noqa: E731
+    vals = _RaggedChamfer.apply(pred, torch.cat(Bc).to(gpu), off(na), off(nb), item(na), item(nb), cnt(na), cnt(nb),
+                                max(na), max(nb))
+    (vals * torch.arange(1, 5, device=gpu)).sum().backward()
+    o = 0
+    for k, (a, b) in enumerate(zip(A, Bc)):
+        ag = a.to(gpu).requires_grad_(True)
+        ref = chamfer_distance_single_shape(ag, b.to(gpu))
+        (ref * (k + 1)).backward()
+        assert abs(float(vals[k]) - float(ref)) <= 1e-6 * float(ref)
+        assert torch.allclose(pred.grad[o:o + len(a)], ag.grad, rtol=1e-5, atol=1e-9)
+        o += len(a)
+    # B-spline evaluation with the affine map and the closed-surface wrap
+    nu, nv = [torch.from_numpy(x.astype(np.float32)).to(gpu) for x in uniform_knot_bspline(20, 20, 3, 3, 30)]
+    ctrl = torch.randn(3, 20, 20, 3, generator=g).to(gpu).requires_grad_(True)
+    aff = torch.randn(3, 3, 4, generator=g).to(gpu)
+    for wrap in (False, True):
+        out = _BSplineEval.apply(ctrl, nu, nv, aff, wrap)
+        ref = evaluate_surface(nu, nv, ctrl) @ aff[:, :, :3].transpose(1, 2) + aff[:, :, 3].unsqueeze(1)
+        if wrap:
+            ref = torch.cat([ref, ref[:, :30]], 1)
+        assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-6)
+        gq = torch.randn(out.shape, generator=g).to(gpu)
+        g1, = torch.autograd.grad(out, ctrl, gq, retain_graph=True)
+        g2, = torch.autograd.grad(ref, ctrl, gq)
+        assert torch.allclose(g1, g2, atol=2e-5)
+    plain = K.bspline_eval(nu, nv, ctrl.detach())
+    assert torch.allclose(plain, evaluate_surface(nu, nv, ctrl.detach()), atol=2e-6)

@@ -1,20 +1,20 @@
 """How many deterministic seg-only steps (triplet + NLL on the bench batch, lr 1e-2, train mode)
-until mean-shift (quantile 0.025, 10 iterations) finds a handful of clusters per shape.
-python tools/pretrain_probe.py"""
+until mean-shift (quantile 0.025, 10 iterations) finds a handful of clusters per shape; also the
+number of occupied centres the non-maximum suppression sees.  python tools/pretrain_probe.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from parsenet_codebase_amd import workloads
-from parsenet_codebase_amd.mean_shift import MeanShift
+from parsenet_codebase_amd.fitting_batch import bandwidth_batch, nms_batch
+from parsenet_codebase_amd.mean_shift import mean_shift_iterations
 
 dev = torch.device("cuda:0")
 step = workloads.ParsenetSegStep(dev, batch=4, num_points=10000)
 np.random.seed(1000)
-ms = MeanShift()
 done = 0
-for target in (0, 10, 20, 40, 60, 80, 120, 160, 240, 320):
+for target in (0, 20, 50, 100, 150, 200, 300, 500, 800, 1200):
     step.model.train()
     while done < target:
         step.step()
@@ -22,9 +22,11 @@ for target in (0, 10, 20, 40, 60, 80, 120, 160, 240, 320):
     step.model.eval()
     with torch.no_grad():
         emb, _, l = step.model(step.x, step.labels, True)
-    counts = []
-    for b in range(4):
-        e = torch.nn.functional.normalize(emb[b].t(), dim=1)
-        _, c, bw, lab = ms.mean_shift(e, 10000, 0.025, 10)
-        counts.append((int(c.shape[0]), len(np.unique(step.labels[b])), round(float(bw), 3)))
-    print("steps %4d  embed loss %.4f  clusters/gt/bw per shape: %s" % (done, float(l.mean()), counts), flush=True)
+        e = torch.nn.functional.normalize(emb.permute(0, 2, 1), dim=2)
+        bw, _ = bandwidth_batch(e, 0.025)
+        new_X = mean_shift_iterations(e, bw, 10)
+        st = nms_batch(new_X, e, bw, 4096)
+    gt = [len(np.unique(step.labels[b])) for b in range(4)]
+    print("steps %4d  embed loss %.4f  clusters %s  occupied centres %s  gt %s  bw %s" % (
+        done, float(l.mean()), st["ncl"].tolist(), st["nocc"].tolist(), gt, [round(float(x), 3) for x in bw]),
+        flush=True)
