@@ -894,11 +894,8 @@ class Evaluation:
             for p in net.parameters():
                 p.requires_grad = False
         self.ms = MeanShift()
-        # batched training path (fitting_batch.py): length of the padded list of occupied centres
-        # in the non-maximum suppression (adapted from the previous call, no synchronisation), and
-        # counters for bench.py's ``segments_per_shape``
+        # batched training path (fitting_batch.py) and counters for bench.py's ``segments_per_shape``
         self.batched = True
-        self.occupied_cap = 1024
         self.stats = {"shapes": 0, "clusters": 0, "fitted": 0}
 
     def guard_mean_shift(self, embedding, quantile, iterations, kernel_type="gaussian"):

@@ -8,8 +8,9 @@ src/primitive_forward.py:925-1047 (fit_one_shape_torch), :708-843 (Fit.fit_*_tor
 by STAGE over all shapes and segments instead of by shape and segment:
 
   clustering   bandwidths, mean-shift iterations and non-maximum suppression of all shapes as
-               batched launches with static shapes (occupied centres / cluster centres are
-               padded lists, no torch.unique / nonzero), ONE download (labels, counts, flags);
+               batched launches (occupied centres / cluster centres are padded lists instead of
+               torch.unique / nonzero results): one small download sizes the neighbour matrix,
+               ONE download brings the cluster ids of all shapes to the host;
   host         Hungarian matching and the segment table of every shape (what the reference also
                does on the host), ONE packed upload;
   primitives   csrc/fitbatch.hip: weighted moments -> fits -> cone pass -> residuals, 4 launches
@@ -22,7 +23,7 @@ by STAGE over all shapes and segments instead of by shape and segment:
   loss         per-shape means, ONE download (distances, fit status, predicted types).
 
 The reference's serial path costs ~250 launches and ~10 host synchronisations per segment; this
-one ~60 launches per shape and 3 synchronisations per step."""
+one ~60 launches per shape and 4 synchronisations per STEP (one per shape at batch 4)."""
 import numpy as np
 import torch
 
@@ -72,12 +73,17 @@ def _padded_true_indices(mask, cap):
     return order[:, :cap], mask.sum(1)
 
 
-def nms_batch(new_X, X, bw, occupied_cap):
-    """MeanShift.nms (src/mean_shift.py:139-179) for all shapes with static shapes.
-    new_X, X (B,N,128) detached, bw (B,).  Returns a dict of device tensors:
-      labels (B,N) int64, cid (B,CMAX) int64 ascending centre ids (padded), ncl (B,), nocc (B,)
-      number of occupied centres (must be <= occupied_cap), nflag (B,) rows the selection kernel
-      flagged (massive ties).  None outside the kernel's fast path."""
+def nms_batch(new_X, X, bw):
+    """MeanShift.nms (src/mean_shift.py:139-179) for all shapes at once.  new_X, X (B,N,128)
+    detached, bw (B,).  Returns a dict: labels (B,N) int64, cid (B,CMAX) int64 ascending centre
+    ids (padded), ncl (B,) on the device, and nocc (B,), nflag (B,) on the HOST — the number of
+    occupied centres sizes the neighbour matrix (one download for the batch), nflag counts rows
+    the selection kernel flagged (massive ties).  None outside the kernel's fast path.
+
+    The reference scores every occupied centre u against ALL N shifted points j with
+    [dist(u,j) < b] * members(j); unoccupied j score 0 and the row maximum is at least members(u)
+    > 0, so only occupied columns can win: the neighbour matrix is (occupied x occupied), in
+    ascending centre order — the first-index tie rule is unchanged."""
     B, N, D = X.shape
     res = K.dot_select(X, new_X, 1, want_value=False)
     if res is None:
@@ -86,13 +92,18 @@ def nms_batch(new_X, X, bw, occupied_cap):
     membership = idx[:, :, 0]
     counts = torch.zeros((B, N), dtype=torch.float32, device=X.device)
     counts.scatter_add_(1, membership, torch.ones((B, N), dtype=torch.float32, device=X.device))
-    U = min(int(occupied_cap), N)
-    uq, nocc = _padded_true_indices(counts > 0, U)
+    occ = counts > 0
+    nocc = occ.sum(1)
+    host = torch.cat([nocc, (flags != 0).sum(1)]).cpu().numpy()          # sync: sizes the next launches
+    nocc_h, nflag_h = host[:B], host[B:]
+    U = int(nocc_h.max())
+    uq, _ = _padded_true_indices(occ, U)
     rowvalid = torch.arange(U, device=X.device).unsqueeze(0) < nocc.unsqueeze(1)
     Cu = torch.gather(new_X, 1, uq.unsqueeze(2).expand(-1, -1, D))
-    dist = 2.0 - 2.0 * torch.bmm(Cu, new_X.transpose(1, 2))                     # (B,U,N)
-    score = (dist < bw.reshape(B, 1, 1)).float() * counts.unsqueeze(1)
-    best = MSM._first_argmax(score, 2)                                         # (B,U)
+    dist = 2.0 - 2.0 * torch.bmm(Cu, Cu.transpose(1, 2))                      # (B,U,U)
+    cnt_u = torch.gather(counts, 1, uq)                                      # padding: unoccupied, count 0
+    score = (dist < bw.reshape(B, 1, 1)).float() * cnt_u.unsqueeze(1)
+    best = torch.gather(uq, 1, MSM._first_argmax(score, 2))                  # (B,U) centre ids
     hits = torch.zeros((B, N), dtype=torch.float32, device=X.device)
     hits.scatter_add_(1, best, rowvalid.float())
     cid, ncl = _padded_true_indices(hits > 0, CMAX)
@@ -101,7 +112,7 @@ def nms_batch(new_X, X, bw, occupied_cap):
     sc = torch.bmm(Csel, X.transpose(1, 2))                                     # (B,CMAX,N)
     sc = torch.where(cvalid.unsqueeze(2), sc, torch.full_like(sc, float("-inf")))
     labels = MSM._first_argmax(sc, 1)
-    return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc, "nflag": (flags != 0).sum(1)}
+    return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc_h, "nflag": nflag_h}
 
 
 # -------------------------------------------------------------------------------------------
@@ -130,7 +141,7 @@ class _PrimitiveFitLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Wn, P, Nrm, tab, stride, sqrt_flag):
-        Wn = Wn.contiguous()
+        Wn, P, Nrm = Wn.contiguous(), P.contiguous(), Nrm.contiguous()
         partial = K.weighted_moments(P, Nrm, Wn, tab["shape"], tab["row"], stride, EPS)
         params, jac, status = K.primitive_fit(partial, tab["type"], tab["rows"])
         cone_direct = K.cone_angle(P, Wn, tab["shape"], tab["row"], tab["type"], status, params, jac, stride, EPS)
@@ -309,37 +320,36 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
     B, N, D = embedding.shape
     dev = embedding.device
     labels, primitives = np.asarray(labels), np.asarray(primitives)
+    points, normals = points.contiguous(), normals.contiguous()
     emb = torch.nn.functional.normalize(embedding, p=2, dim=2)
     fitter = ev.fitter
 
     # ---- clustering, all shapes ---------------------------------------------------------
     state = None
-    cap_used = ev.occupied_cap
     with torch.no_grad():
         bwres = bandwidth_batch(emb, quantile)
     if bwres is not None and D == 128:
         bw, bwflag = bwres
         new_X = MSM.mean_shift_iterations(emb, bw, iterations)
         with torch.no_grad():
-            state = nms_batch(new_X.detach(), emb.detach(), bw, cap_used)
+            state = nms_batch(new_X.detach(), emb.detach(), bw)
     with torch.no_grad():
         # SIOU_matched_segments merges the predicted types before the per-cluster vote
         # (src/segment_utils.py:152-161: 0, 6, 7 -> 9; 8 -> 2)
         lut = torch.tensor([9, 1, 2, 3, 4, 5, 9, 9, 2, 9], dtype=torch.int64, device=dev)
         prim_pred = lut[torch.max(primitives_log_prob, 1)[1]]
     if state is not None:
-        pack = torch.cat([state["labels"].reshape(-1), state["cid"].reshape(-1), state["ncl"], state["nocc"],
-                          state["nflag"], bwflag]).to(torch.int32).cpu().numpy()   # sync 1
+        pack = torch.cat([state["labels"].reshape(-1), state["cid"].reshape(-1), state["ncl"],
+                          bwflag]).to(torch.int32).cpu().numpy()                         # download: cluster ids
         o = 0
         lab_h = pack[o:o + B * N].reshape(B, N); o += B * N
         cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
-        ncl_h, nocc_h, nflag_h, bwflag_h = [pack[o + k * B:o + (k + 1) * B] for k in range(4)]
-        ev.occupied_cap = int(min(N, max(256, 1 << int(np.ceil(np.log2(2 * max(int(nocc_h.max()), 1)))))))
+        ncl_h, bwflag_h = pack[o:o + B], pack[o + B:o + 2 * B]
+        nflag_h = state["nflag"]
     centers, bws, cluster_ids = [], [], []
     for b in range(B):
         # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122)
-        fast = (state is not None and nflag_h[b] == 0 and bwflag_h[b] == 0 and nocc_h[b] <= cap_used
-                and ncl_h[b] <= CMAX)
+        fast = state is not None and nflag_h[b] == 0 and bwflag_h[b] == 0 and ncl_h[b] <= CMAX
         if fast:
             np.random.shuffle(np.arange(N))
         if fast and ncl_h[b] <= 49:
@@ -347,8 +357,8 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
             bws.append(bw[b])
             cluster_ids.append(lab_h[b].astype(np.int64))
         else:
-            # tie-flagged selection rows, more occupied centres than the padded list holds, or the
-            # guard's retry above 49 clusters: this shape alone on the synchronous path
+            # tie-flagged selection rows or the guard's retry above 49 clusters: this shape alone on
+            # the synchronous path
             q = quantile * 1.2 if (fast and ncl_h[b] > 49) else quantile
             c, bwb, ids = ev.guard_mean_shift(emb[b], q, iterations, kernel_type="gaussian")
             centers.append(c)

@@ -512,6 +512,8 @@ def primitive_fit(partial, seg_type, seg_rows):
 
 def cone_angle(P, W, seg_shape, seg_row, seg_type, status, params, jac, stride, eps):
     """Second pass of the cone fit; updates params[:,6] and jac[:,6,:] in place, returns cone_direct (S,)."""
+    require_cuda(P, W, params, jac)
+    P, W = _f32c(P, "P"), _f32c(W, "W")
     B, N, _ = P.shape
     S = seg_shape.shape[0]
     cone_direct = torch.empty(S, dtype=torch.float64, device=P.device)
@@ -542,6 +544,8 @@ def primitive_residual(P, seg_shape, seg_type, gt_off, gt_idx, params, status, s
 def weighted_moments_bwd(P, Nrm, W, seg_shape, seg_row, seg_type, g_dist, dparam, jac, params, cone_direct,
                          stride, eps):
     """d loss / d W (B,Cp,N) fp32 of the batched fits given g_dist (S,) = d loss / d dist."""
+    require_cuda(P, Nrm, W, g_dist)
+    P, Nrm, W = _f32c(P, "P"), _f32c(Nrm, "Nrm"), _f32c(W, "W")
     B, N, _ = P.shape
     S = seg_shape.shape[0]
     gW = torch.zeros_like(W)

@@ -194,7 +194,13 @@ def test_end_to_end_fitting_loss(gpu):
     loss[0].backward()
     assert np.array_equal(canon(ids), canon(g["cluster_ids"]))
     assert sorted(v[0] for v in params.values() if v is not None) == list(g["kinds"])
-    assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 1e-3
+    # The analytic fits are stable: their mean distance is held to 1e-4.  The spline distances go
+    # through SplineNets whose feature-space kNN has near-ties: tests/golden/reference_noise_e2e.txt
+    # (tools/reference_noise.py) shows the reference's OWN arithmetic moving one spline distance by
+    # 9.8 % and the loss by 2.1 % when the input points are scaled by ONE ulp — the band below.
+    assert abs(loss[1] - float(g["geo"])) / float(g["geo"]) < 1e-4
+    assert abs(loss[2] - float(g["spline"])) / float(g["spline"]) < 5e-2
+    assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 3e-2
     assert abs(loss[3] - float(g["s_iou"])) < 1e-6 and abs(loss[4] - float(g["p_iou"])) < 1e-6
     ga = emb.grad.cpu().numpy().astype(np.float64).ravel()
     gb = g["grad_emb"].astype(np.float64).ravel()

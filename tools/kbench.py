@@ -160,6 +160,56 @@ def bench_fitting():
               (b, len(np.unique(lab[b])), len(np.unique(extra[1])), float(res[3]), t))
 
 
+def bench_fitting_batch():
+    """The whole clustering + fitting stage of a step (B = 4 shapes, ground-truth-structured
+    embedding): stage-wise path (fitting_batch.py) against the reference-ordered shape-by-shape
+    path, with kernel launches and host synchronisations counted by torch's profiler."""
+    import numpy as np
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.encoders import DGCNNControlPoints
+    from parsenet_codebase_amd.fitting import Evaluation
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, N = 4, 10000
+    pts, nrm, lab, prim = synthetic.make_batch(0, B, N)
+    ev = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1),
+                    open_path=DGCNNControlPoints(20, num_points=10, mode=0))
+    code = torch.nn.functional.normalize(torch.randn(32, 128), dim=1)
+    emb = torch.stack([torch.nn.functional.normalize(code[torch.from_numpy(lab[b]).long()] + 0.01 * torch.randn(N, 128),
+                                                     dim=1) for b in range(B)]).to(dev).requires_grad_(True)
+    P = torch.from_numpy(pts).to(dev)
+    Nn = torch.from_numpy(nrm).to(dev)
+    logp = torch.log_softmax(torch.randn(B, 10, N, device=dev), 1)
+
+    def run(batched):
+        ev.batched = batched
+        if batched:
+            res = ev.fitting_losses(emb, P, Nn, lab, prim, logp, quantile=0.025, iterations=10, lamb=0.1)
+        else:
+            res = [ev.fitting_loss(emb[b:b + 1], P[b:b + 1], Nn[b:b + 1], lab[b:b + 1], prim[b:b + 1], logp[b:b + 1],
+                                   quantile=0.025, iterations=10, lamb=0.1) for b in range(B)]
+        sum(r[0][0].sum() for r in res).backward()
+        return res
+    for batched in (False, True):
+        run(batched)
+        t = timeit(lambda: run(batched), warmup=1, iters=5)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            res = run(batched)
+            torch.cuda.synchronize()
+        ev_list = prof.events()
+        launches = sum(1 for e in ev_list if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name
+                       and "Memset" not in e.name)
+        syncs = sum(1 for e in ev_list if e.name in ("hipStreamSynchronize", "hipDeviceSynchronize", "hipEventSynchronize",
+                                                     "cudaStreamSynchronize", "cudaDeviceSynchronize",
+                                                     "cudaEventSynchronize"))
+        d2h = sum(1 for e in ev_list if "Memcpy DtoH" in e.name or "Memcpy DtoH" in str(e.name))
+        nseg = sum(sum(1 for v in r[1][0].values() if v is not None) for r in res)
+        print("%-14s %6.1f ms per step of %d shapes (%d fitted segments): %d kernel launches (%.0f per shape), "
+              "%d device->host copies, %d host synchronisations (the profiled pass includes the final one)"
+              % ("stage-wise" if batched else "shape-by-shape", t, B, nseg, launches, launches / B, d2h, syncs))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["knn", "chamfer"]
     for w in which:

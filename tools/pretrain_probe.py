@@ -25,7 +25,7 @@ for target in (0, 20, 50, 100, 150, 200, 300, 500, 800, 1200):
         e = torch.nn.functional.normalize(emb.permute(0, 2, 1), dim=2)
         bw, _ = bandwidth_batch(e, 0.025)
         new_X = mean_shift_iterations(e, bw, 10)
-        st = nms_batch(new_X, e, bw, 4096)
+        st = nms_batch(new_X, e, bw)
     gt = [len(np.unique(step.labels[b])) for b in range(4)]
     print("steps %4d  embed loss %.4f  clusters %s  occupied centres %s  gt %s  bw %s" % (
         done, float(l.mean()), st["ncl"].tolist(), st["nocc"].tolist(), gt, [round(float(x), 3) for x in bw]),
