@@ -23,7 +23,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense peak (v
 HBM_PEAK_GBS = 8000.0
 
 
-def build_workload(name, device, rank):
+def build_workload(name, device, rank, pretrain=300):
     from parsenet_codebase_amd import workloads
     if name == "cfg4":
         B, N = 4, 10000
@@ -33,10 +33,13 @@ def build_workload(name, device, rank):
             "batch_per_gpu": B, "points": N, "k": 80}
     if name == "cfg5":
         B, N = 4, 10000
-        return workloads.ParsenetE2EStep(device, batch=B, num_points=N, first_shape=rank * B), {
+        return workloads.ParsenetE2EStep(device, batch=B, num_points=N, first_shape=rank * B,
+                                         pretrain_steps=pretrain), {
             "workload": "cfg5: ParSeNet e2e (seg + mean-shift 10 it. + per-segment spline/primitive fit + "
                         "Chamfer/residual), 10k pts, batch 4 per GPU, fwd+bwd+allreduce+Adam",
-            "batch_per_gpu": B, "points": N, "k": 80}
+            "batch_per_gpu": B, "points": N, "k": 80,
+            "init": "segmentation network after %d deterministic seg-only steps on the batch (stand-in for the "
+                    "reference's pretrained parsenet_with_normals.pth), frozen random-init SplineNets" % pretrain}
     if name in ("cfg2", "cfg3"):
         B, N = 32, 700
         closed = name == "cfg3"
@@ -66,6 +69,10 @@ def pmc_traffic(kernel_name, arith):
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def _scale(x, k):
+    return None if x is None else x * k
 
 
 def kernel_roofline(step, nprof):
@@ -110,7 +117,9 @@ def kernel_roofline(step, nprof):
     elif dom.startswith("meanshift"):
         # one shape, one iteration: units of 2*N^2*d FLOP (d = 128): forward 2, row pass 3, column pass 4
         units = {"meanshift_fwd": 2, "meanshift_bwd_rows": 3, "meanshift_bwd_cols": 4}[dom]
-        flops = units * 2.0 * N * N * 128
+        # the stage-wise fitting path clusters all shapes of the batch in one launch per pass
+        shapes_per_launch = B if getattr(step, "batched", False) else 1
+        flops = units * 2.0 * N * N * 128 * shapes_per_launch
         ach = flops / avg_s / 1e12
         from parsenet_codebase_amd import mean_shift as _ms
         if _ms.ARITH in ("bf16x3", "fp16x2"):
@@ -119,7 +128,7 @@ def kernel_roofline(step, nprof):
             pieces = 6.0 if _ms.ARITH == "bf16x3" else 3.0
             peak = MFMA_BF16_PEAK_TFLOPS / pieces
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": pmc_traffic(dom, _ms.ARITH),
+                    "frac": ach / peak, "traffic": _scale(pmc_traffic(dom, _ms.ARITH), shapes_per_launch),
                     "avg_launch_ms": table[dom]["avg_ms"],
                     "mfma": ("v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)"
                              if _ms.ARITH == "bf16x3" else
@@ -127,7 +136,8 @@ def kernel_roofline(step, nprof):
                     "executed_tflops": pieces * ach, "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, "f32"),
+                    "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": _scale(pmc_traffic(dom, "f32"), shapes_per_launch),
                     "avg_launch_ms": table[dom]["avg_ms"], "mfma": "v_mfma_f32_32x32x2_f32"}
     else:
         roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -276,6 +286,8 @@ def main():
     ap.add_argument("--workload", default="cfg5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--pretrain", type=int, default=300,
+                    help="cfg5: deterministic seg-only steps before the timed region (see workloads.ParsenetE2EStep)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -292,7 +304,7 @@ def main():
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
 
-    step, cfg = build_workload(args.workload, device, rank)
+    step, cfg = build_workload(args.workload, device, rank, args.pretrain)
     import numpy as np
     np.random.seed(1000 + rank)
 
@@ -325,6 +337,9 @@ def main():
         dist.barrier()
 
     if rank == 0:
+        if hasattr(step, "segments_per_shape"):
+            sps = step.segments_per_shape()
+            cfg = dict(cfg, segments_per_shape=round(sps["fitted"], 2), clusters_per_shape=round(sps["clusters"], 2))
         shapes = step.shapes_per_step() * world * args.steps
         out = {
             "metric": ("shapes/sec fwd+bwd on 10k-pt clouds" if args.workload in ("cfg4", "cfg5")

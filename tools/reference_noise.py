@@ -3,7 +3,7 @@ fp32 rounding noise IN THE REFERENCE'S OWN ARITHMETIC: the oracle (torch-CPU res
 the reference's output on this very fixture at 1e-4) is re-run with the input points scaled by
 1 +- k ulp and with another BLAS thread count.  A near-tie in a SplineNet's feature-space kNN
 (or in the confident-point selection) flips under a 1-ulp perturbation and moves that spline's
-Chamfer distance by ~10 %, the total loss by ~2 %: the band inside which no implementation —
+Chamfer distance by ~10 %, the total loss by ~2 % (and turns the gradient): the band inside which no implementation —
 including the reference on another BLAS build — can be expected to reproduce the fixture's
 value.  Output committed as tests/golden/reference_noise_e2e.txt; the tolerances of
 tests/test_golden_gpu.py::test_end_to_end_fitting_loss cite it.
@@ -26,17 +26,18 @@ def run(scale_pts, threads):
     def dspy(kind,points,params,sqrt=False):
         d=origd(kind,points,params,sqrt); drec.append((kind,float(d))); return d
     RF.distance=dspy
-    emb=torch.from_numpy(g["emb"])
+    emb=torch.from_numpy(g["emb"]).clone().requires_grad_(True)
     np.random.seed(1)
     p=torch.from_numpy(pts*np.float32(scale_pts))
     loss,_=ev.fitting_loss(emb.unsqueeze(0),p.unsqueeze(0),torch.from_numpy(nrm).unsqueeze(0),lab[None],prim[None],quantile=0.025,iterations=10,lamb=0.1)
     RF.distance=origd
-    return float(loss[0]),drec
+    loss[0].backward()
+    return float(loss[0]),drec,emb.grad.double().flatten()
 t=time.time()
-base,d0=run(1.0,8)
-print("base",base,d0,time.time()-t,flush=True)
+base,d0,g0=run(1.0,8)
+print("base",base,d0,"|grad|",float(g0.norm()),"cos(base grad, fixture grad) %.5f" % float(g0 @ torch.from_numpy(g["grad_emb"]).double().flatten() / (g0.norm() * np.linalg.norm(g["grad_emb"].astype(np.float64)))),flush=True)
 for sc,th in ((1.0,1),(1.0,3),(1+1.2e-7,8),(1-1.2e-7,8),(1+2.4e-7,8),(1+6e-7,8)):
-    l,d=run(sc,th)
+    l,d,gr=run(sc,th)
     ref = dict()
     for k, v in d0:
         ref.setdefault(k, []).append(v)
@@ -44,4 +45,6 @@ for sc,th in ((1.0,1),(1.0,3),(1+1.2e-7,8),(1-1.2e-7,8),(1+2.4e-7,8),(1+6e-7,8))
     for k, v in d:
         cur.setdefault(k, []).append(v)
     per = {k: "%.2e" % max(abs(a - b) / b for a, b in zip(sorted(cur[k]), sorted(ref[k]))) for k in ref}
-    print("scale %.9f threads %d loss %.8e rel %.2e  largest per-kind change %s" % (sc, th, l, abs(l - base) / base, per), flush=True)
+    cos = float(gr @ g0 / (gr.norm() * g0.norm()))
+    print("scale %.9f threads %d loss %.8e rel %.2e  cos(grad, base grad) %.4f  largest per-kind change %s"
+          % (sc, th, l, abs(l - base) / base, cos, per), flush=True)
