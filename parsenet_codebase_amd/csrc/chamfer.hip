@@ -8,10 +8,11 @@
 // Bound: fp32 VALU issue.  A pair costs 8 arithmetic instructions that cannot be fused
 // (d = ((dx*dx + dy*dy) + dz*dz), every operation rounded to fp32 exactly like the reference's
 // elementwise path, so minima and arg-mins are bit-identical to the oracle) plus the selection.
-//   * Q query points per lane (coordinates in VGPRs), candidate points staged in LDS as packed
-//     float4 tiles: ONE broadcast ds_read_b128 serves Q x 64 pair evaluations, which takes the
-//     kernel off the LDS issue port (the one-query-per-lane version issued three ds_read_b32
-//     per 11 VALU instructions);
+//   * Q query points per lane (coordinates in VGPRs); the candidates of a group are the same for
+//     every lane, so they are fetched with SCALAR loads (wave-uniform address -> s_load_dwordx8
+//     through the scalar cache) and enter the VALU instructions as SGPR operands: no LDS tile, no
+//     staging pass, no barrier — the one-query-per-lane LDS version issued three ds_read_b32
+//     per 11 VALU instructions and was bound by the LDS port;
 //   * selection per GROUP of 8 candidates: v_min3 chain + one compare/select pair per group
 //     instead of per candidate (8.9 instead of 11 VALU instructions per pair); the arg-min is
 //     the first candidate of the winning group that reproduces the minimum, resolved once per
@@ -23,16 +24,21 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define CH_THREADS 256
-#define CH_TILE 512   // candidate points per LDS tile (8 KiB of float4)
+#define CH_THREADS 128
 #define CH_GROUP 8
+
+__device__ static inline float ch_dist(float qx, float qy, float qz, float cx, float cy, float cz) {
+  const float dx = __fsub_rn(qx, cx);
+  const float dy = __fsub_rn(qy, cy);
+  const float dz = __fsub_rn(qz, cz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
 
 template <int Q>
 __global__ __launch_bounds__(CH_THREADS) void pn_chamfer_nn_kernel(
     const float* __restrict__ q, const int* __restrict__ qoff, int Nq_uniform,
     const float* __restrict__ c, const int* __restrict__ coff, int Nc_uniform, int chunk, int direct,
     unsigned long long* __restrict__ packed, float* __restrict__ mind, int64_t* __restrict__ arg) {
-  __shared__ float4 tile[CH_TILE];
   const int b = blockIdx.z;
   const int q0 = qoff ? qoff[b] : b * Nq_uniform;
   const int Nq = qoff ? qoff[b + 1] - q0 : Nq_uniform;
@@ -58,43 +64,34 @@ __global__ __launch_bounds__(CH_THREADS) void pn_chamfer_nn_kernel(
   }
   const int j_begin = blockIdx.y * chunk;
   const int j_end = min(Nc, j_begin + chunk);
-  for (int j0 = j_begin; j0 < j_end; j0 += CH_TILE) {
-    const int n = min(CH_TILE, j_end - j0);
-    const int npad = (n + CH_GROUP - 1) / CH_GROUP * CH_GROUP;
-    __syncthreads();
-    // coalesced stage: 3n consecutive floats into the xyz lanes of the float4 tile; the tail of
-    // the last group is padded with +inf (distance inf is never strictly smaller)
-    float* tf = (float*)tile;
-    for (int t = threadIdx.x; t < 3 * n; t += CH_THREADS) {
-      const float v = cb[(size_t)3 * j0 + t];
-      const int p = t / 3, k = t - 3 * p;
-      tf[4 * p + k] = v;
-    }
-    for (int p = n + threadIdx.x; p < npad; p += CH_THREADS)
-      tile[p] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
-    __syncthreads();
-    for (int g0 = 0; g0 < npad; g0 += CH_GROUP) {
-      float m[Q];
+  int j = j_begin;
+  for (; j + CH_GROUP <= j_end; j += CH_GROUP) {
+    const float* cj = cb + 3 * (size_t)j;   // wave-uniform: scalar loads
+    float cc[3 * CH_GROUP];
 #pragma unroll
-      for (int r = 0; r < Q; ++r) m[r] = __builtin_inff();
+    for (int t = 0; t < 3 * CH_GROUP; ++t) cc[t] = cj[t];
 #pragma unroll
-      for (int p = 0; p < CH_GROUP; ++p) {
-        const float4 cc = tile[g0 + p];
+    for (int r = 0; r < Q; ++r) {
+      float m = ch_dist(qx[r], qy[r], qz[r], cc[0], cc[1], cc[2]);
 #pragma unroll
-        for (int r = 0; r < Q; ++r) {
-          const float dx = __fsub_rn(qx[r], cc.x);
-          const float dy = __fsub_rn(qy[r], cc.y);
-          const float dz = __fsub_rn(qz[r], cc.z);
-          const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-          m[r] = fminf(m[r], d);
-        }
+      for (int p = 1; p < CH_GROUP; ++p)
+        m = fminf(m, ch_dist(qx[r], qy[r], qz[r], cc[3 * p], cc[3 * p + 1], cc[3 * p + 2]));
+      if (m < best[r]) {   // strict: the first group wins
+        best[r] = m;
+        bestg[r] = j;
       }
+    }
+  }
+  if (j < j_end) {   // last, partial group
 #pragma unroll
-      for (int r = 0; r < Q; ++r)
-        if (m[r] < best[r]) {   // strict: the first group wins
-          best[r] = m[r];
-          bestg[r] = j0 + g0;
-        }
+    for (int r = 0; r < Q; ++r) {
+      float m = __builtin_inff();
+      for (int p = j; p < j_end; ++p)
+        m = fminf(m, ch_dist(qx[r], qy[r], qz[r], cb[3 * (size_t)p], cb[3 * (size_t)p + 1], cb[3 * (size_t)p + 2]));
+      if (m < best[r]) {
+        best[r] = m;
+        bestg[r] = j;
+      }
     }
   }
   // resolve the arg-min inside the winning group: first candidate that reproduces the minimum
@@ -111,13 +108,10 @@ __global__ __launch_bounds__(CH_THREADS) void pn_chamfer_nn_kernel(
     }
     int besti = bestg[r];
     const int gend = min(j_end, bestg[r] + CH_GROUP);
-    for (int j = bestg[r]; j < gend; ++j) {
-      const float dx = __fsub_rn(qx[r], cb[3 * (size_t)j + 0]);
-      const float dy = __fsub_rn(qy[r], cb[3 * (size_t)j + 1]);
-      const float dz = __fsub_rn(qz[r], cb[3 * (size_t)j + 2]);
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    for (int p = bestg[r]; p < gend; ++p) {
+      const float d = ch_dist(qx[r], qy[r], qz[r], cb[3 * (size_t)p + 0], cb[3 * (size_t)p + 1], cb[3 * (size_t)p + 2]);
       if (d == best[r]) {
-        besti = j;
+        besti = p;
         break;
       }
     }
@@ -146,19 +140,19 @@ __global__ void pn_chamfer_unpack_kernel(const unsigned long long* __restrict__ 
 static int chamfer_one_side(const float* q, const int* qoff, int Nq, long long total_q, const float* c,
                             const int* coff, int Nc, int B, unsigned long long* packed, float* mind,
                             int64_t* arg, hipStream_t stream) {
-  // Q queries per lane: more VALU work per LDS read, fewer workgroups — only when the batch
-  // still fills the chip (PN_CHAMFER_Q overrides, for tuning)
+  // Q queries per lane amortise the scalar candidate loads; keep >= ~2000 waves in flight
+  // (PN_CHAMFER_Q overrides, for tuning)
   const long long lanes = (long long)B * Nq;
-  int Q = lanes >= 32768 ? 4 : (lanes >= 8192 ? 2 : 1);
+  int Q = lanes >= 262144 ? 4 : (lanes >= 65536 ? 2 : 1);
   if (const char* e = getenv("PN_CHAMFER_Q")) {
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) Q = v;
   }
   const int qblocks = pn_cdiv(Nq, CH_THREADS * Q);
-  // enough blocks to cover 256 CUs several times over, but never split a
-  // candidate range below one LDS tile
-  int splits = pn_cdiv(2048, (long long)qblocks * B);
-  const int max_splits = pn_cdiv(Nc, CH_TILE);
+  // enough workgroups to cover 256 CUs several times over, but never split a candidate range
+  // below 256 points
+  int splits = pn_cdiv(4096, (long long)qblocks * B);
+  const int max_splits = pn_cdiv(Nc, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int chunk = pn_cdiv(Nc, splits);

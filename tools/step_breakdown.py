@@ -1,0 +1,49 @@
+"""Per-step GPU time of the LAST steps of a rocprofv3 kernel trace of bench.py, grouped by stage
+(kernel-name patterns), and the GPU idle time inside a step.  python tools/step_breakdown.py trace.csv [steps]"""
+import csv
+import sys
+import collections
+
+fn = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+rows = list(csv.DictReader(open(fn)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# steps are delimited by the Adam kernel (multi_tensor_apply) bursts: find the last `steps` optimizer bursts
+names = [r["Kernel_Name"] for r in rows]
+adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n or "adam" in n.lower()]
+bursts = []
+for i in adam:
+    if not bursts or i - bursts[-1][-1] > 50:
+        bursts.append([i])
+    else:
+        bursts[-1].append(i)
+ends = [b[-1] for b in bursts][-(steps + 1):]
+groups = collections.OrderedDict([
+    ("mean-shift iterations", ("pn_ms3_", "pn_ms_", "pn_msh_")),
+    ("bandwidth / nms selection", ("pn_dotsel", "pn_sel", "dot_select", "pn_dot")),
+    ("kNN", ("pn_knn",)),
+    ("edge conv / group norm (HIP)", ("pn_edge", "pn_gn", "pn_transpose", "pn_moments")),
+    ("batched fits (HIP)", ("pn_wmom", "pn_primfit", "pn_cone", "pn_prim_residual", "pn_bspline", "pn_chamfer")),
+    ("GEMM (rocBLAS / hipBLASLt)", ("Cijk", "gemm", "rocblas")),
+    ("elementwise / reductions / sort (torch)", ("",)),
+])
+tot = collections.Counter()
+cnt = collections.Counter()
+busy = 0
+span = 0
+for a, b in zip(ends[:-1], ends[1:]):
+    seg = rows[a + 1:b + 1]
+    span += int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
+    for r in seg:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        busy += d
+        for g, pats in groups.items():
+            if any(p in r["Kernel_Name"] for p in pats):
+                tot[g] += d
+                cnt[g] += 1
+                break
+n = len(ends) - 1
+print("steps analysed: %d; wall per step (first to last kernel) %.2f ms; kernel time %.2f ms; launches per step %.0f"
+      % (n, span / n / 1e6, busy / n / 1e6, sum(cnt.values()) / n))
+for g in groups:
+    print("  %-42s %7.2f ms  %6.0f launches" % (g, tot[g] / n / 1e6, cnt[g] / n))
