@@ -234,11 +234,14 @@ def build_parsenet(cfg, device):
     return model
 
 
-def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000):
-    """train_parsenet.py:142-285.  Returns the per-epoch history (list of dicts)."""
+def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000, model=None, on_step=None):
+    """train_parsenet.py:142-285.  Returns the per-epoch history (list of dicts).
+    ``model``: a ready network instead of a fresh one (tests: identical initial weights on both
+    sides of a parity check); ``on_step(model, flat_gradient)`` is called with the accumulated,
+    rank-averaged gradient right before every ``optimizer.step()``."""
     rank, world, dev = dp.init_from_env()
     device = device or dev
-    model = build_parsenet(cfg, device)
+    model = model if model is not None else build_parsenet(cfg, device)
     sync_module_from_rank0(model)
     bucket = dp.FlatGradBucket(model.parameters())
     optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
@@ -271,6 +274,8 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000):
                 acc["emb"] += embed_loss.item() / num_iter
                 acc["iou"] += iou / num_iter
             bucket.all_reduce_mean()
+            if on_step is not None:
+                on_step(model, bucket.flat)
             optimizer.step()
             for k in tr:
                 tr[k].append(acc[k])

@@ -333,6 +333,50 @@ def main():
     out.update(kron_bu=bu, kron_bv=bv, kron_P=P3, kron_ctrl=ref_approx.fit_bezier_surface_fit_kronecker(P3, bu, bv))
     save("fitting", **out)
 
+    # ---- cylinder fit (primitive_forward.py:784-806) + the reference's own ridge noise -------------
+    # The circle fit on the points projected along the axis is rank deficient by construction, so
+    # fit_sphere_torch always lands in LeastSquares.lstsq's ridge branch: lambda is found by comparing
+    # fp32 singular values with a tolerance of their own size and the system is solved in fp32.  The
+    # fixture therefore also records how far the reference moves AGAINST ITSELF when its inputs are
+    # scaled by 1 +- k ulp or the BLAS thread count changes: the tolerances of the parity tests.
+    def cylinder_run(scale, threads):
+        torch.set_num_threads(threads)
+        rng = np.random.RandomState(31)
+        p, n = synthetic._cylinder(rng, 600)
+        gq = torch.Generator().manual_seed(77)
+        p = (torch.from_numpy(p.astype(np.float32)) + 0.01 * torch.randn(600, 3, generator=gq)) * np.float32(scale)
+        n = torch.nn.functional.normalize(torch.from_numpy(n.astype(np.float32)) +
+                                          0.05 * torch.randn(600, 3, generator=gq), dim=1)
+        w = (torch.rand(600, 1, generator=gq) * 0.9 + 0.1).requires_grad_(True)
+        a, c, r = fit.fit_cylinder_torch(p, n, w)
+        res = dist.distance_from_cylinder(p, [a, c, r])
+        res.backward()
+        return dict(p=p.numpy(), n=n.numpy(), w=w.detach().numpy(), a=a.detach().numpy().ravel(),
+                    c=c.detach().numpy().ravel(), r=float(r), res=float(res), gw=w.grad.numpy().ravel())
+    threads0 = torch.get_num_threads()
+    base = cylinder_run(1.0, threads0)
+    dev = dict(axis=0.0, c_perp=0.0, c_axial=0.0, r=0.0, res=0.0, gw_cos=1.0)
+    for sc, th in ((1.0, 1), (1.0, 3), (1 + 1.2e-7, threads0), (1 - 1.2e-7, threads0), (1 + 2.4e-7, threads0),
+                   (1 - 2.4e-7, threads0), (1 + 6e-7, threads0), (1 - 6e-7, threads0)):
+        cur = cylinder_run(sc, th)
+        sgn = np.sign(np.dot(cur["a"], base["a"]))
+        dc = cur["c"] - base["c"]
+        ax = base["a"]
+        dev["axis"] = max(dev["axis"], float(np.abs(sgn * cur["a"] - base["a"]).max()))
+        dev["c_axial"] = max(dev["c_axial"], float(abs(np.dot(dc, ax))))
+        dev["c_perp"] = max(dev["c_perp"], float(np.linalg.norm(dc - np.dot(dc, ax) * ax)))
+        dev["r"] = max(dev["r"], abs(cur["r"] - base["r"]) / base["r"])
+        dev["res"] = max(dev["res"], abs(cur["res"] - base["res"]) / base["res"])
+        dev["gw_cos"] = min(dev["gw_cos"], float(np.dot(cur["gw"], base["gw"]) /
+                                                 (np.linalg.norm(cur["gw"]) * np.linalg.norm(base["gw"]))))
+    torch.set_num_threads(threads0)
+    print("cylinder: reference against itself under +-1..5 ulp / thread count:", dev)
+    save("cylinder", p=base["p"], n=base["n"], w=base["w"], a_abs_sorted=np.sort(np.abs(base["a"])), a=base["a"],
+         c=base["c"], r=np.float32(base["r"]), res=np.float32(base["res"]), gw=base["gw"],
+         noise_axis=np.float32(dev["axis"]), noise_c_perp=np.float32(dev["c_perp"]),
+         noise_c_axial=np.float32(dev["c_axial"]), noise_r=np.float32(dev["r"]), noise_res=np.float32(dev["res"]),
+         noise_gw_cos=np.float32(dev["gw_cos"]))
+
     # ---- end-to-end fitting loss --------------------------------------------------------------------
     ev = ref_res.Evaluation.__new__(ref_res.Evaluation)
     ev.res_loss = ref_prim.ResidualLoss()
