@@ -51,15 +51,20 @@ def build_workload(name, device, rank, pretrain=300):
     raise SystemExit("unknown workload %r" % name)
 
 
-def pmc_traffic(kernel_name, arith):
+def pmc_traffic(kernel_name, arith, shapes_per_launch=1):
     """HBM-side bytes per launch of a mean-shift kernel from the committed PMC run of the same
     launch configuration (profiles/: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH
     doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
-    the file is not there — bench.py never profiles counters itself."""
+    the file is not there — bench.py never profiles counters itself.  The round-2 file holds the
+    batched launches (4 shapes each) of the default arithmetic; the round-1 files are per shape."""
     import csv
     files = {"fp16x2": ("r01_meanshift_h2_pmc.csv", "pn_msh_kernel<%d>"),
              "bf16x3": ("r01_meanshift_x3_pmc.csv", "pn_ms3_kernel<%d>"),
              "f32": ("r01_meanshift_f32_pmc.csv", "pn_ms_kernel<%d>")}
+    scale = float(shapes_per_launch)
+    if arith == "bf16x3" and shapes_per_launch == 4:
+        files["bf16x3"] = ("r02_meanshift_x3_batch4_pmc.csv", "pn_ms3_kernel<%d>")
+        scale = 1.0
     fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", files[arith][0])
     idx = {"meanshift_fwd": 0, "meanshift_bwd_rows": 1, "meanshift_bwd_cols": 2}.get(kernel_name)
     if idx is None or not os.path.exists(fn):
@@ -68,7 +73,7 @@ def pmc_traffic(kernel_name, arith):
     vals = {r["counter"]: float(r["avg_per_launch"]) for r in csv.DictReader(open(fn)) if r["kernel"] == want}
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 * scale
 
 
 def _scale(x, k):
@@ -128,7 +133,7 @@ def kernel_roofline(step, nprof):
             pieces = 6.0 if _ms.ARITH == "bf16x3" else 3.0
             peak = MFMA_BF16_PEAK_TFLOPS / pieces
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": _scale(pmc_traffic(dom, _ms.ARITH), shapes_per_launch),
+                    "frac": ach / peak, "traffic": pmc_traffic(dom, _ms.ARITH, shapes_per_launch),
                     "avg_launch_ms": table[dom]["avg_ms"],
                     "mfma": ("v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)"
                              if _ms.ARITH == "bf16x3" else
@@ -137,7 +142,7 @@ def kernel_roofline(step, nprof):
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": _scale(pmc_traffic(dom, "f32"), shapes_per_launch),
+                    "traffic": pmc_traffic(dom, "f32", shapes_per_launch),
                     "avg_launch_ms": table[dom]["avg_ms"], "mfma": "v_mfma_f32_32x32x2_f32"}
     else:
         roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -67,9 +67,20 @@ class ParsenetE2EStep(ParsenetSegStep):
         # fits and SplineNets from the first timed step on.
         self.pretrain_steps = int(pretrain_steps)
         if self.pretrain_steps:
-            np.random.seed(4321 + first_shape)
-            for _ in range(self.pretrain_steps):
-                ParsenetSegStep.step(self)
+            # PARSENET_PRETRAIN_CACHE=<file>: keep the pre-trained weights across processes (profiling
+            # runs: the trace then holds end-to-end steps only); the file is tied to the recipe
+            import os
+            cache = os.environ.get("PARSENET_PRETRAIN_CACHE")
+            tag = "seed%d_first%d_B%d_N%d_steps%d" % (seed, first_shape, batch, num_points, self.pretrain_steps)
+            state = torch.load(cache, map_location=device) if cache and os.path.exists(cache) else None
+            if state is not None and state.get("tag") == tag:
+                self.model.load_state_dict(state["model"])
+            else:
+                np.random.seed(4321 + first_shape)
+                for _ in range(self.pretrain_steps):
+                    ParsenetSegStep.step(self)
+                if cache:
+                    torch.save({"tag": tag, "model": self.model.state_dict()}, cache)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
         torch.manual_seed(seed + 1)
         open_net = DGCNNControlPoints(20, num_points=10, mode=0)

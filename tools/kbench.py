@@ -121,6 +121,23 @@ def bench_meanshift():
     _lib.prof_enable(False)
 
 
+def bench_meanshift_batch():
+    """Ten iterations forward + backward on a batch of 4 shapes in one launch per pass (how the
+    stage-wise fitting path clusters a step) — the workload of the PMC traffic runs."""
+    from parsenet_codebase_amd.mean_shift import mean_shift_iterations
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, N = 4, 10000
+    X = torch.nn.functional.normalize(torch.randn(B, N, 128, device=dev), dim=2)
+    b = torch.full((B,), 0.3, device=dev)
+
+    def fwd_bwd():
+        x = X.clone().requires_grad_(True)
+        mean_shift_iterations(x, b, 10).sum().backward()
+    t = timeit(fwd_bwd, warmup=1, iters=3)
+    print("meanshift B=%d N=%d 10 it fwd+bwd: %.2f ms" % (B, N, t))
+
+
 def bench_meanshift_fwd():
     import parsenet_codebase_amd.mean_shift as MS
     dev = torch.device("cuda:0")
