@@ -258,7 +258,7 @@ def build_segment_table(labels, primitives, cluster_ids, N):
     from .fitting import _relaxed_iou_of_labels, solve_dense
     iou = _relaxed_iou_of_labels(cluster_ids, labels)
     rids, cids = solve_dense(1.0 - iou)
-    unique_pred = np.unique(cluster_ids)
+    unique_pred = np.flatnonzero(np.bincount(np.asarray(cluster_ids).astype(np.int64), minlength=1))   # = np.unique
     gcount = np.bincount(np.asarray(labels).astype(np.int64), minlength=50)
     n2 = (N + 1) // 2
     n4 = (n2 + 1) // 2
@@ -294,15 +294,13 @@ def siou_matched_segments_fast(labels, cluster_ids, prim_pred_per_cluster, primi
     g = np.asarray(labels).astype(np.int64)
     conf = np.bincount(p * 50 + g, minlength=2500).reshape(50, 50)
     np_, ng = conf.sum(1), conf.sum(0)
-    _, first = np.unique(g, return_index=True)
-    first_of = dict(zip(np.unique(g).tolist(), first.tolist()))
     ious, ok, pairs = [], [], []
     for r, c in zip(rids, cids):
         if ng[c] == 0 or np_[r] == 0 or ng[c] < 100:
             continue
         inter = conf[r, c]
         ious.append(inter / ((np_[r] + ng[c] - inter) + 1e-8))
-        gt_type = prim[first_of[int(c)]]
+        gt_type = prim[np.argmax(g == c)]          # primitives[gt segment][0]: its first point
         ok.append(gt_type == prim_pred_per_cluster[r])
         pairs.append([gt_type, prim_pred_per_cluster[r]])
     return (np.mean(ious) if ious else float("nan"), np.mean(ok) if ok else float("nan"), [[rids, cids]], pairs)
