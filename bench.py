@@ -63,7 +63,10 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1):
              "f32": ("r01_meanshift_f32_pmc.csv", "pn_ms_kernel<%d>")}
     scale = float(shapes_per_launch)
     if arith == "bf16x3" and shapes_per_launch == 4:
-        files["bf16x3"] = ("r02_meanshift_x3_batch4_pmc.csv", "pn_ms3_kernel<%d>")
+        from parsenet_codebase_amd import mean_shift as _ms
+        # block-sparse launches of the benchmark's own embedding / dense launches (kbench meanshift_batch)
+        files["bf16x3"] = ("r02_meanshift_x3_sparse_cfg5_pmc.csv" if _ms.SPARSE else "r02_meanshift_x3_batch4_pmc.csv",
+                           "pn_ms3_kernel<%d>")
         scale = 1.0
     fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", files[arith][0])
     idx = {"meanshift_fwd": 0, "meanshift_bwd_rows": 1, "meanshift_bwd_cols": 2}.get(kernel_name)
@@ -87,9 +90,11 @@ def kernel_roofline(step, nprof):
     from parsenet_codebase_amd import _lib
     _lib.prof_reset()
     _lib.prof_enable(True)
+    os.environ["PARSENET_MS_STATS"] = "1"      # active fractions of the block-sparse mean-shift plans
     for _ in range(nprof):
         step.step()
     torch.cuda.synchronize()
+    os.environ.pop("PARSENET_MS_STATS", None)
     _lib.prof_enable(False)
     res = _lib.prof_results()
     if not res:
@@ -127,6 +132,16 @@ def kernel_roofline(step, nprof):
         flops = units * 2.0 * N * N * 128 * shapes_per_launch
         ach = flops / avg_s / 1e12
         from parsenet_codebase_amd import mean_shift as _ms
+        sparse = None
+        if _ms.ARITH == "bf16x3" and _ms.SPARSE and _ms.LAST_PLAN_STATS:
+            # block-sparse launches: the waves run the GEMMs of the tile pairs the plan keeps; the
+            # others are rigorously below 1e-9 of the smallest row sum (csrc/meanshift_x3.h)
+            st = _ms.LAST_PLAN_STATS
+            col = {"meanshift_fwd": 1, "meanshift_bwd_rows": 2, "meanshift_bwd_cols": 3}[dom]
+            sparse = {"tile_pairs_executed": sum(t[0] for t in st) / len(st),
+                      "block_lists_visited": sum(t[col] for t in st) / len(st),
+                      "dense_equivalent_tflops": ach}
+            ach = ach * sparse["tile_pairs_executed"]      # FLOPs the matrix cores actually execute
         if _ms.ARITH in ("bf16x3", "fp16x2"):
             # every fp32 product is formed from 6 bf16 (3 fp16) piece products on the 16-bit matrix
             # cores (fp32 accumulate): the roof for ALGORITHMIC fp32 FLOPs is the dense peak / 6 (/ 3)
@@ -139,6 +154,8 @@ def kernel_roofline(step, nprof):
                              if _ms.ARITH == "bf16x3" else
                              "v_mfma_f32_32x32x16_f16, 3 piece products per fp32 product (scaled fp16x2 split)"),
                     "executed_tflops": pieces * ach, "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+            if sparse:
+                roof["block_sparse"] = sparse
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,

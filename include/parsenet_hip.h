@@ -116,6 +116,32 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
                                  void* img_q, void* img_gu, float* opart_q, float* opart_x, float* gq,
                                  float* gx, void* stream);
 
+/* Block-sparse variant.  K_ij = exp((q_i . x_j - 1) / b^2) of src/mean_shift.py:58-64 decays fast
+ * on a clustered embedding; a (32-row tile of q) x (32-row tile of x) pair is skipped when a
+ * rigorous bound from the tiles' bounding caps on the unit sphere shows that ALL its N^2/T^2
+ * terms together stay below rel_eps (1e-9) of the SMALLEST row sum of the q tile — far below the
+ * rounding of the fp32 sums, so the result is the dense one to fp32 noise.  The caller orders
+ * the points so that tiles are local (any order is valid; mean-shift is permutation-equivariant).
+ *   tileinfo : z (B,N,D) unit rows -> cen (B,T,D) normalised tile means, rho (B,T) angular radii
+ *              (+1e-3 slack), T = align_up(N,64)/32.
+ *   plan     : caps of the iterate q and of the data x -> plan (pn_meanshift_x3_plan_bytes):
+ *              the pair predicate (T x T bytes) and, per resident block of each pass, the compact
+ *              list of streamed tiles with at least one pair set.
+ *   iter_fwd_plan / iter_bwd_plan : as iter_fwd / iter_bwd, skipping what the plan of THIS
+ *              iteration excludes (plan == NULL: dense; the backward must get the forward's plan). */
+size_t pn_meanshift_x3_plan_bytes(int B, int N);
+int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, void* stream);
+int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,
+                             const float* bsq, int B, int N, float rel_eps, void* plan, void* stream);
+int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img_x, const float* bsq, int B, int N,
+                                      int D, float* opart, float* rpart, float* y, float* rsum,
+                                      float* unorm, const void* plan, void* stream);
+int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y, const float* q, const float* x,
+                                      const void* img_x, const float* rsum, const float* unorm,
+                                      const float* bsq, int B, int N, int D, float* gu, float* cs,
+                                      void* img_q, void* img_gu, float* opart_q, float* opart_x,
+                                      float* gq, float* gx, const void* plan, void* stream);
+
 /* ---- K-th largest dot product between unit vectors, fp16 x 2 matrix-core passes -----------
  * The bandwidth statistic of src/mean_shift.py:125-137 only needs the VALUE of the K-th nearest
  * neighbour (to 1e-5 after averaging): same engine as pn_dot_select_f32(out_val), with both

@@ -131,20 +131,51 @@ __global__ __launch_bounds__(64 * X3_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void pn_ms3_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
     const u32x4* __restrict__ PB, const float* __restrict__ cs, const float* __restrict__ rs, const float* __restrict__ bsq_, int N,
-    int ntiles, int tiles_per_slice, float* __restrict__ opart, float* __restrict__ rpart) {
+    int ntiles, int tiles_per_slice, float* __restrict__ opart, float* __restrict__ rpart,
+    const unsigned char* __restrict__ pairs, const int* __restrict__ counts, const int* __restrict__ lists,
+    const int* __restrict__ order, int nblk_total, int blk_off) {
   constexpr int NIMG = PASS == 2 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) u32x4 ldsP[2][NIMG][X3_IMG_U4];
   __shared__ __attribute__((aligned(16))) float lds_sc[2][64];
-  const int b = blockIdx.z;
+  // with a plan the (resident block, batch item) pairs are visited longest list first (the
+  // dispatcher hands out workgroups in grid order: the short ones fill the tail)
+  int b = blockIdx.z, rblk = blockIdx.y;
+  if (order) {
+    const int code = order[(size_t)blk_off * gridDim.z + (size_t)blockIdx.z * gridDim.y + blockIdx.y];
+    b = code >> 16;
+    rblk = code & 0xffff;
+  }
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, h = lane >> 5;
   constexpr int NW = X3_WAVES(PASS);
-  const int i0 = (blockIdx.y * NW + wave) * 32;
+  const int i0 = (rblk * NW + wave) * 32;
   const bool wave_on = i0 < N;
   const int S = gridDim.x, slice = blockIdx.x;
-  const int t_begin = slice * tiles_per_slice;
-  const int t_end = min(ntiles, t_begin + tiles_per_slice);
+  // block-sparse plan (pn_meanshift_x3_plan_f32): the streamed tiles this workgroup's resident
+  // block interacts with at all (everything else is below 1e-9 of the smallest row sum), cut
+  // into S slices; without a plan the slices cut the full range
+  const int* __restrict__ lst = nullptr;
+  int t_begin, t_end;
+  if (lists) {
+    const size_t blk = (size_t)b * nblk_total + blk_off + rblk;
+    const int cnt = counts[blk];
+    const int per = (cnt + S - 1) / S;
+    lst = lists + blk * ntiles;
+    t_begin = slice * per;
+    t_end = min(cnt, t_begin + per);
+  } else {
+    t_begin = slice * tiles_per_slice;
+    t_end = min(ntiles, t_begin + tiles_per_slice);
+  }
+  // this wave's own tile against the streamed one: pairs[tQ][tX]
+  const unsigned char* __restrict__ prow = nullptr;
+  int pstride = 0;
+  if (pairs) {
+    const int wt = min(rblk * X3_WAVES(PASS) + wave, ntiles - 1);
+    prow = pairs + (size_t)b * ntiles * ntiles + (PASS == 2 ? (size_t)wt : (size_t)wt * ntiles);
+    pstride = PASS == 2 ? ntiles : 1;
+  }
   const float bsqv = bsq_[b];
   const float hl = (0.5f / bsqv) * MS_LOG2E;
   const size_t bN = (size_t)b * N;
@@ -218,16 +249,20 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     }                                                                             \
   }
   int cur = 0;
-  if (t_begin < t_end) X3_STAGE_P(t_begin, 0);
+#define X3_TILE(E) (lst ? lst[E] : (E))
+  if (t_begin < t_end) X3_STAGE_P(X3_TILE(t_begin), 0);
 #ifdef MS_TIMING
   unsigned long long tb0 = 0, tdma = 0, tg1 = 0, tew = 0, tb1 = 0, tg2 = 0, tall = __builtin_amdgcn_s_memtime();
 #endif
-  for (int mt = t_begin; mt < t_end; ++mt) {
+  for (int e_ = t_begin; e_ < t_end; ++e_) {
+    const int mt = X3_TILE(e_);
     const int j0 = mt * 32;
     MS_T(U0);
     __syncthreads();  // image(s) of tile mt landed; every wave is done with tile mt - 1
     MS_T(U1);
-    if (mt + 1 < t_end) X3_STAGE_P(mt + 1, cur ^ 1);
+    if (e_ + 1 < t_end) X3_STAGE_P(X3_TILE(e_ + 1), cur ^ 1);
+    // wave-level skip: this wave's 32 resident indices do not interact with the streamed tile
+    const bool pair_on = !prow || prow[(size_t)mt * pstride] != 0;
     MS_T(U2);
     u32x4 wh[2], wm[2], wl[2];                                   // weights of the second GEMM
     u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
@@ -237,7 +272,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     f32x16 sa, ta, sb_, tb_;
 #define sb (*(TWO_ACC ? &sb_ : &sa))
 #define tb (*(TWO_ACC ? &tb_ : &ta))
-    if (wave_on) {
+    if (wave_on && pair_on) {
       // ---- first GEMM: S[streamed][resident] (and T with the second operand) ----
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -439,6 +474,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     }
     cur ^= 1;
   }
+#undef X3_TILE
 #ifdef MS_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
     ms_dbg[PASS][0] = tg1;
@@ -485,6 +521,198 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
   return PN_OK;
 }
 
+
+// ---- block-sparse plan ------------------------------------------------------------------
+// K_ij = exp((q_i . x_j - 1) / b^2) decays fast on a clustered embedding: most (row block, tile)
+// pairs contribute less than 1e-9 of the SMALLEST row sum of the block and can be skipped without
+// touching the fp32 result.  The test is rigorous, from per-tile bounding caps on the unit sphere
+// (centre c_t = normalised mean of the 32 rows, angular radius rho_t = max angle to it):
+//   any pair (q in tile A, x in tile B):  cos(min(pi, th + rA + rB)) <= q.x <= cos(max(0, th - rA - rB)),
+//   th = angle(c_A, c_B).
+// For a row tile A of the resident side, L_A = max_B cos(th + rA + rB) bounds every row's BEST
+// dot product from below, hence r_i >= exp((L_A - 1) / b^2) for all its rows; tile B is needed iff
+//   U_AB >= L_A - b^2 * log(N / 1e-9)      (N terms of at most exp((U-1)/b^2) against r_i).
+// The tile that attains L_A always passes, so no row sum can vanish.  pairs[tQ][tX] holds the
+// predicate; the lists hold, per resident block of every pass, the streamed tiles with at least
+// one pair set (pass 0 / 1: blocks of 8 / 4 q tiles against x tiles; pass 2: blocks of 8 x tiles
+// against q tiles).
+#define X3_PLAN_SLACK 1e-3f
+
+// centre and angular radius of every 32-row tile of z (B,N,D); one wave per tile
+__global__ __launch_bounds__(64) void pn_ms3_tileinfo_kernel(const float* __restrict__ z, int N, int ntiles,
+                                                             float* __restrict__ cen, float* __restrict__ rho) {
+  const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  const float* zb = z + (size_t)b * N * MS_D;
+  const int j0 = t * 32, cnt = min(32, N - j0);
+  float s0 = 0.f, s1 = 0.f;
+  for (int j = 0; j < cnt; ++j) {
+    s0 += zb[(size_t)(j0 + j) * MS_D + lane];
+    s1 += zb[(size_t)(j0 + j) * MS_D + lane + 64];
+  }
+  const float nn = sqrtf(pn_wave_sum(s0 * s0 + s1 * s1));
+  float r = 3.2f;   // empty / degenerate tile: interacts with everything
+  float c0 = 0.f, c1 = 0.f;
+  if (cnt > 0 && nn > 1e-6f) {
+    c0 = s0 / nn;
+    c1 = s1 / nn;
+    float mn = 1.f;
+    for (int j = 0; j < cnt; ++j) {
+      const float d = pn_wave_sum(zb[(size_t)(j0 + j) * MS_D + lane] * c0 + zb[(size_t)(j0 + j) * MS_D + lane + 64] * c1);
+      mn = fminf(mn, d);
+    }
+    r = acosf(fminf(fmaxf(mn, -1.f), 1.f)) + X3_PLAN_SLACK;
+  }
+  float* co = cen + ((size_t)b * ntiles + t) * MS_D;
+  co[lane] = c0;
+  co[lane + 64] = c1;
+  if (lane == 0) rho[(size_t)b * ntiles + t] = r;
+}
+
+// pairs[b][tQ][tX]; one workgroup per q tile
+__global__ __launch_bounds__(256) void pn_ms3_pairs_kernel(const float* __restrict__ cenQ,
+                                                           const float* __restrict__ rhoQ,
+                                                           const float* __restrict__ cenX,
+                                                           const float* __restrict__ rhoX,
+                                                           const float* __restrict__ bsq, int ntiles,
+                                                           float logterm, unsigned char* __restrict__ pairs) {
+  __shared__ float cq[MS_D];
+  __shared__ float red[4];
+  extern __shared__ float th_[];   // ntiles angles
+  const int b = blockIdx.y, tq = blockIdx.x;
+  const float* cqg = cenQ + ((size_t)b * ntiles + tq) * MS_D;
+  if (threadIdx.x < MS_D) cq[threadIdx.x] = cqg[threadIdx.x];
+  __syncthreads();
+  const float rq = rhoQ[(size_t)b * ntiles + tq];
+  float best = -2.f;
+  for (int tx = threadIdx.x; tx < ntiles; tx += 256) {
+    const float* cx = cenX + ((size_t)b * ntiles + tx) * MS_D;
+    float d = 0.f;
+    for (int c = 0; c < MS_D; ++c) d = fmaf(cq[c], cx[c], d);
+    const float th = acosf(fminf(fmaxf(d, -1.f), 1.f));
+    th_[tx] = th;
+    const float hi = th + rq + rhoX[(size_t)b * ntiles + tx];
+    best = fmaxf(best, hi >= 3.14159f ? -1.f : cosf(hi));
+  }
+  best = pn_wave_max(best);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  const float L = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float cut = L - bsq[b] * logterm;
+  for (int tx = threadIdx.x; tx < ntiles; tx += 256) {
+    const float lo = th_[tx] - rq - rhoX[(size_t)b * ntiles + tx];
+    const float U = lo <= 0.f ? 1.f : cosf(lo);
+    pairs[((size_t)b * ntiles + tq) * ntiles + tx] = U >= cut ? 1 : 0;
+  }
+}
+
+// compact lists; one wave per resident block: [0,nb0) pass 0, [nb0,nb0+nb1) pass 1, then pass 2
+__global__ __launch_bounds__(64) void pn_ms3_lists_kernel(const unsigned char* __restrict__ pairs, int ntiles,
+                                                          int nb0, int nb1, int nb2, int* __restrict__ counts,
+                                                          int* __restrict__ lists) {
+  const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
+  const int nblk = nb0 + nb1 + nb2;
+  int first, width;
+  bool by_row;   // resident tiles index the rows (q) of pairs
+  if (blk < nb0) { first = blk * 8; width = 8; by_row = true; }
+  else if (blk < nb0 + nb1) { first = (blk - nb0) * 4; width = 4; by_row = true; }
+  else { first = (blk - nb0 - nb1) * 8; width = 8; by_row = false; }
+  const unsigned char* P = pairs + (size_t)b * ntiles * ntiles;
+  int* out = lists + ((size_t)b * nblk + blk) * ntiles;
+  int n = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += 64) {
+    const int t = t0 + lane;
+    bool on = false;
+    if (t < ntiles)
+      for (int w = 0; w < width && first + w < ntiles; ++w)
+        on |= (by_row ? P[(size_t)(first + w) * ntiles + t] : P[(size_t)t * ntiles + first + w]) != 0;
+    const unsigned long long m = __ballot(on);
+    if (on) out[n + pn_mbcnt(m)] = t;
+    n += __popcll(m);
+  }
+  if (lane == 0) counts[(size_t)b * nblk + blk] = n;
+}
+
+// visiting order of the (batch item, resident block) pairs of each pass: longest list first.
+// order[pass offset * B + rank] = (b << 16) | block; one wave per pass.
+__global__ __launch_bounds__(64) void pn_ms3_order_kernel(const int* __restrict__ counts, int B, int nb0, int nb1,
+                                                          int nb2, int* __restrict__ order) {
+  const int pass = blockIdx.x, lane = threadIdx.x;
+  const int nblk = nb0 + nb1 + nb2;
+  const int off = pass == 0 ? 0 : (pass == 1 ? nb0 : nb0 + nb1);
+  const int nb = pass == 0 ? nb0 : (pass == 1 ? nb1 : nb2);
+  const int n = nb * B;
+  for (int e = lane; e < n; e += 64) {
+    const int be = e / nb, re = e - be * nb;
+    const int ce = counts[(size_t)be * nblk + off + re];
+    int rank = 0;
+    for (int f = 0; f < n; ++f) {
+      const int bf = f / nb, rf = f - bf * nb;
+      const int cf = counts[(size_t)bf * nblk + off + rf];
+      rank += (cf > ce) || (cf == ce && f < e);
+    }
+    order[(size_t)off * B + rank] = (be << 16) | re;
+  }
+}
+
+static void x3_plan_layout(int B, int N, int* ntiles, int* nb0, int* nb1, int* nb2, size_t* off_counts,
+                           size_t* off_lists, size_t* total) {
+  *ntiles = (int)pn_align_up(N, 64) / 32;
+  *nb0 = pn_cdiv(N, 256);
+  *nb1 = pn_cdiv(N, 128);
+  *nb2 = pn_cdiv(N, 256);
+  const size_t nblk = (size_t)*nb0 + *nb1 + *nb2;
+  *off_counts = pn_align_up((size_t)B * *ntiles * *ntiles, 256);
+  // [pairs | counts | order | lists]
+  *off_lists = *off_counts + 2 * pn_align_up((size_t)B * nblk * 4, 256);
+  *total = *off_lists + (size_t)B * nblk * *ntiles * 4;
+}
+
+extern "C" size_t pn_meanshift_x3_plan_bytes(int B, int N) {
+  int nt, a, b_, c;
+  size_t oc, ol, tot;
+  x3_plan_layout(B, N, &nt, &a, &b_, &c, &oc, &ol, &tot);
+  return tot;
+}
+
+// cen (B,ntiles,D), rho (B,ntiles) with ntiles = align_up(N,64)/32
+extern "C" int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho,
+                                            void* stream) {
+  PN_CHECK_ARG(z && cen && rho && B > 0 && N > 0, "pn_meanshift_x3_tileinfo_f32: bad arguments");
+  PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
+  const int ntiles = (int)pn_align_up(N, 64) / 32;
+  hipLaunchKernelGGL(pn_ms3_tileinfo_kernel, dim3(ntiles, B), dim3(64), 0, (hipStream_t)stream, z, N, ntiles, cen,
+                     rho);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// plan of one iteration from the tile caps of the iterate (Q) and of the data (X); rel_eps: the
+// skipped mass relative to the smallest row sum (1e-9)
+extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX,
+                                        const float* rhoX, const float* bsq, int B, int N, float rel_eps,
+                                        void* plan, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(cenQ && rhoQ && cenX && rhoX && bsq && plan && B > 0 && N > 0 && rel_eps > 0.f,
+               "pn_meanshift_x3_plan_f32: bad arguments");
+  int nt, nb0, nb1, nb2;
+  size_t oc, ol, tot;
+  x3_plan_layout(B, N, &nt, &nb0, &nb1, &nb2, &oc, &ol, &tot);
+  unsigned char* pairs = (unsigned char*)plan;
+  int* counts = (int*)((char*)plan + oc);
+  int* lists = (int*)((char*)plan + ol);
+  const float logterm = logf((float)N / rel_eps);
+  hipLaunchKernelGGL(pn_ms3_pairs_kernel, dim3(nt, B), dim3(256), nt * sizeof(float), stream, cenQ, rhoQ, cenX,
+                     rhoX, bsq, nt, logterm, pairs);
+  PN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pn_ms3_lists_kernel, dim3(nb0 + nb1 + nb2, B), dim3(64), 0, stream, pairs, nt, nb0, nb1, nb2,
+                     counts, lists);
+  PN_CHECK_LAUNCH();
+  int* order = counts + pn_align_up((size_t)B * (nb0 + nb1 + nb2) * 4, 256) / 4;
+  hipLaunchKernelGGL(pn_ms3_order_kernel, dim3(3), dim3(64), 0, stream, counts, B, nb0, nb1, nb2, order);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
   // blocks_per_cu == 2 selects the 8-wave workgroups (forward, column pass): 256 rows each
   // fill whole rounds of the 256 CUs (one workgroup per CU: the forward runs 8 waves of <= 256
@@ -526,12 +754,38 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
   return best;
 }
 
+// With a plan the lists differ in length from block to block: more, shorter work units pack
+// better behind the longest-first order (measured at B = 4, N = 10 000 on a clustered embedding:
+// 4 / 8 / 4 slices 49.0 ms per step, 3 / 4 / 3 49.9 ms, 2 / 2 / 2 55.7 ms).
+static int x3_sparse_slices(int dense_choice, int sparse_choice) {
+  if (getenv("PN_MS_SLICES")) return dense_choice;   // developer override already applied
+  return sparse_choice > dense_choice ? sparse_choice : dense_choice;
+}
+
 // One forward iteration on the bf16 x 3 path: same contract as pn_meanshift_iter_fwd_f32 with the
 // tile images of x (pn_meanshift_x3_split_f32) in place of x / xt.
+extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img_x, const float* bsq, int B,
+                                                 int N, int D, float* opart, float* rpart, float* y,
+                                                 float* rsum, float* unorm, const void* plan, void* stream_);
 extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, const float* bsq, int B,
                                             int N, int D, float* opart, float* rpart, float* y,
                                             float* rsum, float* unorm, void* stream_) {
+  return pn_meanshift_x3_iter_fwd_plan_f32(q, img_x, bsq, B, N, D, opart, rpart, y, rsum, unorm, nullptr, stream_);
+}
+
+// The same with a block-sparse plan (pn_meanshift_x3_plan_f32 of THIS q against x; NULL = dense).
+extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img_x, const float* bsq, int B,
+                                                 int N, int D, float* opart, float* rpart, float* y,
+                                                 float* rsum, float* unorm, const void* plan, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  int pnt, nb0, nb1, nb2;
+  size_t oc, ol, ptot;
+  x3_plan_layout(B, N, &pnt, &nb0, &nb1, &nb2, &oc, &ol, &ptot);
+  const unsigned char* pairs = (const unsigned char*)plan;
+  const int* counts = plan ? (const int*)((const char*)plan + oc) : nullptr;
+  const int* lists = plan ? (const int*)((const char*)plan + ol) : nullptr;
+  const int nblk = nb0 + nb1 + nb2;
+  const int* order = plan ? counts + pn_align_up((size_t)B * nblk * 4, 256) / 4 : nullptr;
   PN_CHECK_ARG(q && img_x && bsq && opart && rpart && y && rsum && unorm,
                "pn_meanshift_x3_iter_fwd_f32: null pointer");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
@@ -539,6 +793,7 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, c
   const int ntiles = (int)pn_align_up(N, 64) / 32;
   int tps;
   int S = x3_slices(B, N, ntiles, 2, &tps);
+  if (plan) S = x3_sparse_slices(S, 4);
   const int smax = pn_meanshift_slices(B, N);  // the scratch is sized for this many slices
   if (S > smax) {
     S = smax;
@@ -548,7 +803,8 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, c
   {
     PN_PROF("meanshift_fwd", stream);
     hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)img_x,
-                       nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart, rpart);
+                       nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart, rpart, pairs, counts, lists, order,
+                       nblk, 0);
   }
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart,
@@ -561,13 +817,38 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, c
 // the tile images of x in place of xt and two scratch image arrays (images of q and gu, each
 // pn_meanshift_x3_image_bytes(B,N) bytes) in place of (qt, gut).  x itself is still read as the
 // resident operand of the column pass; go is not needed (the column pass folds 1/r into K).
+extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y, const float* q,
+                                                 const float* x, const void* img_x, const float* rsum,
+                                                 const float* unorm, const float* bsq, int B, int N, int D,
+                                                 float* gu, float* cs, void* img_q, void* img_gu,
+                                                 float* opart_q, float* opart_x, float* gq, float* gx,
+                                                 const void* plan, void* stream_);
 extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q,
                                             const float* x, const void* img_x, const float* rsum,
                                             const float* unorm, const float* bsq, int B, int N, int D,
                                             float* gu, float* cs, void* img_q, void* img_gu,
                                             float* opart_q, float* opart_x, float* gq, float* gx,
                                             void* stream_) {
+  return pn_meanshift_x3_iter_bwd_plan_f32(gy, y, q, x, img_x, rsum, unorm, bsq, B, N, D, gu, cs, img_q, img_gu,
+                                           opart_q, opart_x, gq, gx, nullptr, stream_);
+}
+
+// The same with the plan the forward call of this iteration used (NULL = dense).
+extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y, const float* q,
+                                                 const float* x, const void* img_x, const float* rsum,
+                                                 const float* unorm, const float* bsq, int B, int N, int D,
+                                                 float* gu, float* cs, void* img_q, void* img_gu,
+                                                 float* opart_q, float* opart_x, float* gq, float* gx,
+                                                 const void* plan, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  int pnt, nb0, nb1, nb2;
+  size_t oc, ol, ptot;
+  x3_plan_layout(B, N, &pnt, &nb0, &nb1, &nb2, &oc, &ol, &ptot);
+  const unsigned char* pairs = (const unsigned char*)plan;
+  const int* counts = plan ? (const int*)((const char*)plan + oc) : nullptr;
+  const int* lists = plan ? (const int*)((const char*)plan + ol) : nullptr;
+  const int nblk = nb0 + nb1 + nb2;
+  const int* order = plan ? counts + pn_align_up((size_t)B * nblk * 4, 256) / 4 : nullptr;
   PN_CHECK_ARG(gy && y && q && x && img_x && rsum && unorm && bsq && gu && cs && img_q && img_gu &&
                    opart_q && opart_x && gq && gx,
                "pn_meanshift_x3_iter_bwd_f32: null pointer");
@@ -576,11 +857,13 @@ extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, con
   int tps, tps2;
   const int smax = pn_meanshift_slices(B, N);
   int S = x3_slices(B, N, ntiles, 1, &tps);    // row pass: 4-wave workgroups
+  if (plan) S = x3_sparse_slices(S, 8);
   if (S > smax) {
     S = smax;
     tps = pn_cdiv(ntiles, S);
   }
   int S2 = x3_slices(B, N, ntiles, 2, &tps2);  // column pass: 8-wave workgroups
+  if (plan) S2 = x3_sparse_slices(S2, 4);
   if (S2 > smax) {
     S2 = smax;
     tps2 = pn_cdiv(ntiles, S2);
@@ -599,7 +882,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, con
     dim3 grid(S, pn_cdiv(N, 32 * X3_WAVES(1)), B);
     hipLaunchKernelGGL(pn_ms3_kernel<1>, grid, dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
                        (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N,
-                       ntiles, tps, opart_q, nullptr);
+                       ntiles, tps, opart_q, nullptr, pairs, counts, lists, order, nblk, nb0);
   }
   PN_CHECK_LAUNCH();
   {
@@ -607,7 +890,8 @@ extern "C" int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, con
     dim3 grid2(S2, pn_cdiv(N, 32 * X3_WAVES(2)), B);
     hipLaunchKernelGGL(pn_ms3_kernel<2>, grid2, dim3(64 * X3_WAVES(2)), 0, stream, x, nullptr,
                        (const u32x4*)img_q, (const u32x4*)img_gu, (const float*)cs,
-                       (const float*)alpha, bsq, N, ntiles, tps2, opart_x, nullptr);
+                       (const float*)alpha, bsq, N, ntiles, tps2, opart_x, nullptr, pairs, counts, lists, order,
+                       nblk, nb0 + nb1);
   }
   PN_CHECK_LAUNCH();
   const long long ND4 = (long long)N * MS_D / 4;

@@ -313,20 +313,61 @@ def meanshift_x3_split(x):
     return img
 
 
-def meanshift_x3_iter_fwd(q, x_image, bsq, ws):
+def meanshift_x3_tileinfo(z):
+    """z (B,N,128) unit rows -> (centres (B,T,128), angular radii (B,T)) of the 32-row tiles,
+    T = align_up(N, 64) / 32: the bounding caps of the block-sparse plan."""
+    require_cuda(z)
+    z = _f32c(z, "z")
+    B, N, D = z.shape
+    T = (N + 63) // 64 * 2
+    cen = torch.empty((B, T, D), dtype=torch.float32, device=z.device)
+    rho = torch.empty((B, T), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        rc = _lib.load().pn_meanshift_x3_tileinfo_f32(ptr(z), B, N, D, ptr(cen), ptr(rho), current_stream(z.device))
+    check(rc, "pn_meanshift_x3_tileinfo_f32")
+    return cen, rho
+
+
+def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
+    """Block-sparse plan of one iteration (which tile pairs can contribute more than ``rel_eps`` of
+    the smallest row sum): an opaque byte tensor for meanshift_x3_iter_fwd / _bwd."""
+    cq, rq = q_info
+    cx, rx = x_info
+    B = cq.shape[0]
+    lib = _lib.load()
+    plan = torch.empty(lib.pn_meanshift_x3_plan_bytes(B, N), dtype=torch.uint8, device=cq.device)
+    with torch.cuda.device(cq.device):
+        rc = lib.pn_meanshift_x3_plan_f32(ptr(cq), ptr(rq), ptr(cx), ptr(rx), ptr(bsq), B, N, float(rel_eps),
+                                          ptr(plan), current_stream(cq.device))
+    check(rc, "pn_meanshift_x3_plan_f32")
+    return plan
+
+
+def meanshift_x3_plan_stats(plan, B, N):
+    """(active fraction of tile pairs, of pass-0 / pass-1 / pass-2 block x tile pairs) — diagnostics."""
+    T = (N + 63) // 64 * 2
+    nb0, nb1, nb2 = -(-N // 256), -(-N // 128), -(-N // 256)
+    oc = (B * T * T + 255) // 256 * 256
+    pairs = plan[:B * T * T].float().mean().item()
+    counts = plan[oc:oc + B * (nb0 + nb1 + nb2) * 4].view(torch.int32).reshape(B, -1).float()
+    return (pairs, counts[:, :nb0].mean().item() / T, counts[:, nb0:nb0 + nb1].mean().item() / T,
+            counts[:, nb0 + nb1:].mean().item() / T)
+
+
+def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None):
     B, N, D = q.shape
     y = torch.empty_like(q)
     rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
     unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
-        rc = _lib.load().pn_meanshift_x3_iter_fwd_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
-                                                      ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
-                                                      current_stream(q.device))
-    check(rc, "pn_meanshift_x3_iter_fwd_f32")
+        rc = _lib.load().pn_meanshift_x3_iter_fwd_plan_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
+                                                           ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
+                                                           ptr(plan), current_stream(q.device))
+    check(rc, "pn_meanshift_x3_iter_fwd_plan_f32")
     return y, rsum, unorm
 
 
-def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx):
+def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx, plan=None):
     """bf16 x 3 counterpart of meanshift_iter_bwd: returns dL/dq, adds into ``gx``."""
     B, N, D = x.shape
     gy = _f32c(gy, "gy")
@@ -337,11 +378,11 @@ def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx):
         ws.x3_imgs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(2)]
     im = ws.x3_imgs
     with torch.cuda.device(x.device):
-        rc = lib.pn_meanshift_x3_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(x_image), ptr(rsum),
-                                              ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.cs), ptr(im[0]),
-                                              ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq), ptr(gx),
-                                              current_stream(x.device))
-    check(rc, "pn_meanshift_x3_iter_bwd_f32")
+        rc = lib.pn_meanshift_x3_iter_bwd_plan_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(x_image), ptr(rsum),
+                                                   ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.cs),
+                                                   ptr(im[0]), ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq),
+                                                   ptr(gx), ptr(plan), current_stream(x.device))
+    check(rc, "pn_meanshift_x3_iter_bwd_plan_f32")
     return gq
 
 

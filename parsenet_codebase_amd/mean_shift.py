@@ -19,6 +19,47 @@ from ._lib import h2d, require_cuda
 # bits per operand — NARROWER than fp32; faster, never the default, and bench.py labels it.
 # PARSENET_MS_ARITH overrides.
 ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
+# Block-sparse iterations (bf16x3 path, N >= 2048): points are put in a locality order, and tile
+# pairs whose kernel values are rigorously below 1e-9 of the smallest row sum are skipped
+# (csrc/meanshift_x3.h, "block-sparse plan").  PARSENET_MS_SPARSE=0 keeps every launch dense.
+SPARSE = os.environ.get("PARSENET_MS_SPARSE", "1") != "0"
+SPARSE_MIN_N = 2048
+LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
+
+
+def locality_order(x, lloyd=2):
+    """A permutation (B,N) that puts points of the same region of the sphere next to each other:
+    128 cells (spherical k-means: evenly spaced rows of x as seeds, ``lloyd`` refinement steps),
+    cells grouped by 16 coarse cells of the cell centres.  Any permutation is valid — mean-shift
+    is permutation-equivariant; a good one makes the 32-point tiles tight, which is what lets the
+    plan skip tile pairs."""
+    B, N, D = x.shape
+    P, C = 128, 16
+
+    def assign(pts, cen):
+        return torch.bmm(pts, cen.transpose(1, 2)).argmax(2)
+
+    def centres(pts, lab, K, old):
+        # one-hot GEMM instead of index_add_: atomics would make the order — and with it the
+        # summation order of every later launch — vary from run to run
+        hot = torch.nn.functional.one_hot(lab, K).to(pts.dtype)              # (B,n,K)
+        acc = torch.bmm(hot.transpose(1, 2), pts)
+        nrm = acc.norm(dim=2, keepdim=True)
+        return torch.where(nrm > 1e-6, acc / nrm.clamp_min(1e-6), old)      # empty cell: keep its seed
+    cen = x[:, torch.linspace(0, N - 1, P, device=x.device).long()]
+    fine = assign(x, cen)
+    for _ in range(lloyd):
+        cen = centres(x, fine, P, cen)
+        fine = assign(x, cen)
+    ccen = cen[:, :C]
+    coarse = assign(cen, ccen)
+    for _ in range(lloyd):
+        ccen = centres(cen, coarse, C, ccen)
+        coarse = assign(cen, ccen)
+    key = torch.gather(coarse, 1, fine) * P + fine
+    return torch.argsort(key, dim=1, stable=True)
+
+
 _SPLIT = {"fp16x2": (K.meanshift_h2_split, K.meanshift_h2_iter_fwd, K.meanshift_h2_iter_bwd),
           "bf16x3": (K.meanshift_x3_split, K.meanshift_x3_iter_fwd, K.meanshift_x3_iter_bwd)}
 
@@ -34,25 +75,42 @@ class _MeanShiftIterations(torch.autograd.Function):
         if ARITH not in _SPLIT and ARITH != "f32":
             raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
         kern = _SPLIT.get(ARITH) if iterations > 0 else None
+        sparse = SPARSE and kern is not None and ARITH == "bf16x3" and N >= SPARSE_MIN_N
+        perm = inv = None
+        if sparse:   # everything below runs on the locality-ordered points; undone on the way out
+            perm = locality_order(x, int(os.environ.get("PARSENET_MS_LLOYD", "2")))
+            inv = torch.empty_like(perm).scatter_(1, perm, torch.arange(N, device=x.device).expand(B, N))
+            x = torch.gather(x, 1, perm.unsqueeze(2).expand(-1, -1, D))
         x3 = kern[0](x) if kern is not None else None
         # streamed copy of X: pre-split tile images (16-bit pieces) or channel-first fp32 (exact path)
         xt = x3 if x3 is not None else K.meanshift_pack(x)
         ws = K.MeanShiftWorkspace(B, N, D, x.device)
-        iterates, rsums, norms = [x], [], []
+        iterates, rsums, norms, plans = [x], [], [], []
+        x_info = K.meanshift_x3_tileinfo(x) if sparse else None
         q = x
         for _ in range(iterations):
-            if x3 is not None:
+            if sparse:
+                plan = K.meanshift_x3_plan(K.meanshift_x3_tileinfo(q), x_info, bsq, N)
+                plans.append(plan)
+                q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan)
+            elif x3 is not None:
                 q, r, n = kern[1](q, x3, bsq, ws)
             else:
                 q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
             iterates.append(q)
             rsums.append(r)
             norms.append(n)
+        if sparse and os.environ.get("PARSENET_MS_STATS") == "1":
+            global LAST_PLAN_STATS
+            LAST_PLAN_STATS = [K.meanshift_x3_plan_stats(p, B, N) for p in plans]
         ctx.iterations = iterations
         ctx.x3 = x3
         ctx.kern = kern
-        ctx.save_for_backward(xt, bsq, *iterates, *rsums, *norms)
-        return q if iterations > 0 else x.clone()
+        ctx.sparse = sparse
+        ctx.save_for_backward(xt, bsq, *iterates, *rsums, *norms, *plans, *([perm, inv] if sparse else []))
+        if iterations == 0:
+            return x.clone()
+        return torch.gather(q, 1, inv.unsqueeze(2).expand(-1, -1, D)) if sparse else q
 
     @staticmethod
     def backward(ctx, gy):
@@ -62,18 +120,27 @@ class _MeanShiftIterations(torch.autograd.Function):
         iterates = saved[2:3 + T]
         rsums = saved[3 + T:3 + 2 * T]
         norms = saved[3 + 2 * T:3 + 3 * T]
+        plans = saved[3 + 3 * T:3 + 4 * T] if ctx.sparse else None
         x = iterates[0]
         B, N, D = x.shape
         ws = K.MeanShiftWorkspace(B, N, D, x.device, backward=True, exact_f32=ctx.x3 is None)
         gX = torch.zeros_like(x)
         g = gy.contiguous()
+        if ctx.sparse:
+            perm, inv = saved[-2], saved[-1]
+            g = torch.gather(g, 1, perm.unsqueeze(2).expand(-1, -1, D))
         for it in reversed(range(T)):
-            if ctx.x3 is not None:
+            if ctx.sparse:
+                g = K.meanshift_x3_iter_bwd(g, iterates[it + 1], iterates[it], x, ctx.x3, rsums[it], norms[it], bsq,
+                                            ws, gX, plans[it])
+            elif ctx.x3 is not None:
                 g = ctx.kern[2](g, iterates[it + 1], iterates[it], x, ctx.x3, rsums[it], norms[it], bsq, ws, gX)
             else:
                 g = K.meanshift_iter_bwd(g, iterates[it + 1], iterates[it], x, xt, rsums[it], norms[it], bsq,
                                          ws, gX)
         gX += g  # the first iterate is X itself
+        if ctx.sparse:
+            gX = torch.gather(gX, 1, inv.unsqueeze(2).expand(-1, -1, D))
         return gX, None, None
 
 

@@ -65,10 +65,13 @@ def test_batched_stage_equals_shape_by_shape(gpu, N, shared_clustering, monkeypa
     # renumbers the labels and moves the centre by ~1e-4 — amplified by exp(w / 2b^2), b ~ 0.05, to
     # percent-level changes of the memberships (the reference's own choice of representative is
     # decided by the same kind of noise); spline distances also carry the kNN near-tie noise of
-    # tests/golden/reference_noise_e2e.txt -> the segmentation must agree as a partition, the
-    # analytic mean to 5e-3, the rest to the noise band.
+    # tests/golden/reference_noise_e2e.txt (one flipped neighbour: 10 % on that spline) -> the
+    # segmentation must agree as a partition, the analytic mean to 2e-2, the spline mean and the
+    # loss to the noise band of a few flips.
     tight = shared_clustering
-    tol = {0: 2e-5 if tight else 5e-2, 1: 2e-5 if tight else 5e-3, 2: 2e-5 if tight else 1e-1, 3: 1e-9, 4: 1e-9}
+    # (tight bars: 2e-5 on the spline mean; 2e-4 where cylinders enter — the per-segment path builds
+    # their ridge system in fp32 like the reference, the kernels in fp64: tests/golden/cylinder.npz)
+    tol = {0: 2e-4 if tight else 0.25, 1: 2e-4 if tight else 2e-2, 2: 2e-5 if tight else 0.3, 3: 1e-9, 4: 1e-9}
 
     def canon(l):
         _, first = np.unique(l, return_index=True)
