@@ -634,22 +634,27 @@ __global__ __launch_bounds__(64) void pn_ms3_lists_kernel(const unsigned char* _
 
 // visiting order of the (batch item, resident block) pairs of each pass: longest list first.
 // order[pass offset * B + rank] = (b << 16) | block; one wave per pass.
-__global__ __launch_bounds__(64) void pn_ms3_order_kernel(const int* __restrict__ counts, int B, int nb0, int nb1,
-                                                          int nb2, int* __restrict__ order) {
-  const int pass = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void pn_ms3_order_kernel(const int* __restrict__ counts, int B, int nb0, int nb1,
+                                                           int nb2, int* __restrict__ order) {
+  extern __shared__ int cnt_s[];
+  const int pass = blockIdx.x;
   const int nblk = nb0 + nb1 + nb2;
   const int off = pass == 0 ? 0 : (pass == 1 ? nb0 : nb0 + nb1);
   const int nb = pass == 0 ? nb0 : (pass == 1 ? nb1 : nb2);
   const int n = nb * B;
-  for (int e = lane; e < n; e += 64) {
+  for (int e = threadIdx.x; e < n; e += 256) {
     const int be = e / nb, re = e - be * nb;
-    const int ce = counts[(size_t)be * nblk + off + re];
+    cnt_s[e] = counts[(size_t)be * nblk + off + re];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int ce = cnt_s[e];
     int rank = 0;
     for (int f = 0; f < n; ++f) {
-      const int bf = f / nb, rf = f - bf * nb;
-      const int cf = counts[(size_t)bf * nblk + off + rf];
+      const int cf = cnt_s[f];
       rank += (cf > ce) || (cf == ce && f < e);
     }
+    const int be = e / nb, re = e - be * nb;
     order[(size_t)off * B + rank] = (be << 16) | re;
   }
 }
@@ -708,7 +713,8 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
                      counts, lists);
   PN_CHECK_LAUNCH();
   int* order = counts + pn_align_up((size_t)B * (nb0 + nb1 + nb2) * 4, 256) / 4;
-  hipLaunchKernelGGL(pn_ms3_order_kernel, dim3(3), dim3(64), 0, stream, counts, B, nb0, nb1, nb2, order);
+  hipLaunchKernelGGL(pn_ms3_order_kernel, dim3(3), dim3(256), (size_t)B * nb1 * sizeof(int), stream, counts, B, nb0,
+                     nb1, nb2, order);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -26,6 +26,7 @@ The reference's serial path costs ~250 launches and ~10 host synchronisations pe
 one ~60 launches per shape and 4 synchronisations per STEP (one per shape at batch 4)."""
 import numpy as np
 import torch
+from torch.profiler import record_function
 
 from . import kernels as K
 from . import mean_shift as MSM
@@ -324,12 +325,13 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
 
     # ---- clustering, all shapes ---------------------------------------------------------
     state = None
-    with torch.no_grad():
+    with torch.no_grad(), record_function("fit:bandwidth"):
         bwres = bandwidth_batch(emb, quantile)
     if bwres is not None and D == 128:
         bw, bwflag = bwres
-        new_X = MSM.mean_shift_iterations(emb, bw, iterations)
-        with torch.no_grad():
+        with record_function("fit:meanshift_fwd"):
+            new_X = MSM.mean_shift_iterations(emb, bw, iterations)
+        with torch.no_grad(), record_function("fit:nms"):
             state = nms_batch(new_X.detach(), emb.detach(), bw)
     with torch.no_grad():
         # SIOU_matched_segments merges the predicted types before the per-cluster vote
@@ -367,8 +369,9 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
     cen = torch.stack([torch.nn.functional.pad(c, (0, 0, 0, Cp - c.shape[0])) for c in centers], 0)   # (B,Cp,D)
     bwt = torch.stack(bws).detach()
     ncl_t = h2d(np.asarray(ncl_list, dtype=np.int64), dev)
-    Wraw = torch.bmm(cen, emb.transpose(1, 2))                                   # (B,Cp,N)
-    Wn = weights_normalize_batch(Wraw, bwt, ncl_t)
+    with record_function("fit:memberships"):
+        Wraw = torch.bmm(cen, emb.transpose(1, 2))                               # (B,Cp,N)
+        Wn = weights_normalize_batch(Wraw, bwt, ncl_t)
 
     # ---- host: matching + segment tables -------------------------------------------------
     tables, matches = [], []
@@ -415,23 +418,26 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
     if S_p:
         tab = {"shape": T["seg_shape"][:S_p], "row": T["seg_row"][:S_p], "type": T["seg_type"][:S_p],
                "rows": T["seg_rows"][:S_p], "gt_off": T["gt_off"][:S_p + 1], "gt_idx": T["gt_idx"]}
-        d_p, params_p, status = _PrimitiveFitLoss.apply(Wn, points, normals, tab, 4, False)
+        with record_function("fit:primitives"):
+            d_p, params_p, status = _PrimitiveFitLoss.apply(Wn, points, normals, tab, 4, False)
         dists.append(d_p)
     # ---- splines ------------------------------------------------------------------------
     recs = []
     if S_s:
         sb = T["seg_shape"][S_p:].long()
         sr = T["seg_row"][S_p:].long()
-        P2 = points[:, 0::2].detach()[sb]                                    # (S_s,n2,3)
-        w2 = Wn[:, :, 0::2][sb, sr] + EPS                                     # (S_s,n2), differentiable
-        pts_std, std, mean, R = standardize_segments(P2, w2.detach())          # sync 2
-        affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
+        with record_function("fit:standardize"):
+            P2 = points[:, 0::2].detach()[sb]                                # (S_s,n2,3)
+            w2 = Wn[:, :, 0::2][sb, sr] + EPS                                 # (S_s,n2), differentiable
+            pts_std, std, mean, R = standardize_segments(P2, w2.detach())      # sync 2
+            affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
         nu, nv = fitter.nu.to(dev), fitter.nv.to(dev)
         pieces = []
         for lo, hi, net, wrap in ((0, n_open, fitter.open_control_decoder, False),
                                   (n_open, S_s, fitter.closed_control_decoder, True)):
             if hi > lo:
-                ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
+                with record_function("fit:splinenet"):
+                    ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
                 rec = _BSplineEval.apply(ctrl.reshape(hi - lo, 20, 20, 3), nu, nv, affine[lo:hi], wrap)
                 pieces.append(rec.reshape(-1, 3))
                 recs += [rec[k:k + 1] for k in range(hi - lo)]
@@ -439,8 +445,9 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         gt_cloud = points.reshape(B * N, 3)[T["gt_flat"][int(gt_off[S_p]):].long()]
         cnt_a = h2d(np.asarray(na, dtype=np.float32), dev)
         cnt_b = h2d(np.asarray(nb, dtype=np.float32), dev)
-        d_s = _RaggedChamfer.apply(pred, gt_cloud, T["off_a"], T["off_b"], T["item_a"].long(), T["item_b"].long(),
-                                   cnt_a, cnt_b, max(na), max(nb))
+        with record_function("fit:chamfer"):
+            d_s = _RaggedChamfer.apply(pred, gt_cloud, T["off_a"], T["off_b"], T["item_a"].long(),
+                                       T["item_b"].long(), cnt_a, cnt_b, max(na), max(nb))
         dists.append(d_s)
 
     # ---- losses, metrics, ONE download ----------------------------------------------------

@@ -229,6 +229,32 @@ def bench_fitting_batch():
                                                      "cudaStreamSynchronize", "cudaDeviceSynchronize",
                                                      "cudaEventSynchronize"))
         d2h = sum(1 for e in ev_list if "Memcpy DtoH" in e.name or "Memcpy DtoH" in str(e.name))
+        if batched:     # launches and GPU time per stage of the forward (record_function ranges of fitting_batch.py)
+            try:
+                import collections
+                kev = prof.profiler.kineto_results.events()
+                ranges = [(e.name(), e.start_ns(), e.start_ns() + e.duration_ns()) for e in kev
+                          if e.name().startswith("fit:")]
+                launch_t = {e.correlation_id(): e.start_ns() for e in kev
+                            if "LaunchKernel" in e.name() and e.correlation_id() != 0}
+                per = collections.OrderedDict((n, [0, 0.0]) for n, _, _ in ranges)
+                other = [0, 0.0]
+                for e in kev:
+                    if str(e.device_type()).endswith("CUDA") and e.correlation_id() in launch_t and "Memcpy" not in e.name() \
+                            and "Memset" not in e.name():
+                        tl = launch_t[e.correlation_id()]
+                        hit = [(b_ - a_, n) for n, a_, b_ in ranges if a_ <= tl <= b_]
+                        if hit:
+                            n = min(hit)[1]          # innermost enclosing range
+                            per[n][0] += 1
+                            per[n][1] += e.duration_ns()
+                        else:
+                            other[0] += 1
+                            other[1] += e.duration_ns()
+                for n, (c, ns) in list(per.items()) + [("(outside: glue, backward)", other)]:
+                    print("      %-28s %4d launches  %7.2f ms GPU" % (n, c, ns / 1e6))
+            except Exception as ex:      # profiler internals differ between torch builds
+                print("      (per-stage attribution unavailable: %r)" % (ex,))
         nseg = sum(sum(1 for v in r[1][0].values() if v is not None) for r in res)
         print("%-14s %6.1f ms per step of %d shapes (%d fitted segments): %d kernel launches (%.0f per shape), "
               "%d device->host copies, %d host synchronisations (the profiled pass includes the final one)"
