@@ -15,84 +15,138 @@ EPS = np.finfo(np.float32).eps
 
 
 # ---------------------------------------------------------------------------------------
-# src/augment_utils.py
+# augmentation (semantics of src/augment_utils.py) as ONE batched affine map per shape
 # ---------------------------------------------------------------------------------------
-def _rot_y(angle):
+# Four of the reference's five routines are affine maps of a whole shape (x -> x M + t with one
+# M / t per shape) and the fifth adds clipped Gaussian noise.  Here a routine only DRAWS its
+# parameters — from numpy's global RNG, in exactly the order the reference consumes it, so that a
+# seeded run sees the same rotations, shifts and noise — and `Affine.apply` evaluates all shapes
+# of the batch as one batched matrix product on whatever device the points live on (SURVEY
+# section 8f-4: augmentation on the GPU).
+def _axis_rotation(axis, angle):
+    """3x3 rotation about a coordinate axis (0 = x, 1 = y, 2 = z), right-handed, float64."""
     c, s = np.cos(angle), np.sin(angle)
-    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    i, j = (axis + 1) % 3, (axis + 2) % 3
+    R = np.eye(3)
+    R[i, i], R[i, j], R[j, i], R[j, j] = c, -s, s, c
+    return R
+
+
+class Affine:
+    """Per-shape maps x -> x M + t (+ noise): M (B,3,3), t (B,3), noise (B,N,3) or None."""
+
+    def __init__(self, B):
+        self.M = np.tile(np.eye(3), (B, 1, 1))
+        self.t = np.zeros((B, 3))
+        self.noise = None
+
+    def then(self, M=None, t=None, noise=None):
+        """Compose: this map first, then x -> x M + t + noise."""
+        if M is not None:
+            self.M = self.M @ M
+            self.t = np.einsum("bi,bij->bj", self.t, M)
+            if self.noise is not None:
+                self.noise = np.einsum("bni,bij->bnj", self.noise, M)
+        if t is not None:
+            self.t = self.t + t
+        if noise is not None:
+            self.noise = noise if self.noise is None else self.noise + noise
+        return self
+
+    def apply(self, points):
+        """points (B,N,3): numpy array or torch tensor (any device) -> same kind, float32."""
+        import torch
+        as_numpy = isinstance(points, np.ndarray)
+        P = torch.from_numpy(np.ascontiguousarray(points)) if as_numpy else points
+        dt = torch.float64 if P.device.type == "cpu" else torch.float32
+        M = torch.from_numpy(self.M).to(P.device, dt)
+        t = torch.from_numpy(self.t).to(P.device, dt)
+        out = torch.baddbmm(t.unsqueeze(1), P.to(dt), M)
+        if self.noise is not None:
+            out = out + torch.from_numpy(self.noise).to(P.device, dt)
+        out = out.float()
+        return out.numpy() if as_numpy else out
+
+
+def _draw_rotation_y(B, angle=None):
+    """rotate_point_cloud / _by_angle (augment_utils.py:7-45): one uniform angle per shape about y."""
+    M = np.stack([_axis_rotation(1, np.random.uniform() * 2 * np.pi if angle is None else angle)
+                  for _ in range(B)])
+    return dict(M=M)
+
+
+def _draw_perturbation(B, angle_sigma=0.06, angle_clip=0.30):
+    """rotate_perturbation_point_cloud (:48-70): three clipped normal angles per shape, x then y then z."""
+    M = []
+    for _ in range(B):
+        ax, ay, az = np.clip(angle_sigma * np.random.randn(3), -angle_clip, angle_clip)
+        M.append(_axis_rotation(2, az) @ _axis_rotation(1, ay) @ _axis_rotation(0, ax))
+    return dict(M=np.stack(M))
+
+
+def _draw_jitter(B, N, sigma=0.01, clip=0.05):
+    if clip <= 0:
+        raise ValueError("clip must be positive")
+    return dict(noise=np.clip(sigma * np.random.randn(B, N, 3), -clip, clip))
+
+
+def _draw_shift(B, shift_range=0.1):
+    return dict(t=np.random.uniform(-shift_range, shift_range, (B, 3)))
+
+
+def _draw_scale(B, scale_low=0.8, scale_high=1.2):
+    return dict(M=np.random.uniform(scale_low, scale_high, B)[:, None, None] * np.eye(3)[None])
+
+
+def _one(draw, batch_data, *a, **k):
+    B, N, _ = batch_data.shape
+    return Affine(B).then(**draw(B, *([N] if draw is _draw_jitter else []), *a, **k)).apply(batch_data)
 
 
 def rotate_point_cloud(batch_data):
-    """Random rotation about the up (y) axis, one angle per shape (augment_utils.py:7-26)."""
-    out = np.zeros(batch_data.shape, dtype=np.float32)
-    for k in range(batch_data.shape[0]):
-        out[k, ...] = np.dot(batch_data[k, ...].reshape((-1, 3)), _rot_y(np.random.uniform() * 2 * np.pi))
-    return out.astype(np.float32)
+    return _one(_draw_rotation_y, batch_data)
 
 
 def rotate_point_cloud_by_angle(batch_data, rotation_angle):
-    out = np.zeros(batch_data.shape, dtype=np.float32)
-    for k in range(batch_data.shape[0]):
-        out[k, ...] = np.dot(batch_data[k, ...].reshape((-1, 3)), _rot_y(rotation_angle))
-    return out.astype(np.float32)
+    return _one(_draw_rotation_y, batch_data, rotation_angle)
 
 
 def rotate_perturbation_point_cloud(batch_data, angle_sigma=0.06, angle_clip=0.30):
-    """Small random rotation Rz Ry Rx per shape (augment_utils.py:49-73)."""
-    out = np.zeros(batch_data.shape, dtype=np.float32)
-    for k in range(batch_data.shape[0]):
-        a = np.clip(angle_sigma * np.random.randn(3), -angle_clip, angle_clip)
-        Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
-        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
-        Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
-        out[k, ...] = np.dot(batch_data[k, ...].reshape((-1, 3)), np.dot(Rz, np.dot(Ry, Rx)))
-    return out.astype(np.float32)
+    return _one(_draw_perturbation, batch_data, angle_sigma, angle_clip)
 
 
 def jitter_point_cloud(batch_data, sigma=0.01, clip=0.05):
-    B, N, C = batch_data.shape
-    if clip <= 0:
-        raise ValueError("clip must be positive")
-    jittered = np.clip(sigma * np.random.randn(B, N, C), -1 * clip, clip)
-    jittered += batch_data
-    return jittered.astype(np.float32)
+    return _one(_draw_jitter, batch_data, sigma, clip)
 
 
 def shift_point_cloud(batch_data, shift_range=0.1):
-    """One random shift per shape; modifies its argument in place like the reference."""
-    B = batch_data.shape[0]
-    shifts = np.random.uniform(-shift_range, shift_range, (B, 3))
-    for b in range(B):
-        batch_data[b, :, :] += shifts[b, :]
-    return batch_data.astype(np.float32)
+    return _one(_draw_shift, batch_data, shift_range)
 
 
 def random_scale_point_cloud(batch_data, scale_low=0.8, scale_high=1.2):
-    """One random scale per shape; in place like the reference."""
-    B = batch_data.shape[0]
-    scales = np.random.uniform(scale_low, scale_high, B)
-    for b in range(B):
-        batch_data[b, :, :] *= scales[b]
-    return batch_data
+    return _one(_draw_scale, batch_data, scale_low, scale_high)
 
 
 class Augment:
-    """augment_utils.py:122-135: each routine with probability 0.3, in this order."""
+    """augment_utils.py:116-128: perturbation, jitter, shift (0.05), scale, each with probability
+    0.3 in this order — composed into ONE affine map + noise, applied in one launch."""
 
     def augment(self, batch_data):
+        B, N, _ = batch_data.shape
+        A = Affine(B)
         if np.random.random() > 0.7:
-            batch_data = rotate_perturbation_point_cloud(batch_data)
+            A.then(**_draw_perturbation(B))
         if np.random.random() > 0.7:
-            batch_data = jitter_point_cloud(batch_data)
+            A.then(**_draw_jitter(B, N))
         if np.random.random() > 0.7:
-            batch_data = shift_point_cloud(batch_data, 0.05)
+            A.then(**_draw_shift(B, 0.05))
         if np.random.random() > 0.7:
-            batch_data = random_scale_point_cloud(batch_data)
-        return batch_data
+            A.then(**_draw_scale(B))
+        return A.apply(batch_data)
 
 
 # ---------------------------------------------------------------------------------------
-# canonicalisation helpers (dataset_segments.py:262-310)
+# canonical frame (dataset_segments.py:257-279, 131-147): minor principal axis -> x, unit extent
 # ---------------------------------------------------------------------------------------
 def pca_numpy(X):
     S, U = np.linalg.eig(X.T @ X)
@@ -100,46 +154,48 @@ def pca_numpy(X):
 
 
 def rotation_matrix_a_to_b(A, B):
-    """Rotation with B = R A for unit vectors (identity when they are parallel)."""
-    cos = np.dot(A, B)
-    sin = np.linalg.norm(np.cross(B, A))
-    u = A
-    v = B - np.dot(A, B) * A
-    v = v / (np.linalg.norm(v) + EPS)
-    w = np.cross(B, A)
-    w = w / (np.linalg.norm(w) + EPS)
-    F = np.stack([u, v, w], 1)
-    G = np.array([[cos, -sin, 0], [sin, cos, 0], [0, 0, 1]])
-    try:
-        return F @ G @ np.linalg.inv(F)
-    except np.linalg.LinAlgError:
+    """Rotation with B = R A for unit vectors, by Rodrigues' formula about A x B.  (Anti)parallel
+    vectors give the identity — the reference's construction (a change of basis whose matrix is
+    singular then, fitting_utils.py:556-577) falls back to the identity in both cases too."""
+    A, B = np.asarray(A, dtype=np.float64), np.asarray(B, dtype=np.float64)
+    axis = np.cross(A, B)
+    s = np.linalg.norm(axis)
+    if s < EPS:
         return np.eye(3, dtype=np.float32)
+    k = axis / s
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + s * Kx + (1.0 - np.dot(A, B)) * (Kx @ Kx)
 
 
-def _canonicalise(points, normals, anisotropic):
-    """In place on one shape: minor principal axis -> x, divide by the (largest) extent."""
-    S, U = pca_numpy(points)
-    R = rotation_matrix_a_to_b(U[:, np.argmin(S)], np.array([1, 0, 0]))
-    points[...] = (R @ points.T).T
-    if normals is not None:
-        normals[...] = (R @ normals.T).T
-    std = np.max(points, 0) - np.min(points, 0)
-    points[...] = points / (std.reshape((1, 3)) + EPS) if anisotropic else points / (np.max(std) + EPS)
+def canonical_frames(points):
+    """(B,N,3) float array -> rotations (B,3,3) taking the minor principal axis of every shape to
+    +x (LAPACK geev on the host decides the axis' sign, like the reference)."""
+    out = []
+    for p in points:
+        S, U = pca_numpy(np.asarray(p, dtype=np.float32))
+        out.append(rotation_matrix_a_to_b(U[:, np.argmin(S)], np.array([1.0, 0.0, 0.0])))
+    return np.stack(out)
+
+
+def _canonicalise_batch(points, normals, anisotropic):
+    """Rotate every shape into its canonical frame and divide by its extent (largest extent unless
+    anisotropic): one batched product for the whole batch."""
+    R = canonical_frames(points)
+    A = Affine(points.shape[0]).then(M=np.transpose(R, (0, 2, 1)))
+    pts = A.apply(points)
+    nrm = A.apply(normals) if normals is not None else None
+    ext = pts.max(1) - pts.min(1)
+    pts = pts / (ext[:, None, :] + EPS) if anisotropic else pts / (ext.max(1)[:, None, None] + EPS)
+    return pts.astype(np.float32), nrm
 
 
 def normalize_points(points, normals, anisotropic=False):
     """dataset_segments.py:262-279 (used by test.py): centre, noise along the normals (one normal
-    draw per point), canonicalise."""
+    draw per point), canonical frame, unit extent."""
     points = points - np.mean(points, 0, keepdims=True)
     noise = normals * np.clip(np.random.randn(points.shape[0], 1) * 0.01, a_min=-0.01, a_max=0.01)
-    points = points + noise.astype(np.float32)
-    S, U = pca_numpy(points)
-    R = rotation_matrix_a_to_b(U[:, np.argmin(S)], np.array([1, 0, 0]))
-    points = (R @ points.T).T
-    normals = (R @ normals.T).T
-    std = np.max(points, 0) - np.min(points, 0)
-    points = points / (std.reshape((1, 3)) + EPS) if anisotropic else points / (np.max(std) + EPS)
-    return points.astype(np.float32), normals.astype(np.float32)
+    pts, nrm = _canonicalise_batch((points + noise.astype(np.float32))[None], normals[None], anisotropic)
+    return pts[0], nrm[0].astype(np.float32)
 
 
 # ---------------------------------------------------------------------------------------
@@ -173,7 +229,7 @@ class Dataset:
                  test_size=None, normals=False, primitives=False):
         self.batch_size, self.normals, self.primitives = batch_size, normals, primitives
         self.augment_routines = [rotate_perturbation_point_cloud, jitter_point_cloud, shift_point_cloud,
-                                 random_scale_point_cloud, rotate_point_cloud]
+                                 random_scale_point_cloud, rotate_point_cloud]   # dataset_segments.py:88-94
         self.splits = {}
         for name, src, size in (("train", train, train_size), ("val", val, val_size), ("test", test, test_size)):
             if src is None:
@@ -207,12 +263,7 @@ class Dataset:
                     noise = normals * np.clip(np.random.randn(1, points.shape[1], 1) * 0.01, a_min=-0.01, a_max=0.01)
                     points = points + noise.astype(np.float32)
                 if align_canonical:
-                    if points.base is not None or not points.flags.writeable:
-                        points = np.array(points)     # the reference writes into its slices
-                    if normals is not None:
-                        normals = np.array(normals)
-                    for j in range(bs):
-                        _canonicalise(points[j], normals[j] if normals is not None else None, anisotropic)
+                    points, normals = _canonicalise_batch(points, normals, anisotropic)
                 yield [points, lab_all[sl], normals, prm_all[sl] if self.primitives else None]
 
     def get_train(self, randomize=False, augment=False, anisotropic=False, align_canonical=False,
@@ -284,35 +335,34 @@ class DataSetControlPointsPoisson:
     pca_numpy = staticmethod(pca_numpy)
 
     def _batch(self, pts_all, cp_all, batch_id, align_canonical, anisotropic, if_augment, scale_iso=True):
-        Points, controlpoints, scales, RS = [], [], [], []
-        for i in range(self.batch_size):
-            points = pts_all[batch_id * self.batch_size + i]
-            mean = np.mean(points, 0)
-            points = points - mean
-            R = None
-            if align_canonical:
-                S, U = pca_numpy(points)
-                R = rotation_matrix_a_to_b(U[:, np.argmin(S)], np.array([1, 0, 0]))
-                points = (R @ points.T).T
-                RS.append(R)
-            if anisotropic:
-                std = np.abs(np.max(points, 0) - np.min(points, 0)).reshape((1, 3))
-                points = points / (std + EPS)
-            else:
-                std = np.max(np.max(points, 0) - np.min(points, 0))
-                if scale_iso:   # the reference's test loader leaves the points unscaled here
-                    points = points / std
-            scales.append(std)
-            Points.append(points)
-            cp = cp_all[batch_id * self.batch_size + i] - mean.reshape((1, 1, 3))
-            if align_canonical:
-                cp = np.reshape((R @ cp.reshape((self.size_u * self.size_v, 3)).T).T, (self.size_u, self.size_v, 3))
-            cp = cp / (std.reshape((1, 1, 3)) + EPS) if anisotropic else cp / std
-            controlpoints.append(cp)
-        controlpoints, Points = np.stack(controlpoints, 0), np.stack(Points, 0)
+        """One batch, all patches at once: centre on the patch mean, canonical frame (minor axis ->
+        x), extent scaling — per axis (anisotropic) or by the largest extent; control grids follow
+        their patch through the same map.  dataset.py:96-150 does this patch by patch."""
+        sl = slice(batch_id * self.batch_size, (batch_id + 1) * self.batch_size)
+        P = pts_all[sl].astype(np.float32)
+        CP = cp_all[sl].astype(np.float32).reshape(self.batch_size, self.size_u * self.size_v, 3)
+        mean = P.mean(1, keepdims=True)
+        P, CP = P - mean, CP - mean
+        RS = []
+        if align_canonical:
+            R = canonical_frames(P)
+            A = Affine(self.batch_size).then(M=np.transpose(R, (0, 2, 1)))
+            P, CP = A.apply(P), A.apply(CP)
+            RS = list(R)
+        ext = np.abs(P.max(1) - P.min(1))                                    # (B,3)
+        if anisotropic:
+            scales = [e.reshape((1, 3)) for e in ext]
+            P, CP = P / (ext[:, None, :] + EPS), CP / (ext[:, None, :] + EPS)
+        else:
+            big = ext.max(1)
+            scales = list(big)
+            CP = CP / big[:, None, None]
+            if scale_iso:   # the reference's test loader leaves the points unscaled here
+                P = P / big[:, None, None]
+        controlpoints = CP.reshape(self.batch_size, self.size_u, self.size_v, 3)
         if if_augment:
-            Points = self._augment.augment(Points).astype(np.float32)
-        return [Points, None, controlpoints, scales, RS]
+            P = self._augment.augment(P).astype(np.float32)
+        return [P, None, controlpoints, scales, RS]
 
     def load_train_data(self, if_regular_points=False, align_canonical=False, anisotropic=False, if_augment=False):
         while True:

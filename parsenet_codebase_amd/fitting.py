@@ -218,21 +218,7 @@ def match(target, pred_labels):
 # ---------------------------------------------------------------------------------------
 # PCA standardisation (src/fitting_utils.py:493-590)
 # ---------------------------------------------------------------------------------------
-def rotation_matrix_a_to_b(A, B):
-    """Rotation taking unit vector A to B (numpy, float64)."""
-    cos = np.dot(A, B)
-    sin = np.linalg.norm(np.cross(B, A))
-    u = A
-    v = B - np.dot(A, B) * A
-    v = v / (np.linalg.norm(v) + EPS)
-    w = np.cross(B, A)
-    w = w / (np.linalg.norm(w) + EPS)
-    Fm = np.stack([u, v, w], 1)
-    G = np.array([[cos, -sin, 0], [sin, cos, 0], [0, 0, 1]])
-    try:
-        return Fm @ G @ np.linalg.inv(Fm)
-    except np.linalg.LinAlgError:
-        return np.eye(3, dtype=np.float32)
+from .data import rotation_matrix_a_to_b  # noqa: E402  (Rodrigues form; identity for (anti)parallel vectors)
 
 
 def pca_torch(X):
