@@ -138,10 +138,11 @@ def kernel_roofline(step, nprof):
             # others are rigorously below 1e-9 of the smallest row sum (csrc/meanshift_x3.h)
             st = _ms.LAST_PLAN_STATS
             col = {"meanshift_fwd": 1, "meanshift_bwd_rows": 2, "meanshift_bwd_cols": 3}[dom]
-            sparse = {"tile_pairs_executed": sum(t[0] for t in st) / len(st),
-                      "block_lists_visited": sum(t[col] for t in st) / len(st),
-                      "dense_equivalent_tflops": ach}
-            ach = ach * sparse["tile_pairs_executed"]      # FLOPs the matrix cores actually execute
+            pairs = sum(t[0] for t in st) / len(st)
+            sparse = {"tile_pairs_executed": pairs, "block_lists_visited": sum(t[col] for t in st) / len(st),
+                      # `achieved` / `frac` above are ALGORITHMIC (the dense 2 N^2 d units of
+                      # the reference's iteration); these two count only the tile pairs whose GEMMs ran
+                      "tflops_on_executed_pairs": ach * pairs}
         if _ms.ARITH in ("bf16x3", "fp16x2"):
             # every fp32 product is formed from 6 bf16 (3 fp16) piece products on the 16-bit matrix
             # cores (fp32 accumulate): the roof for ALGORITHMIC fp32 FLOPs is the dense peak / 6 (/ 3)
@@ -153,8 +154,10 @@ def kernel_roofline(step, nprof):
                     "mfma": ("v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)"
                              if _ms.ARITH == "bf16x3" else
                              "v_mfma_f32_32x32x16_f16, 3 piece products per fp32 product (scaled fp16x2 split)"),
-                    "executed_tflops": pieces * ach, "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+                    "executed_tflops": pieces * ach * (sparse["tile_pairs_executed"] if sparse else 1.0),
+                    "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
             if sparse:
+                sparse["mfma_frac_on_executed_pairs"] = sparse["tflops_on_executed_pairs"] / peak
                 roof["block_sparse"] = sparse
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,

@@ -702,6 +702,8 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   int nt, nb0, nb1, nb2;
   size_t oc, ol, tot;
   x3_plan_layout(B, N, &nt, &nb0, &nb1, &nb2, &oc, &ol, &tot);
+  PN_CHECK_ARG((size_t)B * nb1 * sizeof(int) <= 48 * 1024 && nb1 < 65536 && B < 32768,
+               "pn_meanshift_x3_plan_f32: %d x %d resident blocks exceed the ordering kernel's LDS table", B, nb1);
   unsigned char* pairs = (unsigned char*)plan;
   int* counts = (int*)((char*)plan + oc);
   int* lists = (int*)((char*)plan + ol);

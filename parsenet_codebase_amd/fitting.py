@@ -218,7 +218,23 @@ def match(target, pred_labels):
 # ---------------------------------------------------------------------------------------
 # PCA standardisation (src/fitting_utils.py:493-590)
 # ---------------------------------------------------------------------------------------
-from .data import rotation_matrix_a_to_b  # noqa: E402  (Rodrigues form; identity for (anti)parallel vectors)
+def rotation_matrix_a_to_b(A, B):
+    """Rotation taking unit vector A to B (numpy, float64), built the reference's way
+    (fitting_utils.py:556-577): in the basis F = [A, (B - (A.B) A)^, (B x A)^] it is the planar
+    rotation G by the angle between them, R = F G F^-1; singular F ((anti)parallel vectors) gives the
+    identity.  Rodrigues' formula (data.rotation_matrix_a_to_b) gives the same matrix to 1e-7 (the
+    reference normalises the basis with "+ EPS") — but the float32 BITS of R decide near-ties of
+    the SplineNet's kNN graph on the standardised points (that difference moves the closed-spline
+    fixture by 3e-5), so the fitting stage keeps the reference's construction."""
+    cos, sin = np.dot(A, B), np.linalg.norm(np.cross(B, A))
+    v = B - np.dot(A, B) * A
+    w = np.cross(B, A)
+    Fm = np.stack([A, v / (np.linalg.norm(v) + EPS), w / (np.linalg.norm(w) + EPS)], 1)
+    G = np.array([[cos, -sin, 0], [sin, cos, 0], [0, 0, 1]])
+    try:
+        return Fm @ G @ np.linalg.inv(Fm)
+    except np.linalg.LinAlgError:
+        return np.eye(3, dtype=np.float32)
 
 
 def pca_torch(X):

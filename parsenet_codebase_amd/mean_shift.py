@@ -75,7 +75,8 @@ class _MeanShiftIterations(torch.autograd.Function):
         if ARITH not in _SPLIT and ARITH != "f32":
             raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
         kern = _SPLIT.get(ARITH) if iterations > 0 else None
-        sparse = SPARSE and kern is not None and ARITH == "bf16x3" and N >= SPARSE_MIN_N
+        sparse = (SPARSE and kern is not None and ARITH == "bf16x3" and N >= SPARSE_MIN_N
+                  and B * ((N + 127) // 128) <= 12288)
         perm = inv = None
         if sparse:   # everything below runs on the locality-ordered points; undone on the way out
             perm = locality_order(x, int(os.environ.get("PARSENET_MS_LLOYD", "2")))
