@@ -255,25 +255,35 @@ def build_segment_table(labels, primitives, cluster_ids, N):
     ground-truth segment of every predicted cluster, its modal primitive type, the sub-sampling
     and minimum-size rules, at most 4 splines.  Returns (segments, match) where a segment is a dict
     {row, key, type, kind ('prim' | 'open' | 'closed'), gt (indices)} in the order the reference
-    fits them, and match = (rids, cids, confusion) for the metrics."""
-    from .fitting import _relaxed_iou_of_labels, solve_dense
-    iou = _relaxed_iou_of_labels(cluster_ids, labels)
+    fits them, and match = (rids, cids, unique_pred, gt counts, confusion matrix, first index of
+    every gt label) for the metrics.  Everything comes from two histograms of the shape: the
+    50 x 50 confusion matrix and the 50 x 10 (gt label, primitive type) table."""
+    from .fitting import solve_dense
+    p = np.asarray(cluster_ids).astype(np.int64)
+    g = np.asarray(labels).astype(np.int64)
+    if p.size and (p.min() < 0 or g.min() < 0 or p.max() >= 50 or g.max() >= 50):
+        raise ValueError("labels must lie in [0, 50) (one-hot width of the reference)")
+    conf = np.bincount(p * 50 + g, minlength=2500).reshape(50, 50)
+    dots = conf.astype(np.float32)
+    # relaxed_iou_fast on the one-hot encodings (segment_utils.py:356-374): integer counts, the
+    # same fp32 expression -> the reference's matrix bit for bit
+    iou = dots / (dots.sum(1, keepdims=True, dtype=np.float32) + dots.sum(0, keepdims=True, dtype=np.float32)
+                  - dots + np.float32(1e-7))
     rids, cids = solve_dense(1.0 - iou)
-    unique_pred = np.flatnonzero(np.bincount(np.asarray(cluster_ids).astype(np.int64), minlength=1))   # = np.unique
-    gcount = np.bincount(np.asarray(labels).astype(np.int64), minlength=50)
+    pcount, gcount = conf.sum(1), conf.sum(0)
+    unique_pred = np.flatnonzero(pcount)                                     # = np.unique(cluster_ids)
+    modal = np.bincount(g * 10 + np.asarray(primitives).astype(np.int64), minlength=500).reshape(50, 10).argmax(1)
     n2 = (N + 1) // 2
     n4 = (n2 + 1) // 2
     segs, spline_count = [], 0
     for index, i in enumerate(unique_pred):
-        if gcount[cids[i]] == 0:
+        c = cids[i]
+        if gcount[c] == 0:
             continue
-        gi = np.nonzero(labels == cids[i])[0]
-        seg_type = int(np.bincount(primitives[gi].astype(np.int64)).argmax())
+        seg_type = int(modal[c])             # most frequent type of the gt segment, smallest on ties
         if seg_type in SPLINE_TYPES:
             spline_count += 1
-            if spline_count > 4 or n2 < 20:
-                continue
-            if n2 < 100:
+            if spline_count > 4 or n2 < 100:
                 continue
             kind = "closed" if seg_type in CLOSED_TYPES else "open"
         elif seg_type in PRIM_CODE:
@@ -282,25 +292,25 @@ def build_segment_table(labels, primitives, cluster_ids, N):
             kind = "prim"
         else:
             raise ValueError("unknown primitive type %r" % (seg_type,))
-        segs.append({"row": index, "key": int(i), "type": seg_type, "kind": kind, "gt": gi})
-    return segs, (rids, cids, unique_pred, gcount)
+        segs.append({"row": index, "key": int(i), "type": seg_type, "kind": kind, "gt": np.flatnonzero(g == c)})
+    return segs, (rids, cids, unique_pred, gcount, conf, g)
 
 
-def siou_matched_segments_fast(labels, cluster_ids, prim_pred_per_cluster, primitives, rids, cids):
+def siou_matched_segments_fast(match, prim_pred_per_cluster, primitives):
     """segment_utils.SIOU_matched_segments (src/segment_utils.py:139-187) from the confusion matrix
-    instead of one boolean mask pair per match: identical values."""
+    of build_segment_table instead of one boolean mask pair per match: identical values."""
     from .fitting import _merge_types
-    prim = _merge_types(primitives)
-    p = np.asarray(cluster_ids).astype(np.int64)
-    g = np.asarray(labels).astype(np.int64)
-    conf = np.bincount(p * 50 + g, minlength=2500).reshape(50, 50)
-    np_, ng = conf.sum(1), conf.sum(0)
+    rids, cids, _, ng, conf, g = match
+    np_ = conf.sum(1)
+    prim = None
     ious, ok, pairs = [], [], []
     for r, c in zip(rids, cids):
         if ng[c] == 0 or np_[r] == 0 or ng[c] < 100:
             continue
         inter = conf[r, c]
         ious.append(inter / ((np_[r] + ng[c] - inter) + 1e-8))
+        if prim is None:
+            prim = _merge_types(primitives)
         gt_type = prim[np.argmax(g == c)]          # primitives[gt segment][0]: its first point
         ok.append(gt_type == prim_pred_per_cluster[r])
         pairs.append([gt_type, prim_pred_per_cluster[r]])
@@ -507,9 +517,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
                 parameters[int(i)] = None
         nseg = sum(1 for bb, _ in all_segs if bb == b)
         Loss = loss_b[b] if nseg else torch.zeros(1, device=dev)
-        rids, cids = matches[b][0], matches[b][1]
-        s_iou, p_iou, _, _ = siou_matched_segments_fast(labels[b], cluster_ids[b], ptype_h[b], primitives[b],
-                                                         rids, cids)
+        s_iou, p_iou, _, _ = siou_matched_segments_fast(matches[b], ptype_h[b], primitives[b])
         ev.stats["shapes"] += 1
         ev.stats["clusters"] += ncl_list[b]
         ev.stats["fitted"] += nseg
