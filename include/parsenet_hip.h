@@ -122,11 +122,13 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
  * terms together stay below rel_eps (1e-9) of the SMALLEST row sum of the q tile — far below the
  * rounding of the fp32 sums, so the result is the dense one to fp32 noise.  The caller orders
  * the points so that tiles are local (any order is valid; mean-shift is permutation-equivariant).
- *   tileinfo : z (B,N,D) unit rows -> cen (B,T,D) normalised tile means, rho (B,T) angular radii
- *              (+1e-3 slack), T = align_up(N,64)/32.
+ *   tileinfo : z (B,N,D) unit rows -> two bounding caps per tile (its rows dealt to two far-apart
+ *              seeds): cen (B,T,2,D) normalised means, rho (B,T,2) angular radii (+1e-3 slack;
+ *              < 0: empty cap), T = align_up(N,64)/32.
  *   plan     : caps of the iterate q and of the data x -> plan (pn_meanshift_x3_plan_bytes):
- *              the pair predicate (T x T bytes) and, per resident block of each pass, the compact
- *              list of streamed tiles with at least one pair set.
+ *              the pair predicate (T x T bytes), per resident block of each pass the compact
+ *              list of streamed tiles with at least one pair set, and the prefix sums of the list
+ *              lengths (the launches cut the concatenated lists into one equal range per CU).
  *   iter_fwd_plan / iter_bwd_plan : as iter_fwd / iter_bwd, skipping what the plan of THIS
  *              iteration excludes (plan == NULL: dense; the backward must get the forward's plan). */
 size_t pn_meanshift_x3_plan_bytes(int B, int N);

@@ -498,7 +498,10 @@ extern "C" int pn_meanshift_slices(int B, int N) {
   int tps;
   const int Np = (int)pn_align_up(N, 64);
   const int sf = ms_slices(B, N, Np, MS_BPC_FWD, &tps), sb = ms_slices(B, N, Np, MS_BPC_BWD, &tps);
-  return sf > sb ? sf : sb;
+  const int s = sf > sb ? sf : sb;
+  // the flat schedule of the block-sparse bf16 x 3 launches (meanshift_x3.h) writes up to
+  // smax - 1 list fragments per block whatever the batch size: keep room for 7
+  return N >= 2048 && s < 8 ? 8 : s;
 }
 
 extern "C" int pn_meanshift_pack_f32(const float* x, int B, int N, int D, float* xt, void* stream) {

@@ -314,14 +314,15 @@ def meanshift_x3_split(x):
 
 
 def meanshift_x3_tileinfo(z):
-    """z (B,N,128) unit rows -> (centres (B,T,128), angular radii (B,T)) of the 32-row tiles,
-    T = align_up(N, 64) / 32: the bounding caps of the block-sparse plan."""
+    """z (B,N,128) unit rows -> (centres (B,T,2,128), angular radii (B,T,2)) of the two bounding
+    caps of every 32-row tile, T = align_up(N, 64) / 32 (radius < 0: empty cap): the geometry the
+    block-sparse plan is derived from."""
     require_cuda(z)
     z = _f32c(z, "z")
     B, N, D = z.shape
     T = (N + 63) // 64 * 2
-    cen = torch.empty((B, T, D), dtype=torch.float32, device=z.device)
-    rho = torch.empty((B, T), dtype=torch.float32, device=z.device)
+    cen = torch.empty((B, T, 2, D), dtype=torch.float32, device=z.device)
+    rho = torch.empty((B, T, 2), dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         rc = _lib.load().pn_meanshift_x3_tileinfo_f32(ptr(z), B, N, D, ptr(cen), ptr(rho), current_stream(z.device))
     check(rc, "pn_meanshift_x3_tileinfo_f32")

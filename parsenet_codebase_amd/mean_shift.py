@@ -24,6 +24,7 @@ ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 # (csrc/meanshift_x3.h, "block-sparse plan").  PARSENET_MS_SPARSE=0 keeps every launch dense.
 SPARSE = os.environ.get("PARSENET_MS_SPARSE", "1") != "0"
 SPARSE_MIN_N = 2048
+SPARSE_MAX_N = 36000        # the plan kernel keeps a 16 x 2T table of angles in LDS
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
 
 
@@ -75,8 +76,7 @@ class _MeanShiftIterations(torch.autograd.Function):
         if ARITH not in _SPLIT and ARITH != "f32":
             raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
         kern = _SPLIT.get(ARITH) if iterations > 0 else None
-        sparse = (SPARSE and kern is not None and ARITH == "bf16x3" and N >= SPARSE_MIN_N
-                  and B * ((N + 127) // 128) <= 12288)
+        sparse = SPARSE and kern is not None and ARITH == "bf16x3" and SPARSE_MIN_N <= N <= SPARSE_MAX_N
         perm = inv = None
         if sparse:   # everything below runs on the locality-ordered points; undone on the way out
             perm = locality_order(x, int(os.environ.get("PARSENET_MS_LLOYD", "2")))
