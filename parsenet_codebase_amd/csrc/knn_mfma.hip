@@ -531,8 +531,26 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
 }
 
 struct KnnWs {
-  size_t xq, xxq, xc, xxc, tilemax, tau, cnt, flags, lists, v1, total;
+  size_t xq, xxq, xc, xxc, tilemax, tau, cnt, flags, lists, v1, img, xxmax, total;
 };
+
+#include "knn_x3.h"
+
+// pass 1 on the bf16 matrix cores (knn_x3.h): the feature metric with 64 or 128 padded channels and
+// enough candidates for the split to pay for its image pass.  PN_KNN_X3=0 disables it, =2 also
+// enables it for the dot-product selections (off by default: on a converged embedding thousands
+// of dot products sit within 1e-6 of the K-th one, the rigorous margin of ~1e-4 then multiplies the
+// survivors, the lists overflow and the flagged rows take the slow path — measured 42 -> 55 ms per
+// cfg5 step; the exact fp32 pass has no such cliff).
+static bool knn_x3_pass1(const KnnPlan& p, int mode) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("PN_KNN_X3");
+    on = e ? atoi(e) : 1;
+  }
+  return on && p.fast && (mode == 0 || (mode == 2 && on >= 2)) && (p.ksteps == 32 || p.ksteps == 64) &&
+         p.Ncp >= 2048;
+}
 
 static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool self, bool v1) {
   KnnWs w;
@@ -557,6 +575,10 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
   w.flags = take((size_t)B * Nq * 4);
   w.lists = take((size_t)B * p.Nqp * 2 * p.S * p.subcap * 8);
   w.v1 = take(v1 ? pn_knn_v1_workspace(B, C, Nq, k, true) : 0);
+  // candidate images + per-item largest squared norm of the bf16 x 3 pass 1 (both metrics qualify)
+  const bool x3 = knn_x3_pass1(p, 0);
+  w.img = take(x3 ? (size_t)B * p.Ncp * p.Cp * 6 : 0);
+  w.xxmax = take(x3 ? (size_t)B * 4 : 0);
   w.total = o;
   return w;
 }
@@ -605,9 +627,65 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     if (!self) knn_prep_launch(stream, q, B, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
   }
   PN_CHECK_LAUNCH();
+  const bool x3p1 = !argmax && knn_x3_pass1(p, mode);
+  u32x4* img = (u32x4*)(base + w.img);
+  unsigned* xxmax = (unsigned*)(base + w.xxmax);
+  if (x3p1) {
+    PN_PROF("knn_x3_image", stream);
+    PN_CHECK_HIP(hipMemsetAsync(xxmax, 0, (size_t)B * 4, stream));
+    dim3 ig(p.Ncp / 32, B);
+    if (p.ksteps == 32)
+      hipLaunchKernelGGL(pn_knn_x3_image_kernel<8>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax);
+    else
+      hipLaunchKernelGGL(pn_knn_x3_image_kernel<16>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax);
+    PN_CHECK_LAUNCH();
+  }
   dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
   for (int pass = 0; pass < (argmax ? 1 : 2); ++pass) {
     const int collect = argmax ? 2 : pass;
+    if (pass == 0 && x3p1) {
+      // workgroups of 4 waves x 32 qsets queries, two per CU; steps of tstep tiles (knn_x3.h).
+      // Slices: whole rounds of the 512 slots where possible, a fixed cost of about one tile each.
+      const int qpw = 128 * p.qsets, ntiles = p.Ncp / 32, tstep = p.ksteps == 32 ? 2 : 1;
+      const long long rowblocks = (long long)B * pn_cdiv(p.Nqp, qpw);
+      int tps1 = ntiles;
+      double best_score = -1.0;
+      for (int t = 8; t <= ntiles; t += 2) {
+        const double rounds = (double)(rowblocks * pn_cdiv(ntiles, t)) / (256.0 * KX_WPE(p.ksteps / 4, mode));
+        const double score = rounds / (double)(long long)(rounds + 0.999999) * (double)t / ((double)t + 1.0);
+        if (score > best_score) {
+          best_score = score;
+          tps1 = t;
+        }
+      }
+      dim3 g1(pn_cdiv(ntiles, tps1), pn_cdiv(p.Nqp, qpw), B);
+      {
+        PN_PROF(mode == 2 ? "sel_x3_pass1_dot" : (p.ksteps == 32 ? "knn_x3_pass1_c64" : "knn_x3_pass1_wide"), stream);
+        if (mode == 0 && p.ksteps == 32)
+          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<8, 2, 0, 2>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
+                             xxc, Nc, p.Ncp, tps1, tilemax);
+        else if (mode == 0)
+          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<16, 1, 0, 1>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
+                             xxc, Nc, p.Ncp, tps1, tilemax);
+        else if (p.ksteps == 32)
+          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<8, 2, 2, 2>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
+                             xxc, Nc, p.Ncp, tps1, tilemax);
+        else
+          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<16, 1, 2, 1>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
+                             xxc, Nc, p.Ncp, tps1, tilemax);
+      }
+      PN_CHECK_LAUNCH();
+      {
+        PN_PROF("knn_tau", stream);
+        hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream,
+                           tilemax, Nq, p.Nqp, p.Ncp / 16, k, tau);
+        const float A = 16.0f * (float)(p.Cp + 4) * 0x1p-24f;
+        hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq, Nq,
+                           p.Nqp, xxmax, A, mode);
+      }
+      PN_CHECK_LAUNCH();
+      continue;
+    }
     static const char* const pass_names[2][5] = {
         {"knn_mfma_pass1_c4", "knn_mfma_pass1_c64", "knn_mfma_pass1_wide", "knn_mfma_pass1_pn",
          "sel_mfma_pass1_dot"},

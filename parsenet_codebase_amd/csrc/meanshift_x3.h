@@ -33,33 +33,6 @@
 #define X3_IMG_U4 1536            // uint4 (16 B) units per 24 KiB tile image
 #define X3_PIECE_U4 512           // per piece
 
-// error-free split of two floats into three packed bf16 pairs (element 0 in the low half)
-struct X3Pieces {
-  uint32_t h, m, l;
-};
-__device__ static inline X3Pieces x3_split2(float a, float b) {
-  f32x2 v = {a, b};
-  bf16x2 ph = __builtin_convertvector(v, bf16x2);
-  f32x2 r = {a - (float)ph[0], b - (float)ph[1]};
-  bf16x2 pm = __builtin_convertvector(r, bf16x2);
-  f32x2 r2 = {r[0] - (float)pm[0], r[1] - (float)pm[1]};
-  bf16x2 pl = __builtin_convertvector(r2, bf16x2);
-  X3Pieces o;
-  o.h = __builtin_bit_cast(uint32_t, ph);
-  o.m = __builtin_bit_cast(uint32_t, pm);
-  o.l = __builtin_bit_cast(uint32_t, pl);
-  return o;
-}
-#define X3_SPLIT_TO(A, B, VH, VM, VL, Q) \
-  {                                      \
-    const X3Pieces _p = x3_split2(A, B); \
-    VH[Q] = _p.h;                        \
-    VM[Q] = _p.m;                        \
-    VL[Q] = _p.l;                        \
-  }
-
-__device__ static inline bf16x8 x3_as_bf16(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
 // x (B,N,D) fp32 -> the image of every 32-point tile (rows >= N are zero).
 // One workgroup per tile; work item = one 16-byte chunk.
 __global__ __launch_bounds__(256) void pn_ms3_split_kernel(const float* __restrict__ x, int N,
