@@ -553,7 +553,7 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 // against q tiles).
 #define X3_PLAN_SLACK 1e-3f
 
-// Two bounding caps per 32-row tile of z (B,N,D); one wave per tile, lane = channels (lane, lane + 64).
+// Two bounding caps per 32-row tile of z (B,N,D); lane = channels (lane, lane + 64).
 // A tile of the locality order often straddles two regions of the sphere (the end of one cell and
 // the start of the next): one cap around all 32 rows would then be wide enough to meet every
 // other tile.  The rows are dealt to two seeds (s1 = the row farthest from the mean direction,
@@ -561,163 +561,211 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 // each group gets its own cap.  cen (B,ntiles,2,D), rho (B,ntiles,2); rho < 0: empty group.
 // (Measured on the cfg5 embedding: active tile pairs 0.29 -> 0.23, visited list entries of the
 // row pass 0.40 -> 0.28 of all.)
-__global__ __launch_bounds__(64) void pn_ms3_tileinfo_kernel(const float* __restrict__ z, int N, int ntiles,
-                                                             float* __restrict__ cen, float* __restrict__ rho) {
-  const int b = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+// (four waves per tile, eight rows each: the dot products of a round are wave-wide sums, and one
+// wave per tile left the SIMDs with a single wave of serial reductions: 53 us per call)
+__global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __restrict__ z, int N, int ntiles,
+                                                              float* __restrict__ cen, float* __restrict__ rho) {
+  __shared__ float part[4][2][MS_D];
+  __shared__ float sd[3][32];
+  __shared__ float smin[4][2];
+  const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const float* zb = z + (size_t)b * N * MS_D;
   const int j0 = t * 32, cnt = min(32, N - j0);
   float* co = cen + ((size_t)b * ntiles + t) * 2 * MS_D;
   float* ro = rho + ((size_t)b * ntiles + t) * 2;
   if (cnt <= 0) {   // padding tile: interacts with everything (its image rows are zero)
-    co[lane] = co[lane + 64] = co[MS_D + lane] = co[MS_D + lane + 64] = 0.f;
-    if (lane == 0) {
+    if (tid < 2 * MS_D) co[tid] = 0.f;
+    if (tid == 0) {
       ro[0] = 3.2f;
       ro[1] = -1.f;
     }
     return;
   }
-  float m0 = 0.f, m1 = 0.f;
-  for (int j = 0; j < cnt; ++j) {
-    m0 += zb[(size_t)(j0 + j) * MS_D + lane];
-    m1 += zb[(size_t)(j0 + j) * MS_D + lane + 64];
+  // this wave's rows 8 wave .. 8 wave + 7, channels (lane, lane + 64)
+  float z0[8], z1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = 8 * wave + i;
+    z0[i] = j < cnt ? zb[(size_t)(j0 + j) * MS_D + lane] : 0.f;
+    z1[i] = j < cnt ? zb[(size_t)(j0 + j) * MS_D + lane + 64] : 0.f;
   }
-  // seeds (the dot products are wave-uniform: every lane takes the same decisions; ties -> first row)
+  // dot products of the rows with a vector (v0, v1) -> sd[slot][0..31]
+#define X3_TI_DOTS(SLOT, V0, V1)                                                    \
+  {                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                 \
+      const float d_ = pn_wave_sum(z0[i] * (V0) + z1[i] * (V1));                    \
+      if (lane == 0) sd[SLOT][8 * wave + i] = d_;                                   \
+    }                                                                               \
+    __syncthreads();                                                                \
+  }
+  float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    p0 += z0[i];
+    p1 += z1[i];
+  }
+  part[wave][0][lane] = p0;
+  part[wave][0][lane + 64] = p1;
+  __syncthreads();
+  const float m0 = (part[0][0][lane] + part[1][0][lane]) + (part[2][0][lane] + part[3][0][lane]);
+  const float m1 = (part[0][0][lane + 64] + part[1][0][lane + 64]) + (part[2][0][lane + 64] + part[3][0][lane + 64]);
+  // seeds: s1 = the row farthest from the mean direction, s2 = the row farthest from s1 (ties -> first row)
+  X3_TI_DOTS(0, m0, m1);
   int ia = 0, ib = 0;
   float best = 3.4e38f;
-  for (int j = 0; j < cnt; ++j) {
-    const float d = pn_wave_sum(zb[(size_t)(j0 + j) * MS_D + lane] * m0 + zb[(size_t)(j0 + j) * MS_D + lane + 64] * m1);
-    if (d < best) {
-      best = d;
+  for (int j = 0; j < cnt; ++j)
+    if (sd[0][j] < best) {
+      best = sd[0][j];
       ia = j;
     }
-  }
   const float a0 = zb[(size_t)(j0 + ia) * MS_D + lane], a1 = zb[(size_t)(j0 + ia) * MS_D + lane + 64];
-  float d1mine = 0.f;   // lane j keeps row j's dot product with s1
+  X3_TI_DOTS(1, a0, a1);
   best = 3.4e38f;
-  for (int j = 0; j < cnt; ++j) {
-    const float d = pn_wave_sum(zb[(size_t)(j0 + j) * MS_D + lane] * a0 + zb[(size_t)(j0 + j) * MS_D + lane + 64] * a1);
-    if (lane == j) d1mine = d;
-    if (d < best) {
-      best = d;
+  for (int j = 0; j < cnt; ++j)
+    if (sd[1][j] < best) {
+      best = sd[1][j];
       ib = j;
     }
-  }
   const float b0 = zb[(size_t)(j0 + ib) * MS_D + lane], b1 = zb[(size_t)(j0 + ib) * MS_D + lane + 64];
-  float d2mine = 0.f;
-  for (int j = 0; j < cnt; ++j) {
-    const float d = pn_wave_sum(zb[(size_t)(j0 + j) * MS_D + lane] * b0 + zb[(size_t)(j0 + j) * MS_D + lane + 64] * b1);
-    if (lane == j) d2mine = d;
-  }
-  const unsigned long long second = __ballot(lane < cnt && d2mine > d1mine);   // bit j: row j goes with s2
+  X3_TI_DOTS(2, b0, b1);
+  unsigned second = 0;   // bit j: row j goes with s2 (larger dot product)
+  for (int j = 0; j < cnt; ++j) second |= sd[2][j] > sd[1][j] ? 1u << j : 0u;
   float s[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int j = 0; j < cnt; ++j) {
-    const int g = (int)((second >> j) & 1ull);
-    const float v0 = zb[(size_t)(j0 + j) * MS_D + lane], v1 = zb[(size_t)(j0 + j) * MS_D + lane + 64];
-    s[0][0] += g ? 0.f : v0;
-    s[0][1] += g ? 0.f : v1;
-    s[1][0] += g ? v0 : 0.f;
-    s[1][1] += g ? v1 : 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int g = (int)((second >> (8 * wave + i)) & 1u);   // rows >= cnt hold zeros
+    s[0][0] += g ? 0.f : z0[i];
+    s[0][1] += g ? 0.f : z1[i];
+    s[1][0] += g ? z0[i] : 0.f;
+    s[1][1] += g ? z1[i] : 0.f;
   }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    part[wave][g][lane] = s[g][0];
+    part[wave][g][lane + 64] = s[g][1];
+  }
+  __syncthreads();
   float r[2], c[2][2];
   bool ok[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const float nn = sqrtf(pn_wave_sum(s[g][0] * s[g][0] + s[g][1] * s[g][1]));
-    const int members = g ? __popcll(second) : cnt - __popcll(second);
+    const float t0 = (part[0][g][lane] + part[1][g][lane]) + (part[2][g][lane] + part[3][g][lane]);
+    const float t1 = (part[0][g][lane + 64] + part[1][g][lane + 64]) + (part[2][g][lane + 64] + part[3][g][lane + 64]);
+    const float nn = sqrtf(pn_wave_sum(t0 * t0 + t1 * t1));
+    const int members = g ? __popc(second) : cnt - __popc(second);
     ok[g] = nn > 1e-6f;
-    c[g][0] = ok[g] ? s[g][0] / nn : 0.f;
-    c[g][1] = ok[g] ? s[g][1] / nn : 0.f;
+    c[g][0] = ok[g] ? t0 / nn : 0.f;
+    c[g][1] = ok[g] ? t1 / nn : 0.f;
     r[g] = members == 0 ? -1.f : 3.2f;   // degenerate group (rows cancel): interacts with everything
   }
   float mn[2] = {1.f, 1.f};
-  for (int j = 0; j < cnt; ++j) {
-    const int g = (int)((second >> j) & 1ull);
-    const float d = pn_wave_sum(zb[(size_t)(j0 + j) * MS_D + lane] * (g ? c[1][0] : c[0][0]) +
-                                zb[(size_t)(j0 + j) * MS_D + lane + 64] * (g ? c[1][1] : c[0][1]));
-    if (g) mn[1] = fminf(mn[1], d); else mn[0] = fminf(mn[0], d);
-  }
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    if (r[g] > 0.f && ok[g]) r[g] = acosf(fminf(fmaxf(mn[g], -1.f), 1.f)) + X3_PLAN_SLACK;
-    co[g * MS_D + lane] = c[g][0];
-    co[g * MS_D + lane + 64] = c[g][1];
+  for (int i = 0; i < 8; ++i) {
+    const int j = 8 * wave + i;
+    const int g = (int)((second >> j) & 1u);
+    const float d = pn_wave_sum(z0[i] * (g ? c[1][0] : c[0][0]) + z1[i] * (g ? c[1][1] : c[0][1]));
+    if (j < cnt) {
+      if (g) mn[1] = fminf(mn[1], d); else mn[0] = fminf(mn[0], d);
+    }
   }
   if (lane == 0) {
-    ro[0] = r[0];
-    ro[1] = r[1];
+    smin[wave][0] = mn[0];
+    smin[wave][1] = mn[1];
   }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float mg = fminf(fminf(smin[0][g], smin[1][g]), fminf(smin[2][g], smin[3][g]));
+      if (r[g] > 0.f && ok[g]) r[g] = acosf(fminf(fmaxf(mg, -1.f), 1.f)) + X3_PLAN_SLACK;
+      co[g * MS_D + lane] = c[g][0];
+      co[g * MS_D + lane + 64] = c[g][1];
+    }
+    if (lane == 0) {
+      ro[0] = r[0];
+      ro[1] = r[1];
+    }
+  }
+#undef X3_TI_DOTS
 }
 
-// pairs[b][tQ][tX]; one workgroup per 8 q tiles (16 caps in LDS), a thread per x cap.
-// Dynamic LDS: th[16][2 * ntiles] angles.
-#define X3_PQ 8
-__global__ __launch_bounds__(256) void pn_ms3_pairs_kernel(const float* __restrict__ cenQ,
-                                                           const float* __restrict__ rhoQ,
-                                                           const float* __restrict__ cenX,
-                                                           const float* __restrict__ rhoX,
-                                                           const float* __restrict__ bsq, int ntiles,
-                                                           float logterm, unsigned char* __restrict__ pairs) {
-  __shared__ __attribute__((aligned(16))) float cq[2 * X3_PQ][MS_D];
-  __shared__ float rq_s[2 * X3_PQ];
-  __shared__ float red[4][2 * X3_PQ];
-  extern __shared__ float th_[];   // [2 * X3_PQ][2 * ntiles]
-  const int b = blockIdx.y, tq0 = blockIdx.x * X3_PQ, tid = threadIdx.x;
-  const int ncap = 2 * ntiles;
-  const int nq = min(X3_PQ, ntiles - tq0) * 2;   // caps of this workgroup
-  for (int e = tid; e < 2 * X3_PQ * MS_D; e += 256) {
-    const int a = e / MS_D;
-    cq[a][e - a * MS_D] = a < nq ? cenQ[((size_t)b * ncap + 2 * tq0 + a) * MS_D + (e - a * MS_D)] : 0.f;
+// pairs[b][tQ][tX] in two sweeps of single-wave workgroups, one per (32 q caps) x (32 x caps) block:
+// the 32 x 32 dot products of the cap centres on the fp32 matrix cores (64 v_mfma_f32_32x32x2_f32;
+// the angles need 1e-3, bf16 would not do).  Lane (col, h) feeds k-step m with channel 64 h + m of
+// row col (the order of the k-steps is free), i.e. reads one contiguous half row.
+//   SWEEP 0: pm[b][q cap][x block] = max over the block's x caps of cos(th + rho_q + rho_x)
+//   SWEEP 1: L_q = max over the x blocks of pm, predicate of every cap pair, OR over the 2 x 2 cap
+//            pairs of a tile pair -> pairs.
+// Recomputing the dot products in the second sweep is cheaper than a (2T)^2 table of angles.
+template <int SWEEP>
+__global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restrict__ cenQ,
+                                                          const float* __restrict__ rhoQ,
+                                                          const float* __restrict__ cenX,
+                                                          const float* __restrict__ rhoX,
+                                                          const float* __restrict__ bsq, int ntiles,
+                                                          float logterm, float* __restrict__ pm,
+                                                          unsigned char* __restrict__ pairs) {
+  const int b = blockIdx.z, qb = blockIdx.y, xb = blockIdx.x, lane = threadIdx.x;
+  const int col = lane & 31, h = lane >> 5;
+  const int ncap = 2 * ntiles, nxb = gridDim.x;
+  const int uq = min(qb * 32 + col, ncap - 1), ux = xb * 32 + col, uxc = min(ux, ncap - 1);
+  const float4* aq = reinterpret_cast<const float4*>(cenQ + ((size_t)b * ncap + uq) * MS_D + 64 * h);
+  const float4* bx = reinterpret_cast<const float4*>(cenX + ((size_t)b * ncap + uxc) * MS_D + 64 * h);
+  float4 av[16], bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    av[e] = aq[e];
+    bv[e] = bx[e];
   }
-  if (tid < 2 * X3_PQ) rq_s[tid] = tid < nq ? rhoQ[(size_t)b * ncap + 2 * tq0 + tid] : -1.f;
-  __syncthreads();
-  float best[2 * X3_PQ];
+  f32x16 acc;
 #pragma unroll
-  for (int a = 0; a < 2 * X3_PQ; ++a) best[a] = -2.f;
-  for (int u = tid; u < ncap; u += 256) {
-    const float4* cx = reinterpret_cast<const float4*>(cenX + ((size_t)b * ncap + u) * MS_D);
-    const float rx = rhoX[(size_t)b * ncap + u];
-    float d[2 * X3_PQ];
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2 * X3_PQ; ++a) d[a] = 0.f;
-    for (int c4 = 0; c4 < MS_D / 4; ++c4) {
-      const float4 v = cx[c4];
-#pragma unroll
-      for (int a = 0; a < 2 * X3_PQ; ++a) {
-        const float4 w = *reinterpret_cast<const float4*>(&cq[a][4 * c4]);
-        d[a] = fmaf(w.x, v.x, fmaf(w.y, v.y, fmaf(w.z, v.z, fmaf(w.w, v.w, d[a]))));
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 2 * X3_PQ; ++a) {
-      const float th = acosf(fminf(fmaxf(d[a], -1.f), 1.f));
-      th_[a * ncap + u] = th;
-      const float hi = th + rq_s[a] + rx;
-      if (rx >= 0.f) best[a] = fmaxf(best[a], hi >= 3.14159f ? -1.f : cosf(hi));
-    }
+  for (int e = 0; e < 16; ++e) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e].x, bv[e].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e].y, bv[e].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e].z, bv[e].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e].w, bv[e].w, acc, 0, 0, 0);
   }
-#pragma unroll
-  for (int a = 0; a < 2 * X3_PQ; ++a) {
-    const float m = pn_wave_max(best[a]);
-    if ((tid & 63) == 0) red[tid >> 6][a] = m;
-  }
-  __syncthreads();
+  // D[i = q cap][j = x cap]: lane holds column j = col, rows i = (r & 3) + 8 (r >> 2) + 4 h
+  const float rx = ux < ncap ? rhoX[(size_t)b * ncap + uxc] : -1.f;
   const float cutoff = bsq[b] * logterm;
-  for (int u = tid; u < ncap; u += 256) {   // ncap is even: the two caps of an x tile sit in one lane pair
-    const float rx = rhoX[(size_t)b * ncap + u];
+  // lane col keeps radius and L of q cap qb * 32 + col; the rows of a lane fetch them by shuffle
+  const int qmine = qb * 32 + col;
+  const float rq_mine = qmine < ncap ? rhoQ[(size_t)b * ncap + qmine] : -1.f;
+  float L_mine = -2.f;
+  if (SWEEP == 1 && qmine < ncap) {
+    const float* pq = pm + ((size_t)b * ncap + qmine) * nxb;
+    for (int e = 0; e < nxb; ++e) L_mine = fmaxf(L_mine, pq[e]);
+  }
 #pragma unroll
-    for (int tq = 0; tq < X3_PQ; ++tq) {
-      bool on = false;
+  for (int r = 0; r < 16; r += 2) {
+    bool on = false;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int a = 2 * tq + k;
-        const float L = fmaxf(fmaxf(red[0][a], red[1][a]), fmaxf(red[2][a], red[3][a]));
-        const float lo = th_[a * ncap + u] - rq_s[a] - rx;
+    for (int k = 0; k < 2; ++k) {
+      const int qi = qb * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2) + 4 * h;   // r even: qi, qi + 1 = one tile
+      const float rq = __shfl(rq_mine, qi - qb * 32, 64);
+      const float th = acosf(fminf(fmaxf(acc[r + k], -1.f), 1.f));
+      if (SWEEP == 0) {
+        const float hi = th + rq + rx;
+        float m = rx >= 0.f ? (hi >= 3.14159f ? -1.f : cosf(hi)) : -2.f;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (col == 0 && qi < ncap) pm[((size_t)b * ncap + qi) * nxb + xb] = m;
+      } else {
+        const float L = __shfl(L_mine, qi - qb * 32, 64);
+        const float lo = th - rq - rx;
         const float U = lo <= 0.f ? 1.f : cosf(lo);
-        on |= rq_s[a] >= 0.f && rx >= 0.f && U >= L - cutoff;
+        on |= rq >= 0.f && rx >= 0.f && U >= L - cutoff;
       }
+    }
+    if (SWEEP == 1) {
+      // the x caps 2v, 2v + 1 of a tile are neighbouring lanes
       const bool other = __shfl_xor((int)on, 1, 64) != 0;
-      if ((u & 1) == 0 && tq0 + tq < ntiles)
-        pairs[((size_t)b * ntiles + tq0 + tq) * ntiles + (u >> 1)] = (on || other) ? 1 : 0;
+      const int tq = (qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) >> 1;
+      if ((col & 1) == 0 && ux < ncap && tq < ntiles)
+        pairs[((size_t)b * ntiles + tq) * ntiles + (ux >> 1)] = (on || other) ? 1 : 0;
     }
   }
 }
@@ -847,6 +895,9 @@ __global__ __launch_bounds__(256) void pn_ms3_combine_bwd_kernel(
   *g = o;
 }
 
+static size_t x3_plan_scratch(int B, int ntiles) {
+  return pn_align_up((size_t)B * 2 * ntiles * pn_cdiv(2 * ntiles, 32) * sizeof(float), 256);
+}
 static void x3_plan_layout(int B, int N, int* ntiles, int* nb0, int* nb1, int* nb2, size_t* off_counts,
                            size_t* off_lists, size_t* total) {
   *ntiles = (int)pn_align_up(N, 64) / 32;
@@ -857,7 +908,7 @@ static void x3_plan_layout(int B, int N, int* ntiles, int* nb0, int* nb1, int* n
   *off_counts = pn_align_up((size_t)B * *ntiles * *ntiles, 256);
   // [pairs | counts | offsets (B * nblk + 3) | lists]
   *off_lists = *off_counts + pn_align_up((size_t)B * nblk * 4, 256) + pn_align_up(((size_t)B * nblk + 3) * 4, 256);
-  *total = *off_lists + (size_t)B * nblk * *ntiles * 4;
+  *total = pn_align_up(*off_lists + (size_t)B * nblk * *ntiles * 4, 256) + x3_plan_scratch(B, *ntiles);
 }
 
 extern "C" size_t pn_meanshift_x3_plan_bytes(int B, int N) {
@@ -873,7 +924,7 @@ extern "C" int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D,
   PN_CHECK_ARG(z && cen && rho && B > 0 && N > 0, "pn_meanshift_x3_tileinfo_f32: bad arguments");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   const int ntiles = (int)pn_align_up(N, 64) / 32;
-  hipLaunchKernelGGL(pn_ms3_tileinfo_kernel, dim3(ntiles, B), dim3(64), 0, (hipStream_t)stream, z, N, ntiles, cen,
+  hipLaunchKernelGGL(pn_ms3_tileinfo_kernel, dim3(ntiles, B), dim3(256), 0, (hipStream_t)stream, z, N, ntiles, cen,
                      rho);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -894,16 +945,12 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   int* counts = (int*)((char*)plan + oc);
   int* lists = (int*)((char*)plan + ol);
   const float logterm = logf((float)N / rel_eps);
-  const size_t pairs_lds = (size_t)2 * X3_PQ * 2 * nt * sizeof(float);
-  PN_CHECK_ARG(pairs_lds <= 144 * 1024, "pn_meanshift_x3_plan_f32: N = %d exceeds the angle table in LDS (N <= 36000)", N);
-  static bool lds_raised = false;
-  if (!lds_raised && pairs_lds > 48 * 1024) {
-    PN_CHECK_HIP(hipFuncSetAttribute((const void*)pn_ms3_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     144 * 1024));
-    lds_raised = true;
-  }
-  hipLaunchKernelGGL(pn_ms3_pairs_kernel, dim3(pn_cdiv(nt, X3_PQ), B), dim3(256),
-                     pairs_lds, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm,
+  // (the scratch of the first sweep — 2 nt x nt / 16 floats per item — sits behind the lists)
+  float* pm = (float*)((char*)plan + tot - x3_plan_scratch(B, nt));
+  const dim3 pgrid(pn_cdiv(2 * nt, 32), pn_cdiv(2 * nt, 32), B);
+  hipLaunchKernelGGL(pn_ms3_pairs_kernel<0>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
+                     pairs);
+  hipLaunchKernelGGL(pn_ms3_pairs_kernel<1>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
                      pairs);
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms3_lists_kernel, dim3(nb0 + nb1 + nb2, B), dim3(64), 0, stream, pairs, nt, nb0, nb1, nb2,

@@ -24,7 +24,7 @@ ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 # (csrc/meanshift_x3.h, "block-sparse plan").  PARSENET_MS_SPARSE=0 keeps every launch dense.
 SPARSE = os.environ.get("PARSENET_MS_SPARSE", "1") != "0"
 SPARSE_MIN_N = 2048
-SPARSE_MAX_N = 36000        # the plan kernel keeps a 16 x 2T table of angles in LDS
+SPARSE_MAX_N = 65535        # block numbers of the plan are 16-bit safe; the T x T predicate stays small
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
 
 
