@@ -44,6 +44,18 @@ CMAX = 64          # padded list of cluster centres (the guard retries above 49 
 # -------------------------------------------------------------------------------------------
 # clustering
 # -------------------------------------------------------------------------------------------
+_CONSTS = {}
+
+
+def _device_const(key, make):
+    """Small constant tensors uploaded once: an upload from pageable memory makes the host wait for
+    everything queued on the stream (see _lib.h2d), once per step is once too often."""
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = make()
+    return t
+
+
 def bandwidth_batch(X, quantile, num_samples=10000):
     """MeanShift.compute_bandwidth (src/mean_shift.py:115-137) for every shape of X (B,N,128):
     (bw (B,) clamped at 0.003, flagged rows per shape (B,)) or None outside the selection
@@ -346,7 +358,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
     with torch.no_grad():
         # SIOU_matched_segments merges the predicted types before the per-cluster vote
         # (src/segment_utils.py:152-161: 0, 6, 7 -> 9; 8 -> 2)
-        lut = torch.tensor([9, 1, 2, 3, 4, 5, 9, 9, 2, 9], dtype=torch.int64, device=dev)
+        lut = _device_const(("merge_lut", dev), lambda: h2d(np.asarray([9, 1, 2, 3, 4, 5, 9, 9, 2, 9], dtype=np.int64), dev))
         prim_pred = lut[torch.max(primitives_log_prob, 1)[1]]
     if state is not None:
         pack = torch.cat([state["labels"].reshape(-1), state["cid"].reshape(-1), state["ncl"],
@@ -441,7 +453,8 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
             w2 = Wn[:, :, 0::2][sb, sr] + EPS                                 # (S_s,n2), differentiable
             pts_std, std, mean, R = standardize_segments(P2, w2.detach())      # sync 2
             affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
-        nu, nv = fitter.nu.to(dev), fitter.nv.to(dev)
+        nu = _device_const(("nu", id(fitter), dev), lambda: fitter.nu.to(dev))
+        nv = _device_const(("nv", id(fitter), dev), lambda: fitter.nv.to(dev))
         pieces = []
         for lo, hi, net, wrap in ((0, n_open, fitter.open_control_decoder, False),
                                   (n_open, S_s, fitter.closed_control_decoder, True)):
