@@ -130,7 +130,13 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
  *              list of streamed tiles with at least one pair set, and the prefix sums of the list
  *              lengths (the launches cut the concatenated lists into one equal range per CU).
  *   iter_fwd_plan / iter_bwd_plan : as iter_fwd / iter_bwd, skipping what the plan of THIS
- *              iteration excludes (plan == NULL: dense; the backward must get the forward's plan). */
+ *              iteration excludes (plan == NULL: dense; the backward must get the forward's plan).
+ *   chain_order : sim (B,P,P) similarities of P = 128 cell centres -> rank (B,P) int32, the position
+ *              of every cell in the greedy nearest-neighbour chain from cell 0 (the order the
+ *              caller lays the cells, hence the points, out in: neighbours in the sequence are
+ *              neighbours on the sphere).  Only a heuristic for locality; never affects results.
+ */
+int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int* rank, void* stream);
 size_t pn_meanshift_x3_plan_bytes(int B, int N);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, void* stream);
 int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,

@@ -930,6 +930,62 @@ extern "C" int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D,
   return PN_OK;
 }
 
+// Greedy nearest-neighbour chain over P = 128 cell centres (the locality order of the caller puts
+// the cells of the sphere in this sequence: neighbouring cells of the sequence are neighbours on
+// the sphere, so the 4- and 8-tile resident blocks that straddle two cells still have similar
+// lists; against sorting the cells by a coarse clustering the visited list entries drop by
+// 14 % / 19 % / 20 % in the three passes on the cfg5 embedding).
+// sim (B,P,P) = dot products of the centres; rank[b][cell] = position in the chain that starts at
+// cell 0 and always moves to the most similar unvisited cell (ties -> smaller index).
+// One workgroup of P threads per batch item; the matrix sits in LDS (64 KiB).
+#define X3_CHAIN_P 128
+__global__ __launch_bounds__(X3_CHAIN_P) void pn_ms3_chain_kernel(const float* __restrict__ sim,
+                                                                  int* __restrict__ rank) {
+  __shared__ float s_sim[X3_CHAIN_P * X3_CHAIN_P];
+  __shared__ float s_v[2];
+  __shared__ int s_i[2];
+  const int b = blockIdx.x, j = threadIdx.x, wave = j >> 6;
+  const float* sb = sim + (size_t)b * X3_CHAIN_P * X3_CHAIN_P;
+  for (int e = j; e < X3_CHAIN_P * X3_CHAIN_P; e += X3_CHAIN_P) s_sim[e] = sb[e];
+  bool used = j == 0;
+  if (j == 0) rank[(size_t)b * X3_CHAIN_P] = 0;
+  int cur = 0;
+  __syncthreads();
+  for (int step = 1; step < X3_CHAIN_P; ++step) {
+    float v = used ? -__builtin_inff() : s_sim[cur * X3_CHAIN_P + j];
+    if (!(v == v)) v = -3.0e38f;   // NaN similarity: last
+    int idx = j;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > v || (ov == v && oi < idx)) {
+        v = ov;
+        idx = oi;
+      }
+    }
+    if ((j & 63) == 0) {
+      s_v[wave] = v;
+      s_i[wave] = idx;
+    }
+    __syncthreads();
+    cur = (s_v[1] > s_v[0] || (s_v[1] == s_v[0] && s_i[1] < s_i[0])) ? s_i[1] : s_i[0];
+    if (j == cur) {
+      used = true;
+      rank[(size_t)b * X3_CHAIN_P + j] = step;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int* rank, void* stream) {
+  PN_CHECK_ARG(sim && rank && B > 0, "pn_meanshift_chain_order_f32: bad arguments");
+  PN_CHECK_ARG(P == X3_CHAIN_P, "pn_meanshift_chain_order_f32: built for %d cells, got %d", X3_CHAIN_P, P);
+  hipLaunchKernelGGL(pn_ms3_chain_kernel, dim3(B), dim3(X3_CHAIN_P), 0, (hipStream_t)stream, sim, rank);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 // plan of one iteration from the tile caps of the iterate (Q) and of the data (X); rel_eps: the
 // skipped mass relative to the smallest row sum (1e-9)
 extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX,

@@ -329,6 +329,19 @@ def meanshift_x3_tileinfo(z):
     return cen, rho
 
 
+def meanshift_chain_order(sim):
+    """sim (B,128,128) similarities of cell centres -> (B,128) int64 position of every cell in the
+    greedy nearest-neighbour chain that starts at cell 0."""
+    require_cuda(sim)
+    sim = _f32c(sim, "sim")
+    B, P, _ = sim.shape
+    rank = torch.empty((B, P), dtype=torch.int32, device=sim.device)
+    with torch.cuda.device(sim.device):
+        rc = _lib.load().pn_meanshift_chain_order_f32(ptr(sim), B, P, ptr(rank), current_stream(sim.device))
+    check(rc, "pn_meanshift_chain_order_f32")
+    return rank.long()
+
+
 def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
     """Block-sparse plan of one iteration (which tile pairs can contribute more than ``rel_eps`` of
     the smallest row sum): an opaque byte tensor for meanshift_x3_iter_fwd / _bwd."""

@@ -30,20 +30,20 @@ LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled w
 
 def locality_order(x, lloyd=2):
     """A permutation (B,N) that puts points of the same region of the sphere next to each other:
-    128 cells (spherical k-means: evenly spaced rows of x as seeds, ``lloyd`` refinement steps),
-    cells grouped by 16 coarse cells of the cell centres.  Any permutation is valid — mean-shift
-    is permutation-equivariant; a good one makes the 32-point tiles tight, which is what lets the
-    plan skip tile pairs."""
+    128 cells (spherical k-means: evenly spaced rows of x as seeds, ``lloyd`` refinement steps)
+    laid out along a greedy nearest-neighbour chain of their centres.  Any permutation is valid —
+    mean-shift is permutation-equivariant; a good one makes the 32-point tiles tight and the tiles
+    of a resident block alike, which is what lets the plan skip tile pairs."""
     B, N, D = x.shape
-    P, C = 128, 16
+    P = 128
 
     def assign(pts, cen):
         return torch.bmm(pts, cen.transpose(1, 2)).argmax(2)
 
-    def centres(pts, lab, K, old):
+    def centres(pts, lab, K_, old):
         # one-hot GEMM instead of index_add_: atomics would make the order — and with it the
         # summation order of every later launch — vary from run to run
-        hot = torch.nn.functional.one_hot(lab, K).to(pts.dtype)              # (B,n,K)
+        hot = torch.nn.functional.one_hot(lab, K_).to(pts.dtype)             # (B,n,K)
         acc = torch.bmm(hot.transpose(1, 2), pts)
         nrm = acc.norm(dim=2, keepdim=True)
         return torch.where(nrm > 1e-6, acc / nrm.clamp_min(1e-6), old)      # empty cell: keep its seed
@@ -52,13 +52,8 @@ def locality_order(x, lloyd=2):
     for _ in range(lloyd):
         cen = centres(x, fine, P, cen)
         fine = assign(x, cen)
-    ccen = cen[:, :C]
-    coarse = assign(cen, ccen)
-    for _ in range(lloyd):
-        ccen = centres(cen, coarse, C, ccen)
-        coarse = assign(cen, ccen)
-    key = torch.gather(coarse, 1, fine) * P + fine
-    return torch.argsort(key, dim=1, stable=True)
+    rank = K.meanshift_chain_order(torch.bmm(cen, cen.transpose(1, 2)))       # (B,P)
+    return torch.argsort(torch.gather(rank, 1, fine), dim=1, stable=True)
 
 
 _SPLIT = {"fp16x2": (K.meanshift_h2_split, K.meanshift_h2_iter_fwd, K.meanshift_h2_iter_bwd),
