@@ -326,3 +326,73 @@ def test_block_sparse_iterations_equal_the_dense_ones(gpu, N, clusters, noise):
         assert pair_frac < 0.5, stats            # most tile pairs are provably irrelevant
     if clusters == 1:
         assert pair_frac > 0.99, stats           # nothing can be skipped on an unstructured cloud
+
+
+def test_tile_caps_contain_their_rows_and_the_plan_keeps_every_heavy_pair(gpu):
+    """Rigour of the block-sparse plan, checked by brute force on a clustered cloud whose tiles
+    straddle clusters (N not a multiple of 32, natural order = no locality at all for half of it):
+    (1) every row of a tile lies inside one of the tile's two bounding caps;
+    (2) for every tile pair the plan drops, the largest kernel value of the pair, times N, stays
+        below 1e-9 of the smallest row sum of the q tile — the bound the kernels rely on."""
+    from parsenet_codebase_amd import kernels as K
+    torch.cuda.set_device(gpu)
+    N, B = 4100, 2
+    g = torch.Generator().manual_seed(11)
+    proto = torch.nn.functional.normalize(torch.randn(6, 128, generator=g), dim=1)
+    lab = torch.randint(0, 6, (B, N), generator=g)
+    lab[:, :N // 2] = torch.sort(lab[:, :N // 2], dim=1)[0]          # first half grouped, second half mixed
+    X = torch.nn.functional.normalize(proto[lab] + 0.15 * torch.randn(B, N, 128, generator=g) / np.sqrt(128), dim=2)
+    Xg = X.to(gpu)
+    cen, rho = K.meanshift_x3_tileinfo(Xg)
+    T = cen.shape[1]
+    assert cen.shape == (B, T, 2, 128) and rho.shape == (B, T, 2) and T == (N + 63) // 64 * 2
+    cen_c, rho_c = cen.cpu().double(), rho.cpu().double()
+    Xd = X.double()
+    for b in range(B):
+        for t in range(T):
+            rows = Xd[b, 32 * t:min(N, 32 * t + 32)]
+            if rows.shape[0] == 0:
+                assert rho_c[b, t, 0] >= 3.14 and rho_c[b, t, 1] < 0           # padding tile: meets everything
+                continue
+            ang = torch.acos((rows @ cen_c[b, t].T).clamp(-1, 1))               # (rows, 2)
+            inside = (ang <= rho_c[b, t][None, :]) & (rho_c[b, t][None, :] >= 0)
+            assert bool(inside.any(1).all()), (b, t)
+    bsq = torch.tensor([0.08 ** 2, 0.12 ** 2], device=gpu)
+    plan = K.meanshift_x3_plan((cen, rho), (cen, rho), bsq, N)
+    pairs = plan[:B * T * T].reshape(B, T, T).cpu().bool()
+    assert 0.05 < pairs.float().mean() < 0.9
+    S = Xd @ Xd.transpose(1, 2)                                                  # (B,N,N) exact enough in fp64
+    for b in range(B):
+        Kmat = torch.exp((S[b] - 1.0) / float(bsq[b]))
+        rsum = Kmat.sum(1)
+        pad = T * 32 - N
+        Kp = torch.nn.functional.pad(Kmat, (0, pad, 0, pad))
+        tile_max = Kp.reshape(T, 32, T, 32).amax(dim=(1, 3))                     # (T,T)
+        rmin = torch.nn.functional.pad(rsum, (0, pad), value=float("inf")).reshape(T, 32).amin(1)
+        dropped = ~pairs[b]
+        dropped[T - 1:, :] = False                                               # the all-padding q tile has no rows
+        bound = (N * tile_max / rmin[:, None])[dropped]
+        assert bound.numel() > 0 and float(bound.max()) <= 1e-9, float(bound.max())
+
+
+def test_chain_order_is_the_greedy_nearest_neighbour_chain(gpu):
+    from parsenet_codebase_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    cen = torch.nn.functional.normalize(torch.randn(3, 128, 128, generator=g), dim=2)
+    cen[1, 7] = cen[1, 3]                                                         # a tie: smaller index first
+    sim = torch.bmm(cen, cen.transpose(1, 2)).to(gpu)
+    rank = K.meanshift_chain_order(sim).cpu()
+    simc = sim.cpu()
+    for b in range(3):
+        used = torch.zeros(128, dtype=torch.bool)
+        cur, order = 0, [0]
+        used[0] = True
+        for _ in range(127):
+            s = simc[b, cur].clone()
+            s[used] = -float("inf")
+            cur = int(torch.nonzero(s == s.max())[0])
+            used[cur] = True
+            order.append(cur)
+        want = torch.empty(128, dtype=torch.long)
+        want[torch.tensor(order)] = torch.arange(128)
+        assert torch.equal(rank[b], want)
