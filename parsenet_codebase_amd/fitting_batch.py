@@ -86,12 +86,20 @@ def _padded_true_indices(mask, cap):
     return order[:, :cap], mask.sum(1)
 
 
-def nms_batch(new_X, X, bw):
+_NMS_WIDTH = {}     # (B, N) -> padded width of the neighbour matrix the previous call needed
+
+
+def nms_batch(new_X, X, bw, width=None):
     """MeanShift.nms (src/mean_shift.py:139-179) for all shapes at once.  new_X, X (B,N,128)
     detached, bw (B,).  Returns a dict: labels (B,N) int64, cid (B,CMAX) int64 ascending centre
-    ids (padded), ncl (B,) on the device, and nocc (B,), nflag (B,) on the HOST — the number of
-    occupied centres sizes the neighbour matrix (one download for the batch), nflag counts rows
-    the selection kernel flagged (massive ties).  None outside the kernel's fast path.
+    ids (padded), ncl, nocc, nflag (B,) and the padded ``width`` of the neighbour matrix.
+    None outside the kernel's fast path.
+
+    The number of occupied centres sizes the neighbour matrix.  Any width >= max(nocc) gives the
+    same result (padding rows are masked), so ``width`` may be a guess — the caller downloads
+    nocc together with the cluster ids and calls again with ``width=None`` if the guess was too
+    small; without a guess nocc is downloaded here (one more synchronisation).  nflag counts the
+    rows the selection kernel flagged (massive ties).
 
     The reference scores every occupied centre u against ALL N shifted points j with
     [dist(u,j) < b] * members(j); unoccupied j score 0 and the row maximum is at least members(u)
@@ -107,9 +115,11 @@ def nms_batch(new_X, X, bw):
     counts.scatter_add_(1, membership, torch.ones((B, N), dtype=torch.float32, device=X.device))
     occ = counts > 0
     nocc = occ.sum(1)
-    host = torch.cat([nocc, (flags != 0).sum(1)]).cpu().numpy()          # sync: sizes the next launches
-    nocc_h, nflag_h = host[:B], host[B:]
-    U = int(nocc_h.max())
+    nflag = (flags != 0).sum(1)
+    if width is None:
+        U = int(nocc.max().item())                                          # sync: sizes the next launches
+    else:
+        U = min(int(width), N)
     uq, _ = _padded_true_indices(occ, U)
     rowvalid = torch.arange(U, device=X.device).unsqueeze(0) < nocc.unsqueeze(1)
     Cu = torch.gather(new_X, 1, uq.unsqueeze(2).expand(-1, -1, D))
@@ -125,7 +135,17 @@ def nms_batch(new_X, X, bw):
     sc = torch.bmm(Csel, X.transpose(1, 2))                                     # (B,CMAX,N)
     sc = torch.where(cvalid.unsqueeze(2), sc, torch.full_like(sc, float("-inf")))
     labels = MSM._first_argmax(sc, 1)
-    return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc_h, "nflag": nflag_h}
+    return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc, "nflag": nflag, "width": U}
+
+
+def nms_width_guess(B, N):
+    """Width for the next nms_batch call of this problem size: a quarter above what the previous
+    one needed, in steps of 256 (None before the first call)."""
+    return _NMS_WIDTH.get((B, N))
+
+
+def nms_width_update(B, N, nocc_max):
+    _NMS_WIDTH[(B, N)] = min(N, (int(nocc_max * 1.25) // 256 + 1) * 256)
 
 
 # -------------------------------------------------------------------------------------------
@@ -354,20 +374,29 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         with record_function("fit:meanshift_fwd"):
             new_X = MSM.mean_shift_iterations(emb, bw, iterations)
         with torch.no_grad(), record_function("fit:nms"):
-            state = nms_batch(new_X.detach(), emb.detach(), bw)
+            state = nms_batch(new_X.detach(), emb.detach(), bw, nms_width_guess(B, N))
     with torch.no_grad():
         # SIOU_matched_segments merges the predicted types before the per-cluster vote
         # (src/segment_utils.py:152-161: 0, 6, 7 -> 9; 8 -> 2)
         lut = _device_const(("merge_lut", dev), lambda: h2d(np.asarray([9, 1, 2, 3, 4, 5, 9, 9, 2, 9], dtype=np.int64), dev))
         prim_pred = lut[torch.max(primitives_log_prob, 1)[1]]
     if state is not None:
-        pack = torch.cat([state["labels"].reshape(-1), state["cid"].reshape(-1), state["ncl"],
-                          bwflag]).to(torch.int32).cpu().numpy()                         # download: cluster ids
+        def download(st):
+            return torch.cat([st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag, st["nocc"],
+                              st["nflag"]]).to(torch.int32).cpu().numpy()                # download: cluster ids
+        pack = download(state)
+        if int(pack[-2 * B:-B].max()) > state["width"]:
+            # the guessed width of the neighbour matrix was too small (the clustering changed a lot
+            # since the last step): once more with the exact one
+            with torch.no_grad():
+                state = nms_batch(new_X.detach(), emb.detach(), bw, None)
+            pack = download(state)
+        nms_width_update(B, N, int(pack[-2 * B:-B].max()))
         o = 0
         lab_h = pack[o:o + B * N].reshape(B, N); o += B * N
         cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
         ncl_h, bwflag_h = pack[o:o + B], pack[o + B:o + 2 * B]
-        nflag_h = state["nflag"]
+        nflag_h = pack[-B:]
     centers, bws, cluster_ids = [], [], []
     for b in range(B):
         # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122)

@@ -174,6 +174,12 @@ def test_static_nms_equals_the_dynamic_one(gpu):
         assert n == ids.shape[0] and torch.equal(st["cid"][b, :n], ids)
         assert torch.equal(st["labels"][b], labels)
         assert int(st["nflag"][b]) == 0
+    # the width of the neighbour matrix may be any guess >= the number of occupied centres (the
+    # training path guesses it from the previous step instead of synchronising for it)
+    wide = nms_batch(new_X, emb, bw, width=int(st["nocc"].max()) + 300)
+    assert wide["width"] == int(st["nocc"].max()) + 300
+    for key in ("labels", "cid", "ncl", "nocc"):
+        assert torch.equal(wide[key], st[key]), key
 
 
 def test_ragged_chamfer_and_bspline_kernels(gpu):
