@@ -973,15 +973,18 @@ class Evaluation:
         return loss, [parameters, cluster_ids.data.cpu().numpy(), weights]
 
     def fitting_losses(self, embedding, points, normals, labels, primitives, primitives_log_prob,
-                       quantile=0.125, iterations=5, lamb=1.0):
+                       quantile=0.125, iterations=5, lamb=1.0, defer_metrics=False):
         """Training-mode ``fitting_loss`` of EVERY shape of the batch (the reference's function
         returns the last shape's): a list of ([Loss, geometric mean, spline mean, s_iou, p_iou],
         [parameters, cluster ids, weights]), computed stage by stage over all shapes and segments
-        (fitting_batch.py) instead of shape by shape and segment by segment."""
+        (fitting_batch.py) instead of shape by shape and segment by segment.
+        ``defer_metrics``: return (losses (B,) on the device, finish) instead; ``finish()`` downloads
+        the metrics and returns the list — a training loop calls it after ``backward()`` has been
+        queued, so that the device does not idle while the host waits for numbers it only logs."""
         from .fitting_batch import fitting_losses_train
         require_cuda(embedding, points, normals)
         return fitting_losses_train(self, embedding, points, normals, labels, primitives, primitives_log_prob,
-                                    quantile, iterations, lamb)
+                                    quantile, iterations, lamb, defer_metrics)
 
     def residual_train_mode(self, points, normals, labels, cluster_ids, primitives, weights, bw, lamb=1.0):
         if not isinstance(cluster_ids, np.ndarray):

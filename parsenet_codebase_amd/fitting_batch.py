@@ -353,7 +353,7 @@ def siou_matched_segments_fast(match, prim_pred_per_cluster, primitives):
 # the stage
 # -------------------------------------------------------------------------------------------
 def fitting_losses_train(ev, embedding, points, normals, labels, primitives, primitives_log_prob, quantile,
-                         iterations, lamb):
+                         iterations, lamb, defer_metrics=False):
     """Training-mode Evaluation.fitting_loss for every shape of the batch.  Returns a list (one
     entry per shape) of ([Loss, geometric mean, spline mean, s_iou, p_iou], [parameters, cluster
     ids, weights]) exactly as the reference's call with that single shape would.
@@ -517,7 +517,17 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         tail = [d_all.detach().double()]
         if S_p:
             tail.append(status.double())
-        host = torch.cat(tail + [ptype.reshape(-1).double()]).cpu().numpy()                    # sync 3
+        tail_dev = torch.cat(tail + [ptype.reshape(-1).double()])
+    else:
+        loss_b = torch.zeros(B, dtype=torch.float32, device=dev)
+        tail_dev = ptype.reshape(-1).double()
+    pf = params_p.float() if S_p else None
+
+    def finish():
+        """Host side of the results: ONE download (distances, fit status, voted types), then the
+        per-shape records.  With ``defer_metrics`` the caller runs this after it has queued the
+        backward pass, so the device never waits for the host between the two."""
+        host = tail_dev.cpu().numpy()                                                          # sync 3
         d_h = host[:S_all]
         st_h = host[S_all:S_all + S_p].astype(np.int64) if S_p else np.zeros(0, np.int64)
         ptype_h = host[S_all + S_p:].astype(np.int64).reshape(B, Cp)
@@ -526,43 +536,40 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
             raise RuntimeError("fitting: %s in segment %d of shape %d" % (
                 "non-finite design matrix / no full-rank ridge system (lstsq)" if st_h[bad] & 1 else
                 "NaN residual distance", prim_segs[bad][1]["key"], prim_segs[bad][0]))
-    else:
-        loss_b = torch.zeros(B, dtype=torch.float32, device=dev)
-        d_h = np.zeros(0)
-        ptype_h = ptype.cpu().numpy()
-    pf = params_p.float() if S_p else None
-
-    out = []
-    for b in range(B):
-        parameters, geo, spl = {}, [], []
-        for k, (bb, s) in enumerate(all_segs):
-            if bb != b:
-                continue
-            dv = 0.1 if d_h[k] > 1 else d_h[k]
-            if s["kind"] == "prim":
-                code, p = PRIM_CODE[s["type"]], pf[k]
-                if code == K.PRIM_PLANE:
-                    parameters[s["key"]] = ["plane", p[0:3].reshape(3, 1), p[3]]
-                elif code == K.PRIM_SPHERE:
-                    parameters[s["key"]] = ["sphere", p[0:3].reshape(1, 3), p[3]]
-                elif code == K.PRIM_CYLINDER:
-                    parameters[s["key"]] = ["cylinder", p[0:3].reshape(3, 1), p[3:6].reshape(1, 3), p[6]]
+        out = []
+        for b in range(B):
+            parameters, geo, spl = {}, [], []
+            for k, (bb, s) in enumerate(all_segs):
+                if bb != b:
+                    continue
+                dv = 0.1 if d_h[k] > 1 else d_h[k]
+                if s["kind"] == "prim":
+                    code, p = PRIM_CODE[s["type"]], pf[k]
+                    if code == K.PRIM_PLANE:
+                        parameters[s["key"]] = ["plane", p[0:3].reshape(3, 1), p[3]]
+                    elif code == K.PRIM_SPHERE:
+                        parameters[s["key"]] = ["sphere", p[0:3].reshape(1, 3), p[3]]
+                    elif code == K.PRIM_CYLINDER:
+                        parameters[s["key"]] = ["cylinder", p[0:3].reshape(3, 1), p[3:6].reshape(1, 3), p[6]]
+                    else:
+                        parameters[s["key"]] = ["cone", p[0:3].reshape(1, 3), p[3:6].reshape(3, 1), p[6:7]]
+                    geo.append(float(dv))
                 else:
-                    parameters[s["key"]] = ["cone", p[0:3].reshape(1, 3), p[3:6].reshape(3, 1), p[6:7]]
-                geo.append(float(dv))
-            else:
-                parameters[s["key"]] = ["open-spline" if s["kind"] == "open" else "closed-spline", recs[k - S_p]]
-                spl.append(float(dv))
-        fitted = {s["key"] for bb, s in all_segs if bb == b}
-        for i in matches[b][2]:              # skipped segments are recorded as None like the reference
-            if int(i) not in fitted and matches[b][3][matches[b][1][i]] > 0:
-                parameters[int(i)] = None
-        nseg = sum(1 for bb, _ in all_segs if bb == b)
-        Loss = loss_b[b] if nseg else torch.zeros(1, device=dev)
-        s_iou, p_iou, _, _ = siou_matched_segments_fast(matches[b], ptype_h[b], primitives[b])
-        ev.stats["shapes"] += 1
-        ev.stats["clusters"] += ncl_list[b]
-        ev.stats["fitted"] += nseg
-        out.append(([Loss, float(np.mean(geo)) if geo else None, float(np.mean(spl)) if spl else None, s_iou, p_iou],
-                    [parameters, cluster_ids[b], Wraw[b, :ncl_list[b]]]))
-    return out
+                    parameters[s["key"]] = ["open-spline" if s["kind"] == "open" else "closed-spline", recs[k - S_p]]
+                    spl.append(float(dv))
+            fitted = {s["key"] for bb, s in all_segs if bb == b}
+            for i in matches[b][2]:              # skipped segments are recorded as None like the reference
+                if int(i) not in fitted and matches[b][3][matches[b][1][i]] > 0:
+                    parameters[int(i)] = None
+            nseg = sum(1 for bb, _ in all_segs if bb == b)
+            Loss = loss_b[b] if nseg else torch.zeros(1, device=dev)
+            s_iou, p_iou, _, _ = siou_matched_segments_fast(matches[b], ptype_h[b], primitives[b])
+            ev.stats["shapes"] += 1
+            ev.stats["clusters"] += ncl_list[b]
+            ev.stats["fitted"] += nseg
+            out.append(([Loss, float(np.mean(geo)) if geo else None, float(np.mean(spl)) if spl else None, s_iou,
+                         p_iou], [parameters, cluster_ids[b], Wraw[b, :ncl_list[b]]]))
+        return out
+    if defer_metrics:
+        return loss_b, finish
+    return finish()

@@ -149,13 +149,15 @@ class ParsenetE2EStep(ParsenetSegStep):
         res_total = 0
         self.evaluation.batched = self.batched
         if self.batched:
-            res = self.evaluation.fitting_losses(emb, self.points, self.normals, self.labels, self.prim_np, log_prob,
-                                                 quantile=0.025, iterations=10, lamb=0.1)
-            res_total = sum(r[0][0].sum() for r in res)
+            loss_b, finish = self.evaluation.fitting_losses(emb, self.points, self.normals, self.labels, self.prim_np,
+                                                            log_prob, quantile=0.025, iterations=10, lamb=0.1,
+                                                            defer_metrics=True)
+            res_total = sum(loss_b[b] for b in range(self.batch))     # the association of the per-shape sum
             loss = loss + res_total / self.batch
             loss.backward()
             self.bucket.all_reduce_mean()
             self.opt.step()
+            self.last_metrics = finish()     # the download of the logged metrics: after everything is queued
             self.last_res = res_total
             return loss
         main = torch.cuda.current_stream(self.device)

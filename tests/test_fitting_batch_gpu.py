@@ -235,3 +235,33 @@ def test_ragged_chamfer_and_bspline_kernels(gpu):
         assert torch.allclose(g1, g2, atol=2e-5)
     plain = K.bspline_eval(nu, nv, ctrl.detach())
     assert torch.allclose(plain, evaluate_surface(nu, nv, ctrl.detach()), atol=2e-6)
+
+
+def test_deferred_metrics_are_the_same_results(gpu):
+    """defer_metrics=True hands back the per-shape losses at once and the host records later
+    (after the caller queued its backward pass): same numbers, same gradient."""
+    torch.cuda.set_device(gpu)
+    B = 2
+    P, Nn, lab, prim, emb, logp = _structured_batch(gpu, B, 3000, (3, 8), noise=0.01)
+    ev = _evaluation(gpu)
+    outs = []
+    for defer in (False, True):
+        e = emb.clone().requires_grad_(True)
+        np.random.seed(5)
+        if defer:
+            loss_b, finish = ev.fitting_losses(e, P, Nn, lab, prim, logp, quantile=0.025, iterations=10, lamb=0.1,
+                                               defer_metrics=True)
+            sum(loss_b[b] for b in range(B)).backward()
+            res = finish()
+        else:
+            res = ev.fitting_losses(e, P, Nn, lab, prim, logp, quantile=0.025, iterations=10, lamb=0.1)
+            sum(r[0][0].sum() for r in res).backward()
+        outs.append((res, e.grad.clone()))
+    (ra, ga), (rb, gb) = outs
+    # (two runs of the same path differ in the last bits: fp32 atomics in the scatter-adds)
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
+    for a, b in zip(ra, rb):
+        assert abs(float(a[0][0]) - float(b[0][0])) <= 1e-6 * abs(float(a[0][0])) + 1e-12
+        for u, v in zip(a[0][1:], b[0][1:]):
+            assert (u is None and v is None) or abs(u - v) <= 1e-6 * abs(u) + 1e-12
+        assert sorted(a[1][0].keys()) == sorted(b[1][0].keys())

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r3j
+mkdir -p $O
+export PARSENET_PRETRAIN_CACHE=/tmp/pretrain_cache.pt
+timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -4 $O/pytest.log
+for i in 1 2; do
+timeout 900 python bench.py --workload cfg5 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg5_$i.json 2> $O/bench_cfg5_$i.err; cut -c1-200 $O/bench_cfg5_$i.json
+done
