@@ -158,6 +158,10 @@ def kernel_roofline(step, nprof):
                     "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
             if sparse:
                 sparse["mfma_frac_on_executed_pairs"] = sparse["tflops_on_executed_pairs"] / peak
+                sparse["note"] = ("achieved/frac count the ALGORITHMIC (dense) work of the reference's iteration; "
+                                  "the launch executes only tile_pairs_executed of it (the rest is proved below "
+                                  "1e-9 of the smallest row sum), so frac can exceed 1; the matrix-core "
+                                  "utilisation of the launch is mfma_frac_on_executed_pairs")
                 roof["block_sparse"] = sparse
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
