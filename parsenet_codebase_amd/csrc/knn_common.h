@@ -27,10 +27,12 @@ __device__ static inline u64 readlane_u64(u64 v, int l) {
   return ((u64)hi << 32) | lo;
 }
 
-// Wave-cooperative: among the n keys at lp[0..n) keep the k largest (compacted to
-// lp[0..k), unordered) and return the k-th largest key.  Requires k <= n <= KNN_CAP.
-__device__ static u64 knn_wave_select(u64* __restrict__ lp, int n, int k,
-                                      uint32_t* __restrict__ hist) {
+// Wave-cooperative: among the n keys at lp[0..n) find the k-th largest key and keep (compacted
+// to lp[0..m), unordered) every key whose VALUE is at least value(k-th) - slack; slack = 0 keeps
+// exactly the k largest.  Returns the k-th largest key, m through ``kept``.
+// Requires k <= n <= KNN_CAP.
+__device__ static u64 knn_wave_select_ge(u64* __restrict__ lp, int n, int k, uint32_t* __restrict__ hist,
+                                         float slack, int* __restrict__ kept) {
   const int lane = threadIdx.x & 63;
   u64 key[KNN_EPL];
 #pragma unroll
@@ -95,7 +97,9 @@ __device__ static u64 knn_wave_select(u64* __restrict__ lp, int n, int k,
     }
   }
   if (!done) kth = prefix;
-  // compact: exactly k keys are >= kth because keys are pairwise distinct
+  // compact: exactly k keys are >= kth because keys are pairwise distinct (slack = 0)
+  const u64 kth_found = kth;
+  if (slack > 0.f) kth = (u64)pn_f2ord(pn_ord2f((uint32_t)(kth >> 32)) - slack) << 32;
   int mine = 0;
 #pragma unroll
   for (int e = 0; e < KNN_EPL; ++e) mine += (e * 64 + lane < n && key[e] >= kth) ? 1 : 0;
@@ -106,12 +110,18 @@ __device__ static u64 knn_wave_select(u64* __restrict__ lp, int n, int k,
     if (lane >= o) inc += t;
   }
   int off = inc - mine;
+  *kept = __builtin_amdgcn_readlane(inc, 63);
 #pragma unroll
   for (int e = 0; e < KNN_EPL; ++e)
     if (e * 64 + lane < n && key[e] >= kth) lp[off++] = key[e];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  return kth;
+  return kth_found;
+}
+
+__device__ static inline u64 knn_wave_select(u64* __restrict__ lp, int n, int k, uint32_t* __restrict__ hist) {
+  int kept;
+  return knn_wave_select_ge(lp, n, k, hist, 0.f, &kept);
 }
 
 // Bitonic sort (descending) of 128 keys held as 2 per lane: element e = r*64 + lane.

@@ -430,26 +430,46 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
   const size_t ql = (size_t)b * Nqp + qp;
   const int qo = knn_perm(perm_q, qp);
   u64* keys = s_keys[wave];
-  // all 2S fill counts with one coalesced load, then register-only bookkeeping
-  const int nsub = 2 * S;  // <= 32
+  // gather: lane s copies sub-list s — all 2 S sub-lists at once (a loop over the lists with one
+  // dependent load each cost ~1 us per list and query)
+  const int nsub = 2 * S;  // <= 64
   const int myc = lane < nsub ? counts[ql * nsub + lane] : 0;
-  int n = 0;
-  bool bad = false;
-  for (int s = 0; s < nsub; ++s) {
-    const int c = __builtin_amdgcn_readlane(myc, s);
-    if (c > subcap || n + c > KNN_CAP) {
-      bad = true;
-      break;
+  int inc = myc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  const int n = __builtin_amdgcn_readlane(inc, 63);
+  const bool bad = __ballot(myc > subcap) != 0 || n > KNN_CAP;
+  if (!bad) {
+    int cmax = myc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+    const int off = inc - myc;
+    if (cmax <= nsub) {   // short lists (kNN graphs): a lane per list
+      const u64* lp = lists + (ql * nsub + lane) * (size_t)subcap;
+      for (int e = 0; e < cmax; ++e) {
+        if (e < myc) {
+          const u64 key = lp[e];
+          // candidate index: permuted -> original, so that ties order by the caller's indices
+          const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
+          keys[off + e] = (key & 0xffffffff00000000ull) |
+                          (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
+        }
+      }
+    } else {              // long lists (K-th value of hundreds): the lanes over the entries of a list
+      for (int s = 0; s < nsub; ++s) {
+        const int c = __builtin_amdgcn_readlane(myc, s), o = __builtin_amdgcn_readlane(off, s);
+        const u64* lp = lists + (ql * nsub + s) * (size_t)subcap;
+        for (int e = lane; e < c; e += 64) {
+          const u64 key = lp[e];
+          const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
+          keys[o + e] = (key & 0xffffffff00000000ull) |
+                        (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
+        }
+      }
     }
-    const u64* lp = lists + (ql * nsub + s) * (size_t)subcap;
-    for (int e = lane; e < c; e += 64) {
-      const u64 key = lp[e];
-      // candidate index: permuted -> original, so that ties order by the caller's indices
-      const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
-      keys[n + e] = (key & 0xffffffff00000000ull) |
-                    (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
-    }
-    n += c;
   }
   if (bad || n < k) {
     // overflow (or NaNs): the caller recomputes flagged queries
@@ -531,26 +551,36 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
 }
 
 struct KnnWs {
-  size_t xq, xxq, xc, xxc, tilemax, tau, cnt, flags, lists, v1, img, xxmax, total;
+  size_t xq, xxq, xc, xxc, tilemax, tau, cnt, flags, lists, v1, img, xxmax, xpm, xxo, total;
 };
 
 #include "knn_x3.h"
 
-// pass 1 on the bf16 matrix cores (knn_x3.h): the feature metric with 64 or 128 padded channels and
-// enough candidates for the split to pay for its image pass.  PN_KNN_X3=0 disables it, =2 also
-// enables it for the dot-product selections (off by default: on a converged embedding thousands
-// of dot products sit within 1e-6 of the K-th one, the rigorous margin of ~1e-4 then multiplies the
-// survivors, the lists overflow and the flagged rows take the slow path — measured 42 -> 55 ms per
-// cfg5 step; the exact fp32 pass has no such cliff).
+// Passes on the bf16 matrix cores (knn_x3.h).  PN_KNN_X3 (read at every call) =
+//   0: none;
+//   1: the threshold pass of the feature metric (64 or 128 padded channels, enough candidates for
+//      the split to pay for its image pass); the deciding pass stays exact fp32;
+//   2 (default): also the collecting pass of the kNN graph of one set; the final sort works on
+//      approximate keys and re-evaluates exactly what they cannot decide (pn_knn_final_x3_kernel).
+//      The error of an approximate value scales with |q||c|, the gaps between near neighbours do
+//      not: in the 64-channel layers of a network in training hundreds of candidates can fall
+//      inside the 2-eps window of the k-th one.  Such queries are NOT flagged (the first version
+//      did, and spent 4.7 ms per cfg4 step in the scan kernel: 9.6 -> 15.3 ms per step): all
+//      candidates of the window get their exact value and the exact selection decides; the lists
+//      have the full capacity of 1024 keys per query.  cfg4: 9.55 -> 9.27 ms per step;
+//   3: also the threshold pass of the dot-product selections (a cliff of the same kind on a
+//      converged embedding: thousands of dot products within 1e-6 of the K-th one overflow the
+//      lists, measured 42 -> 55 ms per cfg5 step; off).
+static int knn_x3_level() {
+  const char* e = getenv("PN_KNN_X3");
+  return e ? atoi(e) : 2;
+}
 static bool knn_x3_pass1(const KnnPlan& p, int mode) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("PN_KNN_X3");
-    on = e ? atoi(e) : 1;
-  }
-  return on && p.fast && (mode == 0 || (mode == 2 && on >= 2)) && (p.ksteps == 32 || p.ksteps == 64) &&
+  const int on = knn_x3_level();
+  return on && p.fast && (mode == 0 || (mode == 2 && on >= 3)) && (p.ksteps == 32 || p.ksteps == 64) &&
          p.Ncp >= 2048;
 }
+#define KX_MAX_SLICES 16   // of the collecting pass (2 x 16 sub-lists per query)
 
 static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool self, bool v1) {
   KnnWs w;
@@ -571,14 +601,19 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
   }
   w.tilemax = take((size_t)B * p.Nqp * (p.Ncp / 16) * 4);
   w.tau = take((size_t)B * p.Nqp * 4);
-  w.cnt = take((size_t)B * p.Nqp * 2 * p.S * 4);
+  const bool x3ws = knn_x3_pass1(p, 0);
+  w.cnt = take((size_t)B * p.Nqp * 2 * (x3ws && p.S < KX_MAX_SLICES ? KX_MAX_SLICES : p.S) * 4);
   w.flags = take((size_t)B * Nq * 4);
-  w.lists = take((size_t)B * p.Nqp * 2 * p.S * p.subcap * 8);
+  // (the collecting pass on approximate values gathers a wider window: full capacity per query)
+  w.lists = take((size_t)B * p.Nqp * (x3ws && self ? KNN_CAP : 2 * p.S * p.subcap) * 8);
   w.v1 = take(v1 ? pn_knn_v1_workspace(B, C, Nq, k, true) : 0);
   // candidate images + per-item largest squared norm of the bf16 x 3 pass 1 (both metrics qualify)
-  const bool x3 = knn_x3_pass1(p, 0);
+  const bool x3 = x3ws;
   w.img = take(x3 ? (size_t)B * p.Ncp * p.Cp * 6 : 0);
   w.xxmax = take(x3 ? (size_t)B * 4 : 0);
+  // point-major fp32 rows + norms in original order: the exact repairs of the approximate final sort
+  w.xpm = take(x3 && self ? (size_t)B * p.Ncp * p.Cp * 4 : 0);
+  w.xxo = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
   w.total = o;
   return w;
 }
@@ -628,16 +663,23 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   }
   PN_CHECK_LAUNCH();
   const bool x3p1 = !argmax && knn_x3_pass1(p, mode);
+  // collecting pass + approximate final: kNN graph of one set, indices only
+  const bool x3p2 = x3p1 && knn_x3_level() >= 2 && self && mode == 0 && out_idx && !out_val;
   u32x4* img = (u32x4*)(base + w.img);
   unsigned* xxmax = (unsigned*)(base + w.xxmax);
+  float* xpm = x3p2 ? (float*)(base + w.xpm) : nullptr;
+  float* xxo = x3p2 ? (float*)(base + w.xxo) : nullptr;
+  const float x3A = 4.0f * (float)(p.Cp + 2) * 0x1p-24f;
   if (x3p1) {
     PN_PROF("knn_x3_image", stream);
     PN_CHECK_HIP(hipMemsetAsync(xxmax, 0, (size_t)B * 4, stream));
     dim3 ig(p.Ncp / 32, B);
     if (p.ksteps == 32)
-      hipLaunchKernelGGL(pn_knn_x3_image_kernel<8>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax);
+      hipLaunchKernelGGL(pn_knn_x3_image_kernel<8>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
+                         xpm, xxo);
     else
-      hipLaunchKernelGGL(pn_knn_x3_image_kernel<16>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax);
+      hipLaunchKernelGGL(pn_knn_x3_image_kernel<16>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
+                         xpm, xxo);
     PN_CHECK_LAUNCH();
   }
   dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
@@ -661,30 +703,59 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
       dim3 g1(pn_cdiv(ntiles, tps1), pn_cdiv(p.Nqp, qpw), B);
       {
         PN_PROF(mode == 2 ? "sel_x3_pass1_dot" : (p.ksteps == 32 ? "knn_x3_pass1_c64" : "knn_x3_pass1_wide"), stream);
+#define KX_GO(NCH, QS, MD, TPS_, KIND_, GRID, TPSL, SUBCAP)                                                        \
+  hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, MD, TPS_, KIND_>), GRID, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, \
+                     img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP)
         if (mode == 0 && p.ksteps == 32)
-          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<8, 2, 0, 2>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
-                             xxc, Nc, p.Ncp, tps1, tilemax);
+          KX_GO(8, 2, 0, 2, 0, g1, tps1, 0);
         else if (mode == 0)
-          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<16, 1, 0, 1>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
-                             xxc, Nc, p.Ncp, tps1, tilemax);
+          KX_GO(16, 1, 0, 1, 0, g1, tps1, 0);
         else if (p.ksteps == 32)
-          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<8, 2, 2, 2>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
-                             xxc, Nc, p.Ncp, tps1, tilemax);
+          KX_GO(8, 2, 2, 2, 0, g1, tps1, 0);
         else
-          hipLaunchKernelGGL((pn_knn_x3_pass1_kernel<16, 1, 2, 1>), g1, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, img,
-                             xxc, Nc, p.Ncp, tps1, tilemax);
+          KX_GO(16, 1, 2, 1, 0, g1, tps1, 0);
       }
       PN_CHECK_LAUNCH();
       {
         PN_PROF("knn_tau", stream);
         hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream,
                            tilemax, Nq, p.Nqp, p.Ncp / 16, k, tau);
-        const float A = 16.0f * (float)(p.Cp + 4) * 0x1p-24f;
         hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq, Nq,
-                           p.Nqp, xxmax, A, mode);
+                           p.Nqp, xxmax, x3A, mode, x3p2 ? 2.0f : 1.0f);
       }
       PN_CHECK_LAUNCH();
-      continue;
+      if (!x3p2) continue;
+      // ---- collecting pass on the approximate values + final sort with exact repairs ----
+      int tps2 = tps1;
+      if (pn_cdiv(ntiles, tps2) > KX_MAX_SLICES) {
+        tps2 = (int)pn_align_up(pn_cdiv(ntiles, KX_MAX_SLICES), 2);
+      }
+      const int S2 = pn_cdiv(ntiles, tps2);
+      int subcap2;
+      subcap2 = KNN_CAP / (2 * S2);   // the whole capacity of a query (knn_mfma_ws)
+      dim3 g2(S2, pn_cdiv(p.Nqp, qpw), B);
+      {
+        PN_PROF(p.ksteps == 32 ? "knn_x3_pass2_c64" : "knn_x3_pass2_wide", stream);
+        if (p.ksteps == 32)
+          KX_GO(8, 2, 0, 2, 1, g2, tps2, subcap2);
+        else
+          KX_GO(16, 1, 0, 1, 1, g2, tps2, subcap2);
+      }
+      PN_CHECK_LAUNCH();
+      {
+        PN_PROF("knn_final", stream);
+        if (p.ksteps == 32)
+          hipLaunchKernelGGL(pn_knn_final_x3_kernel<64>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                             p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
+                             x3A, out_idx, flags);
+        else
+          hipLaunchKernelGGL(pn_knn_final_x3_kernel<128>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                             p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
+                             x3A, out_idx, flags);
+      }
+      PN_CHECK_LAUNCH();
+      return PN_OK;
+#undef KX_GO
     }
     static const char* const pass_names[2][5] = {
         {"knn_mfma_pass1_c4", "knn_mfma_pass1_c64", "knn_mfma_pass1_wide", "knn_mfma_pass1_pn",

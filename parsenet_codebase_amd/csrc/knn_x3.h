@@ -8,11 +8,13 @@
 // it may use any arithmetic with a known error bound:
 //   operands split error-free into three bf16 pieces (24 mantissa bits), 6 of the 9 piece products
 //   on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense instead of 157 TFLOP/s fp32), fp32 accumulate:
-//     |dot~ - dot| <= A |q| |c|,  A = 16 (C + 4) 2^-24
-//   (per fp32 accumulation at most one ulp of a partial sum <= 1.02 |q||c|, 6 C / 16 MFMAs of 16
-//   terms; the three dropped products are below 3 * 2^-24 |q||c|; the same bound again covers the
-//   rounding of the exact chain itself, and the factor 16 instead of 7 leaves room for truncating
-//   instead of rounding accumulators).
+//     |dot~ - dot| <= A |q| |c|,  A = 4 (C + 2) 2^-24
+//   The h.h products have their own accumulator: C accumulated terms, each adding at most one ulp
+//   (2 * 2^-24 if the matrix core truncates instead of rounding) of a partial sum <= |q||c|:
+//   2 C 2^-24.  The five smaller products (<= 2^-8 |q||c| in total per channel) share a second
+//   accumulator: 5 C terms at 2^-7 of that: 0.08 C 2^-24; the three dropped products: 2^-23; the
+//   final sum of the two accumulators: 2^-24; and the exact chain of the oracle deviates from the
+//   real dot product by at most C 2^-24 itself.  Together (3.1 C + 3) 2^-24 < A.
 //   MODE 0 (v = 2 dot - |c|^2 - |q|^2, norms shared with the exact pass):
 //     eps_q = 2 A sqrt(|q|^2 max|c|^2) + 2^-21 (|q|^2 + max|c|^2)
 //   MODE 2 (v = dot):  eps_q = A sqrt(|q|^2 max|c|^2)
@@ -29,20 +31,30 @@ __host__ __device__ static inline int knx_slot(int r, int q) {
 
 // xp (B, 8 NCH, Np) channel-first permuted fp32 (pn_knn_prep_kernel) -> images
 // [B][Np/32][piece 3][32 rows x NCH chunks] and the largest squared norm of each batch item
+// xpm (B,N,8 NCH) / xxo (B,N), when given: the same rows as plain fp32, point-major, at their
+// ORIGINAL index (the exact re-evaluation of near-ties in pn_knn_final_x3_kernel reads them)
 template <int NCH>
 __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __restrict__ xp,
                                                               const float* __restrict__ xxp, int Np,
                                                               u32x4* __restrict__ img,
-                                                              unsigned* __restrict__ xxmax) {
+                                                              unsigned* __restrict__ xxmax, int N, KnnPerm perm,
+                                                              float* __restrict__ xpm, float* __restrict__ xxo) {
   constexpr int CP = 8 * NCH;
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
   const int r = tid & 31;
   const float* src = xp + (size_t)b * CP * Np + (size_t)t * 32 + r;
   u32x4* dst = img + ((size_t)b * (Np / 32) + t) * (3 * 32 * NCH);
+  const int jp = t * 32 + r;
+  const int jo = (xpm && jp < N) ? knn_perm(perm, jp) : -1;
   for (int q = tid >> 5; q < NCH; q += 8) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = src[(size_t)(8 * q + e) * Np];
+    if (jo >= 0) {
+      float4* d = reinterpret_cast<float4*>(xpm + ((size_t)b * N + jo) * CP + 8 * q);
+      d[0] = make_float4(v[0], v[1], v[2], v[3]);
+      d[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
     u32x4 vh, vm, vl;
     X3_SPLIT_TO(v[0], v[1], vh, vm, vl, 0);
     X3_SPLIT_TO(v[2], v[3], vh, vm, vl, 1);
@@ -54,7 +66,9 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
     dst[2 * 32 * NCH + slot] = vl;
   }
   if (tid < 64) {
-    const float m = pn_wave_max(tid < 32 ? xxp[(size_t)b * Np + (size_t)t * 32 + tid] : 0.f);
+    const float nrm = tid < 32 ? xxp[(size_t)b * Np + (size_t)t * 32 + tid] : 0.f;
+    if (tid < 32 && jo >= 0) xxo[(size_t)b * N + jo] = nrm;
+    const float m = pn_wave_max(nrm);
     if (tid == 0) atomicMax(&xxmax[b], __float_as_uint(fmaxf(m, 0.f)));   // norms are >= 0: uint order
   }
 }
@@ -68,11 +82,15 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
 #define KX_NW 4
 // (the 128-channel dot-product variant needs 165 registers: three workgroups per CU)
 #define KX_WPE(NCH, MODE) ((NCH) == 16 && (MODE) == 2 ? 3 : 2)
-template <int NCH, int QSETS, int MODE, int TPS>
-__global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_WPE(NCH, MODE), KX_WPE(NCH, MODE)))) void pn_knn_x3_pass1_kernel(
+// KIND 0: tile maxima; KIND 1: collect the candidates with v~ >= tau (tau already lowered by the
+// margin) into the sub-list of (query, slice, half) like pass 2 of the fp32 engine — the keys carry
+// APPROXIMATE values, pn_knn_final_x3_kernel repairs what the approximation cannot decide.
+template <int NCH, int QSETS, int MODE, int TPS, int KIND>
+__global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_WPE(NCH, MODE), KX_WPE(NCH, MODE)))) void pn_knn_x3_pass_kernel(
     const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
     const u32x4* __restrict__ PC, const float* __restrict__ xxc_, int Nc, int Ncp, int tiles_per_slice,
-    float* __restrict__ tilemax) {
+    float* __restrict__ tilemax, const float* __restrict__ tau, u64* __restrict__ lists,
+    int* __restrict__ counts, int subcap) {
   constexpr int CP = 8 * NCH, KS = NCH / 2, PIECE = 32 * NCH, IMG = 3 * PIECE;
   constexpr int CHUNKS = TPS * IMG / 64;   // 1 KiB DMA chunks per step
   static_assert(CHUNKS % KX_NW == 0 && (TPS == 1 || TPS == 2 || TPS == 4), "chunks are dealt evenly to the waves");
@@ -131,6 +149,17 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     }
     xxq[u] = MODE == 0 ? xxq_[(size_t)b * Nqp + qcl] : 0.f;
   }
+  float tq[QSETS];
+  int mycnt[QSETS];
+  u64* sub[QSETS];
+#pragma unroll
+  for (int u = 0; u < QSETS; ++u) {
+    const int q = q0 + 32 * u + col;
+    const int qcl = q < Nqp ? q : Nqp - 1;
+    tq[u] = (KIND == 1 && q < Nq) ? tau[(size_t)b * Nqp + qcl] : __builtin_inff();
+    mycnt[u] = 0;
+    sub[u] = KIND == 1 ? lists + ((((size_t)b * Nqp + qcl) * gridDim.x + slice) * 2 + h) * (size_t)subcap : nullptr;
+  }
 
   for (int m0 = t_begin; m0 < t_end; m0 += TPS) {
     __syncthreads();  // the batch of step m0 landed; every wave is done with the previous one
@@ -147,17 +176,16 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
       for (int i = 0; i < TPS; ++i) {
         const int j0 = (m0 + i) * 32;
         if (m0 + i < t_end) {
-          // one query set: two accumulators (small / large piece products) keep dependent MFMAs
-          // apart; two sets already interleave
-          constexpr int NACS = QSETS == 1 ? 1 : 0;
-          f32x16 acc[QSETS], acs_[NACS + 1];
-#define KX_ACS(U) (QSETS == 1 ? acs_[0] : acc[U])
+          // two accumulators per query set: the h.h products alone (their C accumulations carry
+          // the rounding that matters: the error bound below counts C ulps, not 6 C) and the five
+          // products that are 2^-8 and smaller
+          f32x16 acc[QSETS], acs[QSETS];
 #pragma unroll
           for (int u = 0; u < QSETS; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               acc[u][r] = 0.f;
-              if (QSETS == 1) acs_[0][r] = 0.f;
+              acs[u][r] = 0.f;
             }
           const u32x4* __restrict__ lp = ldsP[cur] + i * IMG;
 #pragma unroll
@@ -166,15 +194,16 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
             const bf16x8 ah = x3_as_bf16(lp[slot]);
             const bf16x8 am = x3_as_bf16(lp[PIECE + slot]);
             const bf16x8 al = x3_as_bf16(lp[2 * PIECE + slot]);
-#pragma unroll
-            for (int u = 0; u < QSETS; ++u) {
-              KX_ACS(u) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[u][s], KX_ACS(u), 0, 0, 0);
-              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qh[u][s], acc[u], 0, 0, 0);
-              KX_ACS(u) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[u][s], KX_ACS(u), 0, 0, 0);
-              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qm[u][s], acc[u], 0, 0, 0);
-              KX_ACS(u) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qm[u][s], KX_ACS(u), 0, 0, 0);
-              acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[u][s], acc[u], 0, 0, 0);
-            }
+            // (products outermost: consecutive MFMAs go to different accumulators)
+#define KX_P(ACC, A_, B_) _Pragma("unroll") for (int u = 0; u < QSETS; ++u) \
+    ACC[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[u][s], ACC[u], 0, 0, 0)
+            KX_P(acs, al, qh);
+            KX_P(acc, ah, qh);
+            KX_P(acs, ah, ql);
+            KX_P(acs, am, qm);
+            KX_P(acs, am, qh);
+            KX_P(acs, ah, qm);
+#undef KX_P
           }
           // D[candidate = (r&3) + 8(r>>2) + 4h][query = col]
           float xxj[16];
@@ -194,22 +223,26 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
             float tm = -__builtin_inff();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = QSETS == 1 ? acc[u][r] + acs_[0][r] : acc[u][r];
+              float v = acc[u][r] + acs[u][r];
               if (MODE == 0) v = __builtin_fmaf(2.0f, v, -xxj[r]) - xxq[u];
-              if (tail && j0 + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) v = -__builtin_inff();
+              const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+              if (tail && j0 + row >= Nc) v = -__builtin_inff();
               tm = fmaxf(tm, v);
+              if (KIND == 1 && v >= tq[u] && v > -__builtin_inff()) {
+                if (mycnt[u] < subcap) sub[u][mycnt[u]] = knn_key(v, j0 + row);
+                ++mycnt[u];
+              }
             }
 #pragma unroll
             for (int i2 = 0; i2 < TPS; ++i2)
               if (i2 == i) tmv[u][i2] = tm;   // static register indices
           }
-#undef KX_ACS
         }
       }
       // tilemax[q][2 mt + h]: the two halves of a tile sit in lanes col and col + 32; pair them
       // so that a lane writes whole tiles (16 bytes: two tiles, or 8 bytes: one)
 #pragma unroll
-      for (int u = 0; u < QSETS; ++u) {
+      for (int u = 0; u < (KIND == 0 ? QSETS : 0); ++u) {
         const int q = q0 + 32 * u + col;
         float* row = tilemax + ((size_t)b * Nqp + (q < Nqp ? q : 0)) * T16 + 2 * m0;
         float o[TPS];
@@ -233,18 +266,198 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     cur ^= 1;
   }
 #undef KX_STAGE
+  if (KIND == 1 && wave_on) {
+#pragma unroll
+    for (int u = 0; u < QSETS; ++u) {
+      const int q = q0 + 32 * u + col;
+      if (q < Nqp) counts[(((size_t)b * Nqp + q) * gridDim.x + slice) * 2 + h] = mycnt[u];
+    }
+  }
 }
 
 // tau <- tau - eps_q (see the header of this file); one thread per query
+__device__ static inline float knx_eps(float nq, float nc, float A, int mode) {
+  const float cross = sqrtf(nq * nc) * 1.000001f;
+  return (mode == 0 ? 2.0f * A * cross + 0x1p-21f * (nq + nc) : A * cross) * 1.0001f;
+}
+
+// ``times``: 1 when the collecting pass is exact, 2 when it runs on approximate values as well
 __global__ void pn_knn_x3_margin_kernel(float* __restrict__ tau, const float* __restrict__ xxq, int Nq, int Nqp,
-                                        const unsigned* __restrict__ xxmax, float A, int mode) {
+                                        const unsigned* __restrict__ xxmax, float A, int mode, float times) {
   const int b = blockIdx.y;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Nq) return;
   const float nq = xxq[(size_t)b * Nqp + q], nc = __uint_as_float(xxmax[b]);
-  const float cross = sqrtf(nq * nc) * 1.000001f;
-  const float eps = mode == 0 ? 2.0f * A * cross + 0x1p-21f * (nq + nc) : A * cross;
+  const float eps = times * knx_eps(nq, nc, A, mode);
   const float t = tau[(size_t)b * Nqp + q];
   // round down: one more ulp of |t| + eps on top
-  tau[(size_t)b * Nqp + q] = t - eps * 1.0001f - 0x1p-22f * fabsf(t);
+  tau[(size_t)b * Nqp + q] = t - eps - 0x1p-22f * fabsf(t);
+}
+
+// K4 for approximate keys (feature metric, kNN graph of one set): one wave per query.
+//   1. gather the sub-lists (keys: approximate value, candidate index -> ORIGINAL index);
+//   2. keep every candidate whose approximate value is within 2 eps of the k-th largest one — a
+//      candidate below that cannot be among the exact k best (k candidates have v~ >= v~_k, hence
+//      exact v >= v~_k - eps, while its own exact value is < v~_k - 2 eps + eps); more than 128 of
+//      them: all are re-evaluated exactly and the exact selection + sort decide;
+//   3. sort by approximate key.  Two neighbours of the sorted sequence further apart than 2 eps
+//      are certainly in the right order; a RUN of neighbours closer than that is not decided.
+//      Every member of a run that starts at a position < k is re-evaluated EXACTLY (the oracle's
+//      arithmetic: fp32 fma chain over the channels in order, then fma(2, dot, -|c|^2) - |q|^2,
+//      from the point-major fp32 rows) and the sequence is sorted again on the mixed keys — an
+//      exact value stays on its side of every undisputed neighbour (it moves by <= eps, the gap is
+//      > 2 eps), inside a run all values are exact and ties fall to the smaller index as always;
+//   4. the first k entries are the result.
+// On random features about 3 % of the entries are disputed; on tied data (duplicates) whole runs.
+template <int CP>
+__global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
+    const u64* __restrict__ lists, const int* __restrict__ counts, int Nq, int Nqp, int k, int S, int subcap,
+    KnnPerm perm_q, KnnPerm perm_c, const float* __restrict__ xpm, const float* __restrict__ xxo,
+    const unsigned* __restrict__ xxmax, int N, float A, int64_t* __restrict__ out_idx, int* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
+  __shared__ u64 s_keys[4][KNN_CAP];
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qp = blockIdx.x * 4 + wave;
+  if (qp >= Nq) return;
+  const size_t ql = (size_t)b * Nqp + qp;
+  const int qo = knn_perm(perm_q, qp);
+  u64* keys = s_keys[wave];
+  // gather: lane s copies sub-list s (all sub-lists at once: a loop over the 2 S lists, one
+  // dependent load each, cost 20 us per query)
+  const int nsub = 2 * S;   // <= 64
+  const int myc = lane < nsub ? counts[ql * nsub + lane] : 0;
+  int inc = myc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  const int n = __builtin_amdgcn_readlane(inc, 63);
+  bool bad = __ballot(myc > subcap) != 0 || n > KNN_CAP;
+  if (!bad) {
+    int cmax = myc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+    const u64* lp = lists + (ql * nsub + lane) * (size_t)subcap;
+    const int off = inc - myc;
+    for (int e = 0; e < cmax; ++e) {
+      if (e < myc) {
+        const u64 key = lp[e];
+        const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
+        keys[off + e] = (key & 0xffffffff00000000ull) | (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
+      }
+    }
+  }
+  const float nq = xxo[(size_t)b * N + qo];
+  const float eps2 = 2.0f * knx_eps(nq, __uint_as_float(xxmax[b]), A, 0);
+  int m = n;
+  if (!bad && n >= k) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (n > 128) knn_wave_select_ge(keys, n, k, s_hist[wave], eps2, &m);
+  }
+  if (bad || n < k) {
+    if (lane == 0) flags[(size_t)b * Nq + qo] = 1;   // overflow (or NaNs): the caller recomputes flagged queries
+    return;
+  }
+  const float* xq = xpm + ((size_t)b * N + qo) * CP;
+  if (m > 128) {
+    // More candidates inside the window than the sort holds (neighbours much closer to each other
+    // than the error of an approximate distance): every one of them gets its exact value, then
+    // the exact selection and sort of the fp32 engine.
+    for (int e = lane; e < m; e += 64) {
+      const int j = (int)knn_key_index(keys[e]);
+      const float4* xc = reinterpret_cast<const float4*>(xpm + ((size_t)b * N + j) * CP);
+      float4 cv[CP / 4];
+#pragma unroll
+      for (int c4 = 0; c4 < CP / 4; ++c4) cv[c4] = xc[c4];
+      float dot = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < CP / 4; ++c4) {
+        const float4 qv = *reinterpret_cast<const float4*>(xq + 4 * c4);
+        dot = __builtin_fmaf(qv.x, cv[c4].x, dot);
+        dot = __builtin_fmaf(qv.y, cv[c4].y, dot);
+        dot = __builtin_fmaf(qv.z, cv[c4].z, dot);
+        dot = __builtin_fmaf(qv.w, cv[c4].w, dot);
+      }
+      const float t = __builtin_fmaf(2.0f, dot, -xxo[(size_t)b * N + j]);
+      keys[e] = knn_key(__fsub_rn(t, nq), j);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    knn_wave_select(keys, m, k, s_hist[wave]);
+    u64 e0 = lane < k ? keys[lane] : 0ull;
+    u64 e1 = lane + 64 < k ? keys[lane + 64] : 0ull;
+    knn_wave_sort128(e0, e1);
+    int64_t* oo = out_idx + ((size_t)b * Nq + qo) * k;
+    if (lane < k) oo[lane] = knn_key_index(e0);
+    if (lane + 64 < k) oo[lane + 64] = knn_key_index(e1);
+    return;
+  }
+  u64 k0 = lane < m ? keys[lane] : 0ull;
+  u64 k1 = lane + 64 < m ? keys[lane + 64] : 0ull;
+  knn_wave_sort128(k0, k1);
+  // link p: entries p and p + 1 (both real) are closer than 2 eps; positions p = lane (k0), lane + 64 (k1)
+  const float v0 = pn_ord2f((uint32_t)(k0 >> 32)), v1 = pn_ord2f((uint32_t)(k1 >> 32));
+  const float v0n = __shfl_down(v0, 1, 64), v1n = __shfl_down(v1, 1, 64);
+  const float v1first = __shfl(v1, 0, 64);
+  const float nxt0 = lane == 63 ? v1first : v0n;
+  const bool link0 = lane + 1 < m && !(v0 - nxt0 > eps2);
+  const bool link1 = lane + 65 < m && lane < 63 && !(v1 - v1n > eps2);
+  const u64 L0 = __ballot(link0), L1 = __ballot(link1);
+  // a run matters if it starts before position k: member p is disputed iff it is linked to a
+  // neighbour and the first position of its run is < k, i.e. all links between k - 1 and p - 1 are
+  // set or p < k.  run_end = last position reachable from k - 1 through set links.
+  int run_end = k - 1;
+  {
+    // bit p of (L1:L0) = link p; find the first clear bit at a position >= k - 1
+    int p = k - 1;
+    if (p < 64) {
+      const u64 clr = ~L0 >> p;
+      if (clr) p += __builtin_ctzll(clr);
+      else {
+        const u64 clr1 = ~L1;
+        p = 64 + (clr1 ? __builtin_ctzll(clr1) : 63);
+      }
+    } else {
+      const u64 clr1 = ~L1 >> (p - 64);
+      p = clr1 ? p + __builtin_ctzll(clr1) : 127;
+    }
+    run_end = p;
+  }
+  const bool prev0 = lane > 0 ? ((L0 >> (lane - 1)) & 1ull) != 0 : false;
+  const bool prev1 = lane > 0 ? ((L1 >> (lane - 1)) & 1ull) != 0 : ((L0 >> 63) & 1ull) != 0;
+  const bool need0 = lane < m && (link0 || prev0) && lane <= run_end;
+  const bool need1 = lane + 64 < m && (link1 || prev1) && lane + 64 <= run_end;
+  if (__ballot(need0 || need1)) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const bool need = half ? need1 : need0;
+      u64& key = half ? k1 : k0;
+      if (need) {
+        const int j = (int)knn_key_index(key);
+        const float4* xc = reinterpret_cast<const float4*>(xpm + ((size_t)b * N + j) * CP);
+        float4 cv[CP / 4];   // the whole row first: one memory latency, not CP / 4
+#pragma unroll
+        for (int c4 = 0; c4 < CP / 4; ++c4) cv[c4] = xc[c4];
+        float dot = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CP / 4; ++c4) {
+          const float4 qv = *reinterpret_cast<const float4*>(xq + 4 * c4);
+          dot = __builtin_fmaf(qv.x, cv[c4].x, dot);
+          dot = __builtin_fmaf(qv.y, cv[c4].y, dot);
+          dot = __builtin_fmaf(qv.z, cv[c4].z, dot);
+          dot = __builtin_fmaf(qv.w, cv[c4].w, dot);
+        }
+        const float t = __builtin_fmaf(2.0f, dot, -xxo[(size_t)b * N + j]);
+        const float v = __fsub_rn(t, nq);
+        key = knn_key(v, j);
+      }
+    }
+    knn_wave_sort128(k0, k1);
+  }
+  int64_t* o = out_idx + ((size_t)b * Nq + qo) * k;
+  if (lane < k) o[lane] = knn_key_index(k0);
+  if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
 }

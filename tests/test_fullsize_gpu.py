@@ -10,12 +10,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_cfg4_all_three_knn_layers_every_row(gpu):
+@pytest.mark.parametrize("x3_level", ["0", "1", "2"])
+def test_cfg4_all_three_knn_layers_every_row(gpu, x3_level, monkeypatch):
     """PrimitivesEmbeddingDGCNGn mode 5 on the cfg4 batch: the graphs the network builds (layer 1:
     points+normals metric on (4,6,10000); layers 2, 3: feature metric on the 64-channel
-    activations) equal the C oracle's on the same tensors, all 40 000 rows x 80 columns each."""
+    activations) equal the C oracle's on the same tensors, all 40 000 rows x 80 columns each —
+    with the fp32 engine alone (PN_KNN_X3=0), with the threshold pass on the bf16 matrix cores
+    (1, the default) and with the collecting pass and the repairing final sort on them too (2)."""
     from oracle import cbind
     from parsenet_codebase_amd import graph, workloads
+    monkeypatch.setenv("PN_KNN_X3", x3_level)
     torch.cuda.set_device(gpu)
     step = workloads.ParsenetSegStep(gpu, batch=4, num_points=10000)
     seen = []

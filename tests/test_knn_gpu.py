@@ -97,3 +97,24 @@ def test_order_independence_of_the_mfma_path(gpu):
     got = _gpu_knn(xs, 40, gpu)
     want = cbind.knn(xs, 40, 0)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("x3_level", ["1", "2"])
+def test_near_ties_under_the_bf16_passes(gpu, x3_level, monkeypatch):
+    """The passes on the bf16 matrix cores only pre-select: rows with large norms whose neighbours
+    differ by far less than the error of an approximate distance (tight clumps far from the
+    origin, exact duplicates among them) must still come out bit-exact — by the exact repairs of
+    the final sort, or through the flag and the exact scan kernel when a window holds too many."""
+    from oracle import cbind
+    monkeypatch.setenv("PN_KNN_X3", x3_level)
+    rng = np.random.RandomState(7)
+    B, C, N, k = 2, 64, 4200, 80
+    centres = rng.uniform(-3, 3, (B, C, 12)).astype(np.float32)
+    lab = rng.randint(0, 12, (B, N))
+    x = np.take_along_axis(centres, lab[:, None, :].repeat(C, 1), 2)
+    x = x + rng.normal(0, 1.0, (B, C, N)).astype(np.float32) * np.where(lab[:, None, :] < 6, 1e-4, 0.3).astype(np.float32)
+    x[:, :, 100:140] = x[:, :, 60:100]                     # exact duplicates
+    x = np.ascontiguousarray(x.astype(np.float32))
+    got = _gpu_knn(x, k, gpu)
+    want = cbind.knn(x, k, 0)
+    assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
