@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3q
+O=$R/gpurun_out/evidence_r02
 mkdir -p $O
 export PARSENET_PRETRAIN_CACHE=/tmp/pretrain_cache.pt
 # (the first run writes the pre-training cache)
