@@ -150,6 +150,14 @@ int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y, const flo
                                       void* img_q, void* img_gu, float* opart_q, float* opart_x,
                                       float* gq, float* gx, const void* plan, void* stream);
 
+/* K-th largest dot product of every query row with both distance passes in bf16 x 3 arithmetic
+ * (error-free operand split on the bf16 matrix cores, fp32 accumulate: fp32-grade values, not the
+ * fma chain of pn_dot_select_f32) — the bandwidth statistic of src/mean_shift.py:125-137 under the
+ * default mean-shift arithmetic.  q (B,Nq,C), c (B,Nc,C) point-major; workspace and flags as
+ * pn_dot_select_f32 with want_value; PN_ERR_UNSUPPORTED outside C <= 128, Nc >= 2048. */
+int pn_dot_kth_x3_f32(const float* q, int Nq, const float* c, int Nc, int B, int C, int k, float* out_val,
+                      int* flags, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K-th largest dot product between unit vectors, fp16 x 2 matrix-core passes -----------
  * The bandwidth statistic of src/mean_shift.py:125-137 only needs the VALUE of the K-th nearest
  * neighbour (to 1e-5 after averaging): same engine as pn_dot_select_f32(out_val), with both

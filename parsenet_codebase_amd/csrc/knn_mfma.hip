@@ -636,10 +636,13 @@ static void knn_mfma_launch_pass(int kind, dim3 grid, hipStream_t stream, const 
 }
 
 // The shared engine.  self: queries use the candidates' permuted copy (kNN graph of one set).
+// approx_value: the K-th VALUE in the arithmetic of the bf16 x 3 passes (both passes on the matrix
+// cores, no margins: thresholds and collected values come from the same arithmetic) — for
+// statistics that need fp32-grade, not chain-exact, dot products (pn_dot_kth_x3_f32).
 static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, const float* q,
                       int q_pm, int Nq, const float* c, int c_pm, int Nc, int B, int C, int k,
                       int64_t* out_idx, float* out_val, int* flags_out, char* base,
-                      hipStream_t stream) {
+                      hipStream_t stream, bool approx_value = false) {
   float* xc = (float*)(base + w.xc);
   float* xxc = (float*)(base + w.xxc);
   float* xq = (float*)(base + w.xq);
@@ -662,7 +665,11 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     if (!self) knn_prep_launch(stream, q, B, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
   }
   PN_CHECK_LAUNCH();
-  const bool x3p1 = !argmax && knn_x3_pass1(p, mode);
+  const bool x3p1 = !argmax && (approx_value ? knn_x3_pass1(p, 0) : knn_x3_pass1(p, mode));
+  if (approx_value && !(x3p1 && mode == 2 && out_val && !out_idx)) {
+    pn_set_error("select_run: the bf16 x 3 value selection needs C <= 128 and Nc >= 2048");
+    return PN_ERR_UNSUPPORTED;
+  }
   // collecting pass + approximate final: kNN graph of one set, indices only
   const bool x3p2 = x3p1 && knn_x3_level() >= 2 && self && mode == 0 && out_idx && !out_val;
   u32x4* img = (u32x4*)(base + w.img);
@@ -720,10 +727,36 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         PN_PROF("knn_tau", stream);
         hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream,
                            tilemax, Nq, p.Nqp, p.Ncp / 16, k, tau);
-        hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq, Nq,
-                           p.Nqp, xxmax, x3A, mode, x3p2 ? 2.0f : 1.0f);
+        if (!approx_value)
+          hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq, Nq,
+                             p.Nqp, xxmax, x3A, mode, x3p2 ? 2.0f : 1.0f);
       }
       PN_CHECK_LAUNCH();
+      if (approx_value) {
+        // collecting pass in the same arithmetic, then the standard final selection of the value
+        int tpsv = tps1;
+        if (pn_cdiv(ntiles, tpsv) > KX_MAX_SLICES) tpsv = (int)pn_align_up(pn_cdiv(ntiles, KX_MAX_SLICES), 2);
+        const int Sv = pn_cdiv(ntiles, tpsv);
+        int subcapv = (int)pn_align_up(3 * k / (2 * Sv) + 16, 8);
+        if (2 * Sv * subcapv > 2 * p.S * p.subcap) subcapv = (2 * p.S * p.subcap) / (2 * Sv);
+        if (2 * Sv * subcapv > KNN_CAP) subcapv = KNN_CAP / (2 * Sv);
+        dim3 gv(Sv, pn_cdiv(p.Nqp, qpw), B);
+        {
+          PN_PROF("sel_x3_pass2_dot", stream);
+          if (p.ksteps == 32)
+            KX_GO(8, 2, 2, 2, 1, gv, tpsv, subcapv);
+          else
+            KX_GO(16, 1, 2, 1, 1, gv, tpsv, subcapv);
+        }
+        PN_CHECK_LAUNCH();
+        {
+          PN_PROF("knn_final", stream);
+          hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                             p.Nqp, k, Sv, subcapv, perm_q, perm_c, out_idx, out_val, flags);
+        }
+        PN_CHECK_LAUNCH();
+        return PN_OK;
+      }
       if (!x3p2) continue;
       // ---- collecting pass on the approximate values + final sort with exact repairs ----
       int tps2 = tps1;
@@ -815,6 +848,29 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
+}
+
+// K-th largest dot product of every query row, both distance passes in bf16 x 3 arithmetic
+// (error-free operand split, six piece products, fp32 accumulate: fp32-grade values, |error| ~1e-7
+// on unit vectors, not the fma chain of pn_dot_select_f32): for statistics such as the mean-shift
+// bandwidth (src/mean_shift.py:125-137: the K-th nearest-neighbour distance averaged over the
+// points).  Same workspace and flags as pn_dot_select_f32(out_val); PN_ERR_UNSUPPORTED outside the
+// path of the split passes (C <= 128, Nc >= 2048, the fast-path shape rules).
+extern "C" int pn_dot_kth_x3_f32(const float* q, int Nq, const float* c, int Nc, int B, int C, int k,
+                                 float* out_val, int* flags, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  PN_CHECK_ARG(q && c && out_val && flags, "pn_dot_kth_x3_f32: null pointer");
+  PN_CHECK_ARG(B > 0 && C > 0 && Nq > 0 && Nc > 0 && k >= 1 && k <= Nc,
+               "pn_dot_kth_x3_f32: bad sizes (B=%d C=%d Nq=%d Nc=%d k=%d)", B, C, Nq, Nc, k);
+  const KnnPlan p = knn_mfma_plan(2, B, C, Nq, Nc, k, true);
+  if (!p.fast || !knn_x3_pass1(p, 0)) {
+    pn_set_error("pn_dot_kth_x3_f32: shape outside the bf16 x 3 path (C <= 128, Nc >= 2048, Nc/16 >= 2k)");
+    return PN_ERR_UNSUPPORTED;
+  }
+  const KnnWs w = knn_mfma_ws(p, B, C, Nq, k, false, false);
+  PN_CHECK_ARG(workspace && workspace_bytes >= w.total, "pn_dot_kth_x3_f32: workspace too small");
+  return select_run(p, w, 2, false, q, 1, Nq, c, 1, Nc, B, C, k, nullptr, out_val, flags, (char*)workspace,
+                    (hipStream_t)stream, true);
 }
 
 // ---- K-th largest dot product between unit vectors on the fp16 matrix cores ----------------

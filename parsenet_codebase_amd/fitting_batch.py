@@ -69,6 +69,10 @@ def bandwidth_batch(X, quantile, num_samples=10000):
     res = None
     if MSM.ARITH == "fp16x2" and D == 128:
         res = K.dot_kth_unit(Xc, K.meanshift_h2_split(Xc), N, Kq)
+    elif MSM.ARITH == "bf16x3":
+        # the statistic in the arithmetic of the iterations it parametrises: fp32-grade dot products
+        # from the error-free bf16 x 3 split (1e-7 on unit rows; the bandwidth is a mean over N of them)
+        res = K.dot_kth_x3(Xc, Xc, Kq)
     if res is None:
         res = K.dot_select(Xc, Xc, Kq, want_value=True)
     if res is None:

@@ -243,6 +243,31 @@ def dot_select(q, c, k, want_value):
     return out, flags
 
 
+def dot_kth_x3(q, c, k):
+    """K-th largest dot product between the rows of q (B,Nq,C) and c (B,Nc,C) with both distance
+    passes in bf16 x 3 arithmetic (fp32-grade, |error| ~1e-7 on unit rows): (values (B,Nq), flags),
+    or None outside that path (C <= 128, Nc >= 2048, the fast-path shape rules)."""
+    require_cuda(q, c)
+    q, c = _f32c(q, "q"), _f32c(c, "c")
+    B, Nq, C = q.shape
+    Nc = c.shape[1]
+    lib = _lib.load()
+    wsz = lib.pn_dot_select_workspace(B, C, Nq, Nc, int(k), 1)
+    if wsz == 0:
+        return None
+    dev = q.device
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    flags = torch.empty((B, Nq), dtype=torch.int32, device=dev)
+    out = torch.empty((B, Nq), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn_dot_kth_x3_f32(ptr(q), Nq, ptr(c), Nc, B, C, int(k), ptr(out), ptr(flags), ptr(ws), wsz,
+                                   current_stream(dev))
+    if rc == -4:      # PN_ERR_UNSUPPORTED: shape outside the split passes
+        return None
+    check(rc, "pn_dot_kth_x3_f32")
+    return out, flags
+
+
 def dot_kth_unit(q, c_image, Nc, k):
     """K-th largest dot product between the unit rows of q (B,Nq,128) and the candidates whose
     fp16 x 2 tile images are ``c_image`` (meanshift_h2_split): (values (B,Nq), flags) with the

@@ -270,6 +270,10 @@ class MeanShift:
                 # the statistic is a mean of K-th distances compared at 1e-5: both distance passes
                 # on the fp16 matrix cores (values to ~1e-7), same selection engine
                 res = K.dot_kth_unit(Xc, K.meanshift_h2_split(Xc), Xc.shape[1], Kq)
+            elif ARITH == "bf16x3":
+                # ... or on the bf16 cores with the error-free 3-way split: fp32-grade values, the
+                # arithmetic of the iterations this bandwidth parametrises
+                res = K.dot_kth_x3(Xc, Xc, Kq)
             if res is None:
                 res = K.dot_select(Xc, Xc, Kq, want_value=True)
         if res is not None:
