@@ -118,3 +118,32 @@ def test_near_ties_under_the_bf16_passes(gpu, x3_level, monkeypatch):
     got = _gpu_knn(x, k, gpu)
     want = cbind.knn(x, k, 0)
     assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
+
+
+@pytest.mark.parametrize("B,C,N,k", [(1, 128, 3000, 80), (3, 40, 2100, 128), (2, 100, 2049, 20), (1, 64, 4097, 1)])
+@pytest.mark.parametrize("x3_level", ["1", "2"])
+def test_bf16_passes_on_odd_shapes(gpu, B, C, N, k, x3_level, monkeypatch):
+    """The split passes (64- and 128-channel images, padded channels, tails of the last tile,
+    k = 1 and k = 128) against the C oracle."""
+    from oracle import cbind
+    monkeypatch.setenv("PN_KNN_X3", x3_level)
+    rng = np.random.RandomState(C + N)
+    x = (rng.uniform(-1, 1, (B, C, N)) * rng.uniform(0.2, 3.0, (B, C, 1))).astype(np.float32)
+    got = _gpu_knn(x, k, gpu)
+    want = cbind.knn(x, k, 0)
+    assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
+
+
+@pytest.mark.parametrize("C,N,K", [(128, 5000, 125), (64, 2500, 60), (20, 3000, 75)])
+def test_kth_dot_in_bf16x3_arithmetic(gpu, C, N, K):
+    """pn_dot_kth_x3_f32 (the bandwidth statistic under the default arithmetic): the K-th largest
+    dot product of every row to fp32 grade against the exact selection engine."""
+    from parsenet_codebase_amd import kernels as K_
+    g = torch.Generator().manual_seed(C * N)
+    x = torch.nn.functional.normalize(torch.randn(2, N, C, generator=g), dim=2).to(gpu)
+    exact, f0 = K_.dot_select(x, x, K, want_value=True)
+    got = K_.dot_kth_x3(x, x, K)
+    assert got is not None
+    val, f1 = got
+    assert int(f0.sum()) == 0 and int(f1.sum()) == 0
+    assert float((val - exact).abs().max()) < 1e-6
