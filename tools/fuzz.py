@@ -27,6 +27,24 @@ while time.time() - t0 < budget:
     got = K.knn(torch.from_numpy(x).to(dev), k, "feature").cpu().numpy()
     assert np.array_equal(got, cbind.knn(x, k, 0)), ("knn", B, C, N, k)
     n["knn"] += 1
+    # the same on shapes that take the bf16 passes (>= 2048 candidates, <= 128 channels), at a
+    # random PN_KNN_X3 level, with clumped rows (neighbours closer than the error of an
+    # approximate distance) and duplicates
+    os.environ["PN_KNN_X3"] = str(int(rng.randint(0, 3)))
+    B, C, N = int(rng.randint(1, 3)), int(rng.choice([17, 40, 64, 100, 128])), int(rng.randint(2048, 5200))
+    k = int(rng.choice([1, 10, 20, 80, 128]))
+    x = (rng.randn(B, C, N) * rng.choice([0.1, 1.0, 5.0])).astype(np.float32)
+    if rng.rand() < 0.5:
+        cen = (rng.randn(B, C, 9) * 3).astype(np.float32)
+        lab = rng.randint(0, 9, (B, N))
+        x = np.take_along_axis(cen, lab[:, None, :].repeat(C, 1), 2) + x * np.float32(rng.choice([1e-5, 1e-3, 0.1]))
+    if rng.rand() < 0.3:
+        x[:, :, rng.randint(0, N, N // 5)] = x[:, :, :1]
+    x = np.ascontiguousarray(x.astype(np.float32))
+    got = K.knn(torch.from_numpy(x).to(dev), k, "feature").cpu().numpy()
+    assert np.array_equal(got, cbind.knn(x, k, 0)), ("knn_x3", os.environ["PN_KNN_X3"], B, C, N, k)
+    os.environ.pop("PN_KNN_X3")
+    n["knn_x3"] = n.get("knn_x3", 0) + 1
     # points + normals metric
     N = int(rng.randint(60, 1200))
     k = int(rng.randint(1, min(N, 81)))
