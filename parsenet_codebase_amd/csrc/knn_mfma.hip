@@ -712,7 +712,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         PN_PROF(mode == 2 ? "sel_x3_pass1_dot" : (p.ksteps == 32 ? "knn_x3_pass1_c64" : "knn_x3_pass1_wide"), stream);
 #define KX_GO(NCH, QS, MD, TPS_, KIND_, GRID, TPSL, SUBCAP)                                                        \
   hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, MD, TPS_, KIND_>), GRID, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, \
-                     img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP)
+                     img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP, (const unsigned*)xxmax)
         if (mode == 0 && p.ksteps == 32)
           KX_GO(8, 2, 0, 2, 0, g1, tps1, 0);
         else if (mode == 0)

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
     const u32x4* __restrict__ PC, const float* __restrict__ xxc_, int Nc, int Ncp, int tiles_per_slice,
     float* __restrict__ tilemax, const float* __restrict__ tau, u64* __restrict__ lists,
-    int* __restrict__ counts, int subcap) {
+    int* __restrict__ counts, int subcap, const unsigned* __restrict__ xxmax) {
   constexpr int CP = 8 * NCH, KS = NCH / 2, PIECE = 32 * NCH, IMG = 3 * PIECE;
   constexpr int CHUNKS = TPS * IMG / 64;   // 1 KiB DMA chunks per step
   static_assert(CHUNKS % KX_NW == 0 && (TPS == 1 || TPS == 2 || TPS == 4), "chunks are dealt evenly to the waves");
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     }
     xxq[u] = MODE == 0 ? xxq_[(size_t)b * Nqp + qcl] : 0.f;
   }
-  float tq[QSETS];
+  float tq[QSETS], hq[QSETS];
+  const float xxc_max = (KIND == 1 && MODE == 0) ? __uint_as_float(xxmax[b]) : 0.f;
   int mycnt[QSETS];
   u64* sub[QSETS];
 #pragma unroll
@@ -157,6 +158,8 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     const int q = q0 + 32 * u + col;
     const int qcl = q < Nqp ? q : Nqp - 1;
     tq[u] = (KIND == 1 && q < Nq) ? tau[(size_t)b * Nqp + qcl] : __builtin_inff();
+    // threshold of the dot-product form of the test, with 2^-20 of the magnitudes involved as slack
+    hq[u] = 0.5f * (tq[u] + xxq[u]) - 0x1p-20f * (fabsf(tq[u]) + xxq[u] + xxc_max);
     mycnt[u] = 0;
     sub[u] = KIND == 1 ? lists + ((((size_t)b * Nqp + qcl) * gridDim.x + slice) * 2 + h) * (size_t)subcap : nullptr;
   }
@@ -221,16 +224,31 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
 #pragma unroll
           for (int u = 0; u < QSETS; ++u) {
             float tm = -__builtin_inff();
+            if (KIND == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float v = acc[u][r] + acs[u][r];
-              if (MODE == 0) v = __builtin_fmaf(2.0f, v, -xxj[r]) - xxq[u];
-              const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-              if (tail && j0 + row >= Nc) v = -__builtin_inff();
-              tm = fmaxf(tm, v);
-              if (KIND == 1 && v >= tq[u] && v > -__builtin_inff()) {
-                if (mycnt[u] < subcap) sub[u][mycnt[u]] = knn_key(v, j0 + row);
-                ++mycnt[u];
+              for (int r = 0; r < 16; ++r) {
+                float v = acc[u][r] + acs[u][r];
+                if (MODE == 0) v = __builtin_fmaf(2.0f, v, -xxj[r]) - xxq[u];
+                if (tail && j0 + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) v = -__builtin_inff();
+                tm = fmaxf(tm, v);
+              }
+            } else {
+              // 16 tests per lane and tile, ~90 hits per query in all: the test runs in dot-product
+              // space (v >= tau  <=>  dot >= (tau + |q|^2 + |c|^2) / 2, lowered by a slack that
+              // covers the roundings of both forms) and costs an add, an fma and a compare; the
+              // value, the exact test and the bounds of the tail only for the hits
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float d = acc[u][r] + acs[u][r];
+                const float thr = MODE == 0 ? __builtin_fmaf(0.5f, xxj[r], hq[u]) : tq[u];
+                if (d >= thr) {
+                  const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                  const float v = MODE == 0 ? __builtin_fmaf(2.0f, d, -xxj[r]) - xxq[u] : d;
+                  if (v >= tq[u] && j0 + row < Nc) {
+                    if (mycnt[u] < subcap) sub[u][mycnt[u]] = knn_key(v, j0 + row);
+                    ++mycnt[u];
+                  }
+                }
               }
             }
 #pragma unroll
