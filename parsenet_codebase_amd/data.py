@@ -179,7 +179,22 @@ def canonical_frames(points):
 
 def _canonicalise_batch(points, normals, anisotropic):
     """Rotate every shape into its canonical frame and divide by its extent (largest extent unless
-    anisotropic): one batched product for the whole batch."""
+    anisotropic): one batched product for the whole batch.  Device tensors stay on the device: only
+    the 3 x 3 second-moment matrices travel to the host, whose LAPACK ``geev`` decides the axis and
+    its sign like the reference's."""
+    if not isinstance(points, np.ndarray):
+        import torch
+        G = torch.bmm(points.transpose(1, 2), points).cpu().numpy()          # X^T X per shape (pca_numpy)
+        R = []
+        for g in G:
+            S, U = np.linalg.eig(g)
+            R.append(rotation_matrix_a_to_b(U[:, np.argmin(S)], np.array([1.0, 0.0, 0.0])))
+        A = Affine(points.shape[0]).then(M=np.transpose(np.stack(R), (0, 2, 1)))
+        pts = A.apply(points)
+        nrm = A.apply(normals) if normals is not None else None
+        ext = pts.max(1)[0] - pts.min(1)[0]
+        pts = pts / (ext[:, None, :] + EPS) if anisotropic else pts / (ext.max(1)[0][:, None, None] + EPS)
+        return pts, nrm
     R = canonical_frames(points)
     A = Affine(points.shape[0]).then(M=np.transpose(R, (0, 2, 1)))
     pts = A.apply(points)
@@ -226,8 +241,15 @@ class Dataset:
     generators yielding [points, labels, normals | None, primitives | None]."""
 
     def __init__(self, batch_size, train=None, val=None, test=None, train_size=None, val_size=None,
-                 test_size=None, normals=False, primitives=False):
+                 test_size=None, normals=False, primitives=False, device=None):
+        """``device``: keep points and normals of every split resident on that device and run the
+        per-batch work there (gather of the shuffled batch, augmentation map, normal noise,
+        canonical frame and extent): the generators then yield device tensors for points and
+        normals.  The random draws stay on numpy's generator in the reference's order, so both
+        modes see the same maps; labels and primitive types stay host arrays (the losses and the
+        matching read them there)."""
         self.batch_size, self.normals, self.primitives = batch_size, normals, primitives
+        self.device = device
         self.augment_routines = [rotate_perturbation_point_cloud, jitter_point_cloud, shift_point_cloud,
                                  random_scale_point_cloud, rotate_point_cloud]   # dataset_segments.py:88-94
         self.splits = {}
@@ -241,6 +263,11 @@ class Dataset:
                 split["normals"] = a["normals"].astype(np.float32)
             if primitives:
                 split["prim"] = a["prim"]
+            if device is not None:
+                import torch
+                split["points"] = torch.from_numpy(split["points"]).to(device)
+                if normals:
+                    split["normals"] = torch.from_numpy(split["normals"]).to(device)
             self.splits[name] = split
 
     def _iterate(self, name, randomize, augment, anisotropic, align_canonical, if_normal_noise):
@@ -250,18 +277,38 @@ class Dataset:
             order = np.arange(size)
             if randomize:
                 np.random.shuffle(order)
-            pts_all, lab_all = s["points"][order], s["labels"][order]
-            nrm_all = s["normals"][order] if self.normals else None
+            on_device = self.device is not None
+            if on_device:
+                import torch
+
+                def h2d(a, device):     # pinned + stream-ordered for a GPU (see _lib.h2d)
+                    if torch.device(device).type == "cuda":
+                        from ._lib import h2d as pinned
+                        return pinned(a, device)
+                    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+                order_dev = h2d(order, self.device)
+                pts_all = nrm_all = None
+            else:
+                pts_all = s["points"][order]
+                nrm_all = s["normals"][order] if self.normals else None
+            lab_all = s["labels"][order]
             prm_all = s["prim"][order] if self.primitives else None
             for i in range(size // bs):
                 sl = slice(i * bs, (i + 1) * bs)
-                points = pts_all[sl]
-                normals = nrm_all[sl] if self.normals else None
+                if on_device:       # the batch is gathered on the device
+                    points = s["points"][order_dev[sl]]
+                    normals = s["normals"][order_dev[sl]] if self.normals else None
+                else:
+                    points = pts_all[sl]
+                    normals = nrm_all[sl] if self.normals else None
                 if augment:
                     points = self.augment_routines[np.random.choice(np.arange(5))](points)
                 if if_normal_noise and self.normals:
-                    noise = normals * np.clip(np.random.randn(1, points.shape[1], 1) * 0.01, a_min=-0.01, a_max=0.01)
-                    points = points + noise.astype(np.float32)
+                    amp = np.clip(np.random.randn(1, points.shape[1], 1) * 0.01, a_min=-0.01, a_max=0.01)
+                    if on_device:
+                        points = points + normals * h2d(amp.astype(np.float32), self.device)
+                    else:
+                        points = points + (normals * amp).astype(np.float32)
                 if align_canonical:
                     points, normals = _canonicalise_batch(points, normals, anisotropic)
                 yield [points, lab_all[sl], normals, prm_all[sl] if self.primitives else None]

@@ -137,9 +137,11 @@ class SyntheticSegments:
         return self._gen(self.num_train, self.num_val)
 
 
-def open_dataset(cfg, batch_size, rank=0, if_normal_noise=True, augment=False):
+def open_dataset(cfg, batch_size, rank=0, if_normal_noise=True, augment=False, device=None):
     """The trainers' data source: the reference's schema from ``cfg.dataset`` (data.Dataset, with
-    the generator flags of the reference's scripts) or synthetic shapes."""
+    the generator flags of the reference's scripts) or synthetic shapes.  ``device`` (or
+    PARSENET_DATA_ON_DEVICE=1 with the trainer's device): keep the splits resident on the GPU and
+    do gather / augmentation / canonicalisation there (data.Dataset(device=...))."""
     if not cfg.dataset:
         return SyntheticSegments(batch_size, cfg.num_train, cfg.num_val, cfg.num_points,
                                  first_shape=rank * (cfg.num_train + cfg.num_val))
@@ -152,7 +154,7 @@ def open_dataset(cfg, batch_size, rank=0, if_normal_noise=True, augment=False):
                 return f
         raise FileNotFoundError("no %s_data.npz / .h5 under %s" % (split, cfg.dataset))
     ds = Dataset(batch_size, train=path("train"), val=path("val"), train_size=cfg.num_train, val_size=cfg.num_val,
-                 normals=True, primitives=True)
+                 normals=True, primitives=True, device=device)
 
     class _Wrapped:     # bind the flags the reference's scripts pass (train_parsenet.py:104-107)
         def get_train(self, **_):
@@ -209,13 +211,26 @@ def _subsample(arrays, keep, total):
     sel = np.arange(total)
     np.random.shuffle(sel)
     sel = sel[0:keep]
-    return [a[:, sel] for a in arrays]
+    sel_dev = {}
+
+    def take(a):
+        if isinstance(a, torch.Tensor):      # device-resident batches (data.Dataset(device=...))
+            if a.device not in sel_dev:
+                from ._lib import h2d
+                sel_dev[a.device] = h2d(sel, a.device) if a.device.type == "cuda" else torch.from_numpy(sel)
+            return a[:, sel_dev[a.device]]
+        return a[:, sel]
+    return [take(a) for a in arrays]
 
 
 def _to_device(points, normals, primitives, device):
     from ._lib import h2d
-    return (h2d(points.astype(np.float32, copy=False), device), h2d(normals.astype(np.float32, copy=False), device),
-            torch.from_numpy(primitives.astype(np.int64)).to(device))
+
+    def up(a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=device, dtype=torch.float32)
+        return h2d(a.astype(np.float32, copy=False), device)
+    return up(points), up(normals), torch.from_numpy(primitives.astype(np.int64)).to(device)
 
 
 def _seg_forward(model, points, normals, labels, if_normals):
@@ -246,7 +261,8 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000, mod
     bucket = dp.FlatGradBucket(model.parameters())
     optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
     scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=4, min_lr=1e-4)
-    data = data or open_dataset(cfg, cfg.batch_size, rank, augment=True)
+    data = data or open_dataset(cfg, cfg.batch_size, rank, augment=True,
+                                device=device if os.environ.get("PARSENET_DATA_ON_DEVICE") == "1" else None)
     train_it, val_it = data.get_train(), data.get_val()
     name = model_name(cfg, "seg")
     prev_test_loss, history = 1e4, []
@@ -328,7 +344,8 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
     bucket = dp.FlatGradBucket(model.parameters())
     optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
     scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=10, min_lr=1e-4)
-    data = data or open_dataset(cfg, 1, rank, augment=False)
+    data = data or open_dataset(cfg, 1, rank, augment=False,
+                                device=device if os.environ.get("PARSENET_DATA_ON_DEVICE") == "1" else None)
     train_it, val_it = data.get_train(), data.get_val()
     name = model_name(cfg, "seg")
     prev_test_loss, history = 1e4, []

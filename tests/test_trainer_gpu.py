@@ -55,11 +55,14 @@ def test_train_splinenet(gpu, tmp_path, closed):
     assert any(h["saved"] for h in hist)
 
 
-def test_train_parsenet_from_files(gpu, tmp_path):
+@pytest.mark.parametrize("on_device", ["0", "1"])
+def test_train_parsenet_from_files(gpu, tmp_path, on_device, monkeypatch):
     """TrainConfig.dataset: the reference's four-array schema read from {train,val}_data.npz through
-    data.Dataset (shuffle, augmentation, normal noise, canonicalisation as the reference's script)."""
+    data.Dataset (shuffle, augmentation, normal noise, canonicalisation as the reference's script),
+    on the host or — PARSENET_DATA_ON_DEVICE=1 — with the splits resident on the GPU."""
     from parsenet_codebase_amd import synthetic
     from parsenet_codebase_amd.trainer import TrainConfig, train_parsenet
+    monkeypatch.setenv("PARSENET_DATA_ON_DEVICE", on_device)
     for split, first in (("train", 0), ("val", 50)):
         pts, nrm, lab, prim = synthetic.make_batch(first, 4, 1500)
         np.savez(tmp_path / (split + "_data.npz"), points=pts * 3.0 + 1.0, normals=nrm, labels=lab, prim=prim)
@@ -87,3 +90,9 @@ def test_train_splinenet_from_files(gpu, tmp_path):
     torch.manual_seed(3)
     hist = train_splinenet(cfg, closed=False, device=gpu, log=lambda s: None)
     assert len(hist) == 1 and np.isfinite(hist[0]["train_cd"]) and np.isfinite(hist[0]["test_cd"])
+
+
+def test_device_resident_dataset(gpu):
+    """SURVEY 8(f) rank 4, "augmentation on GPU": the data layer with the split resident in HBM."""
+    from tests.test_host_logic import _device_dataset_equals_host
+    _device_dataset_equals_host(gpu, 3e-5)
