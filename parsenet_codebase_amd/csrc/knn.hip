@@ -28,8 +28,9 @@
 
 // xx[b,j] = fma chain over channels [c0, c1) of x[b,c,j]^2
 __global__ void pn_knn_sqnorm_kernel(const float* __restrict__ x, int C, int N, int c0, int c1,
-                                     float* __restrict__ xx) {
+                                     float* __restrict__ xx, const int* __restrict__ gate_any) {
   const int b = blockIdx.y;
+  if (gate_any && !gate_any[b]) return;   // gated fallback: no query of this item was flagged
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
   const float* xb = x + (size_t)b * C * N;
@@ -247,7 +248,7 @@ size_t pn_knn_v1_workspace(int B, int C, int N, int k, bool gated) {
 
 int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
                      void* workspace, size_t workspace_bytes, hipStream_t stream,
-                     const int* gate) {
+                     const int* gate, const int* gate_any) {
   PN_CHECK_ARG(x && idx, "pn_knn: null pointer");
   PN_CHECK_ARG(B > 0 && C > 0 && N > 0, "pn_knn: empty input (B=%d C=%d N=%d)", B, C, N);
   PN_CHECK_ARG(k >= 1 && k <= KNN_MAXK, "pn_knn: k=%d unsupported (1..%d)", k, KNN_MAXK);
@@ -266,7 +267,7 @@ int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64
   u64* lists = (u64*)w;
   dim3 g1(pn_cdiv(N, 256), B);
   hipLaunchKernelGGL(pn_knn_sqnorm_kernel, g1, dim3(256), 0, stream, x, C, N, 0,
-                     mode == 0 ? C : 3, xx);
+                     mode == 0 ? C : 3, xx, gate ? gate_any : nullptr);
   PN_CHECK_LAUNCH();
   dim3 grid(pn_cdiv(N, 256), S, B);
   PN_PROF(gate ? "knn_scan_gated" : "knn_scan", stream);

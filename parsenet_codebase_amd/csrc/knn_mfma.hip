@@ -45,7 +45,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 size_t pn_knn_v1_workspace(int B, int C, int N, int k, bool gated);
 int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
                      void* workspace, size_t workspace_bytes, hipStream_t stream,
-                     const int* gate);
+                     const int* gate, const int* gate_any = nullptr);
 
 struct KnnPerm {
   uint32_t a, c, mask;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void pn_knn_tau_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void pn_knn_final_kernel(
     const u64* __restrict__ lists, const int* __restrict__ counts, int Nq, int Nqp, int k, int S,
     int subcap, KnnPerm perm_q, KnnPerm perm_c, int64_t* __restrict__ out_idx,
-    float* __restrict__ out_val, int* __restrict__ flags) {
+    float* __restrict__ out_val, int* __restrict__ flags, int* __restrict__ anyflag) {
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
   __shared__ u64 s_keys[4][KNN_CAP];
   const int b = blockIdx.y;
@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
   if (bad || n < k) {
     // overflow (or NaNs): the caller recomputes flagged queries
     if (lane == 0) flags[(size_t)b * Nq + qo] = 1;
+    if (lane == 0 && anyflag) anyflag[b] = 1;   // lets the fallback of an item without flags exit at once
     if (out_val && lane == 0) out_val[(size_t)b * Nq + qo] = __builtin_nanf("");
     return;
   }
@@ -603,7 +604,7 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
   w.tau = take((size_t)B * p.Nqp * 4);
   const bool x3ws = knn_x3_pass1(p, 0);
   w.cnt = take((size_t)B * p.Nqp * 2 * (x3ws && p.S < KX_MAX_SLICES ? KX_MAX_SLICES : p.S) * 4);
-  w.flags = take((size_t)B * Nq * 4);
+  w.flags = take(((size_t)B * Nq + B) * 4);   // + one summary word per item
   // (the collecting pass on approximate values gathers a wider window: full capacity per query)
   w.lists = take((size_t)B * p.Nqp * (x3ws && self ? KNN_CAP : 2 * p.S * p.subcap) * 8);
   w.v1 = take(v1 ? pn_knn_v1_workspace(B, C, Nq, k, true) : 0);
@@ -651,6 +652,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   float* tau = (float*)(base + w.tau);
   int* cnt = (int*)(base + w.cnt);
   int* flags = flags_out ? flags_out : (int*)(base + w.flags);
+  int* anyflag = flags_out ? nullptr : flags + (size_t)B * Nq;   // one summary word per item behind the own flags
   u64* lists = (u64*)(base + w.lists);
   // k = 1 without the value (nearest-centre membership): one pass, no threshold, no lists, and
   // no candidate permutation (it only serves the tile-maxima threshold)
@@ -658,7 +660,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   const KnnPerm perm_c = knn_make_perm(Nc, argmax);
   const KnnPerm perm_q = self ? perm_c : knn_make_perm(Nq, true);
 
-  PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)B * Nq * 4, stream));
+  PN_CHECK_HIP(hipMemsetAsync(flags, 0, ((size_t)B * Nq + (flags_out ? 0 : B)) * 4, stream));
   {
     PN_PROF("knn_prep", stream);
     knn_prep_launch(stream, c, B, C, Nc, p.Cp, p.Ncp, mode, c_pm, perm_c, xc, xxc);
@@ -752,7 +754,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         {
           PN_PROF("knn_final", stream);
           hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
-                             p.Nqp, k, Sv, subcapv, perm_q, perm_c, out_idx, out_val, flags);
+                             p.Nqp, k, Sv, subcapv, perm_q, perm_c, out_idx, out_val, flags, (int*)nullptr);
         }
         PN_CHECK_LAUNCH();
         return PN_OK;
@@ -780,11 +782,11 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         if (p.ksteps == 32)
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<64>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags);
+                             x3A, out_idx, flags, anyflag);
         else
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<128>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags);
+                             x3A, out_idx, flags, anyflag);
       }
       PN_CHECK_LAUNCH();
       return PN_OK;
@@ -844,7 +846,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   {
     PN_PROF("knn_final", stream);
     hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists,
-                       cnt, Nq, p.Nqp, k, p.S, p.subcap, perm_q, perm_c, out_idx, out_val, flags);
+                       cnt, Nq, p.Nqp, k, p.S, p.subcap, perm_q, perm_c, out_idx, out_val, flags, anyflag);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -1041,7 +1043,7 @@ extern "C" int pn_dot_kth_unit_h2_f32(const float* q, int Nq, const void* img_c,
   {
     PN_PROF("knn_final", stream);
     hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
-                       p.Nqp, k, S, subcap, ident_q, ident_c, (int64_t*)nullptr, out_val, flags);
+                       p.Nqp, k, S, subcap, ident_q, ident_c, (int64_t*)nullptr, out_val, flags, (int*)nullptr);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -1081,7 +1083,8 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
   // flagged query exit immediately
   PN_PROF("knn_fallback_gate", stream);
   return pn_knn_v1_launch(mode, x, B, C, N, k, idx, base + w.v1,
-                          pn_knn_v1_workspace(B, C, N, k, true), stream, (int*)(base + w.flags));
+                          pn_knn_v1_workspace(B, C, N, k, true), stream, (int*)(base + w.flags),
+                          (int*)(base + w.flags) + (size_t)B * N);
 }
 
 extern "C" int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx,

@@ -331,7 +331,8 @@ template <int CP>
 __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
     const u64* __restrict__ lists, const int* __restrict__ counts, int Nq, int Nqp, int k, int S, int subcap,
     KnnPerm perm_q, KnnPerm perm_c, const float* __restrict__ xpm, const float* __restrict__ xxo,
-    const unsigned* __restrict__ xxmax, int N, float A, int64_t* __restrict__ out_idx, int* __restrict__ flags) {
+    const unsigned* __restrict__ xxmax, int N, float A, int64_t* __restrict__ out_idx, int* __restrict__ flags,
+    int* __restrict__ anyflag) {
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
   __shared__ u64 s_keys[4][KNN_CAP];
   const int b = blockIdx.y;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
   }
   if (bad || n < k) {
     if (lane == 0) flags[(size_t)b * Nq + qo] = 1;   // overflow (or NaNs): the caller recomputes flagged queries
+    if (lane == 0 && anyflag) anyflag[b] = 1;
     return;
   }
   const float* xq = xpm + ((size_t)b * N + qo) * CP;
