@@ -280,7 +280,8 @@ def test_kth_dot_on_the_fp16_cores(gpu, N, k):
         assert np.abs(got - truth).max() < 6e-7
 
 
-@pytest.mark.parametrize("N,clusters,noise", [(10000, 9, 0.25), (4100, 5, 0.2), (3000, 1, 0.0)])
+@pytest.mark.parametrize("N,clusters,noise", [(10000, 9, 0.25), (4100, 5, 0.2), (3000, 1, 0.0), (20000, 12, 0.2),
+                                              (2049, 3, 0.15)])
 def test_block_sparse_iterations_equal_the_dense_ones(gpu, N, clusters, noise):
     """The block-sparse plan (locality order + rigorous tile bounds, csrc/meanshift_x3.h) skips only
     what stays below 1e-9 of the smallest row sum: iterates and gradients equal the dense launches
