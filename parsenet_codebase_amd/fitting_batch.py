@@ -526,12 +526,25 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         loss_b = torch.zeros(B, dtype=torch.float32, device=dev)
         tail_dev = ptype.reshape(-1).double()
     pf = params_p.float() if S_p else None
+    tail_host = tail_event = None
+    if defer_metrics and tail_dev.is_cuda:
+        # stream-ordered copy into pinned memory right here, behind the forward kernels: finish()
+        # then waits for THIS copy only — not for the backward pass and the optimizer step the
+        # caller queues in between — and the host is free to queue the next step meanwhile
+        tail_host = torch.empty(tail_dev.shape, dtype=tail_dev.dtype).pin_memory()
+        tail_host.copy_(tail_dev, non_blocking=True)
+        tail_event = torch.cuda.Event()
+        tail_event.record()
 
     def finish():
         """Host side of the results: ONE download (distances, fit status, voted types), then the
         per-shape records.  With ``defer_metrics`` the caller runs this after it has queued the
         backward pass, so the device never waits for the host between the two."""
-        host = tail_dev.cpu().numpy()                                                          # sync 3
+        if tail_event is not None:
+            tail_event.synchronize()
+            host = tail_host.numpy()
+        else:
+            host = tail_dev.cpu().numpy()                                                      # sync 3
         d_h = host[:S_all]
         st_h = host[S_all:S_all + S_p].astype(np.int64) if S_p else np.zeros(0, np.int64)
         ptype_h = host[S_all + S_p:].astype(np.int64).reshape(B, Cp)
