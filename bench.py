@@ -23,23 +23,35 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 / fp16 dense peak (v
 HBM_PEAK_GBS = 8000.0
 
 
-def build_workload(name, device, rank, pretrain=300):
+POOL = 16             # distinct shapes per rank the timed steps rotate through
+PRETRAIN_POOL = 64    # disjoint shapes of the pre-training stand-in (cfg5)
+
+
+def build_workload(name, device, rank, pretrain=600):
     from parsenet_codebase_amd import workloads
     if name == "cfg4":
         B, N = 4, 10000
-        return workloads.ParsenetSegStep(device, batch=B, num_points=N, first_shape=rank * B), {
+        return workloads.ParsenetSegStep(device, batch=B, num_points=N, first_shape=rank * POOL, pool=POOL), {
             "workload": "cfg4: ParSeNet seg-only points+normals, 10k pts, batch 4 per GPU "
                         "(PrimitivesEmbeddingDGCNGn mode 5, k=80, triplet+NLL, fwd+bwd+allreduce+Adam)",
-            "batch_per_gpu": B, "points": N, "k": 80}
+            "batch_per_gpu": B, "points": N, "k": 80,
+            "pool": "%d distinct shapes per rank (ids %d..%d on rank 0), a new batch of %d every step"
+                    % (POOL, 0, POOL - 1, B)}
     if name == "cfg5":
         B, N = 4, 10000
-        return workloads.ParsenetE2EStep(device, batch=B, num_points=N, first_shape=rank * B,
-                                         pretrain_steps=pretrain), {
+        step = workloads.ParsenetE2EStep(device, batch=B, num_points=N, first_shape=rank * POOL,
+                                         pretrain_steps=pretrain, pool=POOL, pretrain_pool=PRETRAIN_POOL)
+        return step, {
             "workload": "cfg5: ParSeNet e2e (seg + mean-shift 10 it. + per-segment spline/primitive fit + "
                         "Chamfer/residual), 10k pts, batch 4 per GPU, fwd+bwd+allreduce+Adam",
             "batch_per_gpu": B, "points": N, "k": 80,
-            "init": "segmentation network after %d deterministic seg-only steps on the batch (stand-in for the "
-                    "reference's pretrained parsenet_with_normals.pth), frozen random-init SplineNets" % pretrain}
+            "pool": "%d distinct shapes per rank (ids rank*%d ..), a new batch of %d every step; every timed "
+                    "shape is HELD OUT from the pre-training" % (POOL, POOL, B),
+            "init": "segmentation network after %d deterministic seg-only steps (Adam 1e-2) over %d shapes with ids "
+                    "%d.. — disjoint from the timed pool — run by rank 0 and broadcast (stand-in for the reference's "
+                    "pretrained parsenet_with_normals.pth, train_parsenet_e2e.py:82-84); frozen random-init SplineNets"
+                    % (pretrain, PRETRAIN_POOL, workloads.PRETRAIN_FIRST_SHAPE),
+            "pretrain_final_loss": step.pretrain_loss}
     if name in ("cfg2", "cfg3"):
         B, N = 32, 700
         closed = name == "cfg3"
@@ -48,7 +60,49 @@ def build_workload(name, device, rank, pretrain=300):
                         "one-sided Chamfer + permutation regression%s, fwd+bwd+allreduce+Adam"
                         % (name, "closed" if closed else "open", int(closed), "" if closed else " + Laplacian"),
             "batch_per_gpu": B, "points": N, "k": 10}
+    if name == "stub":
+        return StubStep(device, rank, pretrain), {"workload": "stub: control-flow self-test, no kernels"}
     raise SystemExit("unknown workload %r" % name)
+
+
+class StubStep:
+    """--workload stub: a 2-layer perceptron on the CPU with the step interface of the real
+    workloads — pre-training on rank 0 + broadcast, flat gradient bucket, one all-reduce per step.
+    It exists so that the CPU test suite can drive bench.py's WHOLE control flow (pretrain ->
+    broadcast -> timed loop -> dense re-run -> profiled steps -> MAX-reduce -> rank-0 line) on
+    two gloo ranks: a deadlock or a rank mismatch must not first appear on the 8-GPU node."""
+
+    def __init__(self, device, rank, pretrain):
+        from parsenet_codebase_amd import workloads
+        from parsenet_codebase_amd.dp import FlatGradBucket
+        torch.manual_seed(100 + rank)            # ranks start from DIFFERENT weights: the broadcast must fix that
+        self.model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1)).to(device)
+        self.bucket = FlatGradBucket(self.model.parameters())
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-2)
+        self.batch, self.num_points, self.pool = 4, 8, 8
+        g = torch.Generator().manual_seed(7 + rank)
+        self.data = torch.randn(self.pool, 8, generator=g).to(device)
+        self.cursor = 0
+        self.pretrain_loss = None
+
+        def train():
+            for _ in range(pretrain):
+                self.step()
+        workloads.train_on_rank0_then_broadcast(self.model, self.bucket, train)
+        self.cursor = 0
+
+    def shapes_per_step(self):
+        return self.batch
+
+    def step(self):
+        x = self.data[self.cursor:self.cursor + self.batch]
+        self.cursor = (self.cursor + self.batch) % self.pool
+        self.bucket.zero()
+        loss = (self.model(x) ** 2).mean()
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        return loss
 
 
 def pmc_traffic(kernel_name, arith, shapes_per_launch=1):
@@ -65,7 +119,10 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1):
     if arith == "bf16x3" and shapes_per_launch == 4:
         from parsenet_codebase_amd import mean_shift as _ms
         # block-sparse launches of the benchmark's own embedding / dense launches (kbench meanshift_batch)
-        files["bf16x3"] = ("r02_meanshift_x3_sparse_cfg5_pmc.csv" if _ms.SPARSE else "r02_meanshift_x3_batch4_pmc.csv",
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        cand = (["r03_meanshift_x3_sparse_cfg5_pmc.csv", "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if _ms.SPARSE else
+                ["r03_meanshift_x3_dense_cfg5_pmc.csv", "r02_meanshift_x3_batch4_pmc.csv"])
+        files["bf16x3"] = (next((c for c in cand if os.path.exists(os.path.join(prof, c))), cand[-1]),
                            "pn_ms3_kernel<%d>")
         scale = 1.0
     fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", files[arith][0])
@@ -88,11 +145,17 @@ def kernel_roofline(step, nprof):
     on the launch stream, recorded inside the C library), and the roofline entry of the
     dominant one."""
     from parsenet_codebase_amd import _lib
+    from parsenet_codebase_amd import mean_shift as _ms
     _lib.prof_reset()
     _lib.prof_enable(True)
     os.environ["PARSENET_MS_STATS"] = "1"      # active fractions of the block-sparse mean-shift plans
+    plan_stats = []                            # one entry per profiled step: mean over its 10 iterations
     for _ in range(nprof):
+        _ms.LAST_PLAN_STATS = None
         step.step()
+        if _ms.LAST_PLAN_STATS:
+            st = _ms.LAST_PLAN_STATS
+            plan_stats.append([sum(t[c] for t in st) / len(st) for c in range(4)])
     torch.cuda.synchronize()
     os.environ.pop("PARSENET_MS_STATS", None)
     _lib.prof_enable(False)
@@ -131,37 +194,42 @@ def kernel_roofline(step, nprof):
         shapes_per_launch = B if getattr(step, "batched", False) else 1
         flops = units * 2.0 * N * N * 128 * shapes_per_launch
         ach = flops / avg_s / 1e12
-        from parsenet_codebase_amd import mean_shift as _ms
         sparse = None
-        if _ms.ARITH == "bf16x3" and _ms.SPARSE and _ms.LAST_PLAN_STATS:
+        executed = 1.0
+        if _ms.ARITH == "bf16x3" and _ms.SPARSE and plan_stats:
             # block-sparse launches: the waves run the GEMMs of the tile pairs the plan keeps; the
             # others are rigorously below 1e-9 of the smallest row sum (csrc/meanshift_x3.h)
-            st = _ms.LAST_PLAN_STATS
             col = {"meanshift_fwd": 1, "meanshift_bwd_rows": 2, "meanshift_bwd_cols": 3}[dom]
-            pairs = sum(t[0] for t in st) / len(st)
-            sparse = {"tile_pairs_executed": pairs, "block_lists_visited": sum(t[col] for t in st) / len(st),
-                      # `achieved` / `frac` above are ALGORITHMIC (the dense 2 N^2 d units of
-                      # the reference's iteration); these two count only the tile pairs whose GEMMs ran
-                      "tflops_on_executed_pairs": ach * pairs}
+
+            def mmm(c):
+                v = [t[c] for t in plan_stats]
+                return {"min": min(v), "mean": sum(v) / len(v), "max": max(v)}
+            sparse = {"tile_pairs_executed": mmm(0), "block_lists_visited": mmm(col),
+                      "steps_sampled": len(plan_stats),
+                      "note": "fractions of the dense N^2 tile pairs, per profiled step (mean over its 10 "
+                              "iterations); the profiled steps visit every batch of the timed pool once"}
+            executed = sparse["tile_pairs_executed"]["mean"]
         if _ms.ARITH in ("bf16x3", "fp16x2"):
             # every fp32 product is formed from 6 bf16 (3 fp16) piece products on the 16-bit matrix
-            # cores (fp32 accumulate): the roof for ALGORITHMIC fp32 FLOPs is the dense peak / 6 (/ 3)
+            # cores (fp32 accumulate).  `achieved` / `frac`: the piece-product FLOPs the launch EXECUTES
+            # (tile pairs kept by the plan only) against the dense 16-bit MFMA peak — the figure
+            # SQ_VALU_MFMA_BUSY_CYCLES / 32 x 32768 FLOP / duration reproduces.  The work of the
+            # reference's dense fp32 iteration that this launch stands for is reported separately.
             pieces = 6.0 if _ms.ARITH == "bf16x3" else 3.0
-            peak = MFMA_BF16_PEAK_TFLOPS / pieces
-            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": ach / peak, "traffic": pmc_traffic(dom, _ms.ARITH, shapes_per_launch),
+            ach_exec = pieces * ach * executed
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach_exec, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach_exec / MFMA_BF16_PEAK_TFLOPS,
+                    "traffic": pmc_traffic(dom, _ms.ARITH, shapes_per_launch),
                     "avg_launch_ms": table[dom]["avg_ms"],
                     "mfma": ("v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)"
                              if _ms.ARITH == "bf16x3" else
                              "v_mfma_f32_32x32x16_f16, 3 piece products per fp32 product (scaled fp16x2 split)"),
-                    "executed_tflops": pieces * ach * (sparse["tile_pairs_executed"] if sparse else 1.0),
-                    "executed_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+                    "algorithmic_dense_equiv": {
+                        "tflops_fp32": ach, "peak_fp32_via_split": MFMA_BF16_PEAK_TFLOPS / pieces,
+                        "ratio": ach * pieces / MFMA_BF16_PEAK_TFLOPS,
+                        "note": "SURVEY 8d work of the reference's dense iteration (units x 2 N^2 d per shape) / "
+                                "launch duration; exceeds 1 when the plan skips tile pairs — not a roofline fraction"}}
             if sparse:
-                sparse["mfma_frac_on_executed_pairs"] = sparse["tflops_on_executed_pairs"] / peak
-                sparse["note"] = ("achieved/frac count the ALGORITHMIC (dense) work of the reference's iteration; "
-                                  "the launch executes only tile_pairs_executed of it (the rest is proved below "
-                                  "1e-9 of the smallest row sum), so frac can exceed 1; the matrix-core "
-                                  "utilisation of the launch is mfma_frac_on_executed_pairs")
                 roof["block_sparse"] = sparse
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
@@ -174,9 +242,11 @@ def kernel_roofline(step, nprof):
     return roof, table
 
 
-def cpu_baseline(name):
+def cpu_baseline(name, state=None, state_note="random-init weights"):
     """The torch-CPU oracle (restatement of the reference's algorithm) on ONE shape of the same
-    workload, all host cores, one pass (bounded to a few tens of seconds)."""
+    workload (shape 0 of rank 0's timed pool), all host cores; ``state`` = the state_dict the GPU
+    side starts its timed region from, so that both sides cluster and fit the same segments.
+    Bounded: up to 3 passes, no new pass once 45 s are spent (median reported)."""
     import numpy as np
     from oracle import ref_fitting as RF, ref_torch as R
     from parsenet_codebase_amd import synthetic
@@ -188,29 +258,41 @@ def cpu_baseline(name):
     model = R.PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True, num_primitives=10,
                                         loss_function=R.EmbeddingLoss(1.0).triplet_loss, mode=5,
                                         num_channels=6, nn_nb=80)
+    if state is not None:
+        model.load_state_dict({k: v.detach().cpu() for k, v in state.items()})
     pts, nrm, lab, prim = synthetic.make_batch(0, 1, 10000)
     x = torch.from_numpy(np.ascontiguousarray(np.concatenate([pts, nrm], 2).transpose(0, 2, 1)))
     primt = torch.from_numpy(prim)
     ev = None
     if name == "cfg5":
         model.eval()
+        torch.manual_seed(1)        # frozen random-init SplineNets (any fixed weights: their cost is what counts)
         ev = RF.Evaluation(R.DGCNNControlPoints(20, 10, 1), R.DGCNNControlPoints(20, 10, 0))
-    times = []
+    times, fitted, clusters = [], None, None
+    t_begin = time.time()
     for it in range(3):
+        if it and time.time() - t_begin > 45.0:
+            break
         t0 = time.time()
         model.zero_grad()
         e, p, l = model(x, lab, True)
         loss = l.mean() + R.primitive_loss(p, primt)
         if ev is not None:
-            res, _ = ev.fitting_loss(e.permute(0, 2, 1), torch.from_numpy(pts), torch.from_numpy(nrm), lab, prim,
-                                     quantile=0.025, iterations=10, lamb=0.1)
+            res, extra = ev.fitting_loss(e.permute(0, 2, 1), torch.from_numpy(pts), torch.from_numpy(nrm), lab, prim,
+                                         quantile=0.025, iterations=10, lamb=0.1)
             loss = loss + res[0]
+            fitted = sum(1 for v in extra[0].values() if v is not None)
+            clusters = int(np.unique(extra[1]).shape[0])
         loss.backward()
         times.append(time.time() - t0)
     med = sorted(times)[len(times) // 2]
+    what = ""
+    if ev is not None:
+        what = "; this pass found %d clusters and fitted %d segments" % (clusters, fitted)
     return {"value": 1.0 / med, "unit": "shapes/s", "cores": cores, "kind": "port",
-            "sample": "torch-CPU oracle (reference algorithm restated), %s, 1 shape x 10000 pts fwd+bwd, "
-                      "median of %d passes (%s s)" % (name, len(times), ", ".join("%.1f" % t for t in times))}
+            "sample": "torch-CPU oracle (reference algorithm restated), %s, %s, 1 shape (id 0 of the timed pool) x "
+                      "10000 pts fwd+bwd, median of %d passes (%s s)%s"
+                      % (name, state_note, len(times), ", ".join("%.1f" % t for t in times), what)}
 
 
 def oracle_splinenet_step(model, closed, points, control_points, nu, nv, loss_weight=0.9):
@@ -314,8 +396,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--pretrain", type=int, default=300,
+    ap.add_argument("--profile-steps", type=int, default=-1,
+                    help="extra steps with the in-library kernel timers on (default: one pass over the pool)")
+    ap.add_argument("--no-dense", action="store_true", help="cfg5: skip the second timed run with dense mean-shift launches")
+    ap.add_argument("--pretrain", type=int, default=600,
                     help="cfg5: deterministic seg-only steps before the timed region (see workloads.ParsenetE2EStep)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -329,39 +413,91 @@ def main():
         return launch_selftest()
 
     from parsenet_codebase_amd import dp
-    rank, world, device = dp.init_from_env()
-    if device.type != "cuda":
+    stub = args.workload == "stub"
+    rank, world, device = dp.init_from_env(backend="gloo" if stub else None)
+    if device.type != "cuda" and not stub:
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
+    if stub:
+        device = torch.device("cpu")
+    import copy
+    import numpy as np
 
     step, cfg = build_workload(args.workload, device, rank, args.pretrain)
-    import numpy as np
-    np.random.seed(1000 + rank)
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    for _ in range(args.warmup):
-        step.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def snapshot():
+        return {"model": copy.deepcopy(step.model.state_dict()), "opt": copy.deepcopy(step.opt.state_dict()),
+                "cursor": getattr(step, "cursor", 0)}
+
+    def restore(snap):
+        step.model.load_state_dict(snap["model"])
+        step.opt.load_state_dict(copy.deepcopy(snap["opt"]))
+        if hasattr(step, "cursor"):
+            step.cursor = snap["cursor"]
+
+    def timed_run():
+        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        np.random.seed(1000 + rank)
+        for _ in range(args.warmup):
+            step.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step.step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # every run (default launches, dense launches, profiled steps) starts from the pre-trained state
+    if hasattr(step, "warm_paths"):
+        step.warm_paths()
+    start = snapshot()
+    elapsed = timed_run()
+
+    # cfg5: the same steps once more with every mean-shift launch dense (PARSENET_MS_SPARSE=0 at run
+    # time): the block-sparse plans are data dependent, the dense value is their floor
+    elapsed_dense = None
+    sparse_on = False
+    if args.workload == "cfg5":
+        from parsenet_codebase_amd import mean_shift as _ms
+        sparse_on = _ms.SPARSE and _ms.ARITH == "bf16x3"
+    if (sparse_on and not args.no_dense) or stub:
+        restore(start)
+        if sparse_on:
+            _ms.SPARSE = False
+        try:
+            elapsed_dense = timed_run()
+        finally:
+            if sparse_on:
+                _ms.SPARSE = True
 
     # The profiled steps contain the gradient all-reduce, a collective: EVERY rank runs them
     # (only rank 0 keeps the per-kernel table), otherwise rank 0 would pair its all-reduce with
-    # the other ranks' barrier.
-    roof, table = kernel_roofline(step, args.profile_steps)
+    # the other ranks' barrier.  Default: one pass over the timed pool.
+    restore(start)
+    nprof = args.profile_steps
+    if nprof < 0:
+        nprof = max(1, getattr(step, "pool", step.batch) // step.batch)
+    roof, table = (None, {}) if stub else kernel_roofline(step, nprof)
+    if stub:
+        for _ in range(nprof):
+            step.step()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.workload)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
+        cpu = cpu_baseline(args.workload, start["model"] if args.workload == "cfg5" else None,
+                           "the GPU side's pre-trained state_dict" if args.workload == "cfg5" else "random-init weights")
     if world > 1:
         dist.barrier()
 
@@ -383,7 +519,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": _dtype_label(args.workload),
+            "dtype": "f32" if stub else _dtype_label(args.workload),
             "data": "synthetic",
             "config": dict(cfg, parallelism="dp%d" % world, global_batch=step.shapes_per_step() * world,
                            **({"meanshift_products": _ms_arith()} if args.workload == "cfg5" else {})),
@@ -391,6 +527,10 @@ def main():
             "cpu_baseline": cpu,
             "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(table.items())},
         }
+        if elapsed_dense is not None:
+            # same weights, same shapes, same RNG stream, every mean-shift launch dense
+            out["value_dense"] = shapes / elapsed_dense
+            out["ms_per_step_dense"] = 1e3 * elapsed_dense / args.steps
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -697,7 +697,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     if (pass == 0 && x3p1) {
       // workgroups of 4 waves x 32 qsets queries, two per CU; steps of tstep tiles (knn_x3.h).
       // Slices: whole rounds of the 512 slots where possible, a fixed cost of about one tile each.
-      const int qpw = 128 * p.qsets, ntiles = p.Ncp / 32, tstep = p.ksteps == 32 ? 2 : 1;
+      const int qpw = 128 * p.qsets, ntiles = p.Ncp / 32;
       const long long rowblocks = (long long)B * pn_cdiv(p.Nqp, qpw);
       int tps1 = ntiles;
       double best_score = -1.0;

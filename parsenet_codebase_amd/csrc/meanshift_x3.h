@@ -552,6 +552,16 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 // one pair set (pass 0 / 1: blocks of 8 / 4 q tiles against x tiles; pass 2: blocks of 8 x tiles
 // against q tiles).
 #define X3_PLAN_SLACK 1e-3f
+// The cap geometry comes from fp32 dot products of 128 terms: |computed - exact| <= X3_DOT_ERR for
+// unit rows ((D + 2) * 2^-23, worst case; the normalisation error of a centre is inside it).  acos
+// amplifies that error without bound near angle 0 (d -> sqrt(2 d)), so the error is applied to the
+// ARGUMENT, on the side that keeps the bound: a radius is acos(dot - err) >= the true angle, an
+// upper bound of a centre angle acos(dot - err), a lower bound acos(dot + err) (0 when >= 1).
+#define X3_DOT_ERR 1.6e-5f
+// Backward passes reuse the forward plan of their iteration.  The terms they drop are the same
+// kernel values times (q.x - 1) / b^2 factors, so the dropped share of a gradient row is bounded by
+// rel_eps / b^2, not rel_eps: 1e-7 at b = 0.1 (fp32 rounding), 1e-4 at the 0.003 floor of the
+// bandwidth clamp (src/mean_shift.py:34) — a bandwidth at which a row sees only itself.
 
 // Two bounding caps per 32-row tile of z (B,N,D); lane = channels (lane, lane + 64).
 // A tile of the locality order often straddles two regions of the sphere (the end of one cell and
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __res
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float mg = fminf(fminf(smin[0][g], smin[1][g]), fminf(smin[2][g], smin[3][g]));
-      if (r[g] > 0.f && ok[g]) r[g] = acosf(fminf(fmaxf(mg, -1.f), 1.f)) + X3_PLAN_SLACK;
+      if (r[g] > 0.f && ok[g]) r[g] = acosf(fminf(fmaxf(mg - X3_DOT_ERR, -1.f), 1.f)) + X3_PLAN_SLACK;
       co[g * MS_D + lane] = c[g][0];
       co[g * MS_D + lane + 64] = c[g][1];
     }
@@ -746,7 +756,8 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
     for (int k = 0; k < 2; ++k) {
       const int qi = qb * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2) + 4 * h;   // r even: qi, qi + 1 = one tile
       const float rq = __shfl(rq_mine, qi - qb * 32, 64);
-      const float th = acosf(fminf(fmaxf(acc[r + k], -1.f), 1.f));
+      // upper bound of the centre angle for L (sweep 0), lower bound for U (sweep 1)
+      const float th = acosf(fminf(fmaxf(acc[r + k] + (SWEEP == 0 ? -X3_DOT_ERR : X3_DOT_ERR), -1.f), 1.f));
       if (SWEEP == 0) {
         const float hi = th + rq + rx;
         float m = rx >= 0.f ? (hi >= 3.14159f ? -1.f : cosf(hi)) : -2.f;

@@ -9,6 +9,7 @@
 struct PnProfSpan {
   const char* name;
   hipEvent_t a, b;
+  bool bad = false;
 };
 
 static std::mutex g_prof_mu;
@@ -29,8 +30,11 @@ void pn_prof_begin(const char* name, hipStream_t s, int* token) {
   if (!g_prof_on) return;
   PnProfSpan sp;
   sp.name = name;
-  if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) return;
-  hipEventRecord(sp.a, s);
+  if (hipEventCreate(&sp.a) != hipSuccess) return;
+  if (hipEventCreate(&sp.b) != hipSuccess || hipEventRecord(sp.a, s) != hipSuccess) {
+    (void)hipEventDestroy(sp.a);      // an unrecorded span is dropped, never half-timed
+    return;
+  }
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_spans.push_back(sp);
   *token = (int)g_spans.size() - 1;
@@ -39,16 +43,17 @@ void pn_prof_begin(const char* name, hipStream_t s, int* token) {
 void pn_prof_end(hipStream_t s, int token) {
   if (token < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  hipEventRecord(g_spans[token].b, s);
+  if (hipEventRecord(g_spans[token].b, s) != hipSuccess) g_spans[token].bad = true;
 }
 
 static void prof_resolve() {
   for (auto& sp : g_spans) {
-    hipEventSynchronize(sp.b);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, sp.a, sp.b);
-    hipEventDestroy(sp.a);
-    hipEventDestroy(sp.b);
+    const bool ok = !sp.bad && hipEventSynchronize(sp.b) == hipSuccess &&
+                    hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess;
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+    if (!ok) continue;                // a span whose events failed contributes nothing
     bool found = false;
     for (auto& a : g_agg)
       if (a.name == sp.name) {

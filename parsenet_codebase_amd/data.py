@@ -184,7 +184,12 @@ def _canonicalise_batch(points, normals, anisotropic):
     its sign like the reference's."""
     if not isinstance(points, np.ndarray):
         import torch
-        G = torch.bmm(points.transpose(1, 2), points).cpu().numpy()          # X^T X per shape (pca_numpy)
+        # X^T X per shape (pca_numpy), accumulated in fp64 and symmetrised: the fp32 product of the
+        # GPU differs from the host's in the last bits and is not exactly symmetric, which for a
+        # nearly isotropic shape can flip geev's minor axis or its sign (another canonical frame)
+        Pd = points.double()
+        G = torch.bmm(Pd.transpose(1, 2), Pd)
+        G = (0.5 * (G + G.transpose(1, 2))).cpu().numpy()
         R = []
         for g in G:
             S, U = np.linalg.eig(g)

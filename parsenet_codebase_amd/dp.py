@@ -50,6 +50,7 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.collective = True      # False: steps that only one rank runs (workloads.train_on_rank0_then_broadcast)
         o = 0
         for p in self.params:
             n = p.numel()
@@ -61,7 +62,7 @@ class FlatGradBucket:
 
     def all_reduce_mean(self):
         """Average gradients over ranks with one all-reduce (no-op on a single rank)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.collective and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
         return self.flat

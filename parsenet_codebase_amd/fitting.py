@@ -938,8 +938,20 @@ class Evaluation:
         """embedding (B,N,128), points/normals (B,N,3) tensors; labels, primitives (B,N) integer
         arrays; primitives_log_prob (B,10,N).  Returns ([Loss, geometric mean, spline mean, s_iou,
         p_iou], [parameters, cluster ids, weights]) of the last shape, like the reference (which
-        is written for B = 1).  ``prefetched``: per-shape handles of ``prefetch_clustering``."""
+        is written for B = 1).  ``prefetched``: per-shape handles of ``prefetch_clustering``.
+
+        Training calls (not eval / debug / prefetched) go through the STAGE-WISE path by default
+        (``self.batched``: fitting_batch.fitting_losses_train — same decisions and arithmetic,
+        mean-shift products in the library's default arithmetic, see mean_shift.ARITH); set
+        ``evaluation.batched = False`` for the segment-by-segment path.  With B > 1 every shape
+        is fitted and only the last result returned (what the reference's loop leaves behind):
+        use ``fitting_losses`` to get them all — a warning says so once."""
         if self.batched and not eval and prefetched is None and not debug:
+            if embedding.shape[0] > 1 and not getattr(self, "_warned_last_only", False):
+                import warnings
+                warnings.warn("Evaluation.fitting_loss with a batch of %d shapes returns the LAST shape's result "
+                              "only (reference behaviour); call fitting_losses for all of them" % embedding.shape[0])
+                self._warned_last_only = True
             return self.fitting_losses(embedding, points, normals, labels, primitives, primitives_log_prob,
                                        quantile=quantile, iterations=iterations, lamb=lamb)[-1]
         batch_size = embedding.shape[0]

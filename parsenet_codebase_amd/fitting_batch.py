@@ -56,6 +56,16 @@ def _device_const(key, make):
     return t
 
 
+def _fitter_bases(fitter, dev):
+    """Device copies of the fitter's B-spline bases, kept ON the fitter (they die with it; a
+    module-level cache keyed by id() could hand a recycled id another fitter's grid)."""
+    cache = fitter.__dict__.setdefault("_bases_dev", {})
+    hit = cache.get(dev)
+    if hit is None or hit[0] is not fitter.nu or hit[1] is not fitter.nv:
+        hit = cache[dev] = (fitter.nu, fitter.nv, fitter.nu.to(dev), fitter.nv.to(dev))
+    return hit[2], hit[3]
+
+
 def bandwidth_batch(X, quantile, num_samples=10000):
     """MeanShift.compute_bandwidth (src/mean_shift.py:115-137) for every shape of X (B,N,128):
     (bw (B,) clamped at 0.003, flagged rows per shape (B,)) or None outside the selection
@@ -90,7 +100,6 @@ def _padded_true_indices(mask, cap):
     return order[:, :cap], mask.sum(1)
 
 
-_NMS_WIDTH = {}     # (B, N) -> padded width of the neighbour matrix the previous call needed
 
 
 def nms_batch(new_X, X, bw, width=None):
@@ -142,14 +151,15 @@ def nms_batch(new_X, X, bw, width=None):
     return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc, "nflag": nflag, "width": U}
 
 
-def nms_width_guess(B, N):
+def nms_width_guess(ev, B, N):
     """Width for the next nms_batch call of this problem size: a quarter above what the previous
-    one needed, in steps of 256 (None before the first call)."""
-    return _NMS_WIDTH.get((B, N))
+    one needed, in steps of 256 (None before the first call).  The memory lives on the owning
+    Evaluation object, not in the module."""
+    return ev.__dict__.setdefault("_nms_width", {}).get((B, N))
 
 
-def nms_width_update(B, N, nocc_max):
-    _NMS_WIDTH[(B, N)] = min(N, (int(nocc_max * 1.25) // 256 + 1) * 256)
+def nms_width_update(ev, B, N, nocc_max):
+    ev.__dict__.setdefault("_nms_width", {})[(B, N)] = min(N, (int(nocc_max * 1.25) // 256 + 1) * 256)
 
 
 # -------------------------------------------------------------------------------------------
@@ -378,7 +388,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         with record_function("fit:meanshift_fwd"):
             new_X = MSM.mean_shift_iterations(emb, bw, iterations)
         with torch.no_grad(), record_function("fit:nms"):
-            state = nms_batch(new_X.detach(), emb.detach(), bw, nms_width_guess(B, N))
+            state = nms_batch(new_X.detach(), emb.detach(), bw, nms_width_guess(ev, B, N))
     with torch.no_grad():
         # SIOU_matched_segments merges the predicted types before the per-cluster vote
         # (src/segment_utils.py:152-161: 0, 6, 7 -> 9; 8 -> 2)
@@ -395,7 +405,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
             with torch.no_grad():
                 state = nms_batch(new_X.detach(), emb.detach(), bw, None)
             pack = download(state)
-        nms_width_update(B, N, int(pack[-2 * B:-B].max()))
+        nms_width_update(ev, B, N, int(pack[-2 * B:-B].max()))
         o = 0
         lab_h = pack[o:o + B * N].reshape(B, N); o += B * N
         cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
@@ -486,8 +496,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
             w2 = Wn[:, :, 0::2][sb, sr] + EPS                                 # (S_s,n2), differentiable
             pts_std, std, mean, R = standardize_segments(P2, w2.detach())      # sync 2
             affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
-        nu = _device_const(("nu", id(fitter), dev), lambda: fitter.nu.to(dev))
-        nv = _device_const(("nv", id(fitter), dev), lambda: fitter.nv.to(dev))
+        nu, nv = _fitter_bases(fitter, dev)
         pieces = []
         for lo, hi, net, wrap in ((0, n_open, fitter.open_control_decoder, False),
                                   (n_open, S_s, fitter.closed_control_decoder, True)):
@@ -548,6 +557,10 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         d_h = host[:S_all]
         st_h = host[S_all:S_all + S_p].astype(np.int64) if S_p else np.zeros(0, np.int64)
         ptype_h = host[S_all + S_p:].astype(np.int64).reshape(B, Cp)
+        if not np.isfinite(d_h).all():
+            bad = int(np.nonzero(~np.isfinite(d_h))[0][0])
+            raise RuntimeError("fitting: non-finite residual distance in segment %d of shape %d"
+                               % (all_segs[bad][1]["key"], all_segs[bad][0]))
         if (st_h & 5).any():
             bad = int(np.nonzero(st_h & 5)[0][0])
             raise RuntimeError("fitting: %s in segment %d of shape %d" % (

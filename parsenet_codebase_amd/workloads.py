@@ -10,12 +10,38 @@ from .encoders import PrimitivesEmbeddingDGCNGn
 from .losses import EmbeddingLoss, primitive_loss
 
 
+def train_on_rank0_then_broadcast(model, bucket, train):
+    """Every rank must start the timed region from ONE set of weights.  Rank 0 runs ``train()``
+    alone (the bucket's gradient all-reduce is switched off meanwhile: the other ranks are not
+    in those steps), then all parameters and buffers reach the other ranks with one flat
+    broadcast per dtype (trainer.sync_module_from_rank0).  On a single rank: just ``train()``."""
+    import torch.distributed as dist
+    from .trainer import sync_module_from_rank0
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not multi:
+        return train()
+    if dist.get_rank() == 0:
+        bucket.collective = False
+        try:
+            train()
+        finally:
+            bucket.collective = True
+    sync_module_from_rank0(model)
+
+
+PRETRAIN_FIRST_SHAPE = 1000000     # ids of the pre-training shapes: disjoint from every timed pool
+
+
 class ParsenetSegStep:
     """cfg4: ParSeNet segmentation-only training step (train_parsenet.py:151-198): points +
     normals (6 channels), first graph on the points+normals metric, k = 80, triplet embedding
-    loss + NLL primitive loss, forward + backward + one gradient all-reduce + Adam."""
+    loss + NLL primitive loss, forward + backward + one gradient all-reduce + Adam.
 
-    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-2):
+    ``pool`` (a multiple of ``batch``, default = ``batch``): number of distinct shapes resident in
+    HBM; step s works on shapes [s * batch mod pool, + batch) of the pool — the reference's loop
+    draws a new batch every iteration (train_parsenet.py:151-160)."""
+
+    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-2, pool=None):
         torch.manual_seed(seed)
         self.device = device
         self.batch = batch
@@ -26,17 +52,41 @@ class ParsenetSegStep:
                                                mode=5, num_channels=6, nn_nb=nn_nb).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
-        pts, nrm, lab, prim = synthetic.make_batch(first_shape, batch, num_points)
-        x = np.concatenate([pts, nrm], 2).transpose(0, 2, 1)           # (B,6,N)
-        self.x = torch.from_numpy(np.ascontiguousarray(x)).to(device)
-        self.labels = lab                                              # host ints (reference: numpy)
-        self.prim = torch.from_numpy(prim).to(device)
         self.rng_seed = seed
+        self.load_pool(first_shape, batch if pool is None else pool)
+
+    def load_pool(self, first_shape, pool):
+        """Make shapes first_shape .. first_shape + pool - 1 resident (everything a step touches is in
+        HBM before the timed region starts; labels stay host integers like the reference's numpy)."""
+        if pool % self.batch:
+            raise ValueError("pool (%d) must be a multiple of the batch (%d)" % (pool, self.batch))
+        pts, nrm, lab, prim = synthetic.make_batch(first_shape, pool, self.num_points)
+        x = np.concatenate([pts, nrm], 2).transpose(0, 2, 1)           # (P,6,N)
+        self.pool, self.first_shape = pool, first_shape
+        self.pool_x = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        self.pool_points = torch.from_numpy(pts).to(self.device)
+        self.pool_normals = torch.from_numpy(nrm).to(self.device)
+        self.pool_labels = lab                                          # host ints (reference: numpy)
+        self.pool_prim_np = prim
+        self.pool_prim = torch.from_numpy(prim).to(self.device)
+        self.cursor = 0
+        self.select(0)
+
+    def select(self, start):
+        """Views of the batch that starts at pool position ``start`` (no copies)."""
+        sl = slice(start, start + self.batch)
+        self.x, self.labels, self.prim = self.pool_x[sl], self.pool_labels[sl], self.pool_prim[sl]
+        self.points, self.normals, self.prim_np = self.pool_points[sl], self.pool_normals[sl], self.pool_prim_np[sl]
+
+    def next_batch(self):
+        self.select(self.cursor)
+        self.cursor = (self.cursor + self.batch) % self.pool
 
     def shapes_per_step(self):
         return self.batch
 
-    def step(self):
+    def seg_step(self):
+        self.next_batch()
         self.bucket.zero()
         embedding, log_prob, embed_loss = self.model(self.x, self.labels, True)
         loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
@@ -45,6 +95,9 @@ class ParsenetSegStep:
         self.opt.step()
         return loss
 
+    def step(self):
+        return self.seg_step()
+
 
 class ParsenetE2EStep(ParsenetSegStep):
     """cfg5: the end-to-end step of train_parsenet_e2e.py:190-277 per shape — segmentation
@@ -52,45 +105,34 @@ class ParsenetE2EStep(ParsenetSegStep):
     clustering of the embedding (quantile 0.025, 10 iterations), Hungarian matching, weighted
     primitive / SplineNet fits and residual losses (lamb 0.1); loss = triplet + NLL + residual,
     backward through everything, one gradient all-reduce, Adam.  The SplineNets are frozen
-    random-init DGCNNControlPoints (no pretrained weights ship with the reference)."""
+    random-init DGCNNControlPoints (no pretrained weights ship with the reference).
+
+    Initial state.  The reference starts end-to-end training from a segmentation network
+    pre-trained by train_parsenet.py (train_parsenet_e2e.py:82-84 loads parsenet_with_normals.pth)
+    and draws a new shape every iteration (:190-241).  No checkpoint ships with it, so the
+    stand-in is ``pretrain_steps`` deterministic segmentation-only steps (triplet + NLL, Adam
+    ``pretrain_lr``) over ``pretrain_pool`` shapes with ids from PRETRAIN_FIRST_SHAPE on — DISJOINT
+    from the ``pool`` shapes the end-to-end steps then rotate through (held-out data, like the
+    reference's fresh batches).  ``pretrain_pool=None`` keeps the round-2 behaviour (pre-training
+    on the step's own batch; tests and tools that want an over-fitted embedding).  With several
+    ranks only rank 0 trains; the weights reach the others with one flat broadcast."""
 
     def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-4,
-                 pretrain_steps=0):
-        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr=1e-2)
+                 pretrain_steps=0, pool=None, pretrain_pool=None, pretrain_lr=1e-2):
+        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr=pretrain_lr, pool=pool)
         from .encoders import DGCNNControlPoints
         from .fitting import Evaluation
-        # The reference starts end-to-end training from a segmentation network pre-trained by
-        # train_parsenet.py (train_parsenet_e2e.py:82-84 loads parsenet_with_normals.pth); no
-        # checkpoint ships with it, so the stand-in is a fixed number of deterministic
-        # segmentation-only steps (triplet + NLL, Adam 1e-2, train-mode norms) on this batch: the
-        # embedding then HAS cluster structure and every shape goes through matching, primitive
-        # fits and SplineNets from the first timed step on.
         self.pretrain_steps = int(pretrain_steps)
+        self.pretrain_pool = pretrain_pool
+        self.pretrain_loss = None
         if self.pretrain_steps:
-            # PARSENET_PRETRAIN_CACHE=<file>: keep the pre-trained weights across processes (profiling
-            # runs: the trace then holds end-to-end steps only); the file is tied to the recipe
-            import os
-            cache = os.environ.get("PARSENET_PRETRAIN_CACHE")
-            tag = "seed%d_first%d_B%d_N%d_steps%d" % (seed, first_shape, batch, num_points, self.pretrain_steps)
-            state = torch.load(cache, map_location=device) if cache and os.path.exists(cache) else None
-            if state is not None and state.get("tag") == tag:
-                self.model.load_state_dict(state["model"])
-            else:
-                np.random.seed(4321 + first_shape)
-                for _ in range(self.pretrain_steps):
-                    ParsenetSegStep.step(self)
-                if cache:
-                    torch.save({"tag": tag, "model": self.model.state_dict()}, cache)
+            self._pretrain(seed, first_shape, pretrain_lr)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
         torch.manual_seed(seed + 1)
         open_net = DGCNNControlPoints(20, num_points=10, mode=0)
         closed_net = DGCNNControlPoints(20, num_points=10, mode=1)
         self.evaluation = Evaluation(closed_path=closed_net, open_path=open_net)
         self.model.eval()
-        pts, nrm, lab, prim = synthetic.make_batch(first_shape, batch, num_points)
-        self.points = torch.from_numpy(pts).to(device)
-        self.normals = torch.from_numpy(nrm).to(device)
-        self.prim_np = prim
         self.last_res = None
         # The clustering of shape b+1 (few large kernels) is queued on a side stream underneath the
         # fitting stage of shape b (hundreds of tiny launches and the host synchronisations of the
@@ -99,6 +141,42 @@ class ParsenetE2EStep(ParsenetSegStep):
         self.overlap = True       # (shape-by-shape mode) clustering of shape b+1 on a side stream
         self.side = torch.cuda.Stream(device=device)
         self._warmed = False
+
+    def _pretrain(self, seed, first_shape, lr):
+        """See the class docstring.  PARSENET_PRETRAIN_CACHE=<file> keeps the pre-trained weights
+        across processes (profiling runs: the trace then holds end-to-end steps only); the file is
+        tied to the recipe."""
+        import os
+        held_out = self.pretrain_pool is not None
+        cache = os.environ.get("PARSENET_PRETRAIN_CACHE")
+        tag = "seed%d_first%d_B%d_N%d_steps%d_pool%s_lr%g" % (
+            seed, PRETRAIN_FIRST_SHAPE if held_out else first_shape, self.batch, self.num_points,
+            self.pretrain_steps, self.pretrain_pool, lr)
+
+        def train():
+            state = torch.load(cache, map_location=self.device) if cache and os.path.exists(cache) else None
+            if state is not None and state.get("tag") == tag:
+                self.model.load_state_dict(state["model"])
+                self.pretrain_loss = state.get("loss")
+                return
+            timed = (self.first_shape, self.pool)
+            if held_out:
+                self.load_pool(PRETRAIN_FIRST_SHAPE, self.pretrain_pool)
+            np.random.seed(4321 + (0 if held_out else first_shape))
+            tail = []
+            for it in range(self.pretrain_steps):
+                loss = self.seg_step()
+                if it >= self.pretrain_steps - 8:
+                    tail.append(loss.detach())
+            self.pretrain_loss = float(torch.stack(tail).mean())
+            if held_out:
+                self.load_pool(*timed)
+            if cache:
+                torch.save({"tag": tag, "model": self.model.state_dict(), "loss": self.pretrain_loss}, cache)
+        if held_out:
+            train_on_rank0_then_broadcast(self.model, self.bucket, train)
+        else:
+            train()          # round-2 recipe: every rank on its own batch, gradients all-reduced
 
     def segments_per_shape(self):
         st = self.evaluation.stats
@@ -142,6 +220,7 @@ class ParsenetE2EStep(ParsenetSegStep):
     def step(self):
         if not self._warmed:
             self.warm_paths()
+        self.next_batch()
         self.bucket.zero()
         embedding, log_prob, embed_loss = self.model(self.x, self.labels, True)
         loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
@@ -155,9 +234,14 @@ class ParsenetE2EStep(ParsenetSegStep):
             res_total = sum(loss_b[b] for b in range(self.batch))     # the association of the per-shape sum
             loss = loss + res_total / self.batch
             loss.backward()
+            # The fit status (lstsq failure, non-finite residual) rides in the deferred download: it
+            # is read BEFORE the optimizer step, so a degenerate segment raises with the weights
+            # untouched, like the reference's skipped batch (train_parsenet_e2e.py:243-257).  The
+            # copy was queued behind the forward kernels; the device is still busy with the backward
+            # pass while the host waits for it.
+            self.last_metrics = finish()
             self.bucket.all_reduce_mean()
             self.opt.step()
-            self.last_metrics = finish()     # the download of the logged metrics: after everything is queued
             self.last_res = res_total
             return loss
         main = torch.cuda.current_stream(self.device)

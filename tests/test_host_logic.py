@@ -177,6 +177,65 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert r.returncode != 0
 
 
+def test_bench_whole_control_flow_on_two_gloo_ranks():
+    """bench.py's WHOLE control flow on two CPU ranks with the stub step: rank 0 pre-trains alone
+    (gradient all-reduce off) and broadcasts, timed loop, the second (dense) timed run from the
+    restored state, profiled steps, MAX over ranks, rank 0's single JSON line.  A rank mismatch or
+    an unpaired collective anywhere in that sequence deadlocks here — not first on the 8-GPU node."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub",
+                        "--steps", "6", "--warmup", "2", "--pretrain", "5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size_observed"] == 2 and rec["steps"] == 6
+    assert rec["value"] > 0 and rec["value_dense"] > 0 and rec["config"]["global_batch"] == 8
+    # the same on one rank (no process group at all)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--steps", "3",
+                        "--warmup", "1", "--pretrain", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 1
+
+
+def _pretrain_worker(rank, w, port, out):
+    import torch
+    import torch.distributed as dist
+    from parsenet_codebase_amd.dp import FlatGradBucket
+    from parsenet_codebase_amd.workloads import train_on_rank0_then_broadcast
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=w)
+    torch.manual_seed(rank)                       # different weights per rank before
+    net = torch.nn.Linear(3, 2)
+    bucket = FlatGradBucket(net.parameters())
+    ran = []
+
+    def train():
+        ran.append(rank)
+        for _ in range(3):                        # steps with the bucket's reduction call in them, like seg_step
+            bucket.zero()
+            net(torch.ones(1, 3)).sum().backward()
+            bucket.all_reduce_mean()              # must NOT be a collective here: rank 1 is not in these steps
+            with torch.no_grad():
+                net.weight -= 0.1 * net.weight.grad
+    train_on_rank0_then_broadcast(net, bucket, train)
+    state = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.zeros_like(state) for _ in range(w)]
+    dist.all_gather(both, state)
+    out[rank] = bool(torch.equal(both[0], both[1])) and ran == ([0] if rank == 0 else []) and bucket.collective
+    dist.destroy_process_group()
+
+
+def test_pretraining_runs_on_rank0_only_and_is_broadcast():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pretrain_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
 def test_flat_gradient_bucket_allreduce_gloo_world2():
     mgr = mp.Manager()
     out = mgr.dict()
