@@ -27,7 +27,7 @@ POOL = 16             # distinct shapes per rank the timed steps rotate through
 PRETRAIN_POOL = 64    # disjoint shapes of the pre-training stand-in (cfg5)
 
 
-def build_workload(name, device, rank, pretrain=600):
+def build_workload(name, device, rank, pretrain=2000):
     from parsenet_codebase_amd import workloads
     if name == "cfg4":
         B, N = 4, 10000
@@ -196,7 +196,7 @@ def kernel_roofline(step, nprof):
         ach = flops / avg_s / 1e12
         sparse = None
         executed = 1.0
-        if _ms.ARITH == "bf16x3" and _ms.SPARSE and plan_stats:
+        if _ms.ARITH == "bf16x3" and plan_stats:
             # block-sparse launches: the waves run the GEMMs of the tile pairs the plan keeps; the
             # others are rigorously below 1e-9 of the smallest row sum (csrc/meanshift_x3.h)
             col = {"meanshift_fwd": 1, "meanshift_bwd_rows": 2, "meanshift_bwd_cols": 3}[dom]
@@ -399,7 +399,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=-1,
                     help="extra steps with the in-library kernel timers on (default: one pass over the pool)")
     ap.add_argument("--no-dense", action="store_true", help="cfg5: skip the second timed run with dense mean-shift launches")
-    ap.add_argument("--pretrain", type=int, default=600,
+    ap.add_argument("--pretrain", type=int, default=2000,
                     help="cfg5: deterministic seg-only steps before the timed region (see workloads.ParsenetE2EStep)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -469,28 +469,69 @@ def main():
     # cfg5: the same steps once more with every mean-shift launch dense (PARSENET_MS_SPARSE=0 at run
     # time): the block-sparse plans are data dependent, the dense value is their floor
     elapsed_dense = None
-    sparse_on = False
+    ms_mode = None
+    _ms = None
     if args.workload == "cfg5":
         from parsenet_codebase_amd import mean_shift as _ms
-        sparse_on = _ms.SPARSE and _ms.ARITH == "bf16x3"
-    if (sparse_on and not args.no_dense) or stub:
+        if _ms.ARITH == "bf16x3":
+            ms_mode = _ms.SPARSE
+            calls_timed = dict(_ms.CALLS)
+    if (ms_mode not in (None, False) and not args.no_dense) or stub:
         restore(start)
-        if sparse_on:
+        if ms_mode is not None:
             _ms.SPARSE = False
         try:
             elapsed_dense = timed_run()
         finally:
-            if sparse_on:
-                _ms.SPARSE = True
+            if ms_mode is not None:
+                _ms.SPARSE = ms_mode
 
     # The profiled steps contain the gradient all-reduce, a collective: EVERY rank runs them
     # (only rank 0 keeps the per-kernel table), otherwise rank 0 would pair its all-reduce with
-    # the other ranks' barrier.  Default: one pass over the timed pool.
+    # the other ranks' barrier.  Default: one pass over the timed pool.  Their mean-shift launches
+    # are of ONE kind — the kind most timed steps used — so that a kernel family's average launch
+    # duration and its executed work belong together.
     restore(start)
     nprof = args.profile_steps
     if nprof < 0:
         nprof = max(1, getattr(step, "pool", step.batch) // step.batch)
-    roof, table = (None, {}) if stub else kernel_roofline(step, nprof)
+    census = None
+    if ms_mode is not None:
+        tally = torch.tensor([calls_timed["planned"], calls_timed["dense"]], dtype=torch.float64, device=device)
+        if world > 1:     # ONE decision for all ranks: the steps below contain collectives
+            dist.all_reduce(tally)
+        mostly_planned = bool(tally[0] > tally[1])
+        _ms.SPARSE = mostly_planned
+    try:
+        roof, table = (None, {}) if stub else kernel_roofline(step, nprof)
+        if ms_mode is not None and not mostly_planned:
+            # the plans of the timed pool all the same (one planned pass, not timed, not profiled):
+            # how much of the dense work a planned launch WOULD execute on this embedding
+            restore(start)
+            _ms.SPARSE = True
+            os.environ["PARSENET_MS_STATS"] = "1"
+            fr = []
+            for _ in range(max(1, step.pool // step.batch)):
+                _ms.LAST_PLAN_STATS = None
+                step.step()
+                if _ms.LAST_PLAN_STATS:
+                    fr.append(sum(t[0] for t in _ms.LAST_PLAN_STATS) / len(_ms.LAST_PLAN_STATS))
+            os.environ.pop("PARSENET_MS_STATS", None)
+            torch.cuda.synchronize()
+            if fr:
+                census = {"tile_pairs_a_plan_would_keep": {"min": min(fr), "mean": sum(fr) / len(fr), "max": max(fr)},
+                          "steps_sampled": len(fr)}
+    finally:
+        if ms_mode is not None:
+            _ms.SPARSE = ms_mode
+    if ms_mode is not None and roof is not None:
+        roof["meanshift_launches"] = {
+            "mode": {True: "planned (PARSENET_MS_SPARSE=1)", False: "dense (PARSENET_MS_SPARSE=0)"}.get(
+                ms_mode, "auto: plan one call, go dense for %d calls when the lists keep more than %.2f of their "
+                         "entries" % (_ms.AUTO_DENSE_STEPS, _ms.AUTO_DENSE_ABOVE)),
+            "timed_and_warmup_calls": calls_timed, "profiled_as": "planned" if mostly_planned else "dense"}
+        if census:
+            roof["meanshift_launches"].update(census)
     if stub:
         for _ in range(nprof):
             step.step()

@@ -361,6 +361,59 @@ int pn_bspline_eval_f32(const float* nu, const float* nv, const float* ctrl, con
 int pn_bspline_eval_bwd_f32(const float* nu, const float* nv, const float* gout, const float* affine,
                             int S, int gu, int gv, int cu, int cv, int wrap, float* gctrl, void* stream);
 
+/* ---- round-3 fusions (csrc/fused.hip) ------------------------------------------------------
+ * pn_edgeconv_bwd_stats_f32: step A of the fused edge-conv backward WITH its reductions (what
+ * src/model.py:127-156 / src/PointNet.py:186-205 leave to autograd through Conv2d -> Norm ->
+ * LeakyReLU -> max): from gout (B,Cout,N) and the forward's yext (B,N,Cout), mean / rstd writes
+ *   t (B,N,Cout) = gamma * gout * LeakyReLU'(z),  dgamma (Cout), dbeta (Cout) and the group means
+ *   c1c2 ((per_sample ? B : 1), groups, 2) that pn_edgeconv_bwd_f32 consumes (zeros when !dense:
+ *   evaluation-mode BatchNorm).  Fixed-order partial sums, fp64 combination. */
+size_t pn_edgeconv_bwd_stats_workspace(int B, int N, int Cout);
+int pn_edgeconv_bwd_stats_f32(const float* gout, const float* yext, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int B, int N, int k, int Cout,
+                              int groups, int per_sample, int dense, float slope, float* t, float* dgamma,
+                              float* dbeta, float* c1c2, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* Triplet embedding loss, src/segment_loss.py:85-123 (EmbeddingLoss.triplet_loss, the arithmetic
+ * after the numpy sampling): E (rows,D) unit-row embedding (D = 128); item p of P has num <= 32
+ * anchor/positive rows ia[p][:] and negative rows ib[p][:] (row indices into E) and a weight w[p]
+ * (1 / (pairs of its shape + 1e-8));  c_ij = relu(|a_i - p_j|^2 - |a_i - n_j|^2 + margin),
+ * item_loss[p] = w[p] * (sum_ij c_ij - sum_i c_ii) / (#(c_ij > 0) + 1), loss[0] = sum_p item_loss[p];
+ * item_scale[p] = w[p] / (# + 1) is kept for the backward.  _bwd ADDS gout[0] * d loss / d E into gE
+ * (rows,D), which the caller zeroes (a point can be sampled more than once: fp32 atomics). */
+int pn_triplet_fwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib, const float* w,
+                       int P, int num, float margin, float* item_loss, float* item_scale, float* loss,
+                       void* stream);
+int pn_triplet_bwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib,
+                       const float* item_scale, const float* gout, int P, int num, float margin, float* gE,
+                       void* stream);
+
+/* Memberships of the fitting stage in one pass: src/residual_utils.py:120 (weights = center @
+ * embedding^T), src/fitting_utils.py:306-325 (weights_normalize) and the labels of
+ * src/mean_shift.py:176-178 (arg-max over the centres, first index on ties).
+ * cen (B,CP,D) centre rows padded to CP in {16,32,64} (rows >= ncl[b] ignored), emb (B,N,D), D = 128,
+ * bw (B), ncl (B) int64.  Outputs Wraw, prob, Wn (B,CP,N) (padding rows of prob / Wn are zero),
+ * rowstat (B,CP,4) = (min_n prob, max_n (prob - min) + eps, arg-min, arg-max as int bits), labels
+ * (B,N) int64 or NULL.  _bwd: gWraw (B,CP,N) from gWn, the exact gradient of weights_normalize
+ * (min / max route to their first arg-min / arg-max column; clamp passes inclusively); rowgrad
+ * (B,CP,2) is scratch.  d cen and d emb are then two GEMMs on gWraw (the caller's). */
+int pn_membership_fwd_f32(const float* cen, const float* emb, const float* bw, const int64_t* ncl, int B,
+                          int CP, int N, int D, float eps, float* Wraw, float* prob, float* Wn,
+                          float* rowstat, int64_t* labels, void* stream);
+int pn_membership_bwd_f32(const float* gWn, const float* Wraw, const float* prob, const float* rowstat,
+                          const float* bw, const int64_t* ncl, int B, int CP, int N, float* rowgrad,
+                          float* gWraw, void* stream);
+
+/* y = act(x * scale[c] + shift[c]) on (B,C,N): evaluation-mode BatchNorm1d folded with the
+ * activation that follows it (src/model.py:160-176: conv5/bn5 LeakyReLU(0.2), conv6/bn6 and
+ * conv7/bn7 ReLU of the frozen SplineNets).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ * _bwd: gx = gy * scale[c] * act'(y). */
+int pn_affine_act_fwd_f32(const float* x, const float* scale, const float* shift, int B, int C, int N,
+                          int act, float slope, float* y, void* stream);
+int pn_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, int B, int C, int N, int act,
+                          float slope, float* gx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 8   # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 9   # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -111,6 +111,17 @@ SIGNATURES = {
                                     c_int, c_void_p, c_void_p]),
     "pn_bspline_eval_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_void_p]),
+    "pn_edgeconv_bwd_stats_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "pn_edgeconv_bwd_stats_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_float] + [c_void_p] * 5 +
+                                  [c_size_t, c_void_p]),
+    "pn_triplet_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_triplet_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_float, c_void_p, c_void_p]),
+    "pn_membership_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float] + [c_void_p] * 5 + [c_void_p]),
+    "pn_membership_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 2 + [c_void_p]),
+    "pn_affine_act_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p]),
+    "pn_affine_act_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,647 @@
+// Round-3 fusions of what used to be strings of small tensor-library launches on the timed
+// path (profiles/r02_cfg5_torch_sites.txt: 905 launches, 6.2 ms per cfg5 step):
+//   * edge-conv backward, step A with all its reductions (d gamma, d beta, the group means c1 / c2
+//     of the normalisation gradient) — graph.py used ~20 launches per layer for them;
+//   * the triplet embedding loss of src/segment_loss.py:85-123, forward and backward, one
+//     workgroup per (shape, segment pair);
+//   * memberships: centres . embedding^T, weights_normalize (src/fitting_utils.py:306-325) and the
+//     nearest-centre labels of the non-maximum suppression (src/mean_shift.py:176-178) in one pass
+//     over the points, with the exact backward;
+//   * per-channel affine map + activation (evaluation-mode BatchNorm1d + LeakyReLU / ReLU of the
+//     frozen SplineNets' heads, src/model.py:160-176).
+// All reductions have a fixed order (partial sums per workgroup, combined in index order, fp64
+// where a cancellation could matter): results are reproducible run to run.
+#include "common.h"
+
+// =============================================================================================
+// edge-conv backward, step A + reductions
+// =============================================================================================
+// t[b,n,c] = gamma[c] * gout[b,c,n] * (z > 0 ? 1 : slope),  z = gamma*yhat + beta,
+// yhat = (yext - mean) * rstd; partial[b][nblk][c] = (sum gz, sum gz*yhat) over the block's 32 points.
+__global__ __launch_bounds__(256) void pn_ecb_prep_kernel(
+    const float* __restrict__ gout, const float* __restrict__ yext, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int N, int Cout, int Cg, int per_sample, float slope, float* __restrict__ t,
+    float2* __restrict__ partial) {
+  __shared__ float tile[32][33];
+  __shared__ float2 red[8][32];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int G = Cout / Cg;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, n = n0 + tx;
+    if (n < N && c < Cout) tile[i][tx] = gout[((size_t)b * Cout + c) * N + n];
+  }
+  __syncthreads();
+  float a = 0.f, bm = 0.f;
+  const int c = c0 + tx;
+  if (c < Cout) {
+    const int sidx = (per_sample ? b : 0) * G + c / Cg;
+    const float mu = mean[sidx], r = rstd[sidx], ga = gamma[c], be = beta[c];
+    for (int i = ty; i < 32; i += 8) {
+      const int n = n0 + i;
+      if (n < N) {
+        const size_t o = ((size_t)b * N + n) * Cout + c;
+        const float yh = (yext[o] - mu) * r;
+        const float z = __builtin_fmaf(ga, yh, be);
+        const float gz = tile[tx][i] * (z > 0.f ? 1.f : slope);
+        t[o] = gz * ga;
+        a += gz;
+        bm += gz * yh;
+      }
+    }
+  }
+  red[ty][tx] = make_float2(a, bm);
+  __syncthreads();
+  if (ty == 0 && c < Cout) {
+    float2 s = red[0][tx];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      s.x += red[j][tx].x;
+      s.y += red[j][tx].y;
+    }
+    partial[((size_t)b * gridDim.y + blockIdx.y) * Cout + c] = s;
+  }
+}
+
+// AB[b][c] = (sum_n gz, sum_n gz*yhat) in fp64; with per-sample statistics also the group means
+// c1c2[b][g] = (sum_{c in g} gamma_c A, sum_{c in g} gamma_c B) / M.
+__global__ __launch_bounds__(256) void pn_ecb_reduce_kernel(const float2* __restrict__ partial, int nblk,
+                                                            int Cout, int Cg, int per_sample, int dense,
+                                                            double M, const float* __restrict__ gamma,
+                                                            double2* __restrict__ AB, float* __restrict__ c1c2) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+    double a = 0.0, bm = 0.0;
+    for (int j = 0; j < nblk; ++j) {
+      const float2 p = partial[((size_t)b * nblk + j) * Cout + c];
+      a += (double)p.x;
+      bm += (double)p.y;
+    }
+    AB[(size_t)b * Cout + c] = make_double2(a, bm);
+  }
+  if (!per_sample) return;
+  __syncthreads();
+  const int G = Cout / Cg;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    if (dense)
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+        const double2 v = AB[(size_t)b * Cout + c];
+        s1 += (double)gamma[c] * v.x;
+        s2 += (double)gamma[c] * v.y;
+      }
+    c1c2[((size_t)b * G + g) * 2] = (float)(s1 / M);
+    c1c2[((size_t)b * G + g) * 2 + 1] = (float)(s2 / M);
+  }
+}
+
+// dbeta, dgamma over the batch; with batch statistics also c1c2[0][g].
+__global__ __launch_bounds__(256) void pn_ecb_finish_kernel(const double2* __restrict__ AB, int B, int Cout, int Cg,
+                                                            int per_sample, int dense, double M,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ c1c2) {
+  const int G = Cout / Cg;
+  for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+    double a = 0.0, bm = 0.0;
+    for (int b = 0; b < B; ++b) {
+      const double2 v = AB[(size_t)b * Cout + c];
+      a += v.x;
+      bm += v.y;
+    }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)bm;
+  }
+  if (per_sample) return;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    if (dense)
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c)
+        for (int b = 0; b < B; ++b) {
+          const double2 v = AB[(size_t)b * Cout + c];
+          s1 += (double)gamma[c] * v.x;
+          s2 += (double)gamma[c] * v.y;
+        }
+    c1c2[g * 2] = (float)(s1 / M);
+    c1c2[g * 2 + 1] = (float)(s2 / M);
+  }
+}
+
+extern "C" size_t pn_edgeconv_bwd_stats_workspace(int B, int N, int Cout) {
+  return pn_align_up((size_t)B * pn_cdiv(N, 32) * Cout * sizeof(float2), 256) +
+         pn_align_up((size_t)B * Cout * sizeof(double2), 256);
+}
+
+extern "C" int pn_edgeconv_bwd_stats_f32(const float* gout, const float* yext, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, int B, int N, int k, int Cout,
+                                         int groups, int per_sample, int dense, float slope, float* t,
+                                         float* dgamma, float* dbeta, float* c1c2, void* workspace,
+                                         size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(gout && yext && mean && rstd && gamma && beta && t && dgamma && dbeta && c1c2 && workspace,
+               "pn_edgeconv_bwd_stats_f32: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && groups > 0 && Cout % groups == 0,
+               "pn_edgeconv_bwd_stats_f32: B=%d N=%d k=%d Cout=%d groups=%d", B, N, k, Cout, groups);
+  PN_CHECK_ARG(workspace_bytes >= pn_edgeconv_bwd_stats_workspace(B, N, Cout),
+               "pn_edgeconv_bwd_stats_f32: workspace too small");
+  const int nblk = pn_cdiv(N, 32), Cg = Cout / groups;
+  float2* partial = (float2*)workspace;
+  double2* AB = (double2*)((char*)workspace + pn_align_up((size_t)B * nblk * Cout * sizeof(float2), 256));
+  const double M = (double)Cg * N * k * (per_sample ? 1 : B);
+  PN_PROF("edgeconv_bwd_stats", stream);
+  hipLaunchKernelGGL(pn_ecb_prep_kernel, dim3(pn_cdiv(Cout, 32), nblk, B), dim3(256), 0, stream, gout, yext, mean,
+                     rstd, gamma, beta, N, Cout, Cg, per_sample, slope, t, partial);
+  hipLaunchKernelGGL(pn_ecb_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float2*)partial, nblk, Cout, Cg,
+                     per_sample, dense, M, gamma, AB, c1c2);
+  hipLaunchKernelGGL(pn_ecb_finish_kernel, dim3(1), dim3(256), 0, stream, (const double2*)AB, B, Cout, Cg, per_sample,
+                     dense, M, gamma, dgamma, dbeta, c1c2);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// =============================================================================================
+// triplet embedding loss (src/segment_loss.py:85-123)
+// =============================================================================================
+// Item p: rows ia[p][0..num) (anchor / positive segment) and ib[p][0..num) (negative segment) of
+// the unit-row embedding E (rows of D floats).  c[i][j] = relu(|a_i - p_j|^2 - |a_i - n_j|^2 + margin);
+// loss_p = (sum_ij c - sum_i c_ii) / (#(c > 0) + 1) * w[p].  One workgroup per item; rows staged in
+// LDS.  out[p] = loss_p (summed on the host side in index order by a tiny reduction below).
+#define TRI_MAXNUM 32
+template <int D>
+__global__ __launch_bounds__(256) void pn_triplet_fwd_kernel(const float* __restrict__ E, const int64_t* __restrict__ ia,
+                                                             const int64_t* __restrict__ ib, const float* __restrict__ w,
+                                                             int num, float margin, float* __restrict__ item_loss,
+                                                             float* __restrict__ item_scale) {
+  __shared__ float P1[TRI_MAXNUM][D + 1];
+  __shared__ float P2[TRI_MAXNUM][D + 1];
+  __shared__ float rs[4];
+  __shared__ int rc[4];
+  const int p = blockIdx.x;
+  for (int e = threadIdx.x; e < num * D; e += 256) {
+    const int r = e / D, d = e - r * D;
+    P1[r][d] = E[(size_t)ia[(size_t)p * num + r] * D + d];
+    P2[r][d] = E[(size_t)ib[(size_t)p * num + r] * D + d];
+  }
+  __syncthreads();
+  float s = 0.f;
+  int cnt = 0;
+  for (int e = threadIdx.x; e < num * num; e += 256) {
+    const int i = e / num, j = e - i * num;
+    float dp = 0.f, dn = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float a = P1[i][d];
+      const float x = a - P1[j][d], y = a - P2[j][d];
+      dp = __builtin_fmaf(x, x, dp);
+      dn = __builtin_fmaf(y, y, dn);
+    }
+    const float c = fmaxf(dp - dn + margin, 0.f);
+    cnt += c > 0.f;
+    if (i != j) s += c;
+  }
+  s = pn_wave_sum(s);
+  cnt = pn_wave_sum_i(cnt);
+  if ((threadIdx.x & 63) == 0) {
+    rs[threadIdx.x >> 6] = s;
+    rc[threadIdx.x >> 6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    const float sat = (float)(rc[0] + rc[1] + rc[2] + rc[3]) + 1.f;
+    const float sc = w[p] / sat;
+    item_loss[p] = tot * sc;
+    item_scale[p] = sc;
+  }
+}
+
+// sum of the item losses in index order (one thread: P <= a few hundred)
+__global__ void pn_triplet_sum_kernel(const float* __restrict__ item_loss, int P, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += item_loss[p];
+    out[0] = s;
+  }
+}
+
+// Backward: gE[row] += g * scale_p * d c_ij / d row for every active (c > 0, i != j) entry:
+//   d/d a_i = 2 (n_j - p_j),  d/d p_j = -2 (a_i - p_j),  d/d n_j = 2 (a_i - n_j)
+// (a_i = P1[i], p_j = P1[j]).  Per item the three sums are formed per row in LDS-resident form
+// and added to gE with fp32 atomics (a point can be sampled several times; the sums per item are
+// ordered, the cross-item order is the atomics').
+template <int D>
+__global__ __launch_bounds__(256) void pn_triplet_bwd_kernel(const float* __restrict__ E, const int64_t* __restrict__ ia,
+                                                             const int64_t* __restrict__ ib,
+                                                             const float* __restrict__ item_scale,
+                                                             const float* __restrict__ gout, int num, float margin,
+                                                             float* __restrict__ gE) {
+  __shared__ float P1[TRI_MAXNUM][D + 1];
+  __shared__ float P2[TRI_MAXNUM][D + 1];
+  __shared__ unsigned int act[TRI_MAXNUM];      // act[i] bit j: c_ij > 0 and i != j
+  const int p = blockIdx.x;
+  for (int e = threadIdx.x; e < num * D; e += 256) {
+    const int r = e / D, d = e - r * D;
+    P1[r][d] = E[(size_t)ia[(size_t)p * num + r] * D + d];
+    P2[r][d] = E[(size_t)ib[(size_t)p * num + r] * D + d];
+  }
+  if (threadIdx.x < TRI_MAXNUM) act[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int e = threadIdx.x; e < num * num; e += 256) {
+    const int i = e / num, j = e - i * num;
+    float dp = 0.f, dn = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float a = P1[i][d];
+      const float x = a - P1[j][d], y = a - P2[j][d];
+      dp = __builtin_fmaf(x, x, dp);
+      dn = __builtin_fmaf(y, y, dn);
+    }
+    if (dp - dn + margin > 0.f && i != j) atomicOr(&act[i], 1u << j);
+  }
+  __syncthreads();
+  const float g2 = 2.f * gout[0] * item_scale[p];
+  // thread -> (row r, channel d): three gradient rows per r
+  for (int e = threadIdx.x; e < num * D; e += 256) {
+    const int r = e / D, d = e - r * D;
+    // as anchor i = r: sum_j act[r][j] * (n_j - p_j)
+    float ga = 0.f;
+    const unsigned int mr = act[r];
+    for (int j = 0; j < num; ++j)
+      if ((mr >> j) & 1u) ga += P2[j][d] - P1[j][d];
+    // as positive j = r: - sum_i act[i][r] * (a_i - p_r);  as negative j = r: + sum_i act[i][r] * (a_i - n_r)
+    float gp = 0.f, gn = 0.f;
+    const float pr = P1[r][d], nr = P2[r][d];
+    for (int i = 0; i < num; ++i)
+      if ((act[i] >> r) & 1u) {
+        gp -= P1[i][d] - pr;
+        gn += P1[i][d] - nr;
+      }
+    const float g1 = g2 * (ga + gp), gneg = g2 * gn;
+    if (g1 != 0.f) atomicAdd(&gE[(size_t)ia[(size_t)p * num + r] * D + d], g1);
+    if (gneg != 0.f) atomicAdd(&gE[(size_t)ib[(size_t)p * num + r] * D + d], gneg);
+  }
+}
+
+extern "C" int pn_triplet_fwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib,
+                                  const float* w, int P, int num, float margin, float* item_loss,
+                                  float* item_scale, float* loss, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(E && ia && ib && w && item_loss && item_scale && loss, "pn_triplet_fwd_f32: null pointer");
+  PN_CHECK_ARG(P > 0 && rows > 0 && num >= 1 && num <= TRI_MAXNUM, "pn_triplet_fwd_f32: P=%d num=%d (max %d)", P,
+               num, TRI_MAXNUM);
+  if (D != 128) {
+    pn_set_error("pn_triplet_fwd_f32: embedding size %d (128 supported)", D);
+    return PN_ERR_UNSUPPORTED;
+  }
+  PN_PROF("triplet_fwd", stream);
+  hipLaunchKernelGGL(pn_triplet_fwd_kernel<128>, dim3(P), dim3(256), 0, stream, E, ia, ib, w, num, margin, item_loss,
+                     item_scale);
+  hipLaunchKernelGGL(pn_triplet_sum_kernel, dim3(1), dim3(64), 0, stream, (const float*)item_loss, P, loss);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+extern "C" int pn_triplet_bwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib,
+                                  const float* item_scale, const float* gout, int P, int num, float margin,
+                                  float* gE, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(E && ia && ib && item_scale && gout && gE, "pn_triplet_bwd_f32: null pointer");
+  PN_CHECK_ARG(P > 0 && rows > 0 && num >= 1 && num <= TRI_MAXNUM, "pn_triplet_bwd_f32: P=%d num=%d", P, num);
+  if (D != 128) {
+    pn_set_error("pn_triplet_bwd_f32: embedding size %d (128 supported)", D);
+    return PN_ERR_UNSUPPORTED;
+  }
+  PN_PROF("triplet_bwd", stream);
+  hipLaunchKernelGGL(pn_triplet_bwd_kernel<128>, dim3(P), dim3(256), 0, stream, E, ia, ib, item_scale, gout, num,
+                     margin, gE);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// =============================================================================================
+// memberships: centres . embedding^T -> weights_normalize (+ nearest-centre labels)
+// =============================================================================================
+// cen (B,CP,D) padded centre rows (rows >= ncl[b] ignored), emb (B,N,D), bw (B).  Per point n:
+//   Wraw[c] = cen_c . emb_n                    (fp32 fma chain over the channels in order)
+//   p[c]    = exp(clamp(Wraw[c] / b^2 / 2, -75, 75))   for c < ncl, 0 for padding rows
+//   prob[c] = p[c] / sum_c p[c]                (src/fitting_utils.py:314-317)
+//   label   = first arg-max over c < ncl of Wraw[c]      (src/mean_shift.py:176-178)
+// then per row c (second kernel): m = min_n prob, s = max_n (prob - m) + eps and
+//   Wn[c][n] = ncl > 1 ? (prob - m) / s : prob           (:319-324)
+// Block = 64 points x 4 waves; wave w owns centre rows [w * CP/4, (w+1) * CP/4).
+#define MB_D 128
+template <int CP>
+__global__ __launch_bounds__(256) void pn_member_fwd_kernel(const float* __restrict__ cen, const float* __restrict__ emb,
+                                                            const float* __restrict__ bw, const int64_t* __restrict__ ncl,
+                                                            int N, float* __restrict__ Wraw, float* __restrict__ prob,
+                                                            int64_t* __restrict__ labels) {
+  constexpr int RW = CP / 4;                         // rows per wave
+  __shared__ float sc[CP][MB_D];                     // centre rows (wave-uniform reads)
+  __shared__ float psum[4][64];
+  __shared__ float pbest[4][64];
+  __shared__ int pbidx[4][64];
+  const int b = blockIdx.y, n0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nc = (int)ncl[b];
+  for (int e = threadIdx.x; e < CP * MB_D; e += 256) sc[e / MB_D][e % MB_D] = cen[(size_t)b * CP * MB_D + e];
+  __syncthreads();
+  // lane = point: its embedding row streams through registers 4 channels at a time (a 128-byte
+  // line serves 8 consecutive loads of the lane; the 4 waves of the block share the tile in L1)
+  const int nl = n0 + lane < N ? n0 + lane : N - 1;
+  const float4* __restrict__ er = (const float4*)(emb + ((size_t)b * N + nl) * MB_D);
+  float acc[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) acc[i] = 0.f;
+  for (int d4 = 0; d4 < MB_D / 4; ++d4) {
+    const float4 e = er[d4];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float* __restrict__ cr = &sc[wave * RW + i][4 * d4];
+      float a = acc[i];
+      a = __builtin_fmaf(cr[0], e.x, a);
+      a = __builtin_fmaf(cr[1], e.y, a);
+      a = __builtin_fmaf(cr[2], e.z, a);
+      a = __builtin_fmaf(cr[3], e.w, a);
+      acc[i] = a;
+    }
+  }
+  const float bb = bw[b];
+  const float b2 = bb * bb;
+  float p[RW];
+  float s = 0.f, best = -INFINITY;
+  int bidx = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int c = wave * RW + i;
+    const float x = acc[i] / b2 / 2.f;
+    p[i] = c < nc ? expf(fminf(fmaxf(x, -75.f), 75.f)) : 0.f;
+    s += p[i];
+    if (c < nc && acc[i] > best) {
+      best = acc[i];
+      bidx = c;
+    }
+  }
+  psum[wave][lane] = s;
+  pbest[wave][lane] = best;
+  pbidx[wave][lane] = bidx;
+  __syncthreads();
+  const float tot = ((psum[0][lane] + psum[1][lane]) + psum[2][lane]) + psum[3][lane];
+  const int n = n0 + lane;
+  if (n < N) {
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const size_t o = ((size_t)b * CP + wave * RW + i) * N + n;
+      Wraw[o] = acc[i];
+      prob[o] = p[i] / tot;
+    }
+    if (wave == 0 && labels) {
+      float bv = pbest[0][lane];
+      int bi = pbidx[0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (pbest[w][lane] > bv) {       // strictly greater: ties stay with the smaller row index
+          bv = pbest[w][lane];
+          bi = pbidx[w][lane];
+        }
+      labels[(size_t)b * N + n] = bi == 0x7fffffff ? 0 : bi;
+    }
+  }
+}
+
+// one workgroup per (b, c) row: min / max of prob with first-index ties, then Wn.
+// rowstat[b][c] = (m, s, argmin, argmax) as 4 floats (indices bit-cast).
+__global__ __launch_bounds__(256) void pn_member_rows_kernel(const float* __restrict__ prob,
+                                                             const int64_t* __restrict__ ncl, int CP, int N, float eps,
+                                                             float* __restrict__ Wn, float4* __restrict__ rowstat) {
+  __shared__ float smin[4], smax[4];
+  __shared__ int simin[4], simax[4];
+  const int row = blockIdx.x, b = row / CP, c = row % CP;
+  const int nc = (int)ncl[b];
+  const float* __restrict__ pr = prob + (size_t)row * N;
+  float* __restrict__ wr = Wn + (size_t)row * N;
+  if (c >= nc) {
+    for (int n = threadIdx.x; n < N; n += 256) wr[n] = 0.f;
+    if (threadIdx.x == 0) rowstat[row] = make_float4(0.f, 1.f, __int_as_float(0), __int_as_float(0));
+    return;
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  int imn = 0x7fffffff, imx = 0x7fffffff;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float v = pr[n];
+    if (v < mn) { mn = v; imn = n; }
+    if (v > mx) { mx = v; imx = n; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float omn = __shfl_xor(mn, o, 64), omx = __shfl_xor(mx, o, 64);
+    const int oimn = __shfl_xor(imn, o, 64), oimx = __shfl_xor(imx, o, 64);
+    if (omn < mn || (omn == mn && oimn < imn)) { mn = omn; imn = oimn; }
+    if (omx > mx || (omx == mx && oimx < imx)) { mx = omx; imx = oimx; }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    smin[wave] = mn; simin[wave] = imn; smax[wave] = mx; simax[wave] = imx;
+  }
+  __syncthreads();
+  mn = smin[0]; imn = simin[0]; mx = smax[0]; imx = simax[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    if (smin[w] < mn || (smin[w] == mn && simin[w] < imn)) { mn = smin[w]; imn = simin[w]; }
+    if (smax[w] > mx || (smax[w] == mx && simax[w] < imx)) { mx = smax[w]; imx = simax[w]; }
+  }
+  const float s = (mx - mn) + eps;
+  if (threadIdx.x == 0) rowstat[row] = make_float4(mn, s, __int_as_float(imn), __int_as_float(imx));
+  if (nc > 1) {
+    for (int n = threadIdx.x; n < N; n += 256) wr[n] = (pr[n] - mn) / s;
+  } else {
+    for (int n = threadIdx.x; n < N; n += 256) wr[n] = pr[n];
+  }
+}
+
+// Backward, rows: R0 = sum_n g, R1 = sum_n g * (prob - m)  ->  rowgrad[b][c] = (g_den, g_m)
+//   g_den = -R1 / s^2 (goes to the arg-max column),  g_m = -(R0 / s + g_den) (to the arg-min column)
+__global__ __launch_bounds__(256) void pn_member_bwd_rows_kernel(const float* __restrict__ gWn,
+                                                                 const float* __restrict__ prob,
+                                                                 const float4* __restrict__ rowstat,
+                                                                 const int64_t* __restrict__ ncl, int CP, int N,
+                                                                 float2* __restrict__ rowgrad) {
+  __shared__ float r0s[4], r1s[4];
+  const int row = blockIdx.x, b = row / CP, c = row % CP;
+  const int nc = (int)ncl[b];
+  if (c >= nc || nc <= 1) {
+    if (threadIdx.x == 0) rowgrad[row] = make_float2(0.f, 0.f);
+    return;
+  }
+  const float4 st = rowstat[row];
+  const float* __restrict__ g = gWn + (size_t)row * N;
+  const float* __restrict__ pr = prob + (size_t)row * N;
+  float r0 = 0.f, r1 = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float gv = g[n];
+    r0 += gv;
+    r1 = __builtin_fmaf(gv, pr[n] - st.x, r1);
+  }
+  r0 = pn_wave_sum(r0);
+  r1 = pn_wave_sum(r1);
+  if ((threadIdx.x & 63) == 0) {
+    r0s[threadIdx.x >> 6] = r0;
+    r1s[threadIdx.x >> 6] = r1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float R0 = (r0s[0] + r0s[1]) + (r0s[2] + r0s[3]), R1 = (r1s[0] + r1s[1]) + (r1s[2] + r1s[3]);
+    const float gden = -R1 / (st.y * st.y);
+    rowgrad[row] = make_float2(gden, -(R0 / st.y + gden));
+  }
+}
+
+// Backward, points: thread per point, loop over the centre rows.
+template <int CP>
+__global__ __launch_bounds__(256) void pn_member_bwd_points_kernel(
+    const float* __restrict__ gWn, const float* __restrict__ Wraw, const float* __restrict__ prob,
+    const float4* __restrict__ rowstat, const float2* __restrict__ rowgrad, const float* __restrict__ bw,
+    const int64_t* __restrict__ ncl, int N, float* __restrict__ gWraw) {
+  __shared__ float4 sst[CP];
+  __shared__ float2 sgr[CP];
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  const int nc = (int)ncl[b];
+  if (threadIdx.x < CP) {
+    sst[threadIdx.x] = rowstat[(size_t)b * CP + threadIdx.x];
+    sgr[threadIdx.x] = rowgrad[(size_t)b * CP + threadIdx.x];
+  }
+  __syncthreads();
+  if (n >= N) return;
+  const float bb = bw[b];
+  const float b2 = bb * bb;
+  float gp[CP];
+  float dot = 0.f, tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    gp[c] = 0.f;
+    if (c < nc) {
+      const size_t o = ((size_t)b * CP + c) * N + n;
+      float g = gWn[o];
+      if (nc > 1) {
+        g = g / sst[c].y;
+        if (n == __float_as_int(sst[c].w)) g += sgr[c].x;
+        if (n == __float_as_int(sst[c].z)) g += sgr[c].y;
+      }
+      gp[c] = g;
+      dot = __builtin_fmaf(g, prob[o], dot);
+      const float x = Wraw[o] / b2 / 2.f;
+      tot += expf(fminf(fmaxf(x, -75.f), 75.f));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    const size_t o = ((size_t)b * CP + c) * N + n;
+    float out = 0.f;
+    if (c < nc) {
+      const float x = Wraw[o] / b2 / 2.f;
+      const bool inside = x >= -75.f && x <= 75.f;          // torch.clamp passes the gradient inclusively
+      // d prob / d p: (g_c - sum g prob) / tot;  d p / d x = p (inside the clamp);  p / tot = prob
+      out = inside ? (gp[c] - dot) * prob[o] / b2 / 2.f : 0.f;
+    }
+    gWraw[o] = out;
+  }
+  (void)tot;
+}
+
+extern "C" int pn_membership_fwd_f32(const float* cen, const float* emb, const float* bw, const int64_t* ncl, int B,
+                                     int CP, int N, int D, float eps, float* Wraw, float* prob, float* Wn,
+                                     float* rowstat, int64_t* labels, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(cen && emb && bw && ncl && Wraw && prob && Wn && rowstat, "pn_membership_fwd_f32: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_membership_fwd_f32: B=%d N=%d", B, N);
+  if (D != MB_D || (CP != 16 && CP != 32 && CP != 64)) {
+    pn_set_error("pn_membership_fwd_f32: D=%d CP=%d (D = 128 and CP in {16, 32, 64} supported)", D, CP);
+    return PN_ERR_UNSUPPORTED;
+  }
+  PN_PROF("membership_fwd", stream);
+  dim3 grid(pn_cdiv(N, 64), B);
+#define MB_F(C)                                                                                              \
+  hipLaunchKernelGGL(pn_member_fwd_kernel<C>, grid, dim3(256), 0, stream, cen, emb, bw, ncl, N, Wraw, prob, \
+                     labels)
+  if (CP == 16) MB_F(16);
+  else if (CP == 32) MB_F(32);
+  else MB_F(64);
+#undef MB_F
+  hipLaunchKernelGGL(pn_member_rows_kernel, dim3(B * CP), dim3(256), 0, stream, (const float*)prob, ncl, CP, N, eps,
+                     Wn, (float4*)rowstat);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+extern "C" int pn_membership_bwd_f32(const float* gWn, const float* Wraw, const float* prob, const float* rowstat,
+                                     const float* bw, const int64_t* ncl, int B, int CP, int N, float* rowgrad,
+                                     float* gWraw, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(gWn && Wraw && prob && rowstat && bw && ncl && rowgrad && gWraw, "pn_membership_bwd_f32: null pointer");
+  if (CP != 16 && CP != 32 && CP != 64) {
+    pn_set_error("pn_membership_bwd_f32: CP=%d (16, 32, 64 supported)", CP);
+    return PN_ERR_UNSUPPORTED;
+  }
+  PN_PROF("membership_bwd", stream);
+  hipLaunchKernelGGL(pn_member_bwd_rows_kernel, dim3(B * CP), dim3(256), 0, stream, gWn, prob, (const float4*)rowstat,
+                     ncl, CP, N, (float2*)rowgrad);
+  dim3 grid(pn_cdiv(N, 256), B);
+#define MB_B(C)                                                                                          \
+  hipLaunchKernelGGL(pn_member_bwd_points_kernel<C>, grid, dim3(256), 0, stream, gWn, Wraw, prob,        \
+                     (const float4*)rowstat, (const float2*)rowgrad, bw, ncl, N, gWraw)
+  if (CP == 16) MB_B(16);
+  else if (CP == 32) MB_B(32);
+  else MB_B(64);
+#undef MB_B
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// =============================================================================================
+// per-channel affine map + activation on (B,C,N): y = act(x * scale[c] + shift[c])
+// =============================================================================================
+// act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  Backward: gx = gy * scale[c] * act'(y).
+__global__ void pn_affine_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, long long total, int C, int N, int act,
+                                         float slope, float* __restrict__ y) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)((e / N) % C);
+  float v = x[e] * scale[c] + shift[c];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = v > 0.f ? v : v * slope;
+  y[e] = v;
+}
+
+__global__ void pn_affine_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                         const float* __restrict__ scale, long long total, int C, int N, int act,
+                                         float slope, float* __restrict__ gx) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)((e / N) % C);
+  float g = gy[e] * scale[c];
+  if (act == 1) g = y[e] > 0.f ? g : 0.f;
+  else if (act == 2) g = y[e] > 0.f ? g : g * slope;
+  gx[e] = g;
+}
+
+extern "C" int pn_affine_act_fwd_f32(const float* x, const float* scale, const float* shift, int B, int C, int N,
+                                     int act, float slope, float* y, void* stream) {
+  PN_CHECK_ARG(x && scale && shift && y && B > 0 && C > 0 && N > 0 && act >= 0 && act <= 2,
+               "pn_affine_act_fwd_f32: bad arguments");
+  const long long total = (long long)B * C * N;
+  hipLaunchKernelGGL(pn_affine_act_fwd_kernel, dim3(pn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     shift, total, C, N, act, slope, y);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+extern "C" int pn_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, int B, int C, int N, int act,
+                                     float slope, float* gx, void* stream) {
+  PN_CHECK_ARG(gy && y && scale && gx && B > 0 && C > 0 && N > 0 && act >= 0 && act <= 2,
+               "pn_affine_act_bwd_f32: bad arguments");
+  const long long total = (long long)B * C * N;
+  hipLaunchKernelGGL(pn_affine_act_bwd_kernel, dim3(pn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, y,
+                     scale, total, C, N, act, slope, gx);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

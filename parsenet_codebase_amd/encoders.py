@@ -50,6 +50,56 @@ def batch_norm_1d(x, bn):
     return x * scale.view(1, -1, 1) + shift.view(1, -1, 1)
 
 
+class _AffineAct(torch.autograd.Function):
+    """act(x * scale[c] + shift[c]) on (B,C,N) in one launch (csrc/fused.hip); scale / shift are
+    constants of a frozen evaluation-mode BatchNorm (no gradient flows to them)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, act, slope):
+        from . import kernels as K
+        y = K.affine_act_fwd(x, scale, shift, act, slope)
+        ctx.save_for_backward(y, scale)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import kernels as K
+        y, scale = ctx.saved_tensors
+        return K.affine_act_bwd(gy, y, scale, *ctx.cfg), None, None, None, None
+
+
+_ACT = {"none": 0, "relu": 1, "leaky": 2}
+
+
+def conv_bn_act(x, conv, bn, act, slope=0.0):
+    """act(bn(conv1x1(x))) for x (B,Ci,N).  A FROZEN evaluation-mode BatchNorm1d (the SplineNets of
+    the fitting stage: src/model.py:160-176 under eval(), parameters without gradient) is the
+    per-channel affine map it is, folded with the convolution's bias and the activation into ONE
+    launch after the GEMM; scale and shift are cached on the module until one of its tensors
+    changes.  Training mode, or parameters that want a gradient: the generic expressions."""
+    frozen = not (bn.training or bn.running_mean is None) and x.is_cuda and not (
+        torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (bn.weight, bn.bias, conv.bias)))
+    if not frozen:
+        y = batch_norm_1d(conv1x1(x, conv), bn)
+        return F.relu(y) if act == "relu" else F.leaky_relu(y, slope) if act == "leaky" else y
+    src = (bn.running_mean, bn.running_var, bn.weight, bn.bias, conv.bias)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
+    hit = bn.__dict__.get("_pn_affine")
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            scale = torch.rsqrt(bn.running_var + bn.eps)
+            shift = -bn.running_mean * scale
+            if bn.weight is not None:
+                scale = scale * bn.weight
+                shift = shift * bn.weight + bn.bias
+            if conv.bias is not None:
+                shift = shift + conv.bias * scale
+        hit = (key, scale.contiguous(), shift.contiguous())
+        bn.__dict__["_pn_affine"] = hit
+    return _AffineAct.apply(weight_bmm(conv.weight[:, :, 0], x), hit[1], hit[2], _ACT[act], slope)
+
+
 def _edge_layer(cin2, cout, norm):
     # Sequential only to reproduce the reference's parameter names ("convN.0.weight"); the
     # forward pass feeds the weight to the fused kernel instead of calling it.
@@ -103,7 +153,7 @@ class DGCNNControlPoints(nn.Module):
             idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
-        x = F.leaky_relu(batch_norm_1d(conv1x1(torch.cat(feats, dim=1), self.conv5[0]), self.bn5), 0.2)
+        x = conv_bn_act(torch.cat(feats, dim=1), self.conv5[0], self.bn5, "leaky", 0.2)
         if isinstance(weights, torch.Tensor):
             # the reference reshapes to (1,1,-1) (one segment per call); a (B,n) matrix weights
             # every item of a batch of segments with its own memberships
@@ -111,8 +161,8 @@ class DGCNNControlPoints(nn.Module):
         # max over the points (F.adaptive_max_pool1d(x, 1) in the reference; torch's pooling kernel
         # takes 0.5 ms on a 1024 x 5000 input, the reduction 20 us)
         x = x.max(dim=2, keepdim=True)[0]
-        x = F.relu(batch_norm_1d(conv1x1(x, self.conv6), self.bn6))
-        x = F.relu(batch_norm_1d(conv1x1(x, self.conv7), self.bn7))
+        x = conv_bn_act(x, self.conv6, self.bn6, "relu")
+        x = conv_bn_act(x, self.conv7, self.bn7, "relu")
         x = self.tanh(conv1x1(x, self.conv8)[:, :, 0])
         return x.view(batch_size, self.controlpoints * self.controlpoints, 3)
 

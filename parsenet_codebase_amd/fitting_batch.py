@@ -179,6 +179,38 @@ def weights_normalize_batch(Wraw, bw, ncl):
     return torch.where((ncl > 1).reshape(B, 1, 1), shifted, prob)
 
 
+class _Membership(torch.autograd.Function):
+    """centres (B,CP,128) padded, embedding (B,N,128), bandwidths (B,), cluster counts (B,) ->
+    (Wn, Wraw) (B,CP,N): src/residual_utils.py:120 + fitting_utils.weights_normalize in two
+    launches (csrc/fused.hip); backward: two launches + the two GEMMs onto centres and embedding."""
+
+    @staticmethod
+    def forward(ctx, cen, emb, bw, ncl):
+        cen, emb = cen.contiguous(), emb.contiguous()
+        Wraw, prob, Wn, rowstat, _ = K.membership_fwd(cen, emb, bw, ncl, EPS)
+        ctx.save_for_backward(cen, emb, bw, ncl, Wraw, prob, rowstat)
+        ctx.mark_non_differentiable(Wraw)
+        return Wn, Wraw
+
+    @staticmethod
+    def backward(ctx, gWn, _gWraw):
+        cen, emb, bw, ncl, Wraw, prob, rowstat = ctx.saved_tensors
+        gWraw = K.membership_bwd(gWn, Wraw, prob, rowstat, bw, ncl)
+        return torch.bmm(gWraw, emb), torch.bmm(gWraw.transpose(1, 2), cen), None, None
+
+
+def memberships(cen, emb, bw, ncl):
+    """(Wn, Wraw) for padded centre rows; the fused kernels for 128-d embeddings and at most 64
+    centres (the guard retries above 49 anyway), tensor expressions otherwise."""
+    B, Cp, D = cen.shape
+    if D == 128 and Cp <= 64:
+        CP = 16 if Cp <= 16 else 32 if Cp <= 32 else 64
+        cen = torch.nn.functional.pad(cen, (0, 0, 0, CP - Cp))
+        return _Membership.apply(cen, emb, bw.contiguous(), ncl)
+    Wraw = torch.bmm(cen, emb.transpose(1, 2))
+    return weights_normalize_batch(Wraw, bw, ncl), Wraw
+
+
 # -------------------------------------------------------------------------------------------
 # analytic primitives
 # -------------------------------------------------------------------------------------------
@@ -395,10 +427,17 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         lut = _device_const(("merge_lut", dev), lambda: h2d(np.asarray([9, 1, 2, 3, 4, 5, 9, 9, 2, 9], dtype=np.int64), dev))
         prim_pred = lut[torch.max(primitives_log_prob, 1)[1]]
     if state is not None:
+        # auto mode of the block-sparse iterations: the share of list entries the plans of this call
+        # kept (a device scalar, in 1e-6 units) rides in front of the pack
+        auto_stat, MSM.AUTO_STAT = MSM.AUTO_STAT, None
+        head = (torch.zeros(1, device=dev) if auto_stat is None else auto_stat.reshape(1) * 1e6 + 1.0).long()
+
         def download(st):
-            return torch.cat([st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag, st["nocc"],
+            return torch.cat([head, st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag, st["nocc"],
                               st["nflag"]]).to(torch.int32).cpu().numpy()                # download: cluster ids
         pack = download(state)
+        if pack[0] > 0:
+            MSM.auto_report(B, N, (float(pack[0]) - 1.0) * 1e-6)
         if int(pack[-2 * B:-B].max()) > state["width"]:
             # the guessed width of the neighbour matrix was too small (the clustering changed a lot
             # since the last step): once more with the exact one
@@ -406,7 +445,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
                 state = nms_batch(new_X.detach(), emb.detach(), bw, None)
             pack = download(state)
         nms_width_update(ev, B, N, int(pack[-2 * B:-B].max()))
-        o = 0
+        o = 1
         lab_h = pack[o:o + B * N].reshape(B, N); o += B * N
         cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
         ncl_h, bwflag_h = pack[o:o + B], pack[o + B:o + 2 * B]
@@ -435,8 +474,8 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
     bwt = torch.stack(bws).detach()
     ncl_t = h2d(np.asarray(ncl_list, dtype=np.int64), dev)
     with record_function("fit:memberships"):
-        Wraw = torch.bmm(cen, emb.transpose(1, 2))                               # (B,Cp,N)
-        Wn = weights_normalize_batch(Wraw, bwt, ncl_t)
+        Wn, Wraw = memberships(cen, emb, bwt, ncl_t)                             # (B,Cp,N), Cp padded to 16/32/64
+        Cp = Wn.shape[1]
 
     # ---- host: matching + segment tables -------------------------------------------------
     tables, matches = [], []

@@ -111,25 +111,10 @@ class _EdgeConvNormMax(torch.autograd.Function):
         PQ, idx, gamma, beta, yext, argk, s1, mean, rstd = ctx.saved_tensors
         groups, per_sample, slope, dense, k = ctx.cfg
         B, N, Cout = yext.shape
-        gz, yhat = K.edgeconv_bwd_prep(gout, yext, mean, rstd, gamma, beta, groups, per_sample, slope)
-        dbeta = gz.sum((0, 1))
-        dgamma = (gz * yhat).sum((0, 1))
-        t = gz * gamma
-        Cg = Cout // groups
-        if dense:
-            tv = t.view(B, N, groups, Cg).double()
-            yv = yhat.view(B, N, groups, Cg).double()
-            if per_sample:
-                S1 = tv.sum((1, 3))
-                S2 = (tv * yv).sum((1, 3))
-                M = float(Cg * N * k)
-            else:
-                S1 = tv.sum((0, 1, 3)).unsqueeze(0)
-                S2 = (tv * yv).sum((0, 1, 3)).unsqueeze(0)
-                M = float(Cg * N * k * B)
-            c1c2 = torch.stack([S1 / M, S2 / M], -1).float().contiguous()
-        else:
-            c1c2 = torch.zeros((1, groups, 2), dtype=torch.float32, device=PQ.device)
+        # one fused launch group: t = gamma * gout * LeakyReLU'(z), d gamma, d beta and the group means
+        # c1, c2 of the normalisation gradient (fixed-order partial sums, fp64 combination)
+        t, dgamma, dbeta, c1c2 = K.edgeconv_bwd_stats(gout, yext, mean, rstd, gamma.detach(), beta.detach(), groups,
+                                                      per_sample, dense, slope, k)
         dPQ = K.edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense)
         return dPQ, None, dgamma, dbeta, None, None, None, None, None
 

@@ -393,6 +393,18 @@ def meanshift_x3_plan_stats(plan, B, N):
             counts[:, nb0 + nb1:].mean().item() / T)
 
 
+def meanshift_x3_plan_visited(plans, B, N):
+    """Device scalar: the share of (resident block, streamed tile) entries the forward lists of
+    these plans keep, averaged over the plans — what a planned launch costs relative to a dense one.
+    No synchronisation (the caller downloads it with something it waits for anyway)."""
+    T = (N + 63) // 64 * 2
+    nb0, nb1, nb2 = -(-N // 256), -(-N // 128), -(-N // 256)
+    oc = (B * T * T + 255) // 256 * 256
+    n = B * (nb0 + nb1 + nb2) * 4
+    cnt = torch.stack([p[oc:oc + n].view(torch.int32) for p in plans]).reshape(len(plans), B, -1)
+    return cnt[:, :, :nb0].float().mean() / T
+
+
 def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None):
     B, N, D = q.shape
     y = torch.empty_like(q)
@@ -668,3 +680,117 @@ def bspline_eval_bwd(nu, nv, gout, affine, cu, cv, wrap=False):
                                                  int(wrap), ptr(gctrl), current_stream(gout.device))
     check(rc, "pn_bspline_eval_bwd_f32")
     return gctrl
+
+
+# ---- round-3 fusions (csrc/fused.hip) ----------------------------------------------------------
+def edgeconv_bwd_stats(gout, yext, mean, rstd, gamma, beta, groups, per_sample, dense, slope, k):
+    """Step A of the fused edge-conv backward with its reductions: returns (t (B,N,Cout), dgamma,
+    dbeta (Cout), c1c2 ((B or 1), groups, 2))."""
+    require_cuda(gout, yext)
+    gout = _f32c(gout, "gout")
+    B, N, Cout = yext.shape
+    dev = yext.device
+    t = torch.empty_like(yext)
+    dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+    c1c2 = torch.empty((B if per_sample else 1, groups, 2), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    wsz = lib.pn_edgeconv_bwd_stats_workspace(B, N, Cout)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pn_edgeconv_bwd_stats_f32(ptr(gout), ptr(yext), ptr(mean), ptr(rstd), ptr(_f32c(gamma, "gamma")),
+                                           ptr(_f32c(beta, "beta")), B, N, int(k), Cout, int(groups),
+                                           int(per_sample), int(dense), float(slope), ptr(t), ptr(dgamma),
+                                           ptr(dbeta), ptr(c1c2), ptr(ws), wsz, current_stream(dev))
+    check(rc, "pn_edgeconv_bwd_stats_f32")
+    return t, dgamma, dbeta, c1c2
+
+
+def triplet_fwd(E, ia, ib, w, margin):
+    """E (rows,128) fp32; ia, ib (P,num) int64 row indices; w (P,) fp32 -> (loss (1,), item_scale (P,))."""
+    require_cuda(E, ia, ib, w)
+    E = _f32c(E, "E")
+    ia, ib = _i64c(ia, "ia"), _i64c(ib, "ib")
+    P, num = ia.shape
+    dev = E.device
+    item_loss = torch.empty(P, dtype=torch.float32, device=dev)
+    item_scale = torch.empty(P, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_triplet_fwd_f32(ptr(E), E.shape[0], E.shape[1], ptr(ia), ptr(ib), ptr(_f32c(w, "w")), P,
+                                            num, float(margin), ptr(item_loss), ptr(item_scale), ptr(loss),
+                                            current_stream(dev))
+    check(rc, "pn_triplet_fwd_f32")
+    return loss, item_scale
+
+
+def triplet_bwd(E, ia, ib, item_scale, gout, margin):
+    """d loss / d E (rows,128) scaled by gout (1,)."""
+    require_cuda(E, gout)
+    P, num = ia.shape
+    gE = torch.zeros_like(E)
+    with torch.cuda.device(E.device):
+        rc = _lib.load().pn_triplet_bwd_f32(ptr(E), E.shape[0], E.shape[1], ptr(ia), ptr(ib), ptr(item_scale),
+                                            ptr(_f32c(gout.reshape(1), "gout")), P, num, float(margin), ptr(gE),
+                                            current_stream(E.device))
+    check(rc, "pn_triplet_bwd_f32")
+    return gE
+
+
+def membership_fwd(cen, emb, bw, ncl, eps, want_labels=False):
+    """cen (B,CP,128), emb (B,N,128), bw (B,), ncl (B,) int64 -> Wraw, prob, Wn (B,CP,N), rowstat (B,CP,4),
+    labels (B,N) int64 or None."""
+    require_cuda(cen, emb, bw, ncl)
+    cen, emb, bw = _f32c(cen, "cen"), _f32c(emb, "emb"), _f32c(bw, "bw")
+    ncl = _i64c(ncl, "ncl")
+    B, CP, D = cen.shape
+    N = emb.shape[1]
+    dev = emb.device
+    Wraw = torch.empty((B, CP, N), dtype=torch.float32, device=dev)
+    prob = torch.empty_like(Wraw)
+    Wn = torch.empty_like(Wraw)
+    rowstat = torch.empty((B, CP, 4), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, N), dtype=torch.int64, device=dev) if want_labels else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_membership_fwd_f32(ptr(cen), ptr(emb), ptr(bw), ptr(ncl), B, CP, N, D, float(eps),
+                                               ptr(Wraw), ptr(prob), ptr(Wn), ptr(rowstat), ptr(labels),
+                                               current_stream(dev))
+    check(rc, "pn_membership_fwd_f32")
+    return Wraw, prob, Wn, rowstat, labels
+
+
+def membership_bwd(gWn, Wraw, prob, rowstat, bw, ncl):
+    require_cuda(gWn, Wraw)
+    gWn = _f32c(gWn, "gWn")
+    B, CP, N = Wraw.shape
+    rowgrad = torch.empty((B, CP, 2), dtype=torch.float32, device=Wraw.device)
+    gWraw = torch.empty_like(Wraw)
+    with torch.cuda.device(Wraw.device):
+        rc = _lib.load().pn_membership_bwd_f32(ptr(gWn), ptr(Wraw), ptr(prob), ptr(rowstat), ptr(bw), ptr(ncl), B, CP,
+                                               N, ptr(rowgrad), ptr(gWraw), current_stream(Wraw.device))
+    check(rc, "pn_membership_bwd_f32")
+    return gWraw
+
+
+def affine_act_fwd(x, scale, shift, act, slope=0.0):
+    """act(x * scale[c] + shift[c]) on (B,C,N); act 0 none, 1 ReLU, 2 LeakyReLU(slope)."""
+    require_cuda(x, scale, shift)
+    x = _f32c(x, "x")
+    B, C, N = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pn_affine_act_fwd_f32(ptr(x), ptr(_f32c(scale, "scale")), ptr(_f32c(shift, "shift")), B, C, N,
+                                               int(act), float(slope), ptr(y), current_stream(x.device))
+    check(rc, "pn_affine_act_fwd_f32")
+    return y
+
+
+def affine_act_bwd(gy, y, scale, act, slope=0.0):
+    gy = _f32c(gy, "gy")
+    B, C, N = y.shape
+    gx = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        rc = _lib.load().pn_affine_act_bwd_f32(ptr(gy), ptr(y), ptr(_f32c(scale, "scale")), B, C, N, int(act),
+                                               float(slope), ptr(gx), current_stream(y.device))
+    check(rc, "pn_affine_act_bwd_f32")
+    return gx

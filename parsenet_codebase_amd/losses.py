@@ -2,8 +2,32 @@
 import numpy as np
 import torch
 
+from . import kernels as K
 from ._lib import h2d
 import torch.nn.functional as F
+
+
+FUSED = True        # False: the tensor-expression form of the same arithmetic (tests compare the two)
+
+
+class _TripletItems(torch.autograd.Function):
+    """The arithmetic of src/segment_loss.py:97-121 for ALL sampled segment pairs of a batch in one
+    launch (csrc/fused.hip): flat (rows,128) unit-row embedding, ia / ib (P,num) row indices of the
+    anchor-positive / negative samples, w (P,) = 1 / (pairs of the shape + 1e-8) -> sum over the
+    items of w * (sum_ij c_ij - sum_i c_ii) / (#(c > 0) + 1), the count detached like the reference."""
+
+    @staticmethod
+    def forward(ctx, flat, ia, ib, w, margin):
+        flat = flat.contiguous()
+        loss, scale = K.triplet_fwd(flat, ia, ib, w, margin)
+        ctx.save_for_backward(flat, ia, ib, scale)
+        ctx.margin = margin
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, ia, ib, scale = ctx.saved_tensors
+        return K.triplet_bwd(flat, ia, ib, scale, g.contiguous(), ctx.margin), None, None, None, None
 
 
 class EmbeddingLoss:
@@ -74,6 +98,10 @@ class EmbeddingLoss:
             ib = h2d(np.concatenate(ib, 0), dev)
             wts = h2d(np.concatenate(wts, 0), dev)
             flat = out.reshape(B * N, -1)
+            if FUSED and flat.is_cuda and flat.shape[1] == 128 and num <= 32:
+                loss_diff = loss_diff + _TripletItems.apply(flat, ia, ib, wts, float(self.margin))
+                continue
+            # other embedding sizes: the same arithmetic as tensor expressions
             p1, p2 = flat[ia], flat[ib]                              # (P,num,D)
             anchor = p1.unsqueeze(2)
             diff_pos = ((anchor - p1.unsqueeze(1)) ** 2).sum(3)      # (P,num,num)

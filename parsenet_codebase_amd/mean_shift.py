@@ -21,11 +21,41 @@ from ._lib import h2d, require_cuda
 ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 # Block-sparse iterations (bf16x3 path, N >= 2048): points are put in a locality order, and tile
 # pairs whose kernel values are rigorously below 1e-9 of the smallest row sum are skipped
-# (csrc/meanshift_x3.h, "block-sparse plan").  PARSENET_MS_SPARSE=0 keeps every launch dense.
-SPARSE = os.environ.get("PARSENET_MS_SPARSE", "1") != "0"
+# (csrc/meanshift_x3.h, "block-sparse plan").  How much that skips is DATA DEPENDENT: an embedding
+# early in training (small bandwidth, everything in one region of the sphere) keeps ~25 % of the
+# pairs, a converged triplet embedding (clusters a margin apart, bandwidth 0.3-0.5) keeps 70-99 %
+# — and a planned launch that visits every tile is SLOWER than the dense kernel (list traffic,
+# stream-K fragments, plan kernels).  PARSENET_MS_SPARSE: "1" always plan, "0" always dense,
+# "auto" (default): plan one call, look at the share of list entries it kept (the number rides in
+# the fitting stage's cluster-id download: no extra synchronisation), and launch dense for the
+# next AUTO_DENSE_STEPS calls of that problem size when it was above AUTO_DENSE_ABOVE.
+_env_sparse = os.environ.get("PARSENET_MS_SPARSE", "auto")
+SPARSE = True if _env_sparse == "1" else False if _env_sparse == "0" else "auto"
+AUTO_DENSE_ABOVE = 0.75
+AUTO_DENSE_STEPS = 49
+_AUTO = {}                  # (B, N) -> calls left before the next planned (probing) call
+CALLS = {"planned": 0, "dense": 0}   # calls of the bf16x3 iterations by launch kind (bench.py reports them)
+AUTO_STAT = None            # device scalar of the most recent planned call in auto mode (see fitting_batch)
 SPARSE_MIN_N = 2048
 SPARSE_MAX_N = 65535        # block numbers of the plan are 16-bit safe; the T x T predicate stays small
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
+
+
+def use_sparse(B, N):
+    """Whether the next call of this problem size plans its launches (see SPARSE)."""
+    if SPARSE != "auto":
+        return bool(SPARSE)
+    left = _AUTO.get((B, N), 0)
+    if left > 0:
+        _AUTO[(B, N)] = left - 1
+        return False
+    return True
+
+
+def auto_report(B, N, visited):
+    """The share of (resident block, streamed tile) list entries the last planned call kept."""
+    if SPARSE == "auto":
+        _AUTO[(B, N)] = AUTO_DENSE_STEPS if visited > AUTO_DENSE_ABOVE else 0
 
 
 def locality_order(x, lloyd=2):
@@ -71,7 +101,9 @@ class _MeanShiftIterations(torch.autograd.Function):
         if ARITH not in _SPLIT and ARITH != "f32":
             raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
         kern = _SPLIT.get(ARITH) if iterations > 0 else None
-        sparse = SPARSE and kern is not None and ARITH == "bf16x3" and SPARSE_MIN_N <= N <= SPARSE_MAX_N
+        sparse = kern is not None and ARITH == "bf16x3" and SPARSE_MIN_N <= N <= SPARSE_MAX_N and use_sparse(B, N)
+        if kern is not None and ARITH == "bf16x3":
+            CALLS["planned" if sparse else "dense"] += 1
         perm = inv = None
         if sparse:   # everything below runs on the locality-ordered points; undone on the way out
             perm = locality_order(x, int(os.environ.get("PARSENET_MS_LLOYD", "2")))
@@ -96,9 +128,11 @@ class _MeanShiftIterations(torch.autograd.Function):
             iterates.append(q)
             rsums.append(r)
             norms.append(n)
+        global LAST_PLAN_STATS, AUTO_STAT
         if sparse and os.environ.get("PARSENET_MS_STATS") == "1":
-            global LAST_PLAN_STATS
             LAST_PLAN_STATS = [K.meanshift_x3_plan_stats(p, B, N) for p in plans]
+        if sparse and SPARSE == "auto" and plans:
+            AUTO_STAT = K.meanshift_x3_plan_visited(plans, B, N)
         ctx.iterations = iterations
         ctx.x3 = x3
         ctx.kern = kern

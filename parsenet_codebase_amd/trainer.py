@@ -327,15 +327,50 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000, mod
     return history
 
 
-def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, keep_train=8000, keep_val=8000):
+def accumulate_or_skip(bucket, optimizer, num_iter, micro, world=1, device=None, on_step=None, model=None,
+                       on_exception=None):
+    """One optimizer step of train_parsenet_e2e.py:174-277: zero the gradients, run ``micro(i)`` —
+    forward + backward of micro-batch i, accumulating into the bucket — ``num_iter`` times; an
+    exception in ANY micro-batch drops the whole step ("mistake", :243-257): the partial sums stay
+    in the bucket until the next step zeroes them and the optimizer does not move.  With several
+    ranks the drop is collective — a one-element all-reduce of the flag, so that no rank enters the
+    gradient all-reduce alone — and a completed step averages the accumulated gradients over the
+    ranks with the bucket's single all-reduce.  ``on_step(model, flat)`` sees the accumulated,
+    rank-averaged gradient right before ``optimizer.step()``.  Returns True if the step was taken."""
+    bucket.zero()
+    mistake = False
+    for i in range(num_iter):
+        try:
+            micro(i)
+        except Exception:       # degenerate segment: the reference drops the step
+            if on_exception is not None:
+                on_exception(traceback.format_exc())
+            mistake = True
+            break
+    if world > 1:   # a skipped step must be skipped by every rank (the all-reduce is collective)
+        flag = torch.tensor([1.0 if mistake else 0.0], device=device)
+        dist.all_reduce(flag)
+        mistake = bool(flag.item() > 0)
+    if mistake:
+        return False
+    bucket.all_reduce_mean()
+    if on_step is not None:
+        on_step(model, bucket.flat)
+    optimizer.step()
+    return True
+
+
+def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, keep_train=8000, keep_val=8000,
+                       model=None, on_step=None):
     """train_parsenet_e2e.py:164-470: batch 1 per micro-step, 5 micro-steps per optimizer step,
     norm layers frozen (model.eval()), loss = triplet + NLL + residual (lamb 0.1); a fitting
     exception skips the whole step ("mistake"); validation through fitting_loss(eval=True, lamb 1)
-    drives the scheduler (patience 10) and the checkpoint."""
+    drives the scheduler (patience 10) and the checkpoint.  ``model`` / ``on_step``: as in
+    train_parsenet (parity tests)."""
     from .fitting import Evaluation
     rank, world, dev = dp.init_from_env()
     device = device or dev
-    model = build_parsenet(cfg, device)
+    model = model if model is not None else build_parsenet(cfg, device)
     if evaluation is None:   # no pretrained SplineNets ship with the reference: frozen random init
         evaluation = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1).to(device),
                                 open_path=DGCNNControlPoints(20, num_points=10, mode=0).to(device))
@@ -356,10 +391,10 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
         tr = {"loss": [], "prim": [], "emb": [], "res": [], "res_g": [], "res_s": [], "iou": [], "seg_iou": []}
         skipped = 0
         for _ in range(steps):
-            bucket.zero()
             acc = {k: 0.0 for k in ("loss", "prim", "emb", "res", "iou", "seg_iou")}
-            res_g, res_s, mistake = [], [], False
-            for _ in range(num_iter):
+            res_g, res_s = [], []
+
+            def micro(_i):
                 points, labels, normals, primitives_ = next(train_it)
                 points, labels, normals, primitives_ = _subsample([points, labels, normals, primitives_],
                                                                   min(keep_train, points.shape[1]), points.shape[1])
@@ -367,15 +402,9 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
                 embedding, log_prob, embed_loss = _seg_forward(model, pts, nrm, labels, cfg.normals)
                 embed_loss = torch.mean(embed_loss)
                 p_loss = primitive_loss(log_prob, prim)
-                try:
-                    res_loss, _ = evaluation.fitting_loss(embedding.permute(0, 2, 1), pts, nrm, labels, primitives_,
-                                                          log_prob, quantile=0.025, iterations=10, lamb=lamb,
-                                                          eval=False)
-                except Exception:       # degenerate segment: the reference drops the step
-                    if rank == 0:
-                        log("exception in training: " + traceback.format_exc().splitlines()[-1])
-                    mistake = True
-                    break
+                res_loss, _ = evaluation.fitting_loss(embedding.permute(0, 2, 1), pts, nrm, labels, primitives_,
+                                                      log_prob, quantile=0.025, iterations=10, lamb=lamb,
+                                                      eval=False)
                 s_iou, iou = res_loss[3:]
                 loss = embed_loss + p_loss + 1 * res_loss[0]
                 loss.backward()
@@ -389,15 +418,13 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
                 acc["prim"] += p_loss.item() / num_iter
                 acc["iou"] += iou / num_iter
                 acc["emb"] += embed_loss.item() / num_iter
-            if world > 1:   # a skipped step must be skipped by every rank (the all-reduce is collective)
-                flag = torch.tensor([1.0 if mistake else 0.0], device=device)
-                dist.all_reduce(flag)
-                mistake = bool(flag.item() > 0)
-            if mistake:
+
+            def report(tb):
+                if rank == 0:
+                    log("exception in training: " + tb.splitlines()[-1])
+            if not accumulate_or_skip(bucket, optimizer, num_iter, micro, world, device, on_step, model, report):
                 skipped += 1
                 continue
-            bucket.all_reduce_mean()
-            optimizer.step()
             for k in acc:
                 tr[k].append(acc[k])
             tr["res_g"].append(float(np.mean(res_g)) if res_g else 1e-3)

@@ -10,6 +10,13 @@ from .encoders import PrimitivesEmbeddingDGCNGn
 from .losses import EmbeddingLoss, primitive_loss
 
 
+def _adam(params, lr):
+    """torch.optim.Adam with the multi-tensor FUSED kernel on the GPU: the same update rule in one
+    or two launches instead of a dozen foreach launches per step."""
+    params = list(params)
+    return torch.optim.Adam(params, lr=lr, fused=bool(params and params[0].is_cuda))
+
+
 def train_on_rank0_then_broadcast(model, bucket, train):
     """Every rank must start the timed region from ONE set of weights.  Rank 0 runs ``train()``
     alone (the bucket's gradient all-reduce is switched off meanwhile: the other ranks are not
@@ -51,7 +58,7 @@ class ParsenetSegStep:
                                                num_primitives=10, loss_function=self.loss.triplet_loss,
                                                mode=5, num_channels=6, nn_nb=nn_nb).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.opt = _adam(self.model.parameters(), lr)
         self.rng_seed = seed
         self.load_pool(first_shape, batch if pool is None else pool)
 
@@ -127,7 +134,7 @@ class ParsenetE2EStep(ParsenetSegStep):
         self.pretrain_loss = None
         if self.pretrain_steps:
             self._pretrain(seed, first_shape, pretrain_lr)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.opt = _adam(self.model.parameters(), lr)
         torch.manual_seed(seed + 1)
         open_net = DGCNNControlPoints(20, num_points=10, mode=0)
         closed_net = DGCNNControlPoints(20, num_points=10, mode=1)
@@ -304,7 +311,7 @@ class SplineNetStep:
         self.loss_weight = loss_weight
         self.model = DGCNNControlPoints(20, num_points=10, mode=1 if closed else 0).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.opt = _adam(self.model.parameters(), lr)
         nu, nv = uniform_knot_bspline(20, 20, 3, 3, 30 if closed else 40)
         self.nu = torch.from_numpy(nu.astype(np.float32)).to(device)
         self.nv = torch.from_numpy(nv.astype(np.float32)).to(device)

@@ -409,6 +409,40 @@ def main():
          p_iou=np.float32(loss[4]), cluster_ids=ids.astype(np.int32), kinds=np.array(kinds),
          grad_emb=er.grad.numpy().astype(np.float32))
 
+    # ---- the same call of the REFERENCE under 1-ulp input scalings: its own fp32 noise band ---------
+    # (tests/golden/reference_noise_e2e.txt; the bars of tests/test_golden_gpu.py::
+    # test_end_to_end_fitting_loss cite this file.  Everything below is the imported reference's
+    # arithmetic — src.residual_utils.Evaluation.fitting_loss — not the oracle's.)
+    base_grad = er.grad.double().flatten().clone()
+    base_vals = (float(loss[0]), float(loss[1]), float(loss[2]))
+    lines = ["# produced by tests/golden/make_golden.py from the IMPORTED REFERENCE (src.residual_utils.Evaluation."
+             "fitting_loss on the e2e fixture's shape and embedding); points scaled by (1 + k ulp), BLAS threads varied",
+             "base loss %.8e geometric mean %.8e spline mean %.8e |grad| %.6e"
+             % (base_vals + (float(base_grad.norm()),))]
+    worst = {"loss": 0.0, "geo": 0.0, "spline": 0.0, "cos": 1.0}
+    for sc, th in ((1.0, 1), (1.0, 3), (1 + 1.2e-7, 8), (1 - 1.2e-7, 8), (1 + 2.4e-7, 8), (1 - 2.4e-7, 8),
+                   (1 + 6e-7, 8)):
+        torch.set_num_threads(th)
+        e2 = emb.clone().requires_grad_(True)
+        np.random.seed(1)
+        l2, _ = ev.fitting_loss(e2.unsqueeze(0), torch.from_numpy(pts * np.float32(sc)).unsqueeze(0),
+                                torch.from_numpy(nrm).unsqueeze(0), lab[None], prim[None].copy(), logp,
+                                quantile=0.025, iterations=10, lamb=0.1)
+        l2[0].backward()
+        g2 = e2.grad.double().flatten()
+        cos = float(g2 @ base_grad / (g2.norm() * base_grad.norm()))
+        rel = [abs(float(a) - b) / b for a, b in zip(l2[:3], base_vals)]
+        lines.append("scale %.9f threads %d loss %.8e rel %.2e  geometric mean rel %.2e  spline mean rel %.2e  "
+                     "cos(grad, base grad) %.4f" % (sc, th, float(l2[0]), rel[0], rel[1], rel[2], cos))
+        worst = {"loss": max(worst["loss"], rel[0]), "geo": max(worst["geo"], rel[1]),
+                 "spline": max(worst["spline"], rel[2]), "cos": min(worst["cos"], cos)}
+    torch.set_num_threads(8)
+    lines.append("band: loss %.2e geometric mean %.2e spline mean %.2e gradient cos >= %.4f"
+                 % (worst["loss"], worst["geo"], worst["spline"], worst["cos"]))
+    with open(os.path.join(HERE, "reference_noise_e2e.txt"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("reference_noise_e2e.txt:", lines[-1])
+
     # ---- evaluation-mode fitting (fitting_loss(eval=True) -> residual_eval_mode) ---------------------
     # open3d is absent: the reference's remove_outliers (open3d remove_statistical_outlier) is
     # replaced by the oracle's restatement of that published algorithm — the one step of this

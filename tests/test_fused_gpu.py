@@ -1,0 +1,172 @@
+"""GPU: the round-3 fused kernels (csrc/fused.hip) against the tensor expressions they replace —
+which are the oracle-checked restatements of the reference's lines (tests/test_golden_gpu.py,
+test_fitting_batch_gpu.py, test_encoder_gpu.py run the same paths against the fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+@pytest.mark.parametrize("per_sample,dense,Cout,groups", [(True, True, 64, 2), (False, True, 128, 128),
+                                                          (False, False, 64, 64), (True, True, 256, 4)])
+def test_edgeconv_backward_stats(gpu, per_sample, dense, Cout, groups):
+    """t, d gamma, d beta, c1 / c2 of graph._EdgeConvNormMax.backward: the fused launch group vs
+    pn_edgeconv_bwd_prep_f32 + the fp64 tensor reductions it replaces."""
+    from parsenet_codebase_amd import kernels as K
+    torch.manual_seed(0)
+    B, N, k, slope = 3, 1000, 20, 0.2
+    yext = torch.randn(B, N, Cout, device=gpu)
+    gout = torch.randn(B, Cout, N, device=gpu)
+    gamma = torch.randn(Cout, device=gpu)
+    beta = torch.randn(Cout, device=gpu)
+    S = B if per_sample else 1
+    mean = 0.1 * torch.randn(S, groups, device=gpu)
+    rstd = 1.0 + 0.1 * torch.rand(S, groups, device=gpu)
+    t, dgamma, dbeta, c1c2 = K.edgeconv_bwd_stats(gout, yext, mean, rstd, gamma, beta, groups, per_sample, dense,
+                                                  slope, k)
+    gz, yhat = K.edgeconv_bwd_prep(gout, yext, mean, rstd, gamma, beta, groups, per_sample, slope)
+    assert torch.equal(t, gz * gamma)
+    assert _rel(dbeta, gz.double().sum((0, 1))) < 1e-6 and _rel(dgamma, (gz.double() * yhat.double()).sum((0, 1))) < 1e-6
+    Cg = Cout // groups
+    tv = (gz * gamma).view(B, N, groups, Cg).double()
+    yv = yhat.view(B, N, groups, Cg).double()
+    if per_sample:
+        ref = torch.stack([tv.sum((1, 3)), (tv * yv).sum((1, 3))], -1) / float(Cg * N * k)
+    else:
+        ref = torch.stack([tv.sum((0, 1, 3)), (tv * yv).sum((0, 1, 3))], -1).unsqueeze(0) / float(Cg * N * k * B)
+    if not dense:
+        ref = torch.zeros_like(ref)
+    assert c1c2.shape == ref.shape and float((c1c2.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + 1e-30)
+
+
+def test_edgeconv_layer_gradients_unchanged(gpu):
+    """The whole layer through autograd (GroupNorm statistics) against a plain torch edge conv."""
+    from parsenet_codebase_amd import graph
+    torch.manual_seed(1)
+    B, C, N, k, Cout = 2, 16, 600, 12, 64
+    x = torch.randn(B, C, N, device=gpu, requires_grad=True)
+    w = (0.2 * torch.randn(Cout, 2 * C, 1, 1, device=gpu)).requires_grad_(True)
+    gn = torch.nn.GroupNorm(2, Cout).to(gpu)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(Cout))
+        gn.bias.copy_(torch.randn(Cout))
+    idx = graph.knn(x, k)
+    out = graph.edge_conv_norm_max(x, idx, w, gn, 0.2)
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    got = [x.grad.clone(), w.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()]
+    x.grad = w.grad = gn.weight.grad = gn.bias.grad = None
+    xt = x.transpose(1, 2)
+    nb = torch.gather(xt.unsqueeze(1).expand(-1, N, -1, -1), 2, idx.unsqueeze(3).expand(-1, -1, -1, C))
+    feat = torch.cat([nb - xt.unsqueeze(2), xt.unsqueeze(2).expand(-1, -1, k, -1)], 3).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.leaky_relu(gn(torch.nn.functional.conv2d(feat, w)), 0.2).max(3)[0]
+    assert _rel(out, ref) < 1e-5
+    (ref * g).sum().backward()
+    for a, b in zip(got, [x.grad, w.grad, gn.weight.grad, gn.bias.grad]):
+        assert _rel(a, b) < 2e-4, _rel(a, b)
+
+
+@pytest.mark.parametrize("num", [30, 7])
+def test_triplet_loss_kernel(gpu, num):
+    """EmbeddingLoss.triplet_loss (src/segment_loss.py:31-124): fused kernels vs the tensor-expression
+    form, same numpy RNG draws; loss and gradient with respect to the network output."""
+    from parsenet_codebase_amd import losses
+    B, N, S = 3, 400, 6
+    rng = np.random.RandomState(0)
+    labels = rng.randint(0, S, (B, N))
+    if num < 30:
+        N = 40
+        labels = labels[:, :N] % 8          # N // S + 1 < 30 -> fewer samples per segment
+    out = torch.randn(B, 128, N, device=gpu)
+    res = {}
+    for fused in (True, False):
+        losses.FUSED = fused
+        try:
+            o = out.clone().requires_grad_(True)
+            np.random.seed(5)
+            l = losses.EmbeddingLoss(margin=1.0).triplet_loss(o, labels)
+            l.sum().backward()
+            res[fused] = (l.detach().clone(), o.grad.clone(), np.random.get_state()[1][:4].tolist())
+        finally:
+            losses.FUSED = True
+    assert res[True][2] == res[False][2]
+    assert _rel(res[True][0], res[False][0]) < 2e-6
+    assert _rel(res[True][1], res[False][1]) < 2e-5
+
+
+@pytest.mark.parametrize("ncls", [[1, 5, 16], [33, 2, 49], [12, 12, 7]])
+def test_membership_kernels(gpu, ncls):
+    """Wraw, weights_normalize and its gradient onto centres and embedding: fused vs
+    fitting_batch.weights_normalize_batch(bmm(...)) through autograd; labels = first arg-max."""
+    from parsenet_codebase_amd import fitting_batch as FB, kernels as K
+    torch.manual_seed(2)
+    B, N, D = len(ncls), 3000, 128
+    Cp = max(ncls)
+    emb = torch.nn.functional.normalize(torch.randn(B, N, D, device=gpu), dim=2)
+    pick = torch.randint(0, N, (B, Cp), device=gpu)
+    cen = torch.gather(emb, 1, pick.unsqueeze(2).expand(-1, -1, D)) + 0.05 * torch.randn(B, Cp, D, device=gpu)
+    ncl = torch.tensor(ncls, device=gpu)
+    cen = cen * (torch.arange(Cp, device=gpu).unsqueeze(0) < ncl.unsqueeze(1)).unsqueeze(2)    # padded rows: zeros
+    bw = torch.tensor([0.3, 0.11, 0.45][:B], device=gpu)
+    g = torch.randn(B, Cp, N, device=gpu)
+    c1, e1 = cen.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    Wn1, Wraw1 = FB.memberships(c1, e1, bw, ncl)
+    (Wn1[:, :Cp] * g).sum().backward()
+    c2, e2 = cen.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    Wraw2 = torch.bmm(c2, e2.transpose(1, 2))
+    Wn2 = FB.weights_normalize_batch(Wraw2, bw, ncl)
+    (Wn2 * g).sum().backward()
+    assert Wn1.shape[1] in (16, 32, 64)
+    if Wn1.shape[1] > Cp:
+        assert float(Wn1[:, Cp:].abs().max()) == 0
+    assert _rel(Wraw1[:, :Cp], Wraw2) < 2e-6
+    assert float((Wn1[:, :Cp] - Wn2).abs().max()) < 2e-5
+    assert _rel(c1.grad, c2.grad) < 2e-4 and _rel(e1.grad, e2.grad) < 2e-4
+    # labels: first arg-max over the valid centre rows of the kernel's own Wraw
+    CP = Wn1.shape[1]
+    cpad = torch.nn.functional.pad(cen, (0, 0, 0, CP - Cp))
+    Wraw, _, _, _, lab = K.membership_fwd(cpad, emb, bw, ncl, 1e-7, want_labels=True)
+    valid = torch.arange(CP, device=gpu).view(1, CP, 1) < ncl.view(B, 1, 1)
+    sc = torch.where(valid, Wraw, torch.full_like(Wraw, float("-inf")))
+    from parsenet_codebase_amd.mean_shift import _first_argmax
+    assert torch.equal(lab, _first_argmax(sc, 1))
+
+
+@pytest.mark.parametrize("act", ["leaky", "relu", "none"])
+def test_frozen_batchnorm_affine(gpu, act):
+    """encoders.conv_bn_act with a frozen evaluation-mode BatchNorm1d vs conv -> bn -> activation."""
+    from parsenet_codebase_amd.encoders import conv_bn_act
+    torch.manual_seed(3)
+    conv = torch.nn.Conv1d(96, 160, 1).to(gpu)
+    bn = torch.nn.BatchNorm1d(160).to(gpu)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(160))
+        bn.running_var.copy_(torch.rand(160) + 0.5)
+        bn.weight.copy_(torch.randn(160))
+        bn.bias.copy_(torch.randn(160))
+    for p in list(conv.parameters()) + list(bn.parameters()):
+        p.requires_grad = False
+    bn.eval()
+    x = torch.randn(5, 96, 333, device=gpu, requires_grad=True)
+    y = conv_bn_act(x, conv, bn, act, 0.2)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    gx = x.grad.clone()
+    x.grad = None
+    r = bn(conv(x))
+    r = torch.relu(r) if act == "relu" else torch.nn.functional.leaky_relu(r, 0.2) if act == "leaky" else r
+    (r * g).sum().backward()
+    assert _rel(y, r) < 2e-6 and _rel(gx, x.grad) < 2e-5
+    # the cache follows in-place changes of the statistics
+    with torch.no_grad():
+        bn.running_mean.add_(1.0)
+    y2 = conv_bn_act(x, conv, bn, act, 0.2)
+    r2 = bn(conv(x))
+    r2 = torch.relu(r2) if act == "relu" else torch.nn.functional.leaky_relu(r2, 0.2) if act == "leaky" else r2
+    assert _rel(y2, r2) < 2e-6

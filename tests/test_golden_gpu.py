@@ -196,16 +196,25 @@ def test_end_to_end_fitting_loss(gpu):
     assert sorted(v[0] for v in params.values() if v is not None) == list(g["kinds"])
     # The analytic fits are stable: their mean distance is held to 1e-4.  The spline distances go
     # through SplineNets whose feature-space kNN has near-ties: tests/golden/reference_noise_e2e.txt
-    # (tools/reference_noise.py) shows the reference's OWN arithmetic moving one spline distance by
-    # 9.8 % and the loss by 2.1 % when the input points are scaled by ONE ulp — the band below.
+    # — written by make_golden.py from the IMPORTED REFERENCE re-run on this very fixture with the
+    # input points scaled by 1 +- k ulp — records how far the reference moves against itself (one
+    # spline distance flips by 9.8 %: spline mean and loss 2.1 %, gradient cos 0.81).  An
+    # implementation lands on one side of that near-tie or the other, so the bars ARE that band
+    # (read from the file, a quarter of slack on top), not a guessed number.
+    import os
+    import re
+    band = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_noise_e2e.txt")
+                ).read().strip().splitlines()[-1]
+    m = re.match(r"band: loss (\S+) geometric mean (\S+) spline mean (\S+) gradient cos >= (\S+)", band)
+    band_loss, band_geo, band_spline, band_cos = [float(v) for v in m.groups()]
+    assert band_geo < 1e-5
     assert abs(loss[1] - float(g["geo"])) / float(g["geo"]) < 1e-4
-    assert abs(loss[2] - float(g["spline"])) / float(g["spline"]) < 5e-2
-    assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 3e-2
+    assert abs(loss[2] - float(g["spline"])) / float(g["spline"]) < 1.25 * band_spline + 1e-4
+    assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < 1.25 * band_loss + 1e-4
     assert abs(loss[3] - float(g["s_iou"])) < 1e-6 and abs(loss[4] - float(g["p_iou"])) < 1e-6
     ga = emb.grad.cpu().numpy().astype(np.float64).ravel()
     gb = g["grad_emb"].astype(np.float64).ravel()
-    # same file: the reference's own gradient turns to cos 0.81 against itself under the 1-ulp scaling
-    assert float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb))) > 0.9
+    assert float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb))) > band_cos - 0.02
 
 
 def test_end_to_end_fitting_loss_eval_mode(gpu):

@@ -17,7 +17,7 @@ if cache and os.path.exists(cache):
     st = torch.load(cache)
     e, bw = st["e"].to(dev).float(), st["bw"].to(dev)
 else:
-    step = workloads.ParsenetE2EStep(dev, batch=4, num_points=10000, pretrain_steps=300)
+    step = workloads.ParsenetE2EStep(dev, batch=4, num_points=10000, pretrain_steps=2000, pool=16, pretrain_pool=64)
     step.model.eval()
     with torch.no_grad():
         emb, _, _ = step.model(step.x, step.labels, True)

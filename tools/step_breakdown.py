@@ -22,7 +22,8 @@ groups = collections.OrderedDict([
     ("mean-shift iterations", ("pn_ms3_", "pn_ms_", "pn_msh_")),
     ("bandwidth / nms selection", ("pn_dotsel", "pn_sel", "dot_select", "pn_dot")),
     ("kNN", ("pn_knn",)),
-    ("edge conv / group norm (HIP)", ("pn_edge", "pn_gn", "pn_transpose", "pn_moments")),
+    ("edge conv / group norm (HIP)", ("pn_edge", "pn_ecb", "pn_gn", "pn_transpose", "pn_moments", "pn_rev_")),
+    ("fused glue: triplet / memberships / affine (HIP)", ("pn_triplet", "pn_member", "pn_affine")),
     ("batched fits (HIP)", ("pn_wmom", "pn_primfit", "pn_cone", "pn_prim_residual", "pn_bspline", "pn_chamfer")),
     ("GEMM (rocBLAS / hipBLASLt)", ("Cijk", "gemm", "rocblas")),
     ("elementwise / reductions / sort (torch)", ("",)),

@@ -9,7 +9,7 @@ from parsenet_codebase_amd import workloads
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 dev = torch.device("cuda:0")
-step = workloads.ParsenetSegStep(dev) if which == "cfg4" else workloads.ParsenetE2EStep(dev, pretrain_steps=300)
+step = workloads.ParsenetSegStep(dev) if which == "cfg4" else workloads.ParsenetE2EStep(dev, pretrain_steps=2000, pool=16, pretrain_pool=64)
 if which != "cfg4":
     step.warm_paths()
 for _ in range(3):
