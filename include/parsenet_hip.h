@@ -405,6 +405,20 @@ int pn_membership_bwd_f32(const float* gWn, const float* Wraw, const float* prob
                           const float* bw, const int64_t* ncl, int B, int CP, int N, float* rowgrad,
                           float* gWraw, void* stream);
 
+/* Non-maximum suppression of the shifted points, src/mean_shift.py:139-179, without leaving the
+ * device.  pn_nms_occupied_f32: membership (B,N) int64 = nearest shifted point of every input point
+ * (pn_dot_select_f32, k = 1) -> counts (B,N) int32 members per shifted point (np.unique's counts,
+ * :150-153), uq (B,U) int64 the occupied ones in ascending order (zero-padded), nocc (B) their number
+ * (may exceed U: the caller retries with a larger U).  pn_nms_vote_f32: G (B,U,U) = Cu Cu^T of the
+ * occupied centres -> every occupied centre votes for the FIRST arg-max of [2 - 2 G < bw] * counts
+ * (:160-168; distance < b, not b^2, like the reference; only occupied columns can win: an
+ * unoccupied one scores 0 and the centre itself scores its own count) -> hits (B,N) int32 scratch,
+ * cid (B,cmax) int64 the voted centres in ascending order (zero-padded), ncl (B) their number. */
+int pn_nms_occupied_f32(const int64_t* membership, int B, int N, int U, int* counts, int64_t* uq, int64_t* nocc,
+                        void* stream);
+int pn_nms_vote_f32(const float* G, const int64_t* uq, const int64_t* nocc, const int* counts, const float* bw,
+                    int B, int N, int U, int cmax, int* hits, int64_t* cid, int64_t* ncl, void* stream);
+
 /* y = act(x * scale[c] + shift[c]) on (B,C,N): evaluation-mode BatchNorm1d folded with the
  * activation that follows it (src/model.py:160-176: conv5/bn5 LeakyReLU(0.2), conv6/bn6 and
  * conv7/bn7 ReLU of the frozen SplineNets).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).

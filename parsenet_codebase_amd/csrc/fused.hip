@@ -65,39 +65,37 @@ __global__ __launch_bounds__(256) void pn_ecb_prep_kernel(
   }
 }
 
-// AB[b][c] = (sum_n gz, sum_n gz*yhat) in fp64; with per-sample statistics also the group means
-// c1c2[b][g] = (sum_{c in g} gamma_c A, sum_{c in g} gamma_c B) / M.
+// AB[b][c] = (sum_n gz, sum_n gz*yhat) in fp64.  Block = 16 channels x 16 strided sub-sums over the
+// point blocks, combined in sub-sum order (fixed order; a single thread walking all ~300 partials of
+// a channel made this a latency-bound 80 us launch).
 __global__ __launch_bounds__(256) void pn_ecb_reduce_kernel(const float2* __restrict__ partial, int nblk,
-                                                            int Cout, int Cg, int per_sample, int dense,
-                                                            double M, const float* __restrict__ gamma,
-                                                            double2* __restrict__ AB, float* __restrict__ c1c2) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
-    double a = 0.0, bm = 0.0;
-    for (int j = 0; j < nblk; ++j) {
+                                                            int Cout, double2* __restrict__ AB) {
+  __shared__ double2 red[16][16];
+  const int b = blockIdx.y;
+  const int cl = threadIdx.x & 15, jg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a = 0.0, bm = 0.0;
+  if (c < Cout)
+    for (int j = jg; j < nblk; j += 16) {
       const float2 p = partial[((size_t)b * nblk + j) * Cout + c];
       a += (double)p.x;
       bm += (double)p.y;
     }
-    AB[(size_t)b * Cout + c] = make_double2(a, bm);
-  }
-  if (!per_sample) return;
+  red[jg][cl] = make_double2(a, bm);
   __syncthreads();
-  const int G = Cout / Cg;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    double s1 = 0.0, s2 = 0.0;
-    if (dense)
-      for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
-        const double2 v = AB[(size_t)b * Cout + c];
-        s1 += (double)gamma[c] * v.x;
-        s2 += (double)gamma[c] * v.y;
-      }
-    c1c2[((size_t)b * G + g) * 2] = (float)(s1 / M);
-    c1c2[((size_t)b * G + g) * 2 + 1] = (float)(s2 / M);
+  if (jg == 0 && c < Cout) {
+    double2 s = red[0][cl];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      s.x += red[j][cl].x;
+      s.y += red[j][cl].y;
+    }
+    AB[(size_t)b * Cout + c] = s;
   }
 }
 
-// dbeta, dgamma over the batch; with batch statistics also c1c2[0][g].
+// dbeta, dgamma over the batch and the group means c1c2[s][g] = (sum gamma_c A, sum gamma_c B) / M
+// over the channels of group g (and over the batch for batch statistics).
 __global__ __launch_bounds__(256) void pn_ecb_finish_kernel(const double2* __restrict__ AB, int B, int Cout, int Cg,
                                                             int per_sample, int dense, double M,
                                                             const float* __restrict__ gamma,
@@ -114,18 +112,19 @@ __global__ __launch_bounds__(256) void pn_ecb_finish_kernel(const double2* __res
     dbeta[c] = (float)a;
     dgamma[c] = (float)bm;
   }
-  if (per_sample) return;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  const int S = per_sample ? B : 1;
+  for (int e = threadIdx.x; e < S * G; e += blockDim.x) {
+    const int sidx = e / G, g = e - sidx * G;
     double s1 = 0.0, s2 = 0.0;
     if (dense)
       for (int c = g * Cg; c < (g + 1) * Cg; ++c)
-        for (int b = 0; b < B; ++b) {
+        for (int b = per_sample ? sidx : 0; b < (per_sample ? sidx + 1 : B); ++b) {
           const double2 v = AB[(size_t)b * Cout + c];
           s1 += (double)gamma[c] * v.x;
           s2 += (double)gamma[c] * v.y;
         }
-    c1c2[g * 2] = (float)(s1 / M);
-    c1c2[g * 2 + 1] = (float)(s2 / M);
+    c1c2[(size_t)e * 2] = (float)(s1 / M);
+    c1c2[(size_t)e * 2 + 1] = (float)(s2 / M);
   }
 }
 
@@ -153,8 +152,8 @@ extern "C" int pn_edgeconv_bwd_stats_f32(const float* gout, const float* yext, c
   PN_PROF("edgeconv_bwd_stats", stream);
   hipLaunchKernelGGL(pn_ecb_prep_kernel, dim3(pn_cdiv(Cout, 32), nblk, B), dim3(256), 0, stream, gout, yext, mean,
                      rstd, gamma, beta, N, Cout, Cg, per_sample, slope, t, partial);
-  hipLaunchKernelGGL(pn_ecb_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float2*)partial, nblk, Cout, Cg,
-                     per_sample, dense, M, gamma, AB, c1c2);
+  hipLaunchKernelGGL(pn_ecb_reduce_kernel, dim3(pn_cdiv(Cout, 16), B), dim3(256), 0, stream, (const float2*)partial,
+                     nblk, Cout, AB);
   hipLaunchKernelGGL(pn_ecb_finish_kernel, dim3(1), dim3(256), 0, stream, (const double2*)AB, B, Cout, Cg, per_sample,
                      dense, M, gamma, dgamma, dbeta, c1c2);
   PN_CHECK_LAUNCH();
@@ -642,6 +641,116 @@ extern "C" int pn_affine_act_bwd_f32(const float* gy, const float* y, const floa
   const long long total = (long long)B * C * N;
   hipLaunchKernelGGL(pn_affine_act_bwd_kernel, dim3(pn_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, y,
                      scale, total, C, N, act, slope, gx);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// =============================================================================================
+// non-maximum suppression of the shifted points (src/mean_shift.py:139-179), device side
+// =============================================================================================
+// counts[b][membership[b][n]] += 1 (integer atomics: order-independent)
+__global__ void pn_nms_count_kernel(const int64_t* __restrict__ membership, int N, long long total,
+                                    int* __restrict__ counts) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int b = (int)(e / N);
+  atomicAdd(&counts[(size_t)b * N + membership[e]], 1);
+}
+
+// ascending indices of the entries with flag[b][n] > 0, one workgroup of 1024 threads per item:
+// out[b][0..cnt) = indices (at most cap are written), out[b][cnt..cap) = 0, count[b] = cnt (uncapped).
+__global__ __launch_bounds__(1024) void pn_nms_compact_kernel(const int* __restrict__ flag, int N, int cap,
+                                                              int64_t* __restrict__ out, int64_t* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int n = n0 + tid;
+    const bool on = n < N && flag[(size_t)b * N + n] > 0;
+    const unsigned long long m = __ballot(on);
+    const int before = pn_mbcnt(m);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int base = carry;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int pos = base + before;
+    if (on && pos < cap) out[(size_t)b * cap + pos] = n;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      carry += t;
+    }
+    __syncthreads();
+  }
+  const int cnt = carry;
+  for (int p = cnt + tid; p < cap; p += 1024) out[(size_t)b * cap + p] = 0;
+  if (tid == 0) count[b] = cnt;
+}
+
+// vote of every occupied centre u (row of G = Cu . Cu^T, U x U): the first v maximising
+// [2 - 2 G[u][v] < bw] * cnt[uq[v]]  (distance < b, not b^2, like the reference) -> hits[uq[v]] = 1.
+// One wave per row; rows >= nocc[b] and columns >= nocc[b] are padding.
+__global__ __launch_bounds__(256) void pn_nms_vote_kernel(const float* __restrict__ G, const int64_t* __restrict__ uq,
+                                                          const int64_t* __restrict__ nocc,
+                                                          const int* __restrict__ counts, const float* __restrict__ bw,
+                                                          int N, int U, int* __restrict__ hits) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int no = (int)min((long long)nocc[b], (long long)U);
+  if (u >= no) return;
+  const float bb = bw[b];
+  const float* __restrict__ g = G + ((size_t)b * U + u) * U;
+  const int64_t* __restrict__ uqb = uq + (size_t)b * U;
+  const int* __restrict__ cb = counts + (size_t)b * N;
+  float best = -1.f;
+  int bi = 0x7fffffff;
+  for (int v = lane; v < no; v += 64) {
+    const float d = 2.0f - 2.0f * g[v];
+    const float sc = d < bb ? (float)cb[uqb[v]] : 0.f;
+    if (sc > best) {       // ascending v per lane: the first maximum of the lane is kept
+      best = sc;
+      bi = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+    }
+  }
+  if (lane == 0) hits[(size_t)b * N + uqb[bi]] = 1;
+}
+
+extern "C" int pn_nms_occupied_f32(const int64_t* membership, int B, int N, int U, int* counts, int64_t* uq,
+                                   int64_t* nocc, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(membership && counts && uq && nocc && B > 0 && N > 0 && U > 0, "pn_nms_occupied_f32: bad arguments");
+  PN_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * N * sizeof(int), stream));
+  PN_PROF("nms_occupied", stream);
+  const long long total = (long long)B * N;
+  hipLaunchKernelGGL(pn_nms_count_kernel, dim3(pn_cdiv(total, 256)), dim3(256), 0, stream, membership, N, total, counts);
+  hipLaunchKernelGGL(pn_nms_compact_kernel, dim3(B), dim3(1024), 0, stream, (const int*)counts, N, U, uq, nocc);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+extern "C" int pn_nms_vote_f32(const float* G, const int64_t* uq, const int64_t* nocc, const int* counts,
+                               const float* bw, int B, int N, int U, int cmax, int* hits, int64_t* cid,
+                               int64_t* ncl, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(G && uq && nocc && counts && bw && hits && cid && ncl && B > 0 && N > 0 && U > 0 && cmax > 0,
+               "pn_nms_vote_f32: bad arguments");
+  PN_CHECK_HIP(hipMemsetAsync(hits, 0, (size_t)B * N * sizeof(int), stream));
+  PN_PROF("nms_vote", stream);
+  hipLaunchKernelGGL(pn_nms_vote_kernel, dim3(pn_cdiv(U, 4), B), dim3(256), 0, stream, G, uq, nocc, counts, bw, N, U,
+                     hits);
+  hipLaunchKernelGGL(pn_nms_compact_kernel, dim3(B), dim3(1024), 0, stream, (const int*)hits, N, cmax, cid, ncl);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -93,62 +93,55 @@ def bandwidth_batch(X, quantile, num_samples=10000):
     return torch.clamp(bw, min=0.003), (flags != 0).sum(1)
 
 
-def _padded_true_indices(mask, cap):
-    """For every row of a (B,N) boolean mask the ascending indices of its True entries, padded
-    (with indices of False entries) to ``cap`` columns, and the number of True entries."""
-    order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)
-    return order[:, :cap], mask.sum(1)
-
-
-
-
-def nms_batch(new_X, X, bw, width=None):
+def nms_batch(new_X, X, bw, width=None, labels=True):
     """MeanShift.nms (src/mean_shift.py:139-179) for all shapes at once.  new_X, X (B,N,128)
-    detached, bw (B,).  Returns a dict: labels (B,N) int64, cid (B,CMAX) int64 ascending centre
-    ids (padded), ncl, nocc, nflag (B,) and the padded ``width`` of the neighbour matrix.
-    None outside the kernel's fast path.
+    detached, bw (B,).  Returns a dict: labels (B,N) int64 (None with ``labels=False``: the caller
+    takes them from the membership kernel it runs anyway), cid (B,CMAX) int64 ascending centre ids
+    (padded), ncl, nocc, nflag (B,) and the padded ``width`` of the neighbour matrix.  None outside
+    the kernel's fast path.
 
     The number of occupied centres sizes the neighbour matrix.  Any width >= max(nocc) gives the
-    same result (padding rows are masked), so ``width`` may be a guess — the caller downloads
-    nocc together with the cluster ids and calls again with ``width=None`` if the guess was too
-    small; without a guess nocc is downloaded here (one more synchronisation).  nflag counts the
-    rows the selection kernel flagged (massive ties).
+    same result (padding is masked), so ``width`` may be a guess — the caller downloads nocc
+    together with the cluster ids and calls again with ``width=None`` if the guess was too small;
+    without a guess nocc is downloaded here (one more synchronisation).  nflag counts the rows the
+    selection kernel flagged (massive ties).
 
     The reference scores every occupied centre u against ALL N shifted points j with
     [dist(u,j) < b] * members(j); unoccupied j score 0 and the row maximum is at least members(u)
     > 0, so only occupied columns can win: the neighbour matrix is (occupied x occupied), in
-    ascending centre order — the first-index tie rule is unchanged."""
+    ascending centre order — the first-index tie rule is unchanged.  Counting, the ordered lists of
+    occupied / voted centres and the vote itself are three small kernels (csrc/fused.hip:
+    pn_nms_occupied_f32, pn_nms_vote_f32) around one GEMM."""
     B, N, D = X.shape
     res = K.dot_select(X, new_X, 1, want_value=False)
     if res is None:
         return None
     idx, flags = res
-    membership = idx[:, :, 0]
-    counts = torch.zeros((B, N), dtype=torch.float32, device=X.device)
-    counts.scatter_add_(1, membership, torch.ones((B, N), dtype=torch.float32, device=X.device))
-    occ = counts > 0
-    nocc = occ.sum(1)
     nflag = (flags != 0).sum(1)
+    cap = N if width is None else min(int(width), N)
+    counts, uq, nocc = K.nms_occupied(idx[:, :, 0], cap)
+    U = cap
     if width is None:
-        U = int(nocc.max().item())                                          # sync: sizes the next launches
-    else:
-        U = min(int(width), N)
-    uq, _ = _padded_true_indices(occ, U)
-    rowvalid = torch.arange(U, device=X.device).unsqueeze(0) < nocc.unsqueeze(1)
+        U = max(int(nocc.max().item()), 1)                                    # sync: sizes the next launches
+        uq = uq[:, :U].contiguous()
     Cu = torch.gather(new_X, 1, uq.unsqueeze(2).expand(-1, -1, D))
-    dist = 2.0 - 2.0 * torch.bmm(Cu, Cu.transpose(1, 2))                      # (B,U,U)
-    cnt_u = torch.gather(counts, 1, uq)                                      # padding: unoccupied, count 0
-    score = (dist < bw.reshape(B, 1, 1)).float() * cnt_u.unsqueeze(1)
-    best = torch.gather(uq, 1, MSM._first_argmax(score, 2))                  # (B,U) centre ids
-    hits = torch.zeros((B, N), dtype=torch.float32, device=X.device)
-    hits.scatter_add_(1, best, rowvalid.float())
-    cid, ncl = _padded_true_indices(hits > 0, CMAX)
-    cvalid = torch.arange(cid.shape[1], device=X.device).unsqueeze(0) < ncl.unsqueeze(1)
+    cid, ncl = K.nms_vote(torch.bmm(Cu, Cu.transpose(1, 2)), uq, nocc, counts, bw, CMAX)
+    out = {"labels": None, "cid": cid, "ncl": ncl, "nocc": nocc, "nflag": nflag, "width": U}
+    if labels:
+        out["labels"] = centre_labels(new_X, X, cid, ncl, bw)
+    return out
+
+
+def centre_labels(new_X, X, cid, ncl, bw):
+    """labels = first arg-max over the pruned centres of centre . x (src/mean_shift.py:176-178)."""
+    B, N, D = X.shape
     Csel = torch.gather(new_X, 1, cid.unsqueeze(2).expand(-1, -1, D))
+    if D == 128 and cid.shape[1] in (16, 32, 64):
+        return K.membership_fwd(Csel, X, bw, torch.clamp(ncl, max=cid.shape[1]), EPS, want_labels=True)[4]
+    cvalid = torch.arange(cid.shape[1], device=X.device).unsqueeze(0) < ncl.unsqueeze(1)
     sc = torch.bmm(Csel, X.transpose(1, 2))                                     # (B,CMAX,N)
     sc = torch.where(cvalid.unsqueeze(2), sc, torch.full_like(sc, float("-inf")))
-    labels = MSM._first_argmax(sc, 1)
-    return {"labels": labels, "cid": cid, "ncl": ncl, "nocc": nocc, "nflag": nflag, "width": U}
+    return MSM._first_argmax(sc, 1)
 
 
 def nms_width_guess(ev, B, N):
@@ -187,13 +180,13 @@ class _Membership(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cen, emb, bw, ncl):
         cen, emb = cen.contiguous(), emb.contiguous()
-        Wraw, prob, Wn, rowstat, _ = K.membership_fwd(cen, emb, bw, ncl, EPS)
+        Wraw, prob, Wn, rowstat, labels = K.membership_fwd(cen, emb, bw, ncl, EPS, want_labels=True)
         ctx.save_for_backward(cen, emb, bw, ncl, Wraw, prob, rowstat)
-        ctx.mark_non_differentiable(Wraw)
-        return Wn, Wraw
+        ctx.mark_non_differentiable(Wraw, labels)
+        return Wn, Wraw, labels
 
     @staticmethod
-    def backward(ctx, gWn, _gWraw):
+    def backward(ctx, gWn, _gWraw, _glabels):
         cen, emb, bw, ncl, Wraw, prob, rowstat = ctx.saved_tensors
         gWraw = K.membership_bwd(gWn, Wraw, prob, rowstat, bw, ncl)
         return torch.bmm(gWraw, emb), torch.bmm(gWraw.transpose(1, 2), cen), None, None
@@ -206,7 +199,7 @@ def memberships(cen, emb, bw, ncl):
     if D == 128 and Cp <= 64:
         CP = 16 if Cp <= 16 else 32 if Cp <= 32 else 64
         cen = torch.nn.functional.pad(cen, (0, 0, 0, CP - Cp))
-        return _Membership.apply(cen, emb, bw.contiguous(), ncl)
+        return _Membership.apply(cen, emb, bw.contiguous(), ncl)[:2]
     Wraw = torch.bmm(cen, emb.transpose(1, 2))
     return weights_normalize_batch(Wraw, bw, ncl), Wraw
 
@@ -295,6 +288,33 @@ def _host_minor_axis_rotation(cov):
     return rotation_matrix_a_to_b(smallest_ev, np.array([1, 0, 0])).astype(np.float32)
 
 
+def host_minor_axis_rotations(cov):
+    """_host_minor_axis_rotation for a stack cov (S,3,3) (float32 CPU tensor) -> (S,3,3) float32
+    numpy, bit for bit the per-matrix function's result but ~6x cheaper on the host (the device
+    idles meanwhile): ONE batched geev call (LAPACK is still entered once per matrix, with the same
+    input), and rotation_matrix_a_to_b specialised to B = (1, 0, 0) with the two np.cross calls and
+    the dots written out in the float64 scalar operations numpy performs for them; norm, inv and
+    the two matrix products stay numpy's (tests/test_host_logic.py pins the equality)."""
+    w, v = torch.linalg.eig(cov)
+    k = torch.min(w.real, 1)[1].numpy()
+    U = v.real.numpy()
+    out = np.empty((cov.shape[0], 3, 3), dtype=np.float32)
+    for s in range(cov.shape[0]):
+        A = U[s][:, k[s]]
+        a0, a1, a2 = float(A[0]), float(A[1]), float(A[2])
+        cos = a0 * 1.0 + a1 * 0.0 + a2 * 0.0                      # np.dot(A, B)
+        wv = np.array([0.0 * a2 - 0.0 * a1, 0.0 * a0 - 1.0 * a2, 1.0 * a1 - 0.0 * a0])    # np.cross(B, A)
+        sin = np.linalg.norm(wv)
+        vv = np.array([1.0 - cos * a0, 0.0 - cos * a1, 0.0 - cos * a2])                  # B - dot * A
+        Fm = np.stack([A.astype(np.float64), vv / (np.linalg.norm(vv) + EPS), wv / (np.linalg.norm(wv) + EPS)], 1)
+        G = np.array([[cos, -sin, 0], [sin, cos, 0], [0, 0, 1]])
+        try:
+            out[s] = (Fm @ G @ np.linalg.inv(Fm)).astype(np.float32)
+        except np.linalg.LinAlgError:
+            out[s] = np.eye(3, dtype=np.float32)
+    return out
+
+
 def standardize_segments(P2, w):
     """standardize_point_torch (src/fitting_utils.py:512-553) for S segments at once.
     P2 (S,n,3) sub-sampled points of each segment's shape, w (S,n) memberships (+EPS).
@@ -313,7 +333,7 @@ def standardize_segments(P2, w):
         Pc = P2 - mean.unsqueeze(1)
         cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
         cov_h = cov.cpu()                                        # host step of the reference
-        R = torch.from_numpy(np.stack([_host_minor_axis_rotation(cov_h[s]) for s in range(S)], 0))
+        R = torch.from_numpy(host_minor_axis_rotations(cov_h))
         R = R.pin_memory().to(P2.device, non_blocking=True)
         Pr = torch.bmm(Pc, R.transpose(1, 2))
         wp = Pr * w.unsqueeze(2)
@@ -419,8 +439,20 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         bw, bwflag = bwres
         with record_function("fit:meanshift_fwd"):
             new_X = MSM.mean_shift_iterations(emb, bw, iterations)
-        with torch.no_grad(), record_function("fit:nms"):
-            state = nms_batch(new_X.detach(), emb.detach(), bw, nms_width_guess(ev, B, N))
+
+        def cluster(width):
+            """NMS down to the padded list of centres, then — still on the device, before anything is
+            downloaded — the memberships of ALL CMAX padded centre rows (rows >= ncl are masked in
+            the kernel), whose first output are the cluster labels the host is waiting for."""
+            with torch.no_grad(), record_function("fit:nms"):
+                st = nms_batch(new_X.detach(), emb.detach(), bw, width, labels=False)
+            if st is not None:
+                with record_function("fit:memberships"):
+                    cen_all = torch.gather(new_X, 1, st["cid"].unsqueeze(2).expand(-1, -1, D))       # (B,CMAX,D)
+                    st["cen"] = cen_all
+                    st["Wn"], st["Wraw"], st["labels"] = _Membership.apply(cen_all, emb, bw, torch.clamp(st["ncl"], max=CMAX))
+            return st
+        state = cluster(nms_width_guess(ev, B, N))
     with torch.no_grad():
         # SIOU_matched_segments merges the predicted types before the per-cluster vote
         # (src/segment_utils.py:152-161: 0, 6, 7 -> 9; 8 -> 2)
@@ -441,8 +473,7 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         if int(pack[-2 * B:-B].max()) > state["width"]:
             # the guessed width of the neighbour matrix was too small (the clustering changed a lot
             # since the last step): once more with the exact one
-            with torch.no_grad():
-                state = nms_batch(new_X.detach(), emb.detach(), bw, None)
+            state = cluster(None)
             pack = download(state)
         nms_width_update(ev, B, N, int(pack[-2 * B:-B].max()))
         o = 1
@@ -451,31 +482,37 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         ncl_h, bwflag_h = pack[o:o + B], pack[o + B:o + 2 * B]
         nflag_h = pack[-B:]
     centers, bws, cluster_ids = [], [], []
+    all_fast = state is not None
     for b in range(B):
         # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122)
         fast = state is not None and nflag_h[b] == 0 and bwflag_h[b] == 0 and ncl_h[b] <= CMAX
         if fast:
             np.random.shuffle(np.arange(N))
         if fast and ncl_h[b] <= 49:
-            centers.append(new_X[b][state["cid"][b, :int(ncl_h[b])]])
+            centers.append(state["cen"][b, :int(ncl_h[b])])
             bws.append(bw[b])
             cluster_ids.append(lab_h[b].astype(np.int64))
         else:
             # tie-flagged selection rows or the guard's retry above 49 clusters: this shape alone on
             # the synchronous path
+            all_fast = False
             q = quantile * 1.2 if (fast and ncl_h[b] > 49) else quantile
             c, bwb, ids = ev.guard_mean_shift(emb[b], q, iterations, kernel_type="gaussian")
             centers.append(c)
             bws.append(bwb.reshape(()))
             cluster_ids.append(ids.cpu().numpy().astype(np.int64))
     ncl_list = [int(c.shape[0]) for c in centers]
-    Cp = max(ncl_list)
-    cen = torch.stack([torch.nn.functional.pad(c, (0, 0, 0, Cp - c.shape[0])) for c in centers], 0)   # (B,Cp,D)
-    bwt = torch.stack(bws).detach()
-    ncl_t = h2d(np.asarray(ncl_list, dtype=np.int64), dev)
-    with record_function("fit:memberships"):
-        Wn, Wraw = memberships(cen, emb, bwt, ncl_t)                             # (B,Cp,N), Cp padded to 16/32/64
-        Cp = Wn.shape[1]
+    if all_fast:
+        # the memberships the device computed before the download are the ones to use
+        Wn, Wraw, bwt, Cp = state["Wn"], state["Wraw"], bw, CMAX
+    else:
+        Cp = max(ncl_list)
+        cen = torch.stack([torch.nn.functional.pad(c, (0, 0, 0, Cp - c.shape[0])) for c in centers], 0)   # (B,Cp,D)
+        bwt = torch.stack(bws).detach()
+        ncl_t = h2d(np.asarray(ncl_list, dtype=np.int64), dev)
+        with record_function("fit:memberships"):
+            Wn, Wraw = memberships(cen, emb, bwt, ncl_t)                         # (B,Cp,N), Cp padded to 16/32/64
+            Cp = Wn.shape[1]
 
     # ---- host: matching + segment tables -------------------------------------------------
     tables, matches = [], []

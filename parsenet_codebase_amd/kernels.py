@@ -794,3 +794,36 @@ def affine_act_bwd(gy, y, scale, act, slope=0.0):
                                                float(slope), ptr(gx), current_stream(y.device))
     check(rc, "pn_affine_act_bwd_f32")
     return gx
+
+
+def nms_occupied(membership, U):
+    """membership (B,N) int64 -> (counts (B,N) int32, uq (B,U) int64 ascending occupied centres, nocc (B,) int64)."""
+    require_cuda(membership)
+    membership = _i64c(membership, "membership")
+    B, N = membership.shape
+    dev = membership.device
+    counts = torch.empty((B, N), dtype=torch.int32, device=dev)
+    uq = torch.empty((B, U), dtype=torch.int64, device=dev)
+    nocc = torch.empty(B, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_nms_occupied_f32(ptr(membership), B, N, int(U), ptr(counts), ptr(uq), ptr(nocc),
+                                             current_stream(dev))
+    check(rc, "pn_nms_occupied_f32")
+    return counts, uq, nocc
+
+
+def nms_vote(G, uq, nocc, counts, bw, cmax):
+    """G (B,U,U) Gram matrix of the occupied centres -> (cid (B,cmax) int64 ascending voted centres, ncl (B,))."""
+    require_cuda(G, uq, nocc, counts, bw)
+    G = _f32c(G, "G")
+    B, U, _ = G.shape
+    N = counts.shape[1]
+    dev = G.device
+    hits = torch.empty((B, N), dtype=torch.int32, device=dev)
+    cid = torch.empty((B, cmax), dtype=torch.int64, device=dev)
+    ncl = torch.empty(B, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_nms_vote_f32(ptr(G), ptr(uq), ptr(nocc), ptr(counts), ptr(_f32c(bw, "bw")), B, N, U,
+                                         int(cmax), ptr(hits), ptr(cid), ptr(ncl), current_stream(dev))
+    check(rc, "pn_nms_vote_f32")
+    return cid, ncl

@@ -161,6 +161,18 @@ def make_batch(first_id, batch, num_points=10000, **kw):
     return tuple(np.stack([it[j] for it in items], 0) for j in range(4))
 
 
+def make_batch_ids(ids, num_points=10000, **kw):
+    """make_batch for an explicit list of shape ids."""
+    items = [make_shape(i, num_points, **kw) for i in ids]
+    return tuple(np.stack([it[j] for it in items], 0) for j in range(4))
+
+
+# shape ids in [0, 3000) whose patches are planes, spheres and cones only: every fit of the fitting
+# stage is then well conditioned (no cylinder: its circle fit always takes the reference's noisy
+# fp32 ridge branch; no SplineNet: kNN near-ties) — whole-step gradient parity tests use them
+ANALYTIC_WELL_POSED_IDS = (68, 160, 172, 200, 382, 395, 436, 486, 633, 821, 984, 1022, 1341, 1360, 1542, 1569)
+
+
 def make_spline_patches(first_id, batch, num_points=700, grid=20, closed=False):
     """SplineNet inputs (cfg1-3): points (B,N,3) sampled on random smooth bicubic control grids
     (grid x grid x 3, returned as the regression target), canonicalised like

@@ -118,15 +118,20 @@ def sync_module_from_rank0(*modules):
 class SyntheticSegments:
     """Stand-in for dataset_segments.Dataset: endless generators of analytic shapes."""
 
-    def __init__(self, batch_size, num_train, num_val, num_points=10000, first_shape=0):
+    def __init__(self, batch_size, num_train, num_val, num_points=10000, first_shape=0, ids=None):
         self.batch_size, self.num_train, self.num_val = batch_size, num_train, num_val
         self.num_points, self.first = num_points, first_shape
+        self.ids = ids          # explicit shape ids (position p of the stream -> ids[p]) instead of first_shape + p
 
     def _gen(self, lo, count):
         i = 0
         while True:
             ids = lo + (i % max(count // self.batch_size, 1)) * self.batch_size
-            pts, nrm, lab, prim = synthetic.make_batch(self.first + ids, self.batch_size, self.num_points)
+            if self.ids is not None:
+                pts, nrm, lab, prim = synthetic.make_batch_ids(
+                    [self.ids[(ids + j) % len(self.ids)] for j in range(self.batch_size)], self.num_points)
+            else:
+                pts, nrm, lab, prim = synthetic.make_batch(self.first + ids, self.batch_size, self.num_points)
             yield pts, lab, nrm, prim
             i += 1
 

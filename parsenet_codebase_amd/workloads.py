@@ -48,7 +48,8 @@ class ParsenetSegStep:
     HBM; step s works on shapes [s * batch mod pool, + batch) of the pool — the reference's loop
     draws a new batch every iteration (train_parsenet.py:151-160)."""
 
-    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-2, pool=None):
+    def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-2, pool=None,
+                 shape_ids=None):
         torch.manual_seed(seed)
         self.device = device
         self.batch = batch
@@ -60,14 +61,19 @@ class ParsenetSegStep:
         self.bucket = FlatGradBucket(self.model.parameters())
         self.opt = _adam(self.model.parameters(), lr)
         self.rng_seed = seed
-        self.load_pool(first_shape, batch if pool is None else pool)
+        if shape_ids is not None:
+            self.load_pool(first_shape, len(shape_ids), ids=shape_ids)
+        else:
+            self.load_pool(first_shape, batch if pool is None else pool)
 
-    def load_pool(self, first_shape, pool):
-        """Make shapes first_shape .. first_shape + pool - 1 resident (everything a step touches is in
-        HBM before the timed region starts; labels stay host integers like the reference's numpy)."""
+    def load_pool(self, first_shape, pool, ids=None):
+        """Make shapes first_shape .. first_shape + pool - 1 (or the explicit ``ids``) resident
+        (everything a step touches is in HBM before the timed region starts; labels stay host
+        integers like the reference's numpy)."""
         if pool % self.batch:
             raise ValueError("pool (%d) must be a multiple of the batch (%d)" % (pool, self.batch))
-        pts, nrm, lab, prim = synthetic.make_batch(first_shape, pool, self.num_points)
+        pts, nrm, lab, prim = (synthetic.make_batch_ids(ids, self.num_points) if ids is not None else
+                               synthetic.make_batch(first_shape, pool, self.num_points))
         x = np.concatenate([pts, nrm], 2).transpose(0, 2, 1)           # (P,6,N)
         self.pool, self.first_shape = pool, first_shape
         self.pool_x = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
@@ -125,8 +131,9 @@ class ParsenetE2EStep(ParsenetSegStep):
     ranks only rank 0 trains; the weights reach the others with one flat broadcast."""
 
     def __init__(self, device, batch=4, num_points=10000, nn_nb=80, first_shape=0, seed=0, lr=1e-4,
-                 pretrain_steps=0, pool=None, pretrain_pool=None, pretrain_lr=1e-2):
-        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr=pretrain_lr, pool=pool)
+                 pretrain_steps=0, pool=None, pretrain_pool=None, pretrain_lr=1e-2, shape_ids=None):
+        super().__init__(device, batch, num_points, nn_nb, first_shape, seed, lr=pretrain_lr, pool=pool,
+                         shape_ids=shape_ids)
         from .encoders import DGCNNControlPoints
         from .fitting import Evaluation
         self.pretrain_steps = int(pretrain_steps)
