@@ -122,6 +122,8 @@ SIGNATURES = {
     "pn_membership_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 2 + [c_void_p]),
     "pn_nms_occupied_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pn_nms_vote_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 3 + [c_void_p]),
+    "pn_weighted_max_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float] + [c_void_p] * 3 + [c_void_p]),
+    "pn_weighted_max_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_void_p]),
     "pn_affine_act_fwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p]),
     "pn_affine_act_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p]),
 }

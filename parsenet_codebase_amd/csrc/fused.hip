@@ -754,3 +754,105 @@ extern "C" int pn_nms_vote_f32(const float* G, const int64_t* uq, const int64_t*
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
+
+// =============================================================================================
+// SplineNet head: max over the points of  act(x * scale[c] + shift[c]) * w[s][n]
+// =============================================================================================
+// src/model.py:160-170 under eval(): conv5 -> bn5 -> LeakyReLU, "x *= weights", adaptive max pool —
+// for a FROZEN network (no gradient to x): out[s][c] = max_n, idx[s][c] = its first arg-max,
+// val[s][c] = the activation there (the factor of w in the product).  One workgroup per (s, c) row.
+__global__ __launch_bounds__(256) void pn_wmax_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ w,
+                                                          int C, int N, int act, float slope, float* __restrict__ out,
+                                                          int* __restrict__ idx, float* __restrict__ val) {
+  __shared__ float sm[4], sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x, s = row / C, c = row - s * C;
+  const float sc = scale[c], sh = shift[c];
+  const float* __restrict__ xr = x + (size_t)row * N;
+  const float* __restrict__ wr = w + (size_t)s * N;
+  float best = -INFINITY, bv = 0.f;
+  int bi = 0x7fffffff;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float v = xr[n] * sc + sh;
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = v > 0.f ? v : v * slope;
+    const float p = v * wr[n];
+    if (p > best) {
+      best = p;
+      bi = n;
+      bv = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64), ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) {
+      best = ob;
+      bi = oi;
+      bv = ov;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[wave] = best;
+    si[wave] = bi;
+    sv[wave] = bv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (sm[k] > best || (sm[k] == best && si[k] < bi)) {
+        best = sm[k];
+        bi = si[k];
+        bv = sv[k];
+      }
+    out[row] = best;
+    idx[row] = bi;
+    val[row] = bv;
+  }
+}
+
+// gw[s][n] = sum over the channels whose arg-max is n of g[s][c] * val[s][c], channels in order
+// (one workgroup per s; the sums are formed in LDS by one thread: C additions).
+__global__ __launch_bounds__(256) void pn_wmax_bwd_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                          const float* __restrict__ val, int C, int N,
+                                                          float* __restrict__ gw) {
+  extern __shared__ float acc[];
+  const int s = blockIdx.x;
+  for (int n = threadIdx.x; n < N; n += 256) acc[n] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int c = 0; c < C; ++c) {
+      const int i = idx[(size_t)s * C + c];
+      if (i >= 0 && i < N) acc[i] += g[(size_t)s * C + c] * val[(size_t)s * C + c];
+    }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) gw[(size_t)s * N + n] = acc[n];
+}
+
+extern "C" int pn_weighted_max_fwd_f32(const float* x, const float* scale, const float* shift, const float* w, int S,
+                                       int C, int N, int act, float slope, float* out, int* idx, float* val,
+                                       void* stream) {
+  PN_CHECK_ARG(x && scale && shift && w && out && idx && val && S > 0 && C > 0 && N > 0 && act >= 0 && act <= 2,
+               "pn_weighted_max_fwd_f32: bad arguments");
+  PN_PROF("weighted_max_fwd", (hipStream_t)stream);
+  hipLaunchKernelGGL(pn_wmax_fwd_kernel, dim3(S * C), dim3(256), 0, (hipStream_t)stream, x, scale, shift, w, C, N, act,
+                     slope, out, idx, val);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+extern "C" int pn_weighted_max_bwd_f32(const float* g, const int* idx, const float* val, int S, int C, int N,
+                                       float* gw, void* stream) {
+  PN_CHECK_ARG(g && idx && val && gw && S > 0 && C > 0 && N > 0, "pn_weighted_max_bwd_f32: bad arguments");
+  if ((size_t)N * sizeof(float) > 64 * 1024) {
+    pn_set_error("pn_weighted_max_bwd_f32: N=%d exceeds the LDS accumulator (16384 points)", N);
+    return PN_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(pn_wmax_bwd_kernel, dim3(S), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream, g, idx, val,
+                     C, N, gw);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

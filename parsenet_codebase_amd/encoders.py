@@ -72,17 +72,15 @@ class _AffineAct(torch.autograd.Function):
 _ACT = {"none": 0, "relu": 1, "leaky": 2}
 
 
-def conv_bn_act(x, conv, bn, act, slope=0.0):
-    """act(bn(conv1x1(x))) for x (B,Ci,N).  A FROZEN evaluation-mode BatchNorm1d (the SplineNets of
-    the fitting stage: src/model.py:160-176 under eval(), parameters without gradient) is the
-    per-channel affine map it is, folded with the convolution's bias and the activation into ONE
-    launch after the GEMM; scale and shift are cached on the module until one of its tensors
-    changes.  Training mode, or parameters that want a gradient: the generic expressions."""
+def _frozen_affine(conv, bn, x):
+    """(scale, shift) of ``bn(conv(.) )`` as a per-channel affine map after the bias-free GEMM, or
+    None unless ``bn`` is a frozen evaluation-mode BatchNorm (running statistics, no tensor of it
+    or the convolution's bias wants a gradient) on the GPU.  Cached on the module until one of its
+    tensors changes."""
     frozen = not (bn.training or bn.running_mean is None) and x.is_cuda and not (
         torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (bn.weight, bn.bias, conv.bias)))
     if not frozen:
-        y = batch_norm_1d(conv1x1(x, conv), bn)
-        return F.relu(y) if act == "relu" else F.leaky_relu(y, slope) if act == "leaky" else y
+        return None
     src = (bn.running_mean, bn.running_var, bn.weight, bn.bias, conv.bias)
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
     hit = bn.__dict__.get("_pn_affine")
@@ -97,7 +95,40 @@ def conv_bn_act(x, conv, bn, act, slope=0.0):
                 shift = shift + conv.bias * scale
         hit = (key, scale.contiguous(), shift.contiguous())
         bn.__dict__["_pn_affine"] = hit
-    return _AffineAct.apply(weight_bmm(conv.weight[:, :, 0], x), hit[1], hit[2], _ACT[act], slope)
+    return hit[1], hit[2]
+
+
+def conv_bn_act(x, conv, bn, act, slope=0.0):
+    """act(bn(conv1x1(x))) for x (B,Ci,N).  A FROZEN evaluation-mode BatchNorm1d (the SplineNets of
+    the fitting stage: src/model.py:160-176 under eval(), parameters without gradient) is the
+    per-channel affine map it is, folded with the convolution's bias and the activation into ONE
+    launch after the GEMM.  Training mode, or parameters that want a gradient: the generic
+    expressions."""
+    aff = _frozen_affine(conv, bn, x)
+    if aff is None:
+        y = batch_norm_1d(conv1x1(x, conv), bn)
+        return F.relu(y) if act == "relu" else F.leaky_relu(y, slope) if act == "leaky" else y
+    return _AffineAct.apply(weight_bmm(conv.weight[:, :, 0], x), aff[0], aff[1], _ACT[act], slope)
+
+
+class _WeightedMax(torch.autograd.Function):
+    """max_n act(y * scale + shift) * w for y (S,C,N), w (S,N) -> (S,C): the frozen SplineNet's
+    conv5 / bn5 / LeakyReLU, membership weighting and max pool in one pass (csrc/fused.hip); the
+    only gradient is the one to the memberships w."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift, w, act, slope):
+        from . import kernels as K
+        out, idx, val = K.weighted_max_fwd(y, scale, shift, w, act, slope)
+        ctx.save_for_backward(idx, val)
+        ctx.n = y.shape[2]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import kernels as K
+        idx, val = ctx.saved_tensors
+        return None, None, None, K.weighted_max_bwd(g, idx, val, ctx.n), None, None
 
 
 def _edge_layer(cin2, cout, norm):
@@ -153,7 +184,20 @@ class DGCNNControlPoints(nn.Module):
             idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
-        x = conv_bn_act(torch.cat(feats, dim=1), self.conv5[0], self.bn5, "leaky", 0.2)
+        cat = torch.cat(feats, dim=1)
+        aff = _frozen_affine(self.conv5[0], self.bn5, cat)
+        if (aff is not None and isinstance(weights, torch.Tensor) and weights.numel() == batch_size * cat.shape[2]
+                and cat.shape[2] <= 16384 and not (torch.is_grad_enabled() and (
+                    cat.requires_grad or self.conv5[0].weight.requires_grad))):
+            # frozen network inside the fitting stage: activation, membership weighting and the max over
+            # the points in ONE pass over the 1024-channel features (they are never written out)
+            x = _WeightedMax.apply(weight_bmm(self.conv5[0].weight[:, :, 0], cat), aff[0], aff[1],
+                                   weights.reshape(batch_size, -1), _ACT["leaky"], 0.2).unsqueeze(2)
+            x = conv_bn_act(x, self.conv6, self.bn6, "relu")
+            x = conv_bn_act(x, self.conv7, self.bn7, "relu")
+            x = self.tanh(conv1x1(x, self.conv8)[:, :, 0])
+            return x.view(batch_size, self.controlpoints * self.controlpoints, 3)
+        x = conv_bn_act(cat, self.conv5[0], self.bn5, "leaky", 0.2)
         if isinstance(weights, torch.Tensor):
             # the reference reshapes to (1,1,-1) (one segment per call); a (B,n) matrix weights
             # every item of a batch of segments with its own memberships

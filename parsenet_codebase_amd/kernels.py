@@ -827,3 +827,31 @@ def nms_vote(G, uq, nocc, counts, bw, cmax):
                                          int(cmax), ptr(hits), ptr(cid), ptr(ncl), current_stream(dev))
     check(rc, "pn_nms_vote_f32")
     return cid, ncl
+
+
+def weighted_max_fwd(x, scale, shift, w, act, slope=0.0):
+    """max over n of act(x * scale[c] + shift[c]) * w[s, n]: x (S,C,N), w (S,N) -> (out (S,C), idx int32, val)."""
+    require_cuda(x, scale, shift, w)
+    x, w = _f32c(x, "x"), _f32c(w, "w")
+    S, C, N = x.shape
+    dev = x.device
+    out = torch.empty((S, C), dtype=torch.float32, device=dev)
+    idx = torch.empty((S, C), dtype=torch.int32, device=dev)
+    val = torch.empty((S, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().pn_weighted_max_fwd_f32(ptr(x), ptr(_f32c(scale, "scale")), ptr(_f32c(shift, "shift")), ptr(w),
+                                                 S, C, N, int(act), float(slope), ptr(out), ptr(idx), ptr(val),
+                                                 current_stream(dev))
+    check(rc, "pn_weighted_max_fwd_f32")
+    return out, idx, val
+
+
+def weighted_max_bwd(g, idx, val, N):
+    g = _f32c(g, "g")
+    S, C = g.shape
+    gw = torch.empty((S, N), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = _lib.load().pn_weighted_max_bwd_f32(ptr(g), ptr(idx), ptr(val), S, C, int(N), ptr(gw),
+                                                 current_stream(g.device))
+    check(rc, "pn_weighted_max_bwd_f32")
+    return gw
