@@ -105,32 +105,37 @@ class StubStep:
         return loss
 
 
-def pmc_traffic(kernel_name, arith, shapes_per_launch=1):
+def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     """HBM-side bytes per launch of a mean-shift kernel from the committed PMC run of the same
     launch configuration (profiles/: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH
     doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
-    the file is not there — bench.py never profiles counters itself.  The round-2 file holds the
-    batched launches (4 shapes each) of the default arithmetic; the round-1 files are per shape."""
+    the file is not there — bench.py never profiles counters itself.  The round-3 file was
+    collected inside ``bench.py --workload cfg5`` (batched launches of 4 shapes; it holds the dense
+    launches — the largest grid of a kernel — and the few planned ones of the auto mode's probes:
+    256 workgroups); the round-1 files are per shape."""
     import csv
     files = {"fp16x2": ("r01_meanshift_h2_pmc.csv", "pn_msh_kernel<%d>"),
              "bf16x3": ("r01_meanshift_x3_pmc.csv", "pn_ms3_kernel<%d>"),
              "f32": ("r01_meanshift_f32_pmc.csv", "pn_ms_kernel<%d>")}
     scale = float(shapes_per_launch)
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     if arith == "bf16x3" and shapes_per_launch == 4:
-        from parsenet_codebase_amd import mean_shift as _ms
-        # block-sparse launches of the benchmark's own embedding / dense launches (kbench meanshift_batch)
-        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        cand = (["r03_meanshift_x3_sparse_cfg5_pmc.csv", "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if _ms.SPARSE else
-                ["r03_meanshift_x3_dense_cfg5_pmc.csv", "r02_meanshift_x3_batch4_pmc.csv"])
+        cand = ["r03_meanshift_x3_dense_cfg5_pmc.csv"] + (["r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
+                                                          ["r02_meanshift_x3_batch4_pmc.csv"])
         files["bf16x3"] = (next((c for c in cand if os.path.exists(os.path.join(prof, c))), cand[-1]),
                            "pn_ms3_kernel<%d>")
         scale = 1.0
-    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", files[arith][0])
+    fn = os.path.join(prof, files[arith][0])
     idx = {"meanshift_fwd": 0, "meanshift_bwd_rows": 1, "meanshift_bwd_cols": 2}.get(kernel_name)
     if idx is None or not os.path.exists(fn):
         return None
     want = files[arith][1] % idx
-    vals = {r["counter"]: float(r["avg_per_launch"]) for r in csv.DictReader(open(fn)) if r["kernel"] == want}
+    rows = [r for r in csv.DictReader(open(fn)) if r["kernel"] == want]
+    grids = sorted({int(r["grid_size"]) for r in rows if r.get("grid_size", "").isdigit()})
+    if len(grids) > 1:      # dense launches: the largest grid; planned (flat schedule): the smallest
+        pick = str(grids[0] if planned else grids[-1])
+        rows = [r for r in rows if r["grid_size"] == pick]
+    vals = {r["counter"]: float(r["avg_per_launch"]) for r in rows}
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 * scale
@@ -219,7 +224,7 @@ def kernel_roofline(step, nprof):
             ach_exec = pieces * ach * executed
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach_exec, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach_exec / MFMA_BF16_PEAK_TFLOPS,
-                    "traffic": pmc_traffic(dom, _ms.ARITH, shapes_per_launch),
+                    "traffic": pmc_traffic(dom, _ms.ARITH, shapes_per_launch, planned=bool(plan_stats)),
                     "avg_launch_ms": table[dom]["avg_ms"],
                     "mfma": ("v_mfma_f32_32x32x16_bf16, 6 piece products per fp32 product (bf16x3 split)"
                              if _ms.ARITH == "bf16x3" else

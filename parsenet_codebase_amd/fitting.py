@@ -998,6 +998,17 @@ class Evaluation:
         return fitting_losses_train(self, embedding, points, normals, labels, primitives, primitives_log_prob,
                                     quantile, iterations, lamb, defer_metrics)
 
+    def fitting_losses_pipelined(self, embedding, points, normals, labels, primitives, primitives_log_prob,
+                                 quantile=0.125, iterations=5, lamb=1.0, chunks=2):
+        """``fitting_losses(defer_metrics=True)`` with the batch cut into ``chunks`` groups whose
+        clustering is queued up front, so that the device works on the next group while the host
+        matches the previous one (fitting_batch.fitting_losses_train_pipelined).  Returns
+        (losses (B,) on the device, finish)."""
+        from .fitting_batch import fitting_losses_train_pipelined
+        require_cuda(embedding, points, normals)
+        return fitting_losses_train_pipelined(self, embedding, points, normals, labels, primitives,
+                                              primitives_log_prob, quantile, iterations, lamb, chunks)
+
     def residual_train_mode(self, points, normals, labels, cluster_ids, primitives, weights, bw, lamb=1.0):
         if not isinstance(cluster_ids, np.ndarray):
             cluster_ids = cluster_ids.data.cpu().numpy()

@@ -424,6 +424,60 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
     entry per shape) of ([Loss, geometric mean, spline mean, s_iou, p_iou], [parameters, cluster
     ids, weights]) exactly as the reference's call with that single shape would.
     ``ev``: the owning fitting.Evaluation (SplineNets, mean-shift object, slow-path helpers)."""
+    stage = _fitting_stage(ev, embedding, points, normals, labels, primitives, primitives_log_prob, quantile,
+                           iterations, lamb, defer_metrics)
+    next(stage)                      # clustering queued, the cluster-id download under way
+    try:
+        next(stage)                  # host matching, fits, losses
+    except StopIteration as done:
+        return done.value
+    raise RuntimeError("fitting stage: unexpected second suspension")
+
+
+def fitting_losses_train_pipelined(ev, embedding, points, normals, labels, primitives, primitives_log_prob, quantile,
+                                   iterations, lamb, chunks=2):
+    """The same stage for a batch cut into ``chunks`` groups of shapes, software-pipelined: the
+    clustering of EVERY group is queued first (bandwidth, ten mean-shift iterations, NMS,
+    memberships, and the stream-ordered copy of its cluster ids into pinned memory), only then
+    does the host turn to group 0 — it waits for that group's copy alone, and while it runs the
+    Hungarian matching and builds the segment tables the device is busy with the next group's
+    iterations instead of idling (one group: the device waits for the host at that point, ~2-5 ms
+    per step, more on a busy host).  The reference processes shapes strictly one after the other
+    (train_parsenet_e2e.py:190-241); shapes are independent, so the grouping changes no result
+    (numpy's RNG is consumed in shape order: all draws happen in the host part).
+    Returns (losses (B,) on the device, finish) like ``fitting_losses_train(defer_metrics=True)``."""
+    B = embedding.shape[0]
+    chunks = max(1, min(int(chunks), B))
+    bounds = [(B * c // chunks, B * (c + 1) // chunks) for c in range(chunks)]
+    labels, primitives = np.asarray(labels), np.asarray(primitives)
+    stages = [_fitting_stage(ev, embedding[lo:hi], points[lo:hi], normals[lo:hi], labels[lo:hi], primitives[lo:hi],
+                             primitives_log_prob[lo:hi], quantile, iterations, lamb, True) for lo, hi in bounds]
+    for st in stages:
+        next(st)
+    parts = []
+    for st in stages:
+        try:
+            next(st)
+        except StopIteration as done:
+            parts.append(done.value)
+            continue
+        raise RuntimeError("fitting stage: unexpected second suspension")
+    loss_b = torch.cat([p[0] for p in parts])
+
+    def finish():
+        out = []
+        for _, fin in parts:
+            out += fin()
+        return out
+    return loss_b, finish
+
+
+def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitives_log_prob, quantile, iterations,
+                   lamb, defer_metrics):
+    """Generator behind the two functions above: runs up to the point where the host needs the
+    cluster ids (their copy into pinned memory is queued, an event recorded), yields ONCE, and on
+    resumption waits for that copy and does the rest.  Returns (via StopIteration) what
+    fitting_losses_train returns."""
     B, N, D = embedding.shape
     dev = embedding.device
     labels, primitives = np.asarray(labels), np.asarray(primitives)
@@ -464,10 +518,25 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         auto_stat, MSM.AUTO_STAT = MSM.AUTO_STAT, None
         head = (torch.zeros(1, device=dev) if auto_stat is None else auto_stat.reshape(1) * 1e6 + 1.0).long()
 
+        def start_download(st):
+            """Stream-ordered copy of the cluster ids (and the few counters riding along) into pinned
+            memory + an event: the host blocks on THIS copy only, whatever else is queued behind it."""
+            dev_pack = torch.cat([head, st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag,
+                                  st["nocc"], st["nflag"]]).to(torch.int32)
+            host = torch.empty(dev_pack.shape, dtype=torch.int32).pin_memory()
+            host.copy_(dev_pack, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            return host, done
+
         def download(st):
-            return torch.cat([head, st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag, st["nocc"],
-                              st["nflag"]]).to(torch.int32).cpu().numpy()                # download: cluster ids
-        pack = download(state)
+            host, done = start_download(st)
+            done.synchronize()
+            return host.numpy()
+        pending = start_download(state)
+        yield                                                    # (a pipelined caller queues the next group here)
+        pending[1].synchronize()                                 # download: cluster ids
+        pack = pending[0].numpy()
         if pack[0] > 0:
             MSM.auto_report(B, N, (float(pack[0]) - 1.0) * 1e-6)
         if int(pack[-2 * B:-B].max()) > state["width"]:
@@ -481,6 +550,8 @@ def fitting_losses_train(ev, embedding, points, normals, labels, primitives, pri
         cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
         ncl_h, bwflag_h = pack[o:o + B], pack[o + B:o + 2 * B]
         nflag_h = pack[-B:]
+    else:
+        yield
     centers, bws, cluster_ids = [], [], []
     all_fast = state is not None
     for b in range(B):

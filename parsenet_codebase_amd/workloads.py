@@ -152,6 +152,10 @@ class ParsenetE2EStep(ParsenetSegStep):
         # fitting stage of shape b (hundreds of tiny launches and the host synchronisations of the
         # Hungarian matching): the reference processes one shape after the other.
         self.batched = True       # stage-wise over the whole batch (fitting_batch.py); False: shape by shape
+        # groups of shapes whose clustering is queued ahead of the host's matching work (PARSENET_FIT_CHUNKS;
+        # 1: the whole batch as one group)
+        import os
+        self.chunks = int(os.environ.get("PARSENET_FIT_CHUNKS", "2"))
         self.overlap = True       # (shape-by-shape mode) clustering of shape b+1 on a side stream
         self.side = torch.cuda.Stream(device=device)
         self._warmed = False
@@ -242,9 +246,9 @@ class ParsenetE2EStep(ParsenetSegStep):
         res_total = 0
         self.evaluation.batched = self.batched
         if self.batched:
-            loss_b, finish = self.evaluation.fitting_losses(emb, self.points, self.normals, self.labels, self.prim_np,
-                                                            log_prob, quantile=0.025, iterations=10, lamb=0.1,
-                                                            defer_metrics=True)
+            loss_b, finish = self.evaluation.fitting_losses_pipelined(
+                emb, self.points, self.normals, self.labels, self.prim_np, log_prob, quantile=0.025, iterations=10,
+                lamb=0.1, chunks=self.chunks)
             res_total = sum(loss_b[b] for b in range(self.batch))     # the association of the per-shape sum
             loss = loss + res_total / self.batch
             loss.backward()

@@ -265,3 +265,41 @@ def test_deferred_metrics_are_the_same_results(gpu):
         for u, v in zip(a[0][1:], b[0][1:]):
             assert (u is None and v is None) or abs(u - v) <= 1e-6 * abs(u) + 1e-12
         assert sorted(a[1][0].keys()) == sorted(b[1][0].keys())
+
+
+def test_pipelined_groups_equal_the_whole_batch(gpu):
+    """fitting_losses_pipelined (clustering of every group of shapes queued before the host turns to
+    the first group's matching) against the one-group stage: same numpy RNG consumption, losses and
+    gradient with respect to the embedding; chunk counts that do not divide the batch included."""
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.encoders import DGCNNControlPoints
+    from parsenet_codebase_amd.fitting import Evaluation
+    torch.cuda.set_device(gpu)
+    torch.manual_seed(0)
+    B, N = 3, 3000
+    pts, nrm, lab, prim = synthetic.make_batch(20, B, N, min_segments=4, max_segments=5)
+    g = torch.Generator().manual_seed(1)
+    embs = []
+    for b in range(B):
+        S = int(lab[b].max()) + 1
+        proto = torch.nn.functional.normalize(torch.randn(S, 128, generator=g), dim=1)
+        embs.append(proto[torch.from_numpy(lab[b])] + 0.15 * torch.randn(N, 128, generator=g) / np.sqrt(128))
+    emb0 = torch.stack(embs).to(gpu)
+    logp = torch.log_softmax(torch.randn(B, 10, N, generator=g), 1).to(gpu)
+    P, Nr = torch.from_numpy(pts).to(gpu), torch.from_numpy(nrm).to(gpu)
+    ev = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1),
+                    open_path=DGCNNControlPoints(20, num_points=10, mode=0))
+    out = {}
+    for chunks in (1, 2, 3):
+        e = emb0.clone().requires_grad_(True)
+        np.random.seed(7)
+        loss_b, finish = ev.fitting_losses_pipelined(e, P, Nr, lab, prim, logp, quantile=0.025, iterations=10,
+                                                     lamb=0.1, chunks=chunks)
+        loss_b.sum().backward()
+        res = finish()
+        out[chunks] = (loss_b.detach().clone(), e.grad.clone(), [r[1][1] for r in res], np.random.get_state()[2])
+    for chunks in (2, 3):
+        assert out[chunks][3] == out[1][3]
+        assert all(np.array_equal(a, b) for a, b in zip(out[chunks][2], out[1][2]))
+        assert float((out[chunks][0] - out[1][0]).abs().max()) <= 1e-6 * float(out[1][0].abs().max())
+        assert float((out[chunks][1] - out[1][1]).abs().max()) <= 1e-5 * float(out[1][1].abs().max())

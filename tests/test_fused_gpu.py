@@ -188,9 +188,10 @@ def test_frozen_splinenet_head_weighted_max(gpu):
         p.requires_grad = False
     pts = torch.randn(3, 3, 1500, device=gpu) * 0.3
     res = []
+    w0 = torch.rand(3, 1500, device=gpu)
     for fused in (True, False):
         net.bn5.weight.requires_grad = not fused          # a parameter that wants a gradient: generic path
-        w = torch.rand(3, 1500, device=gpu, requires_grad=True)
+        w = w0.clone().requires_grad_(True)
         out = net(pts, w)
         g = torch.randn_like(out)
         (out * g).sum().backward() if fused else (out * res[0][2]).sum().backward()
