@@ -170,14 +170,38 @@ def check(rc, what):
 
 
 def ptr(t):
-    """Raw device pointer of a tensor (None -> NULL)."""
+    """Raw device pointer of a tensor as a plain int (None -> NULL); the argtypes table converts.
+    (No ctypes object per argument: a training step marshals ~4 000 pointers.)"""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """``torch.cuda.device(device)`` only when ``device`` is not already current (one process per
+    GPU: it always is): the context manager's two device switches and their Python frames cost more
+    than the launch they guard, ~400 times per training step."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def current_stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's current HIP stream on ``device`` as a raw handle (an int for the c_void_p slot)."""
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
 
 
 def require_cuda(*tensors):

@@ -132,11 +132,20 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
     Cout = w.shape[0]
     if w.shape[1] != 2 * C:
         raise ValueError("edge conv weight expects %d input channels, got %d" % (2 * C, w.shape[1]))
-    wa, wb = w[:, :C], w[:, C:]
     # W [xj - xi ; xi] = Wa xj + (Wb - Wa) xi: one GEMM on points
-    wcat = torch.cat([wa, wb - wa], 0)                     # (2Cout, C)
+    frozen = not (weight.requires_grad and torch.is_grad_enabled())
+    hit = norm.__dict__.get("_pn_wcat") if frozen else None
+    key = (weight.data_ptr(), weight._version, C)
+    if hit is not None and hit[0] == key:
+        wcat_t = hit[1]                                    # frozen layer (the SplineNets of the fitting stage)
+    else:
+        wa, wb = w[:, :C], w[:, C:]
+        wcat_t = torch.cat([wa, wb - wa], 0).t()           # (C, 2Cout)
+        if frozen:
+            wcat_t = wcat_t.detach().contiguous()
+            norm.__dict__["_pn_wcat"] = (key, wcat_t)
     # batched with stride 0 on the weight: no transposing copy of x (see encoders.weight_bmm)
-    PQ = torch.bmm(x.transpose(1, 2), wcat.t().unsqueeze(0).expand(B, -1, -1))   # (B,N,2Cout)
+    PQ = torch.bmm(x.transpose(1, 2), wcat_t.unsqueeze(0).expand(B, -1, -1))   # (B,N,2Cout)
     if isinstance(norm, torch.nn.GroupNorm):
         out, _ = _EdgeConvNormMax.apply(PQ, idx, norm.weight, norm.bias, norm.num_groups, True, norm.eps,
                                         slope, None)
@@ -160,8 +169,12 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
                     norm.running_mean.mul_(1 - mom).add_(mean.float(), alpha=mom)
                     norm.running_var.mul_(1 - mom).add_((var * (M / max(M - 1.0, 1.0))).float(), alpha=mom)
             return out
-        rstd = torch.rsqrt(norm.running_var + norm.eps)
+        rkey = (norm.running_var.data_ptr(), norm.running_var._version, norm.eps)
+        rhit = norm.__dict__.get("_pn_rstd")
+        if rhit is None or rhit[0] != rkey:
+            rhit = (rkey, torch.rsqrt(norm.running_var + norm.eps))
+            norm.__dict__["_pn_rstd"] = rhit
         out, _ = _EdgeConvNormMax.apply(PQ, idx, gamma, beta, Cout, False, norm.eps, slope,
-                                        (norm.running_mean, rstd))
+                                        (norm.running_mean, rhit[1]))
         return out
     raise TypeError("unsupported norm layer %r" % (norm,))

@@ -42,7 +42,7 @@ def chamfer_nn(a, b, side_a=True, side_b=True):
         argB = torch.empty((B, Nb), dtype=torch.int64, device=dev)
     wsz = lib.pn_chamfer_nn_workspace(B, Na, Nb)
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.pn_chamfer_nn_f32(ptr(a), ptr(b), B, Na, Nb, ptr(minA), ptr(argA), ptr(minB),
                                    ptr(argB), ptr(ws), wsz, current_stream(dev))
     check(rc, "pn_chamfer_nn_f32")
@@ -66,7 +66,7 @@ def knn(x, k, metric="feature"):
     idx = torch.empty((B, N, k), dtype=torch.int64, device=dev)
     wsz = lib.pn_knn_workspace(B, C, N, k)
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if metric == "feature":
             rc = lib.pn_knn_f32(ptr(x), B, C, N, k, ptr(idx), ptr(ws), wsz, current_stream(dev))
         elif metric == "points_normals":
@@ -91,7 +91,7 @@ def transpose12(x):
     x = _f32c(x, "x")
     B, R, C = x.shape
     out = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.load().pn_transpose_f32(ptr(x), ptr(out), B, R, C, current_stream(x.device))
     check(rc, "pn_transpose_f32")
     return out
@@ -105,7 +105,7 @@ def edge_feature_fwd(xt, idx):
     B, N, C = xt.shape
     k = idx.shape[2]
     feat = torch.empty((B, N, k, 2 * C), dtype=torch.float32, device=xt.device)
-    with torch.cuda.device(xt.device):
+    with _lib.on_device(xt.device):
         rc = _lib.load().pn_edge_feature_fwd_f32(ptr(xt), ptr(idx), B, N, k, C, ptr(feat),
                                                  current_stream(xt.device))
     check(rc, "pn_edge_feature_fwd_f32")
@@ -120,7 +120,7 @@ def edge_feature_bwd(gfeat, idx):
     B, N, k, C2 = gfeat.shape
     C = C2 // 2
     gxt = torch.empty((B, N, C), dtype=torch.float32, device=gfeat.device)
-    with torch.cuda.device(gfeat.device):
+    with _lib.on_device(gfeat.device):
         rc = _lib.load().pn_edge_feature_bwd_f32(ptr(gfeat), ptr(idx), B, N, k, C, ptr(gxt),
                                                  current_stream(gfeat.device))
     check(rc, "pn_edge_feature_bwd_f32")
@@ -142,7 +142,7 @@ def edgeconv_reduce_fwd(PQ, idx, gamma, groups, per_sample):
     s1 = torch.empty((B, N, Cout), dtype=torch.float32, device=dev)
     argk = torch.empty((B, N, Cout), dtype=torch.uint8, device=dev)
     stats = torch.empty((B if per_sample else 1, groups, 2), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_edgeconv_reduce_fwd_f32(ptr(PQ), ptr(idx), ptr(gamma), B, N, k, Cout, groups,
                                                     int(per_sample), ptr(yext), ptr(argk), ptr(s1),
                                                     ptr(stats), current_stream(dev))
@@ -156,7 +156,7 @@ def moments(stats, count, eps):
     n = stats.numel() // 2
     mean = torch.empty(stats.shape[:-1], dtype=torch.float32, device=stats.device)
     rstd = torch.empty_like(mean)
-    with torch.cuda.device(stats.device):
+    with _lib.on_device(stats.device):
         rc = _lib.load().pn_moments_f32(ptr(stats), n, float(count), float(eps), ptr(mean), ptr(rstd),
                                         current_stream(stats.device))
     check(rc, "pn_moments_f32")
@@ -168,7 +168,7 @@ def edgeconv_finalize_fwd(yext, mean, rstd, gamma, beta, groups, per_sample, slo
     require_cuda(yext)
     B, N, Cout = yext.shape
     out = torch.empty((B, Cout, N), dtype=torch.float32, device=yext.device)
-    with torch.cuda.device(yext.device):
+    with _lib.on_device(yext.device):
         rc = _lib.load().pn_edgeconv_finalize_fwd_f32(ptr(yext), ptr(_f32c(mean, "mean")),
                                                       ptr(_f32c(rstd, "rstd")), ptr(_f32c(gamma, "gamma")),
                                                       ptr(_f32c(beta, "beta")), B, N, Cout, groups,
@@ -185,7 +185,7 @@ def edgeconv_bwd_prep(gout, yext, mean, rstd, gamma, beta, groups, per_sample, s
     B, N, Cout = yext.shape
     gz = torch.empty_like(yext)
     yhat = torch.empty_like(yext)
-    with torch.cuda.device(yext.device):
+    with _lib.on_device(yext.device):
         rc = _lib.load().pn_edgeconv_bwd_prep_f32(ptr(gout), ptr(yext), ptr(mean), ptr(rstd),
                                                   ptr(_f32c(gamma, "gamma")), ptr(_f32c(beta, "beta")), B, N,
                                                   Cout, groups, int(per_sample), float(slope), ptr(gz),
@@ -204,7 +204,7 @@ def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, den
     lib = _lib.load()
     wsz = lib.pn_edgeconv_bwd_workspace(B, N, k)
     ws = torch.empty(wsz, dtype=torch.uint8, device=PQ.device)
-    with torch.cuda.device(PQ.device):
+    with _lib.on_device(PQ.device):
         rc = lib.pn_edgeconv_bwd_f32(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk), ptr(mean),
                                      ptr(rstd), ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout, groups,
                                      int(per_sample), int(dense), ptr(dPQ), ptr(ws), wsz,
@@ -236,7 +236,7 @@ def dot_select(q, c, k, want_value):
     else:
         out = torch.empty((B, Nq, k), dtype=torch.int64, device=dev)
         args = (ptr(out), None)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.pn_dot_select_f32(ptr(q), Nq, ptr(c), Nc, B, C, int(k), args[0], args[1], ptr(flags),
                                    ptr(ws), wsz, current_stream(dev))
     check(rc, "pn_dot_select_f32")
@@ -259,7 +259,7 @@ def dot_kth_x3(q, c, k):
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
     flags = torch.empty((B, Nq), dtype=torch.int32, device=dev)
     out = torch.empty((B, Nq), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.pn_dot_kth_x3_f32(ptr(q), Nq, ptr(c), Nc, B, C, int(k), ptr(out), ptr(flags), ptr(ws), wsz,
                                    current_stream(dev))
     if rc == -4:      # PN_ERR_UNSUPPORTED: shape outside the split passes
@@ -283,7 +283,7 @@ def dot_kth_unit(q, c_image, Nc, k):
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
     flags = torch.empty((B, Nq), dtype=torch.int32, device=dev)
     out = torch.empty((B, Nq), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.pn_dot_kth_unit_h2_f32(ptr(q), Nq, ptr(c_image), int(Nc), B, C, int(k), ptr(out), ptr(flags),
                                         ptr(ws), wsz, current_stream(dev))
     check(rc, "pn_dot_kth_unit_h2_f32")
@@ -319,7 +319,7 @@ def meanshift_pack(x):
     B, N, D = x.shape
     Np = (N + 63) // 64 * 64
     xt = torch.empty((B, D, Np), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.load().pn_meanshift_pack_f32(ptr(x), B, N, D, ptr(xt), current_stream(x.device))
     check(rc, "pn_meanshift_pack_f32")
     return xt
@@ -332,7 +332,7 @@ def meanshift_x3_split(x):
     B, N, D = x.shape
     lib = _lib.load()
     img = torch.empty(lib.pn_meanshift_x3_image_bytes(B, N), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.pn_meanshift_x3_split_f32(ptr(x), B, N, D, ptr(img), current_stream(x.device))
     check(rc, "pn_meanshift_x3_split_f32")
     return img
@@ -348,7 +348,7 @@ def meanshift_x3_tileinfo(z):
     T = (N + 63) // 64 * 2
     cen = torch.empty((B, T, 2, D), dtype=torch.float32, device=z.device)
     rho = torch.empty((B, T, 2), dtype=torch.float32, device=z.device)
-    with torch.cuda.device(z.device):
+    with _lib.on_device(z.device):
         rc = _lib.load().pn_meanshift_x3_tileinfo_f32(ptr(z), B, N, D, ptr(cen), ptr(rho), current_stream(z.device))
     check(rc, "pn_meanshift_x3_tileinfo_f32")
     return cen, rho
@@ -361,7 +361,7 @@ def meanshift_chain_order(sim):
     sim = _f32c(sim, "sim")
     B, P, _ = sim.shape
     rank = torch.empty((B, P), dtype=torch.int32, device=sim.device)
-    with torch.cuda.device(sim.device):
+    with _lib.on_device(sim.device):
         rc = _lib.load().pn_meanshift_chain_order_f32(ptr(sim), B, P, ptr(rank), current_stream(sim.device))
     check(rc, "pn_meanshift_chain_order_f32")
     return rank.long()
@@ -375,7 +375,7 @@ def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
     B = cq.shape[0]
     lib = _lib.load()
     plan = torch.empty(lib.pn_meanshift_x3_plan_bytes(B, N), dtype=torch.uint8, device=cq.device)
-    with torch.cuda.device(cq.device):
+    with _lib.on_device(cq.device):
         rc = lib.pn_meanshift_x3_plan_f32(ptr(cq), ptr(rq), ptr(cx), ptr(rx), ptr(bsq), B, N, float(rel_eps),
                                           ptr(plan), current_stream(cq.device))
     check(rc, "pn_meanshift_x3_plan_f32")
@@ -410,7 +410,7 @@ def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None):
     y = torch.empty_like(q)
     rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
     unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         rc = _lib.load().pn_meanshift_x3_iter_fwd_plan_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
                                                            ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
                                                            ptr(plan), current_stream(q.device))
@@ -428,7 +428,7 @@ def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx, plan=N
         nbytes = lib.pn_meanshift_x3_image_bytes(B, N)
         ws.x3_imgs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(2)]
     im = ws.x3_imgs
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.pn_meanshift_x3_iter_bwd_plan_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(x_image), ptr(rsum),
                                                    ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.cs),
                                                    ptr(im[0]), ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq),
@@ -444,7 +444,7 @@ def meanshift_h2_split(x):
     B, N, D = x.shape
     lib = _lib.load()
     img = torch.empty(lib.pn_meanshift_h2_image_bytes(B, N), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.pn_meanshift_h2_split_f32(ptr(x), B, N, D, ptr(img), current_stream(x.device))
     check(rc, "pn_meanshift_h2_split_f32")
     return img
@@ -455,7 +455,7 @@ def meanshift_h2_iter_fwd(q, x_image, bsq, ws):
     y = torch.empty_like(q)
     rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
     unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         rc = _lib.load().pn_meanshift_h2_iter_fwd_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
                                                       ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
                                                       current_stream(q.device))
@@ -473,7 +473,7 @@ def meanshift_h2_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx):
         nbytes = lib.pn_meanshift_h2_image_bytes(B, N)
         ws.h2_imgs = [torch.empty(nbytes, dtype=torch.uint8, device=x.device) for _ in range(2)]
     im = ws.h2_imgs
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.pn_meanshift_h2_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(x_image), ptr(rsum),
                                               ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.cs), ptr(im[0]),
                                               ptr(im[1]), ptr(ws.opart), ptr(ws.opart_x), ptr(gq), ptr(gx),
@@ -487,7 +487,7 @@ def meanshift_iter_fwd(q, x, xt, bsq, ws):
     y = torch.empty_like(x)
     rsum = torch.empty((B, N), dtype=torch.float32, device=x.device)
     unorm = torch.empty((B, N), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.load().pn_meanshift_iter_fwd_f32(ptr(q), ptr(x), ptr(xt), ptr(bsq), B, N, D, ptr(ws.opart),
                                                    ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
                                                    current_stream(x.device))
@@ -500,7 +500,7 @@ def meanshift_iter_bwd(gy, y, q, x, xt, rsum, unorm, bsq, ws, gx):
     B, N, D = x.shape
     gy = _f32c(gy, "gy")
     gq = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.load().pn_meanshift_iter_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(x), ptr(xt), ptr(rsum),
                                                    ptr(unorm), ptr(bsq), B, N, D, ptr(ws.gu), ptr(ws.go),
                                                    ptr(ws.cs), ptr(ws.qt), ptr(ws.gut), ptr(ws.opart),
@@ -519,7 +519,7 @@ def sym3_eig(G):
     M = G.shape[0]
     evals = torch.empty((M, 3), dtype=torch.float64, device=G.device)
     evecs = torch.empty((M, 3, 3), dtype=torch.float64, device=G.device)
-    with torch.cuda.device(G.device):
+    with _lib.on_device(G.device):
         rc = _lib.load().pn_sym3_eig_f64(ptr(G), M, ptr(evals), ptr(evecs), current_stream(G.device))
     check(rc, "pn_sym3_eig_f64")
     return evals, evecs
@@ -555,7 +555,7 @@ def chamfer_nn_ragged(a, off_a, max_a, b, off_b, max_b, side_a=True, side_b=True
         argB = torch.empty(TB, dtype=torch.int64, device=dev)
     wsz = lib.pn_chamfer_nn_ragged_workspace(TA, TB)
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.pn_chamfer_nn_ragged_f32(ptr(a), ptr(off_a), TA, int(max_a), ptr(b), ptr(off_b), TB, int(max_b),
                                           B, ptr(minA), ptr(argA), ptr(minB), ptr(argB), ptr(ws), wsz,
                                           current_stream(dev))
@@ -578,7 +578,7 @@ def weighted_moments(P, Nrm, W, seg_shape, seg_row, stride, eps):
     lib = _lib.load()
     partial = torch.empty((S, lib.pn_weighted_moments_chunks(), lib.pn_weighted_moments_count()),
                           dtype=torch.float64, device=P.device)
-    with torch.cuda.device(P.device):
+    with _lib.on_device(P.device):
         rc = lib.pn_weighted_moments_f64(ptr(P), ptr(Nrm), ptr(W), B, N, Cp, int(stride), float(eps),
                                          ptr(_i32c(seg_shape, "seg_shape")), ptr(_i32c(seg_row, "seg_row")), S,
                                          ptr(partial), current_stream(P.device))
@@ -594,7 +594,7 @@ def primitive_fit(partial, seg_type, seg_rows):
     params = torch.empty((S, FIT_NPAR), dtype=torch.float64, device=dev)
     jac = torch.empty((S, FIT_NPAR, partial.shape[2]), dtype=torch.float64, device=dev)
     status = torch.empty(S, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_primitive_fit_f64(ptr(partial.contiguous()), ptr(_i32c(seg_type, "seg_type")),
                                               ptr(_i32c(seg_rows, "seg_rows")), S, ptr(params), ptr(jac),
                                               ptr(status), current_stream(dev))
@@ -609,7 +609,7 @@ def cone_angle(P, W, seg_shape, seg_row, seg_type, status, params, jac, stride, 
     B, N, _ = P.shape
     S = seg_shape.shape[0]
     cone_direct = torch.empty(S, dtype=torch.float64, device=P.device)
-    with torch.cuda.device(P.device):
+    with _lib.on_device(P.device):
         rc = _lib.load().pn_cone_angle_f64(ptr(P), ptr(W), B, N, W.shape[1], int(stride), float(eps),
                                            ptr(seg_shape), ptr(seg_row), ptr(seg_type), ptr(status), S,
                                            ptr(params), ptr(jac), ptr(cone_direct), current_stream(P.device))
@@ -624,7 +624,7 @@ def primitive_residual(P, seg_shape, seg_type, gt_off, gt_idx, params, status, s
     S = seg_shape.shape[0]
     dist = torch.empty(S, dtype=torch.float32, device=P.device)
     dparam = torch.zeros((S, FIT_NPAR), dtype=torch.float64, device=P.device)
-    with torch.cuda.device(P.device):
+    with _lib.on_device(P.device):
         rc = _lib.load().pn_primitive_residual_f32(ptr(_f32c(P, "P")), B, N, ptr(seg_shape), ptr(seg_type),
                                                    ptr(_i32c(gt_off, "gt_off")), ptr(_i32c(gt_idx, "gt_idx")), S,
                                                    ptr(params), int(bool(sqrt_flag)), ptr(dist), ptr(dparam),
@@ -641,7 +641,7 @@ def weighted_moments_bwd(P, Nrm, W, seg_shape, seg_row, seg_type, g_dist, dparam
     B, N, _ = P.shape
     S = seg_shape.shape[0]
     gW = torch.zeros_like(W)
-    with torch.cuda.device(P.device):
+    with _lib.on_device(P.device):
         rc = _lib.load().pn_weighted_moments_bwd_f32(ptr(P), ptr(Nrm), ptr(W), B, N, W.shape[1], int(stride),
                                                      float(eps), ptr(seg_shape), ptr(seg_row), ptr(seg_type), S,
                                                      ptr(_f32c(g_dist, "g_dist")), ptr(dparam), ptr(jac),
@@ -660,7 +660,7 @@ def bspline_eval(nu, nv, ctrl, affine=None, wrap=False):
     if affine is not None:
         affine = _f32c(affine, "affine")
     out = torch.empty((S, (gu + int(wrap)) * gv, 3), dtype=torch.float32, device=ctrl.device)
-    with torch.cuda.device(ctrl.device):
+    with _lib.on_device(ctrl.device):
         rc = _lib.load().pn_bspline_eval_f32(ptr(nu), ptr(nv), ptr(ctrl), ptr(affine), S, gu, gv, cu, cv, int(wrap),
                                              ptr(out), current_stream(ctrl.device))
     check(rc, "pn_bspline_eval_f32")
@@ -675,7 +675,7 @@ def bspline_eval_bwd(nu, nv, gout, affine, cu, cv, wrap=False):
     if affine is not None:
         affine = _f32c(affine, "affine")
     gctrl = torch.empty((S, cu, cv, 3), dtype=torch.float32, device=gout.device)
-    with torch.cuda.device(gout.device):
+    with _lib.on_device(gout.device):
         rc = _lib.load().pn_bspline_eval_bwd_f32(ptr(nu), ptr(nv), ptr(gout), ptr(affine), S, gu, gv, cu, cv,
                                                  int(wrap), ptr(gctrl), current_stream(gout.device))
     check(rc, "pn_bspline_eval_bwd_f32")
@@ -697,7 +697,7 @@ def edgeconv_bwd_stats(gout, yext, mean, rstd, gamma, beta, groups, per_sample, 
     lib = _lib.load()
     wsz = lib.pn_edgeconv_bwd_stats_workspace(B, N, Cout)
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.pn_edgeconv_bwd_stats_f32(ptr(gout), ptr(yext), ptr(mean), ptr(rstd), ptr(_f32c(gamma, "gamma")),
                                            ptr(_f32c(beta, "beta")), B, N, int(k), Cout, int(groups),
                                            int(per_sample), int(dense), float(slope), ptr(t), ptr(dgamma),
@@ -716,7 +716,7 @@ def triplet_fwd(E, ia, ib, w, margin):
     item_loss = torch.empty(P, dtype=torch.float32, device=dev)
     item_scale = torch.empty(P, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_triplet_fwd_f32(ptr(E), E.shape[0], E.shape[1], ptr(ia), ptr(ib), ptr(_f32c(w, "w")), P,
                                             num, float(margin), ptr(item_loss), ptr(item_scale), ptr(loss),
                                             current_stream(dev))
@@ -729,7 +729,7 @@ def triplet_bwd(E, ia, ib, item_scale, gout, margin):
     require_cuda(E, gout)
     P, num = ia.shape
     gE = torch.zeros_like(E)
-    with torch.cuda.device(E.device):
+    with _lib.on_device(E.device):
         rc = _lib.load().pn_triplet_bwd_f32(ptr(E), E.shape[0], E.shape[1], ptr(ia), ptr(ib), ptr(item_scale),
                                             ptr(_f32c(gout.reshape(1), "gout")), P, num, float(margin), ptr(gE),
                                             current_stream(E.device))
@@ -751,7 +751,7 @@ def membership_fwd(cen, emb, bw, ncl, eps, want_labels=False):
     Wn = torch.empty_like(Wraw)
     rowstat = torch.empty((B, CP, 4), dtype=torch.float32, device=dev)
     labels = torch.empty((B, N), dtype=torch.int64, device=dev) if want_labels else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_membership_fwd_f32(ptr(cen), ptr(emb), ptr(bw), ptr(ncl), B, CP, N, D, float(eps),
                                                ptr(Wraw), ptr(prob), ptr(Wn), ptr(rowstat), ptr(labels),
                                                current_stream(dev))
@@ -765,7 +765,7 @@ def membership_bwd(gWn, Wraw, prob, rowstat, bw, ncl):
     B, CP, N = Wraw.shape
     rowgrad = torch.empty((B, CP, 2), dtype=torch.float32, device=Wraw.device)
     gWraw = torch.empty_like(Wraw)
-    with torch.cuda.device(Wraw.device):
+    with _lib.on_device(Wraw.device):
         rc = _lib.load().pn_membership_bwd_f32(ptr(gWn), ptr(Wraw), ptr(prob), ptr(rowstat), ptr(bw), ptr(ncl), B, CP,
                                                N, ptr(rowgrad), ptr(gWraw), current_stream(Wraw.device))
     check(rc, "pn_membership_bwd_f32")
@@ -778,7 +778,7 @@ def affine_act_fwd(x, scale, shift, act, slope=0.0):
     x = _f32c(x, "x")
     B, C, N = x.shape
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.load().pn_affine_act_fwd_f32(ptr(x), ptr(_f32c(scale, "scale")), ptr(_f32c(shift, "shift")), B, C, N,
                                                int(act), float(slope), ptr(y), current_stream(x.device))
     check(rc, "pn_affine_act_fwd_f32")
@@ -789,7 +789,7 @@ def affine_act_bwd(gy, y, scale, act, slope=0.0):
     gy = _f32c(gy, "gy")
     B, C, N = y.shape
     gx = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _lib.on_device(y.device):
         rc = _lib.load().pn_affine_act_bwd_f32(ptr(gy), ptr(y), ptr(_f32c(scale, "scale")), B, C, N, int(act),
                                                float(slope), ptr(gx), current_stream(y.device))
     check(rc, "pn_affine_act_bwd_f32")
@@ -805,7 +805,7 @@ def nms_occupied(membership, U):
     counts = torch.empty((B, N), dtype=torch.int32, device=dev)
     uq = torch.empty((B, U), dtype=torch.int64, device=dev)
     nocc = torch.empty(B, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_nms_occupied_f32(ptr(membership), B, N, int(U), ptr(counts), ptr(uq), ptr(nocc),
                                              current_stream(dev))
     check(rc, "pn_nms_occupied_f32")
@@ -822,7 +822,7 @@ def nms_vote(G, uq, nocc, counts, bw, cmax):
     hits = torch.empty((B, N), dtype=torch.int32, device=dev)
     cid = torch.empty((B, cmax), dtype=torch.int64, device=dev)
     ncl = torch.empty(B, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_nms_vote_f32(ptr(G), ptr(uq), ptr(nocc), ptr(counts), ptr(_f32c(bw, "bw")), B, N, U,
                                          int(cmax), ptr(hits), ptr(cid), ptr(ncl), current_stream(dev))
     check(rc, "pn_nms_vote_f32")
@@ -838,7 +838,7 @@ def weighted_max_fwd(x, scale, shift, w, act, slope=0.0):
     out = torch.empty((S, C), dtype=torch.float32, device=dev)
     idx = torch.empty((S, C), dtype=torch.int32, device=dev)
     val = torch.empty((S, C), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_weighted_max_fwd_f32(ptr(x), ptr(_f32c(scale, "scale")), ptr(_f32c(shift, "shift")), ptr(w),
                                                  S, C, N, int(act), float(slope), ptr(out), ptr(idx), ptr(val),
                                                  current_stream(dev))
@@ -850,7 +850,7 @@ def weighted_max_bwd(g, idx, val, N):
     g = _f32c(g, "g")
     S, C = g.shape
     gw = torch.empty((S, N), dtype=torch.float32, device=g.device)
-    with torch.cuda.device(g.device):
+    with _lib.on_device(g.device):
         rc = _lib.load().pn_weighted_max_bwd_f32(ptr(g), ptr(idx), ptr(val), S, C, int(N), ptr(gw),
                                                  current_stream(g.device))
     check(rc, "pn_weighted_max_bwd_f32")

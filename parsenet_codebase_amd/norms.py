@@ -20,7 +20,7 @@ def _rows_fwd(y, want_ext):
     if want_ext:
         ext = [torch.empty_like(rsum), torch.empty((B, C), dtype=torch.int32, device=dev),
                torch.empty_like(rsum), torch.empty((B, C), dtype=torch.int32, device=dev)]
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = _lib.load().pn_gn_rows_fwd_f32(ptr(y), B, C, N, ptr(rsum), ptr(rsq), ptr(ext[0]), ptr(ext[1]),
                                             ptr(ext[2]), ptr(ext[3]), current_stream(dev))
     check(rc, "pn_gn_rows_fwd_f32")
@@ -31,7 +31,7 @@ def _group_moments(rsum, rsq, groups, N, eps):
     B, C = rsum.shape
     mean = torch.empty((B, groups), dtype=torch.float32, device=rsum.device)
     rstd = torch.empty_like(mean)
-    with torch.cuda.device(rsum.device):
+    with _lib.on_device(rsum.device):
         rc = _lib.load().pn_gn_group_moments_f32(ptr(rsum), ptr(rsq), B, C, groups, N, float(eps), ptr(mean),
                                                  ptr(rstd), current_stream(rsum.device))
     check(rc, "pn_gn_group_moments_f32")
@@ -41,7 +41,7 @@ def _group_moments(rsum, rsq, groups, N, eps):
 def _group_bwd(ra, rb, gamma, groups, N):
     B, C = ra.shape
     c1c2 = torch.empty((B, groups, 2), dtype=torch.float32, device=ra.device)
-    with torch.cuda.device(ra.device):
+    with _lib.on_device(ra.device):
         rc = _lib.load().pn_gn_group_bwd_f32(ptr(ra), ptr(rb), ptr(gamma), B, C, groups, N, ptr(c1c2),
                                              current_stream(ra.device))
     check(rc, "pn_gn_group_bwd_f32")
@@ -51,7 +51,7 @@ def _group_bwd(ra, rb, gamma, groups, N):
 def _apply_bwd(gout, y, mean, rstd, gamma, beta, c1c2, groups, relu, gsp=None, arg=None):
     B, C, N = y.shape
     dy = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _lib.on_device(y.device):
         rc = _lib.load().pn_gn_apply_bwd_f32(ptr(gout), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                                              ptr(c1c2), B, C, groups, N, int(relu), ptr(gsp), ptr(arg), ptr(dy),
                                              current_stream(y.device))
@@ -68,7 +68,7 @@ class _GroupNormReLU(torch.autograd.Function):
         rsum, rsq, _ = _rows_fwd(y, False)
         mean, rstd = _group_moments(rsum, rsq, groups, N, eps)
         out = torch.empty_like(y)
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             rc = _lib.load().pn_gn_apply_fwd_f32(ptr(y), ptr(mean), ptr(rstd), ptr(gamma_c), ptr(beta_c), B, C,
                                                  groups, N, int(relu), ptr(out), current_stream(y.device))
         check(rc, "pn_gn_apply_fwd_f32")
@@ -84,7 +84,7 @@ class _GroupNormReLU(torch.autograd.Function):
         gout = _f(gout)
         ra = torch.empty((B, C), dtype=torch.float32, device=y.device)
         rb = torch.empty_like(ra)
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             rc = _lib.load().pn_gn_rows_bwd_f32(ptr(gout), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), B,
                                                 C, groups, N, int(relu), ptr(ra), ptr(rb),
                                                 current_stream(y.device))

@@ -152,10 +152,13 @@ class ParsenetE2EStep(ParsenetSegStep):
         # fitting stage of shape b (hundreds of tiny launches and the host synchronisations of the
         # Hungarian matching): the reference processes one shape after the other.
         self.batched = True       # stage-wise over the whole batch (fitting_batch.py); False: shape by shape
-        # groups of shapes whose clustering is queued ahead of the host's matching work (PARSENET_FIT_CHUNKS;
-        # 1: the whole batch as one group)
+        # groups of shapes whose clustering is queued ahead of the host's matching work (PARSENET_FIT_CHUNKS).
+        # Default 1 = the whole batch as one group: the pipelined form gives identical results
+        # (tests/test_fitting_batch_gpu.py) but MEASURED slower on this stack (2 groups: 102 instead of
+        # 77 ms per step on the same box; smaller launches, twice the fitting-stage launches, and uploads
+        # that queue behind the other group's iterations) — kept as an option, not used
         import os
-        self.chunks = int(os.environ.get("PARSENET_FIT_CHUNKS", "2"))
+        self.chunks = int(os.environ.get("PARSENET_FIT_CHUNKS", "1"))
         self.overlap = True       # (shape-by-shape mode) clustering of shape b+1 on a side stream
         self.side = torch.cuda.Stream(device=device)
         self._warmed = False

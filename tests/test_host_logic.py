@@ -459,7 +459,7 @@ def test_auto_mode_of_the_block_sparse_iterations():
     try:
         key = (4, 10000)
         assert MSM.use_sparse(*key)                      # nothing known: plan
-        MSM.auto_report(*key, 0.91)                      # a converged embedding: nothing to skip
+        MSM.auto_report(*key, 0.97)                      # a converged embedding: nothing to skip
         seq = [MSM.use_sparse(*key) for _ in range(MSM.AUTO_DENSE_STEPS + 1)]
         assert seq == [False] * MSM.AUTO_DENSE_STEPS + [True]
         MSM.auto_report(*key, 0.27)                      # an embedding early in training: keep planning
