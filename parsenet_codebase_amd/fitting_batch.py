@@ -344,6 +344,31 @@ def standardize_segments(P2, w):
     return pts, std, mean, R
 
 
+# PARSENET_SPLINE_GRAPH=1: the forward (and the backward to the memberships) of a FROZEN SplineNet on
+# S segments of n points as two captured hipGraphs per (net, S, n) (torch.cuda.make_graphed_callables):
+# ~100 launches of the host window of the fitting stage become two.  Everything inside is
+# stream-ordered device work (kNN with its on-device fallback, GEMMs, fused kernels; workspaces
+# from the graph's private pool); the weights are constants by address (frozen).  Same kernels, same
+# results as the eager call.
+SPLINE_GRAPH = __import__("os").environ.get("PARSENET_SPLINE_GRAPH", "0") == "1"
+
+
+def splinenet_forward(net, x, w):
+    """net(x (S,3,n), w (S,n)) -> control points (S,400,3) for a frozen evaluation-mode SplineNet."""
+    if not (SPLINE_GRAPH and x.is_cuda and not net.training and torch.is_grad_enabled() and w.requires_grad
+            and not x.requires_grad and not any(p.requires_grad for p in net.parameters())):
+        return net(x, w)
+    cache = net.__dict__.setdefault("_pn_graphs", {})
+    key = (tuple(x.shape), x.device.index)
+    fn = cache.get(key)
+    if fn is None:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        sx = (0.3 * torch.randn(x.shape, generator=g)).to(x.device)
+        sw = torch.rand(w.shape, generator=g).to(x.device).requires_grad_(True)
+        fn = cache[key] = torch.cuda.make_graphed_callables(lambda a, b: net(a, b), (sx, sw))
+    return fn(x.contiguous(), w.contiguous())
+
+
 # -------------------------------------------------------------------------------------------
 # host side: matching and the segment table
 # -------------------------------------------------------------------------------------------
@@ -649,7 +674,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
                                   (n_open, S_s, fitter.closed_control_decoder, True)):
             if hi > lo:
                 with record_function("fit:splinenet"):
-                    ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
+                    ctrl = splinenet_forward(net, pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
                 rec = _BSplineEval.apply(ctrl.reshape(hi - lo, 20, 20, 3), nu, nv, affine[lo:hi], wrap)
                 pieces.append(rec.reshape(-1, 3))
                 recs += [rec[k:k + 1] for k in range(hi - lo)]
