@@ -344,31 +344,6 @@ def standardize_segments(P2, w):
     return pts, std, mean, R
 
 
-# PARSENET_SPLINE_GRAPH=1: the forward (and the backward to the memberships) of a FROZEN SplineNet on
-# S segments of n points as two captured hipGraphs per (net, S, n) (torch.cuda.make_graphed_callables):
-# ~100 launches of the host window of the fitting stage become two.  Everything inside is
-# stream-ordered device work (kNN with its on-device fallback, GEMMs, fused kernels; workspaces
-# from the graph's private pool); the weights are constants by address (frozen).  Same kernels, same
-# results as the eager call.
-SPLINE_GRAPH = __import__("os").environ.get("PARSENET_SPLINE_GRAPH", "0") == "1"
-
-
-def splinenet_forward(net, x, w):
-    """net(x (S,3,n), w (S,n)) -> control points (S,400,3) for a frozen evaluation-mode SplineNet."""
-    if not (SPLINE_GRAPH and x.is_cuda and not net.training and torch.is_grad_enabled() and w.requires_grad
-            and not x.requires_grad and not any(p.requires_grad for p in net.parameters())):
-        return net(x, w)
-    cache = net.__dict__.setdefault("_pn_graphs", {})
-    key = (tuple(x.shape), x.device.index)
-    fn = cache.get(key)
-    if fn is None:
-        g = torch.Generator(device="cpu").manual_seed(0)
-        sx = (0.3 * torch.randn(x.shape, generator=g)).to(x.device)
-        sw = torch.rand(w.shape, generator=g).to(x.device).requires_grad_(True)
-        fn = cache[key] = torch.cuda.make_graphed_callables(lambda a, b: net(a, b), (sx, sw))
-    return fn(x.contiguous(), w.contiguous())
-
-
 # -------------------------------------------------------------------------------------------
 # host side: matching and the segment table
 # -------------------------------------------------------------------------------------------
@@ -560,6 +535,14 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             return host.numpy()
         pending = start_download(state)
         yield                                                    # (a pipelined caller queues the next group here)
+        # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122), i.e. one
+        # per shape on the fast path.  They are drawn HERE, while the device is still clustering and the
+        # host would only wait, instead of after the download when the device waits for the host; should
+        # a shape turn out to need the synchronous path the state is rewound and the draws are redone
+        # in the reference's order below.
+        rng_state = np.random.get_state()
+        for _ in range(B):
+            np.random.shuffle(np.arange(N))
         pending[1].synchronize()                                 # download: cluster ids
         pack = pending[0].numpy()
         if pack[0] > 0:
@@ -575,14 +558,17 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         cid_h = pack[o:o + B * CMAX].reshape(B, CMAX); o += B * CMAX
         ncl_h, bwflag_h = pack[o:o + B], pack[o + B:o + 2 * B]
         nflag_h = pack[-B:]
+        predrawn = all(nflag_h[b] == 0 and bwflag_h[b] == 0 and ncl_h[b] <= 49 for b in range(B))
+        if not predrawn:
+            np.random.set_state(rng_state)
     else:
+        predrawn = False
         yield
     centers, bws, cluster_ids = [], [], []
     all_fast = state is not None
     for b in range(B):
-        # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122)
         fast = state is not None and nflag_h[b] == 0 and bwflag_h[b] == 0 and ncl_h[b] <= CMAX
-        if fast:
+        if fast and not predrawn:
             np.random.shuffle(np.arange(N))
         if fast and ncl_h[b] <= 49:
             centers.append(state["cen"][b, :int(ncl_h[b])])
@@ -674,7 +660,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
                                   (n_open, S_s, fitter.closed_control_decoder, True)):
             if hi > lo:
                 with record_function("fit:splinenet"):
-                    ctrl = splinenet_forward(net, pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
+                    ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
                 rec = _BSplineEval.apply(ctrl.reshape(hi - lo, 20, 20, 3), nu, nv, affine[lo:hi], wrap)
                 pieces.append(rec.reshape(-1, 3))
                 recs += [rec[k:k + 1] for k in range(hi - lo)]

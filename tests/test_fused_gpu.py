@@ -199,32 +199,3 @@ def test_frozen_splinenet_head_weighted_max(gpu):
     net.bn5.weight.requires_grad = False
     assert _rel(res[0][0], res[1][0]) < 5e-6
     assert _rel(res[0][1], res[1][1]) < 5e-5
-
-
-def test_graphed_splinenet_forward_equals_eager(gpu):
-    """fitting_batch.splinenet_forward with PARSENET_SPLINE_GRAPH=1 (forward and the backward to the
-    memberships replayed from captured hipGraphs) against the eager call: same kernels, so the
-    control points and the gradient must agree to the last bits on fresh inputs, replay after replay."""
-    from parsenet_codebase_amd import fitting_batch as FB
-    from parsenet_codebase_amd.encoders import DGCNNControlPoints
-    torch.manual_seed(6)
-    net = DGCNNControlPoints(20, num_points=10, mode=1).to(gpu).eval()
-    for p in net.parameters():
-        p.requires_grad = False
-    saved, FB.SPLINE_GRAPH = FB.SPLINE_GRAPH, True
-    try:
-        for trial in range(3):
-            x = 0.3 * torch.randn(2, 3, 1200, device=gpu)
-            w0 = torch.rand(2, 1200, device=gpu)
-            g = torch.randn(2, 400, 3, device=gpu)
-            w1 = w0.clone().requires_grad_(True)
-            out1 = FB.splinenet_forward(net, x, w1)
-            (out1 * g).sum().backward()
-            o1, g1 = out1.detach().clone(), w1.grad.clone()
-            w2 = w0.clone().requires_grad_(True)
-            out2 = net(x, w2)
-            (out2 * g).sum().backward()
-            assert _rel(o1, out2) < 1e-6 and _rel(g1, w2.grad) < 1e-5, (trial, _rel(o1, out2), _rel(g1, w2.grad))
-        assert len(net.__dict__["_pn_graphs"]) == 1
-    finally:
-        FB.SPLINE_GRAPH = saved

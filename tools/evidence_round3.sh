@@ -9,7 +9,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence_r03
 mkdir -p $O
 (free -g | head -2; nproc; lscpu | grep "Model name") > $O/host.txt 2>&1
-timeout 1500 python -m pytest tests -m gpu -q -s --durations=10 > $O/pytest.log 2>&1; echo "rc $?" >> $O/pytest.log
+timeout 1700 python -m pytest tests -m gpu -q -s --durations=10 > $O/pytest.log 2>&1; echo "rc $?" >> $O/pytest.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "rc $?" >> $O/smoke.log
 timeout 1200 python bench.py > $O/bench_cfg5.json 2> $O/bench_cfg5.err
 export PARSENET_PRETRAIN_CACHE=/tmp/pretrain_cache.pt
 timeout 900 python bench.py --workload cfg5 --no-cpu-baseline > $O/bench_cfg5_b.json 2> $O/bench_cfg5_b.err
@@ -35,4 +36,4 @@ find $O -name "*kernel_trace.csv" -delete
 python tools/condense_r02.py pmc r03_meanshift_x3_dense_cfg5_pmc.csv pn_ms3_kernel $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ; cp profiles/r03_meanshift_x3_dense_cfg5_pmc.csv $O/
 timeout 600 python tools/torch_sites.py > $O/torch_sites.txt 2>&1
 timeout 600 python tools/host_cprofile.py > $O/host_cprofile.txt 2>&1
-cat $O/host.txt; grep -i "parity\|eval-mode\|passed\|failed\|^rc " $O/pytest.log | cut -c1-900; for f in bench_cfg5 bench_cfg5_b bench_cfg5_planned bench_cfg4 bench_cfg2 bench_cfg3; do cut -c1-330 $O/$f.json; done; cat $O/breakdown.txt; cat $O/r03_meanshift_x3_dense_cfg5_pmc.csv; grep -v "amdgpu.ids" $O/torch_sites.txt | head -16
+tail -2 $O/smoke.log; cat $O/host.txt; grep -i "parity\|eval-mode\|passed\|failed\|^rc " $O/pytest.log | cut -c1-900; for f in bench_cfg5 bench_cfg5_b bench_cfg5_planned bench_cfg4 bench_cfg2 bench_cfg3; do cut -c1-330 $O/$f.json; done; cat $O/breakdown.txt; cat $O/r03_meanshift_x3_dense_cfg5_pmc.csv; grep -v "amdgpu.ids" $O/torch_sites.txt | head -16
