@@ -347,7 +347,19 @@ def standardize_segments(P2, w):
 # -------------------------------------------------------------------------------------------
 # host side: matching and the segment table
 # -------------------------------------------------------------------------------------------
-def build_segment_table(labels, primitives, cluster_ids, N):
+def precompute_ground_truth(labels, primitives):
+    """The part of build_segment_table that depends on the ground truth alone — label array, modal
+    primitive type of every gt segment, the point lists of the gt segments — so that the host can
+    prepare it while the device is still clustering and it has nothing else to do."""
+    g = np.asarray(labels).astype(np.int64)
+    if g.size and (g.min() < 0 or g.max() >= 50):
+        raise ValueError("labels must lie in [0, 50) (one-hot width of the reference)")
+    modal = np.bincount(g * 10 + np.asarray(primitives).astype(np.int64), minlength=500).reshape(50, 10).argmax(1)
+    lists = {int(c): np.flatnonzero(g == c) for c in np.flatnonzero(np.bincount(g, minlength=50))}
+    return g, modal, lists
+
+
+def build_segment_table(labels, primitives, cluster_ids, N, pre=None):
     """What residual_train_mode + fit_one_shape_torch decide on the host for ONE shape
     (src/residual_utils.py:154-200, src/primitive_forward.py:938-1020): Hungarian matching, the
     ground-truth segment of every predicted cluster, its modal primitive type, the sub-sampling
@@ -358,8 +370,8 @@ def build_segment_table(labels, primitives, cluster_ids, N):
     50 x 50 confusion matrix and the 50 x 10 (gt label, primitive type) table."""
     from .fitting import solve_dense
     p = np.asarray(cluster_ids).astype(np.int64)
-    g = np.asarray(labels).astype(np.int64)
-    if p.size and (p.min() < 0 or g.min() < 0 or p.max() >= 50 or g.max() >= 50):
+    g, modal, gt_lists = pre if pre is not None else precompute_ground_truth(labels, primitives)
+    if p.size and (p.min() < 0 or p.max() >= 50):
         raise ValueError("labels must lie in [0, 50) (one-hot width of the reference)")
     conf = np.bincount(p * 50 + g, minlength=2500).reshape(50, 50)
     dots = conf.astype(np.float32)
@@ -370,7 +382,6 @@ def build_segment_table(labels, primitives, cluster_ids, N):
     rids, cids = solve_dense(1.0 - iou)
     pcount, gcount = conf.sum(1), conf.sum(0)
     unique_pred = np.flatnonzero(pcount)                                     # = np.unique(cluster_ids)
-    modal = np.bincount(g * 10 + np.asarray(primitives).astype(np.int64), minlength=500).reshape(50, 10).argmax(1)
     n2 = (N + 1) // 2
     n4 = (n2 + 1) // 2
     segs, spline_count = [], 0
@@ -390,7 +401,7 @@ def build_segment_table(labels, primitives, cluster_ids, N):
             kind = "prim"
         else:
             raise ValueError("unknown primitive type %r" % (seg_type,))
-        segs.append({"row": index, "key": int(i), "type": seg_type, "kind": kind, "gt": np.flatnonzero(g == c)})
+        segs.append({"row": index, "key": int(i), "type": seg_type, "kind": kind, "gt": gt_lists[int(c)]})
     return segs, (rids, cids, unique_pred, gcount, conf, g)
 
 
@@ -543,6 +554,8 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         rng_state = np.random.get_state()
         for _ in range(B):
             np.random.shuffle(np.arange(N))
+        # ... and so is everything the matching needs from the ground truth alone
+        gt_pre = [precompute_ground_truth(labels[b], primitives[b]) for b in range(B)]
         pending[1].synchronize()                                 # download: cluster ids
         pack = pending[0].numpy()
         if pack[0] > 0:
@@ -563,6 +576,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             np.random.set_state(rng_state)
     else:
         predrawn = False
+        gt_pre = [None] * B
         yield
     centers, bws, cluster_ids = [], [], []
     all_fast = state is not None
@@ -599,7 +613,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
     # ---- host: matching + segment tables -------------------------------------------------
     tables, matches = [], []
     for b in range(B):
-        segs, m = build_segment_table(labels[b], primitives[b], cluster_ids[b], N)
+        segs, m = build_segment_table(labels[b], primitives[b], cluster_ids[b], N, gt_pre[b])
         tables.append(segs)
         matches.append(m)
     prim_segs = [(b, s) for b in range(B) for s in tables[b] if s["kind"] == "prim"]
@@ -609,11 +623,14 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
     all_segs = prim_segs + spl_segs
     S_p, S_s = len(prim_segs), len(spl_segs)
 
-    # one packed upload of every integer table
-    parts, where = [], {}
+    # ONE packed upload of every table (float tables travel as their bit patterns)
+    parts, where, floats = [], {}, set()
 
-    def add(name, arr):
-        a = np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)
+    def add(name, arr, dtype=np.int32):
+        a = np.ascontiguousarray(arr, dtype=dtype).reshape(-1)
+        if dtype == np.float32:
+            floats.add(name)
+            a = a.view(np.int32)
         where[name] = (sum(p.size for p in parts), a.size)
         parts.append(a)
     gt_lists = [s["gt"] for _, s in all_segs]
@@ -632,8 +649,13 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         add("off_b", np.concatenate([[0], np.cumsum(nb)]))
         add("item_a", np.repeat(np.arange(S_s), na))
         add("item_b", np.repeat(np.arange(S_s), nb))
+        add("cnt_a", na, np.float32)
+        add("cnt_b", nb, np.float32)
+    add("scale", [lamb if s_["kind"] != "prim" else 1.0 for _, s_ in all_segs], np.float32)
+    add("cnt_shape", np.maximum(np.bincount(np.asarray([b for b, _ in all_segs], dtype=np.int64), minlength=B), 1),
+        np.float32)
     dev_tab = h2d(np.concatenate(parts) if parts else np.zeros(1, np.int32), dev)
-    T = {k: dev_tab[o:o + n] for k, (o, n) in where.items()}
+    T = {k: (dev_tab[o:o + n].view(torch.float32) if k in floats else dev_tab[o:o + n]) for k, (o, n) in where.items()}
 
     dists = []
     params_p = status = None
@@ -666,11 +688,9 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
                 recs += [rec[k:k + 1] for k in range(hi - lo)]
         pred = torch.cat(pieces, 0)
         gt_cloud = points.reshape(B * N, 3)[T["gt_flat"][int(gt_off[S_p]):].long()]
-        cnt_a = h2d(np.asarray(na, dtype=np.float32), dev)
-        cnt_b = h2d(np.asarray(nb, dtype=np.float32), dev)
         with record_function("fit:chamfer"):
             d_s = _RaggedChamfer.apply(pred, gt_cloud, T["off_a"], T["off_b"], T["item_a"].long(),
-                                       T["item_b"].long(), cnt_a, cnt_b, max(na), max(nb))
+                                       T["item_b"].long(), T["cnt_a"], T["cnt_b"], max(na), max(nb))
         dists.append(d_s)
 
     # ---- losses, metrics, ONE download ----------------------------------------------------
@@ -680,11 +700,10 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         ptype = torch.max(torch.bmm(hot, Wraw.detach().transpose(1, 2)), 1)[1]               # (B,Cp)
     if S_all:
         d_all = torch.cat(dists)
-        scale = h2d(np.asarray([lamb if s["kind"] != "prim" else 1.0 for _, s in all_segs], dtype=np.float32), dev)
         d_used = torch.where(d_all.detach() > 1, torch.full_like(d_all, 0.1), d_all)   # degenerate case -> constant
-        cnt_shape = np.bincount([b for b, _ in all_segs], minlength=B).astype(np.float32)
-        loss_b = torch.zeros(B, dtype=torch.float32, device=dev).index_add_(0, T["seg_shape"].long(), d_used * scale)
-        loss_b = loss_b / h2d(np.maximum(cnt_shape, 1.0), dev)
+        loss_b = torch.zeros(B, dtype=torch.float32, device=dev).index_add_(0, T["seg_shape"].long(),
+                                                                              d_used * T["scale"])
+        loss_b = loss_b / T["cnt_shape"]
         tail = [d_all.detach().double()]
         if S_p:
             tail.append(status.double())
