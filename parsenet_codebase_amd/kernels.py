@@ -394,15 +394,13 @@ def meanshift_x3_plan_stats(plan, B, N):
 
 
 def meanshift_x3_plan_visited(plans, B, N):
-    """Device scalar: the share of (resident block, streamed tile) entries the forward lists of
-    these plans keep, averaged over the plans — what a planned launch costs relative to a dense one.
-    No synchronisation (the caller downloads it with something it waits for anyway)."""
+    """Device scalar: the share of the N^2 tile pairs the plans keep, averaged over the plans — what
+    the planned launches execute relative to dense ones (their duration follows it: measured 0.73 of
+    the dense launch at 0.71 of the pairs, 0.83 at 0.85).  No synchronisation (the caller downloads
+    it with something it waits for anyway)."""
     T = (N + 63) // 64 * 2
-    nb0, nb1, nb2 = -(-N // 256), -(-N // 128), -(-N // 256)
-    oc = (B * T * T + 255) // 256 * 256
-    n = B * (nb0 + nb1 + nb2) * 4
-    cnt = torch.stack([p[oc:oc + n].view(torch.int32) for p in plans]).reshape(len(plans), B, -1)
-    return cnt[:, :, :nb0].float().mean() / T
+    n = B * T * T
+    return torch.stack([p[:n].float().mean() for p in plans]).mean()
 
 
 def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None):

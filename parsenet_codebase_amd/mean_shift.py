@@ -25,15 +25,16 @@ ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 # early in training (small bandwidth, everything in one region of the sphere) keeps ~25 % of the
 # pairs, a triplet embedding after 2000 pre-training steps on held-out shapes 70-90 %, and above a
 # bandwidth of ~0.26 NOTHING can be skipped (b^2 ln(N / 1e-9) exceeds the range of a dot product).
-# A planned launch costs what it visits (measured at 0.77 of the list entries: 0.73 of the dense
-# launch, matrix cores at 0.59 vs 0.61 of peak) plus ~1.2 ms of plan kernels per call of ten
-# iterations: it pays below ~0.9 of the entries.  PARSENET_MS_SPARSE: "1" always plan, "0" always
-# dense, "auto" (default): plan one call, look at the share of list entries it kept (the number
-# rides in the fitting stage's cluster-id download: no extra synchronisation), and launch dense
-# for the next AUTO_DENSE_STEPS calls of that problem size when it was above AUTO_DENSE_ABOVE.
+# The duration of a planned launch follows the share of tile pairs it executes (measured: 0.73 of
+# the dense launch at 0.71 of the pairs, 0.83 at 0.85; matrix cores at 0.59-0.61 of peak on the
+# executed pairs, like the dense kernel) plus ~1.2 ms of plan kernels per call of ten iterations:
+# it pays below ~0.93 of the pairs.  PARSENET_MS_SPARSE: "1" always plan, "0" always dense, "auto"
+# (default): plan one call, look at the share of pairs its plans kept (the number rides in the
+# fitting stage's cluster-id download: no extra synchronisation), and launch dense for the next
+# AUTO_DENSE_STEPS calls of that problem size when it was above AUTO_DENSE_ABOVE.
 _env_sparse = os.environ.get("PARSENET_MS_SPARSE", "auto")
 SPARSE = True if _env_sparse == "1" else False if _env_sparse == "0" else "auto"
-AUTO_DENSE_ABOVE = 0.9
+AUTO_DENSE_ABOVE = 0.93
 AUTO_DENSE_STEPS = 49
 _AUTO = {}                  # (B, N) -> calls left before the next planned (probing) call
 CALLS = {"planned": 0, "dense": 0}   # calls of the bf16x3 iterations by launch kind (bench.py reports them)
@@ -55,7 +56,7 @@ def use_sparse(B, N):
 
 
 def auto_report(B, N, visited):
-    """The share of (resident block, streamed tile) list entries the last planned call kept."""
+    """The share of tile pairs the plans of the last planned call kept."""
     if SPARSE == "auto":
         _AUTO[(B, N)] = AUTO_DENSE_STEPS if visited > AUTO_DENSE_ABOVE else 0
 
