@@ -215,14 +215,71 @@ def require_cuda(*tensors):
                 % t.device)
 
 
+class _PinnedRing:
+    """Persistent page-locked staging buffers.  Allocating pinned memory is a driver call that can
+    take MILLISECONDS (tens of them on a busy host: the kernel trace of a cfg5 step showed single
+    40 ms holes in front of the first kernel after an upload), and the sizes of a step's tables
+    change with the number of segments, which defeats torch's caching host allocator.  A ring of
+    fixed-size slots allocated once: a slot is reused only after the event recorded behind its last
+    copy has completed (normally long before its turn comes round again)."""
+
+    def __init__(self, slots=32, nbytes=1 << 20):
+        self.nbytes, self.slots, self.next = nbytes, [None] * slots, 0
+
+    def take(self, nbytes):
+        """(uint8 pinned view of ``nbytes``, slot) or (None, None) when the request exceeds a slot."""
+        if nbytes > self.nbytes:
+            return None, None
+        i = self.next
+        self.next = (i + 1) % len(self.slots)
+        slot = self.slots[i]
+        if slot is None:
+            slot = self.slots[i] = {"buf": torch.empty(self.nbytes, dtype=torch.uint8).pin_memory(),
+                                    "event": torch.cuda.Event(), "armed": False}
+        elif slot["armed"]:
+            slot["event"].synchronize()
+        return slot["buf"][:max(nbytes, 1)], slot
+
+    @staticmethod
+    def arm(slot):
+        """Record the slot's event on the current stream: call right after queuing the copy."""
+        slot["event"].record()
+        slot["armed"] = True
+
+
+_RING = _PinnedRing()
+
+
+def pinned_like(shape, dtype):
+    """A pinned host tensor of ``shape`` / ``dtype`` from the ring (plus its slot, to be armed after
+    the copy that fills or drains it), or a freshly pinned one (slot None) when it does not fit."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    raw, slot = _RING.take(nbytes)
+    if raw is None:
+        return torch.empty(tuple(shape), dtype=dtype).pin_memory(), None
+    return raw[:nbytes].view(dtype).reshape(tuple(shape)), slot
+
+
 def h2d(array, device):
     """Host array -> device tensor through pinned memory, stream-ordered (non_blocking).  A
     pageable-memory copy makes the host wait for everything queued on the stream; the fitting
-    stage issues dozens of small index uploads per shape, each of which would drain the GPU."""
+    stage issues several small table uploads per step, each of which would drain the GPU.  The
+    pinned staging memory comes from a ring allocated once (see _PinnedRing)."""
     import numpy as np
-    import torch
     t = torch.from_numpy(np.ascontiguousarray(array))
-    return t.pin_memory().to(device, non_blocking=True)
+    if device.type != "cuda":
+        return t.to(device)
+    host, slot = pinned_like(t.shape, t.dtype)
+    if slot is None:
+        host.copy_(t)
+        return host.to(device, non_blocking=True)
+    host.copy_(t)
+    out = host.to(device, non_blocking=True)
+    _PinnedRing.arm(slot)
+    return out
 
 
 def prof_enable(on=True):

@@ -30,7 +30,7 @@ from torch.profiler import record_function
 
 from . import kernels as K
 from . import mean_shift as MSM
-from ._lib import h2d
+from ._lib import _PinnedRing, h2d, pinned_like
 
 EPS = float(np.finfo(np.float32).eps)
 SPLINE_TYPES = (0, 2, 6, 7, 9, 8)
@@ -332,9 +332,14 @@ def standardize_segments(P2, w):
         mean = (P2 * wsel.unsqueeze(2)).sum(1) / (wsel.sum(1, keepdim=True) + EPS)
         Pc = P2 - mean.unsqueeze(1)
         cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
-        cov_h = cov.cpu()                                        # host step of the reference
-        R = torch.from_numpy(host_minor_axis_rotations(cov_h))
-        R = R.pin_memory().to(P2.device, non_blocking=True)
+        cov_h, slot = pinned_like(cov.shape, cov.dtype)          # host step of the reference: download ...
+        cov_h.copy_(cov, non_blocking=True)
+        if slot is not None:
+            _PinnedRing.arm(slot)
+            slot["event"].synchronize()
+        else:
+            torch.cuda.current_stream(cov.device).synchronize()
+        R = h2d(host_minor_axis_rotations(cov_h), P2.device)       # ... batched geev, upload
         Pr = torch.bmm(Pc, R.transpose(1, 2))
         wp = Pr * w.unsqueeze(2)
         big = torch.full_like(wp, float("inf"))
@@ -534,8 +539,11 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             memory + an event: the host blocks on THIS copy only, whatever else is queued behind it."""
             dev_pack = torch.cat([head, st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag,
                                   st["nocc"], st["nflag"]]).to(torch.int32)
-            host = torch.empty(dev_pack.shape, dtype=torch.int32).pin_memory()
+            host, slot = pinned_like(dev_pack.shape, torch.int32)      # staging ring: no pinned allocation per step
             host.copy_(dev_pack, non_blocking=True)
+            if slot is not None:
+                _PinnedRing.arm(slot)
+                return host, slot["event"]
             done = torch.cuda.Event()
             done.record()
             return host, done
@@ -717,10 +725,14 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         # stream-ordered copy into pinned memory right here, behind the forward kernels: finish()
         # then waits for THIS copy only — not for the backward pass and the optimizer step the
         # caller queues in between — and the host is free to queue the next step meanwhile
-        tail_host = torch.empty(tail_dev.shape, dtype=tail_dev.dtype).pin_memory()
+        tail_host, slot = pinned_like(tail_dev.shape, tail_dev.dtype)
         tail_host.copy_(tail_dev, non_blocking=True)
-        tail_event = torch.cuda.Event()
-        tail_event.record()
+        if slot is not None:
+            _PinnedRing.arm(slot)
+            tail_event = slot["event"]
+        else:
+            tail_event = torch.cuda.Event()
+            tail_event.record()
 
     def finish():
         """Host side of the results: ONE download (distances, fit status, voted types), then the
