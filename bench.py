@@ -472,6 +472,11 @@ def main():
     # belong to no steady-state step (the W warm-up steps the caller asks for follow as usual).
     if hasattr(step, "warm_paths"):
         step.warm_paths()
+    # everything allocated so far (modules, pools, compiled wrappers) is permanent: take it out of the
+    # cyclic collector's generations so that a full collection in the middle of a step stays short
+    import gc
+    gc.collect()
+    gc.freeze()
     start = snapshot()
     if hasattr(step, "pool") and not stub:
         for _ in range(max(1, step.pool // step.batch)):

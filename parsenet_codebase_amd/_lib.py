@@ -250,6 +250,15 @@ class _PinnedRing:
 _RING = _PinnedRing()
 
 
+def wait_event(event):
+    """Block the host until ``event`` has completed — by polling.  hipEventSynchronize puts the
+    thread to sleep, and on a busy host (the pool's boxes are shared) the wake-up alone costs up to
+    milliseconds while the device sits idle behind the very copy the host waits for; the three waits
+    of a training step are short, a spinning core is cheap."""
+    while not event.query():
+        pass
+
+
 def pinned_like(shape, dtype):
     """A pinned host tensor of ``shape`` / ``dtype`` from the ring (plus its slot, to be armed after
     the copy that fills or drains it), or a freshly pinned one (slot None) when it does not fit."""

@@ -30,7 +30,7 @@ from torch.profiler import record_function
 
 from . import kernels as K
 from . import mean_shift as MSM
-from ._lib import _PinnedRing, h2d, pinned_like
+from ._lib import _PinnedRing, h2d, pinned_like, wait_event
 
 EPS = float(np.finfo(np.float32).eps)
 SPLINE_TYPES = (0, 2, 6, 7, 9, 8)
@@ -336,7 +336,7 @@ def standardize_segments(P2, w):
         cov_h.copy_(cov, non_blocking=True)
         if slot is not None:
             _PinnedRing.arm(slot)
-            slot["event"].synchronize()
+            wait_event(slot["event"])
         else:
             torch.cuda.current_stream(cov.device).synchronize()
         R = h2d(host_minor_axis_rotations(cov_h), P2.device)       # ... batched geev, upload
@@ -550,7 +550,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
 
         def download(st):
             host, done = start_download(st)
-            done.synchronize()
+            wait_event(done)
             return host.numpy()
         pending = start_download(state)
         yield                                                    # (a pipelined caller queues the next group here)
@@ -564,7 +564,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             np.random.shuffle(np.arange(N))
         # ... and so is everything the matching needs from the ground truth alone
         gt_pre = [precompute_ground_truth(labels[b], primitives[b]) for b in range(B)]
-        pending[1].synchronize()                                 # download: cluster ids
+        wait_event(pending[1])                                   # download: cluster ids
         pack = pending[0].numpy()
         if pack[0] > 0:
             MSM.auto_report(B, N, (float(pack[0]) - 1.0) * 1e-6)
@@ -739,7 +739,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         per-shape records.  With ``defer_metrics`` the caller runs this after it has queued the
         backward pass, so the device never waits for the host between the two."""
         if tail_event is not None:
-            tail_event.synchronize()
+            wait_event(tail_event)
             host = tail_host.numpy()
         else:
             host = tail_dev.cpu().numpy()                                                      # sync 3
