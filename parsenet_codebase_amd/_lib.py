@@ -224,19 +224,22 @@ class _PinnedRing:
     copy has completed (normally long before its turn comes round again)."""
 
     def __init__(self, slots=32, nbytes=1 << 20):
-        self.nbytes, self.slots, self.next = nbytes, [None] * slots, 0
+        self.nbytes, self.nslots, self.slots, self.next = nbytes, slots, None, 0
 
     def take(self, nbytes):
         """(uint8 pinned view of ``nbytes``, slot) or (None, None) when the request exceeds a slot."""
         if nbytes > self.nbytes:
             return None, None
+        if self.slots is None:
+            # ONE page-locked allocation for the whole ring, at the first use (not one per slot spread
+            # over the first dozens of uploads — i.e. over somebody's timed steps)
+            whole = torch.empty(self.nslots * self.nbytes, dtype=torch.uint8).pin_memory()
+            self.slots = [{"buf": whole[i * self.nbytes:(i + 1) * self.nbytes], "event": torch.cuda.Event(),
+                           "armed": False} for i in range(self.nslots)]
         i = self.next
-        self.next = (i + 1) % len(self.slots)
+        self.next = (i + 1) % self.nslots
         slot = self.slots[i]
-        if slot is None:
-            slot = self.slots[i] = {"buf": torch.empty(self.nbytes, dtype=torch.uint8).pin_memory(),
-                                    "event": torch.cuda.Event(), "armed": False}
-        elif slot["armed"]:
+        if slot["armed"]:
             slot["event"].synchronize()
         return slot["buf"][:max(nbytes, 1)], slot
 

@@ -814,22 +814,43 @@ __global__ __launch_bounds__(256) void pn_wmax_fwd_kernel(const float* __restric
   }
 }
 
-// gw[s][n] = sum over the channels whose arg-max is n of g[s][c] * val[s][c], channels in order
-// (one workgroup per s; the sums are formed in LDS by one thread: C additions).
-__global__ __launch_bounds__(256) void pn_wmax_bwd_kernel(const float* __restrict__ g, const int* __restrict__ idx,
-                                                          const float* __restrict__ val, int C, int N,
-                                                          float* __restrict__ gw) {
+// gw[s][n] = sum over the channels whose arg-max is n of g[s][c] * val[s][c], channels in order.
+// One wave per segment walks the channels 64 at a time; lanes that hit the same point are resolved
+// inside the wave (the lowest lane of a group adds the group's terms in lane = channel order), so
+// the accumulation order is exactly the serial one, without a serial loop of C additions.
+__global__ __launch_bounds__(64) void pn_wmax_bwd_kernel(const float* __restrict__ g, const int* __restrict__ idx,
+                                                         const float* __restrict__ val, int C, int N,
+                                                         float* __restrict__ gw) {
   extern __shared__ float acc[];
-  const int s = blockIdx.x;
-  for (int n = threadIdx.x; n < N; n += 256) acc[n] = 0.f;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  for (int n = lane; n < N; n += 64) acc[n] = 0.f;
   __syncthreads();
-  if (threadIdx.x == 0)
-    for (int c = 0; c < C; ++c) {
-      const int i = idx[(size_t)s * C + c];
-      if (i >= 0 && i < N) acc[i] += g[(size_t)s * C + c] * val[(size_t)s * C + c];
+  for (int base = 0; base < C; base += 64) {
+    const int c = base + lane;
+    int i = -1;
+    float v = 0.f;
+    if (c < C) {
+      i = idx[(size_t)s * C + c];
+      v = g[(size_t)s * C + c] * val[(size_t)s * C + c];
+      if (i < 0 || i >= N) i = -1;
     }
-  __syncthreads();
-  for (int n = threadIdx.x; n < N; n += 256) gw[(size_t)s * N + n] = acc[n];
+    unsigned long long todo = __ballot(i >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int li = __shfl(i, leader, 64);
+      unsigned long long same = __ballot(i == li);
+      todo &= ~same;
+      float sum = acc[li];                 // (one address for the whole wave: a broadcast read)
+      while (same) {                       // ascending lanes = ascending channels: the serial order
+        const int l = __ffsll((long long)same) - 1;
+        sum += __shfl(v, l, 64);
+        same &= same - 1;
+      }
+      if (lane == leader) acc[li] = sum;
+    }
+    __syncthreads();
+  }
+  for (int n = lane; n < N; n += 64) gw[(size_t)s * N + n] = acc[n];
 }
 
 extern "C" int pn_weighted_max_fwd_f32(const float* x, const float* scale, const float* shift, const float* w, int S,
@@ -851,7 +872,7 @@ extern "C" int pn_weighted_max_bwd_f32(const float* g, const int* idx, const flo
     pn_set_error("pn_weighted_max_bwd_f32: N=%d exceeds the LDS accumulator (16384 points)", N);
     return PN_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(pn_wmax_bwd_kernel, dim3(S), dim3(256), (size_t)N * sizeof(float), (hipStream_t)stream, g, idx, val,
+  hipLaunchKernelGGL(pn_wmax_bwd_kernel, dim3(S), dim3(64), (size_t)N * sizeof(float), (hipStream_t)stream, g, idx, val,
                      C, N, gw);
   PN_CHECK_LAUNCH();
   return PN_OK;
