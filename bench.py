@@ -546,8 +546,8 @@ def main():
     if ms_mode is not None and roof is not None:
         roof["meanshift_launches"] = {
             "mode": {True: "planned (PARSENET_MS_SPARSE=1)", False: "dense (PARSENET_MS_SPARSE=0)"}.get(
-                ms_mode, "auto: plan one call, go dense for %d calls when its plans keep more than %.2f of the tile "
-                         "pairs" % (_ms.AUTO_DENSE_STEPS, _ms.AUTO_DENSE_ABOVE)),
+                ms_mode, "auto: plan %d calls, go dense for %d calls when their plans keep more than %.2f of the "
+                         "tile pairs on average" % (_ms.AUTO_SAMPLES, _ms.AUTO_DENSE_STEPS, _ms.AUTO_DENSE_ABOVE)),
             "timed_and_warmup_calls": calls_timed, "profiled_as": "planned" if mostly_planned else "dense"}
         if census:
             roof["meanshift_launches"].update(census)

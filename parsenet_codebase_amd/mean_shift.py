@@ -29,14 +29,15 @@ ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 # the dense launch at 0.71 of the pairs, 0.83 at 0.85; matrix cores at 0.59-0.61 of peak on the
 # executed pairs, like the dense kernel) plus ~1.2 ms of plan kernels per call of ten iterations:
 # it pays below ~0.93 of the pairs.  PARSENET_MS_SPARSE: "1" always plan, "0" always dense, "auto"
-# (default): plan one call, look at the share of pairs its plans kept (the number rides in the
-# fitting stage's cluster-id download: no extra synchronisation), and launch dense for the next
-# AUTO_DENSE_STEPS calls of that problem size when it was above AUTO_DENSE_ABOVE.
+# (default): plan AUTO_SAMPLES calls, look at the share of pairs their plans kept (the number rides
+# in the fitting stage's cluster-id download: no extra synchronisation), and launch dense for the
+# next AUTO_DENSE_STEPS calls of that problem size when their mean was above AUTO_DENSE_ABOVE.
 _env_sparse = os.environ.get("PARSENET_MS_SPARSE", "auto")
 SPARSE = True if _env_sparse == "1" else False if _env_sparse == "0" else "auto"
 AUTO_DENSE_ABOVE = 0.93
-AUTO_DENSE_STEPS = 49
-_AUTO = {}                  # (B, N) -> calls left before the next planned (probing) call
+AUTO_DENSE_STEPS = 48
+AUTO_SAMPLES = 4
+_AUTO = {}                  # (B, N) -> {calls left before the next planned (probing) calls, shares of the last ones}
 CALLS = {"planned": 0, "dense": 0}   # calls of the bf16x3 iterations by launch kind (bench.py reports them)
 AUTO_STAT = None            # device scalar of the most recent planned call in auto mode (see fitting_batch)
 SPARSE_MIN_N = 2048
@@ -48,17 +49,23 @@ def use_sparse(B, N):
     """Whether the next call of this problem size plans its launches (see SPARSE)."""
     if SPARSE != "auto":
         return bool(SPARSE)
-    left = _AUTO.get((B, N), 0)
-    if left > 0:
-        _AUTO[(B, N)] = left - 1
+    st = _AUTO.get((B, N))
+    if st is not None and st["left"] > 0:
+        st["left"] -= 1
         return False
     return True
 
 
-def auto_report(B, N, visited):
-    """The share of tile pairs the plans of the last planned call kept."""
-    if SPARSE == "auto":
-        _AUTO[(B, N)] = AUTO_DENSE_STEPS if visited > AUTO_DENSE_ABOVE else 0
+def auto_report(B, N, share):
+    """The share of tile pairs the plans of the last planned call kept.  The shapes of a batch differ
+    (0.70 ... 0.95 inside one pool of 16): the decision to launch dense is taken on the mean of
+    AUTO_SAMPLES consecutive planned calls, not on one."""
+    if SPARSE != "auto":
+        return
+    st = _AUTO.setdefault((B, N), {"left": 0, "hist": []})
+    st["hist"] = (st["hist"] + [float(share)])[-AUTO_SAMPLES:]
+    if len(st["hist"]) >= AUTO_SAMPLES and sum(st["hist"]) / len(st["hist"]) > AUTO_DENSE_ABOVE:
+        st["left"], st["hist"] = AUTO_DENSE_STEPS, []
 
 
 def locality_order(x, lloyd=2):

@@ -450,20 +450,24 @@ def test_batched_host_rotations_equal_the_per_segment_function_bit_for_bit():
 
 
 def test_auto_mode_of_the_block_sparse_iterations():
-    """mean_shift.use_sparse / auto_report: plan one call; when its lists kept more than
-    AUTO_DENSE_ABOVE of their entries launch dense for AUTO_DENSE_STEPS calls, then probe again;
-    PARSENET_MS_SPARSE=1 / 0 (SPARSE True / False) override."""
+    """mean_shift.use_sparse / auto_report: plan AUTO_SAMPLES calls; when their plans kept more than
+    AUTO_DENSE_ABOVE of the tile pairs on average launch dense for AUTO_DENSE_STEPS calls, then
+    probe again; PARSENET_MS_SPARSE=1 / 0 (SPARSE True / False) override."""
     from parsenet_codebase_amd import mean_shift as MSM
     saved, MSM.SPARSE = MSM.SPARSE, "auto"
     MSM._AUTO.clear()
     try:
         key = (4, 10000)
-        assert MSM.use_sparse(*key)                      # nothing known: plan
-        MSM.auto_report(*key, 0.97)                      # a converged embedding: nothing to skip
+        for share in (0.99, 0.97, 0.98):                 # one dense-looking batch decides nothing
+            assert MSM.use_sparse(*key)
+            MSM.auto_report(*key, share)
+        assert MSM.use_sparse(*key)
+        MSM.auto_report(*key, 0.96)                      # four in a row: a converged embedding
         seq = [MSM.use_sparse(*key) for _ in range(MSM.AUTO_DENSE_STEPS + 1)]
         assert seq == [False] * MSM.AUTO_DENSE_STEPS + [True]
-        MSM.auto_report(*key, 0.27)                      # an embedding early in training: keep planning
-        assert all(MSM.use_sparse(*key) for _ in range(5))
+        for share in (0.95, 0.7, 0.8, 0.75):             # mean 0.8: keep planning
+            MSM.auto_report(*key, share)
+            assert MSM.use_sparse(*key)
         assert MSM.use_sparse(2, 5000)                   # another problem size has its own memory
         MSM.SPARSE = False
         assert not MSM.use_sparse(*key)
