@@ -219,10 +219,27 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
     for (int u = 0; u < 4; ++u) d1[h][u] = d2[h][u] = 0.0;
 
   const int p0 = (blockIdx.x * EC_WAVES + wave) * EC_PPW;
+  // The neighbour list of a point lives in registers (lane l holds entries l and l + 64; k <= 128)
+  // and is fetched ONE POINT AHEAD: the row gathers then depend on a lane shuffle instead of on a
+  // load of the index that has just been issued (the profile showed 80 % of the wave cycles waiting
+  // on that chain of two dependent loads per step), and several gathers can be in flight.
+  const bool regs = k <= 128;
+  int nlo = 0, nhi = 0;
+  if (regs && p0 < N) {
+    const int64_t* __restrict__ ib0 = idx + ((size_t)b * N + p0) * k;
+    nlo = lane < k ? (int)ib0[lane] : 0;
+    nhi = lane + 64 < k ? (int)ib0[lane + 64] : 0;
+  }
   for (int pi = 0; pi < EC_PPW; ++pi) {
     const int i = p0 + pi;
     if (i >= N) break;  // wave-uniform
     const int64_t* __restrict__ ib = idx + ((size_t)b * N + i) * k;
+    const int jlo = nlo, jhi = nhi;
+    if (regs && pi + 1 < EC_PPW && i + 1 < N) {
+      const int64_t* __restrict__ ibn = ib + k;
+      nlo = lane < k ? (int)ibn[lane] : 0;
+      nhi = lane + 64 < k ? (int)ibn[lane + 64] : 0;
+    }
     float4x q[NCH], best[NCH], s1[NCH], s2[NCH];
     int arg[NCH][4];
 #pragma unroll
@@ -236,23 +253,40 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
         arg[h][u] = 0;
       }
     }
-    for (int kk0 = 0; kk0 < k; kk0 += RPI) {
-      const int kk = kk0 + rg;
-      if (kk < k) {
-        const int j = (int)ib[kk];
+    // two steps of the neighbour loop per trip, both row gathers issued before either is used
+    for (int kk0 = 0; kk0 < k; kk0 += 2 * RPI) {
+      const int kka = kk0 + rg, kkb = kka + RPI;
+      // (the shuffles are executed by every lane: the source lane must be active)
+      const int sa = kka < 64 ? __shfl(jlo, kka & 63, 64) : __shfl(jhi, (kka - 64) & 63, 64);
+      const int sb = kkb < 64 ? __shfl(jlo, kkb & 63, 64) : __shfl(jhi, (kkb - 64) & 63, 64);
+      const bool oa = kka < k, ob = kkb < k;
+      const int ja = oa ? (regs ? sa : (int)ib[kka]) : i;      // inactive: a row that exists
+      const int jb = ob ? (regs ? sb : (int)ib[kkb]) : i;
+      float4x va[NCH], vb[NCH];
 #pragma unroll
-        for (int h = 0; h < NCH; ++h) {
-          const float4x v = ld4(PQb + (size_t)j * 2 * COUT + (cl + h * 64) * 4);
+      for (int h = 0; h < NCH; ++h) {
+        va[h] = ld4(PQb + (size_t)ja * 2 * COUT + (cl + h * 64) * 4);
+        vb[h] = ld4(PQb + (size_t)jb * 2 * COUT + (cl + h * 64) * 4);
+      }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float y = v.v[u] + q[h].v[u];
-            const float ys = y * sgn[h][u];
-            if (ys > best[h].v[u]) {
-              best[h].v[u] = ys;
-              arg[h][u] = kk;
+      for (int half = 0; half < 2; ++half) {
+        const bool on = half ? ob : oa;
+        const int kk = half ? kkb : kka;
+        if (on) {
+#pragma unroll
+          for (int h = 0; h < NCH; ++h) {
+            const float4x v = half ? vb[h] : va[h];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float y = v.v[u] + q[h].v[u];
+              const float ys = y * sgn[h][u];
+              if (ys > best[h].v[u]) {
+                best[h].v[u] = ys;
+                arg[h][u] = kk;
+              }
+              s1[h].v[u] += y;
+              s2[h].v[u] = __builtin_fmaf(y, y, s2[h].v[u]);
             }
-            s1[h].v[u] += y;
-            s2[h].v[u] = __builtin_fmaf(y, y, s2[h].v[u]);
           }
         }
       }
