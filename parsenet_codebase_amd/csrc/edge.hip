@@ -713,13 +713,29 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
   for (int h = 0; h < NCH; ++h)
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[h].v[u] = 0.f;
-  for (int e = e0 + rg; e < e1; e += RPI) {
-    const int i = rb[e];
+  // the source list of the point 64 entries at a time in registers (one coalesced load), two row
+  // gathers in flight per trip: same summation order per lane (entries rg, rg + RPI, ... ascending)
+  for (int base = e0; base < e1; base += 64) {
+    const int mine = base + lane < e1 ? rb[base + lane] : j;
+    const int cnt = e1 - base < 64 ? e1 - base : 64;
+    for (int t0 = 0; t0 < cnt; t0 += 2 * RPI) {
+      const int ta = t0 + rg, tb = ta + RPI;
+      const int sa = __shfl(mine, ta & 63, 64), sb = __shfl(mine, tb & 63, 64);
+      const bool oa = ta < cnt, ob = tb < cnt;
+      const int ia = oa ? sa : j, ib_ = ob ? sb : j;
+      float4x qa[NCH], qb[NCH];
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const float4x q = ld4(PQb + (size_t)i * 2 * COUT + COUT + (cl + h * 64) * 4);
+      for (int h = 0; h < NCH; ++h) {
+        qa[h] = ld4(PQb + (size_t)ia * 2 * COUT + COUT + (cl + h * 64) * 4);
+        qb[h] = ld4(PQb + (size_t)ib_ * 2 * COUT + COUT + (cl + h * 64) * 4);
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[h].v[u] += q.v[u];
+      for (int h = 0; h < NCH; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (oa) acc[h].v[u] += qa[h].v[u];
+          if (ob) acc[h].v[u] += qb[h].v[u];
+        }
     }
   }
 #pragma unroll
