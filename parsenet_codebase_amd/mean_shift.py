@@ -40,6 +40,9 @@ AUTO_SAMPLES = 4
 _AUTO = {}                  # (B, N) -> {calls left before the next planned (probing) calls, shares of the last ones}
 CALLS = {"planned": 0, "dense": 0}   # calls of the bf16x3 iterations by launch kind (bench.py reports them)
 AUTO_STAT = None            # device scalar of the most recent planned call in auto mode (see fitting_batch)
+# what a plan may drop: tile pairs whose N terms together stay below this share of the SMALLEST row
+# sum of the q tile (csrc/meanshift_x3.h)
+PLAN_REL_EPS = float(os.environ.get("PARSENET_MS_REL_EPS", "1e-9"))
 SPARSE_MIN_N = 2048
 SPARSE_MAX_N = 65535        # block numbers of the plan are 16-bit safe; the T x T predicate stays small
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
@@ -128,7 +131,7 @@ class _MeanShiftIterations(torch.autograd.Function):
         q = x
         for _ in range(iterations):
             if sparse:
-                plan = K.meanshift_x3_plan(K.meanshift_x3_tileinfo(q), x_info, bsq, N)
+                plan = K.meanshift_x3_plan(K.meanshift_x3_tileinfo(q), x_info, bsq, N, PLAN_REL_EPS)
                 plans.append(plan)
                 q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan)
             elif x3 is not None:
