@@ -109,10 +109,9 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     """HBM-side bytes per launch of a mean-shift kernel from the committed PMC run of the same
     launch configuration (profiles/: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH
     doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
-    the file is not there — bench.py never profiles counters itself.  The round-3 file was
-    collected inside ``bench.py --workload cfg5`` (batched launches of 4 shapes; it holds the dense
-    launches — the largest grid of a kernel — and the few planned ones of the auto mode's probes:
-    256 workgroups); the round-1 files are per shape."""
+    the file is not there — bench.py never profiles counters itself.  The round-3 files were
+    collected inside ``bench.py --workload cfg5`` (batched launches of 4 shapes): one for planned
+    launches (256 workgroups), one for dense ones; the round-1 files are per shape."""
     import csv
     files = {"fp16x2": ("r01_meanshift_h2_pmc.csv", "pn_msh_kernel<%d>"),
              "bf16x3": ("r01_meanshift_x3_pmc.csv", "pn_ms3_kernel<%d>"),
@@ -120,8 +119,8 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     scale = float(shapes_per_launch)
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     if arith == "bf16x3" and shapes_per_launch == 4:
-        cand = ["r03_meanshift_x3_dense_cfg5_pmc.csv"] + (["r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
-                                                          ["r02_meanshift_x3_batch4_pmc.csv"])
+        cand = (["r03_meanshift_x3_planned_cfg5_pmc.csv", "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
+                ["r03_meanshift_x3_dense_cfg5_pmc.csv", "r02_meanshift_x3_batch4_pmc.csv"])
         files["bf16x3"] = (next((c for c in cand if os.path.exists(os.path.join(prof, c))), cand[-1]),
                            "pn_ms3_kernel<%d>")
         scale = 1.0

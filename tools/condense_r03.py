@@ -71,7 +71,7 @@ if os.path.exists(log):
     open(os.path.join(P, "r03_gpu_suite.txt"), "w").write(
         "# python -m pytest tests -m gpu -q -s --durations=10 on the evidence box (tools/evidence_round3.sh)\n" +
         "\n".join(keep) + "\n")
-pmc = os.path.join(SRC, "r03_meanshift_x3_dense_cfg5_pmc.csv")
+pmc = os.path.join(SRC, "r03_meanshift_x3_planned_cfg5_pmc.csv")
 if os.path.exists(pmc):
-    shutil.copy(pmc, os.path.join(P, "r03_meanshift_x3_dense_cfg5_pmc.csv"))
+    shutil.copy(pmc, os.path.join(P, "r03_meanshift_x3_planned_cfg5_pmc.csv"))
 print(sorted(f for f in os.listdir(P) if f.startswith("r03_")))

@@ -33,7 +33,7 @@ find $O/pmc_SQ -name "*kernel_trace.csv" -delete
 cd $R
 python tools/step_breakdown.py $O/s5/b_kernel_trace.csv > $O/breakdown.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete
-python tools/condense_r02.py pmc r03_meanshift_x3_dense_cfg5_pmc.csv pn_ms3_kernel $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ; cp profiles/r03_meanshift_x3_dense_cfg5_pmc.csv $O/
+python tools/condense_r02.py pmc r03_meanshift_x3_planned_cfg5_pmc.csv pn_ms3_kernel $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ; cp profiles/r03_meanshift_x3_planned_cfg5_pmc.csv $O/
 timeout 600 python tools/torch_sites.py > $O/torch_sites.txt 2>&1
 timeout 600 python tools/host_cprofile.py > $O/host_cprofile.txt 2>&1
-tail -2 $O/smoke.log; cat $O/host.txt; grep -i "parity\|eval-mode\|passed\|failed\|^rc " $O/pytest.log | cut -c1-900; for f in bench_cfg5 bench_cfg5_b bench_cfg5_planned bench_cfg4 bench_cfg2 bench_cfg3; do cut -c1-330 $O/$f.json; done; cat $O/breakdown.txt; cat $O/r03_meanshift_x3_dense_cfg5_pmc.csv; grep -v "amdgpu.ids" $O/torch_sites.txt | head -16
+tail -2 $O/smoke.log; cat $O/host.txt; grep -i "parity\|eval-mode\|passed\|failed\|^rc " $O/pytest.log | cut -c1-900; for f in bench_cfg5 bench_cfg5_b bench_cfg5_planned bench_cfg4 bench_cfg2 bench_cfg3; do cut -c1-330 $O/$f.json; done; cat $O/breakdown.txt; cat $O/r03_meanshift_x3_planned_cfg5_pmc.csv; grep -v "amdgpu.ids" $O/torch_sites.txt | head -16
