@@ -70,6 +70,29 @@ __global__ __launch_bounds__(256) void pn_edge_feature_vec_kernel(
     const int e = lane / C4, c4 = lane - e * C4;
     if (e >= epw) return;
     const float4 ctr = xb[(size_t)n * C4 + c4];
+    if (k <= 128 && epw * C4 == 64) {
+      // the whole neighbour list in registers (one coalesced load: lane l holds entries l, l + 64);
+      // the row gathers take their index from a lane shuffle and two of them are in flight per
+      // trip — the chain "load index -> load row -> store" per step was what the wave waited for
+      const int jlo = lane < k ? (int)ib[lane] : n, jhi = lane + 64 < k ? (int)ib[lane + 64] : n;
+      for (int kk0 = 0; kk0 < k; kk0 += 2 * epw) {
+        const int ka = kk0 + e, kb = ka + epw;
+        const int sa = ka < 64 ? __shfl(jlo, ka & 63, 64) : __shfl(jhi, (ka - 64) & 63, 64);
+        const int sb = kb < 64 ? __shfl(jlo, kb & 63, 64) : __shfl(jhi, (kb - 64) & 63, 64);
+        const bool oa = ka < k, ob = kb < k;
+        const float4 na = xb[(size_t)(oa ? sa : n) * C4 + c4];
+        const float4 nbv = xb[(size_t)(ob ? sb : n) * C4 + c4];
+        if (oa) {
+          fo[(size_t)ka * 2 * C4 + c4] = make_float4(na.x - ctr.x, na.y - ctr.y, na.z - ctr.z, na.w - ctr.w);
+          fo[(size_t)ka * 2 * C4 + C4 + c4] = ctr;
+        }
+        if (ob) {
+          fo[(size_t)kb * 2 * C4 + c4] = make_float4(nbv.x - ctr.x, nbv.y - ctr.y, nbv.z - ctr.z, nbv.w - ctr.w);
+          fo[(size_t)kb * 2 * C4 + C4 + c4] = ctr;
+        }
+      }
+      return;
+    }
     for (int kk = e; kk < k; kk += epw) {
       const int j = (int)ib[kk];
       const float4 nb = xb[(size_t)j * C4 + c4];
