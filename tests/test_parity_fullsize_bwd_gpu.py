@@ -185,10 +185,12 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
              ["%.2e" % r for r in rel_res], ["%.5f" % c for c in cos_res], cos_res_all, cos_net, cos_all,
              float((flat_r - net_r).norm() / net_r.norm())))
     assert min(len(np.unique(i)) for i in ids_r) >= 3
-    # What is well posed is asserted tightly: the network terms (losses 1e-4, gradient cos 0.9999;
+    # What is well posed is asserted tightly: the network terms (NLL 1e-4, gradient cos 0.9999;
     # measured 1.000000) and the flat parameter gradient of the WHOLE loss (cos > 0.999; measured
     # 0.99998 and 0.99978 in two runs).
-    assert abs(float(el_g.mean()) - float(el_r.mean())) <= 1e-4 * abs(float(el_r.mean()))
+    # (the triplet loss divides by the COUNT of active hinge terms, src/segment_loss.py:113-118: one term
+    # within 1e-6 of the hinge on either side moves it by 1 / count ~ 1e-3 relative; measured 4e-6 ... 3.5e-4)
+    assert abs(float(el_g.mean()) - float(el_r.mean())) <= 2e-3 * abs(float(el_r.mean()))
     assert abs(float(nll_g) - float(nll_r)) <= 1e-4 * abs(float(nll_r))
     assert cos_net > 0.9999, cos_net
     assert cos_all > 0.999, cos_all
