@@ -128,8 +128,8 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     idx = {"meanshift_fwd": 0, "meanshift_bwd_rows": 1, "meanshift_bwd_cols": 2}.get(kernel_name)
     if idx is None or not os.path.exists(fn):
         return None
-    want = files[arith][1] % idx
-    rows = [r for r in csv.DictReader(open(fn)) if r["kernel"] == want]
+    want = (files[arith][1] % idx)[:-1]       # "pn_ms3_kernel<2": also "<2, true>" (ping-pong schedule)
+    rows = [r for r in csv.DictReader(open(fn)) if r["kernel"].startswith(want)]
     grids = sorted({int(r["grid_size"]) for r in rows if r.get("grid_size", "").isdigit()})
     if len(grids) > 1:      # dense launches: the largest grid; planned (flat schedule): the smallest
         pick = str(grids[0] if planned else grids[-1])

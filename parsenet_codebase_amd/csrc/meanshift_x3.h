@@ -98,8 +98,36 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
 // cs, rs      per-row c_i and alpha_i = 1/(r_i b^2): of the resident row (PASS 1) / streamed (PASS 2)
 // grid (slices, blocks of 128 resident indices, B), 256 threads: wave w owns 32 w .. 32 w + 31.
 // LDS: images double buffered: 48 KiB (PASS 0/1), 96 KiB (PASS 2); one barrier per tile.
+// Scalar (SMEM) loads of plan data inside the ping-pong loop: the lists and pair flags are
+// read-only for the whole launch, and through the constant address space a uniform address is a
+// s_load_dword tracked by lgkmcnt — the loop then has no vector-memory operation besides the
+// LDS DMA, so no compiler-placed vmcnt(0) (all it can express once a DMA is in flight) ever waits
+// for an image that was only just requested.
+typedef const __attribute__((address_space(4))) int* x3_cptr_i;
+typedef const __attribute__((address_space(4))) unsigned* x3_cptr_u;
+__device__ static inline int x3_cint(const int* p) { return ((x3_cptr_i)p)[0]; }
+__device__ static inline int x3_cflag(const unsigned char* p) {   // one byte via its aligned dword
+  const uintptr_t a = (uintptr_t)p;
+  const unsigned raw = ((x3_cptr_u)(a & ~(uintptr_t)3))[0];
+  return (int)((raw >> ((unsigned)(a & 3) * 8u)) & 0xffu);
+}
+
 #define X3_WAVES(PASS) ((PASS) == 1 ? 4 : 8)  // forward / column pass: 8 waves (2 per SIMD) share the LDS images
-template <int PASS>
+// PP ("ping-pong", 8-wave passes only): the two waves of a SIMD run half a tile apart.  With one
+// barrier per tile both waves of a SIMD enter the elementwise stage (VALU only) of the same tile
+// one after the other while the matrix pipe has nothing else to do for the later one (in-kernel
+// timers, column pass: one wave of the SIMD waits 4 000 of 18 500 cycles per tile at the barrier
+// for its sibling, whose stage nobody overlaps).  Here
+// waves 0-3 (one per SIMD) lead and waves 4-7 trail by one half step: a tile is two half steps
+// (H1: first GEMM + stage, H2: second GEMM) separated by workgroup barriers, so that in every
+// half step one wave of the SIMD is in H1 and the other in H2 and the stage of either is covered
+// by MFMAs of the other.  An image lives for 3 half steps: three LDS buffers; each wave issues its
+// share of the DMA for tile k + 2 at the END of its own H2(k) — the leading and the trailing
+// waves at different times, behind the MFMAs of the other group, instead of all eight in one
+// burst behind the barrier (325 / 1 400 cycles per tile in which no wave issued an MFMA).
+// Vector-memory traffic of the loop is the DMA alone (plan data through scalar loads), and the
+// only vmcnt wait is the explicit one at the end of H1: the DMA has a whole half step to land.
+template <int PASS, bool OPT>
 __global__ __launch_bounds__(64 * X3_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void pn_ms3_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
@@ -108,12 +136,28 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     const unsigned char* __restrict__ pairs, const int* __restrict__ counts, const int* __restrict__ lists,
     const int* __restrict__ offs, int nblk_total, int blk_off, int nbp, int nbB, int cmin, int sstride) {
   constexpr int NIMG = PASS == 2 ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) u32x4 ldsP[2][NIMG][X3_IMG_U4];
-  __shared__ __attribute__((aligned(16))) float lds_sc[2][64];
+  constexpr bool PP = OPT && X3_WAVES(PASS) == 8;   // the row pass runs one wave per SIMD: no ping-pong
+  constexpr int NBUF = PP ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) u32x4 ldsP[NBUF][NIMG][X3_IMG_U4];
+  __shared__ __attribute__((aligned(16))) float lds_sc[NBUF][64];
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  // (ping-pong: the wave number as a scalar — list / flag / image addresses become scalar too)
+  const int wave = PP ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, lane = tid & 63;
   const int col = lane & 31, h = lane >> 5;
   constexpr int NW = X3_WAVES(PASS);
+  // ping-pong group of this wave: 0 = leading, 1 = trailing, one of each per SIMD whatever the
+  // placement of the waves (order of arrival at a per-SIMD counter; SIMD id = HW_ID[5:4])
+  int grp = 0;
+  if (PP) {
+    __shared__ int lds_simd[4];
+    if (tid < 4) lds_simd[tid] = 0;
+    __syncthreads();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    int g = 0;
+    if (lane == 0) g = atomicAdd(&lds_simd[(hwid >> 4) & 3], 1);
+    grp = __builtin_amdgcn_readfirstlane(g) & 1;
+  }
   // Work of this workgroup.
   //  dense (no plan): grid (slices, resident blocks, B): one block, one slice of the full range.
   //  flat plan (offs): grid (G): the lists of all (batch item, resident block) pairs of the pass
@@ -179,11 +223,19 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
   const u32x4* __restrict__ PBb = PASS == 2 ? PB + boff : nullptr;
 
   // a 24 KiB image = 24 chunks of 1 KiB (64 lanes x 16 B), dealt evenly to the NW waves
+  // (ping-pong: scalar base of the wave's chunks + one 32-bit lane offset for every DMA)
+  const unsigned lane16 = (unsigned)lane * 16u;
 #define X3_STAGE(SRC, DST)                                                        \
   {                                                                               \
-    _Pragma("unroll") for (int u = 0; u < 24 / NW; ++u) {                         \
-      const int q = wave * (24 / NW) + u;                                         \
-      X3_GLDS16((SRC) + q * 64 + lane, &(DST)[q * 64]);                           \
+    if (PP) {                                                                     \
+      const char* s_ = reinterpret_cast<const char*>(SRC) + (size_t)(wave * (24 / NW)) * 1024; \
+      _Pragma("unroll") for (int u = 0; u < 24 / NW; ++u)                         \
+        X3_GLDS16(s_ + (u * 1024 + lane16), &(DST)[(wave * (24 / NW) + u) * 64]); \
+    } else {                                                                      \
+      _Pragma("unroll") for (int u = 0; u < 24 / NW; ++u) {                       \
+        const int q = wave * (24 / NW) + u;                                       \
+        X3_GLDS16((SRC) + q * 64 + lane, &(DST)[q * 64]);                         \
+      }                                                                           \
     }                                                                             \
   }
 #define X3_STAGE_P(MT, BUF)                                                       \
@@ -193,20 +245,32 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       X3_STAGE(PBb + (size_t)(MT) * X3_IMG_U4, ldsP[BUF][NIMG - 1]);              \
       if (wave == 0) { /* c_i | alpha_i of the 32 streamed rows */                \
         const int jc = min((MT) * 32 + (lane & 31), N - 1);                       \
-        __builtin_amdgcn_global_load_lds((x3_gptr)((lane < 32 ? cs : rs) + bN + jc), \
-                                         (x3_lptr)&lds_sc[BUF][0], 4, 0, 0);      \
+        if (PP) { /* two half-wave DMAs from scalar bases (lane l writes word l of lds_sc) */ \
+          const unsigned o_ = (unsigned)jc * 4u;                                  \
+          if (lane < 32)                                                          \
+            __builtin_amdgcn_global_load_lds((x3_gptr)(reinterpret_cast<const char*>(cs + bN) + o_), \
+                                             (x3_lptr)&lds_sc[BUF][0], 4, 0, 0);  \
+          else                                                                    \
+            __builtin_amdgcn_global_load_lds((x3_gptr)(reinterpret_cast<const char*>(rs + bN) + o_), \
+                                             (x3_lptr)&lds_sc[BUF][0], 4, 0, 0);  \
+        } else {                                                                  \
+          __builtin_amdgcn_global_load_lds((x3_gptr)((lane < 32 ? cs : rs) + bN + jc), \
+                                           (x3_lptr)&lds_sc[BUF][0], 4, 0, 0);    \
+        }                                                                         \
       }                                                                           \
     }                                                                             \
   }
   int cur = 0;
-#define X3_TILE(E) (lst ? lst[E] : (E))
+#define X3_TILE(E) (lst ? (PP ? x3_cint(lst + (E)) : lst[E]) : (E))
+#define X3_FLAG(MT) (PP ? x3_cflag(prow + (size_t)(MT) * pstride) : (int)prow[(size_t)(MT) * pstride])
   // the first image is on its way while the resident rows are fetched and split
   // tile numbers two entries ahead and this wave's pair flag one entry ahead: neither load is
   // waited for between the barrier and the first MFMA (the row pass runs one wave per SIMD)
   int mt_cur = t_begin < t_end ? X3_TILE(t_begin) : 0;
   int mt_nxt = t_begin + 1 < t_end ? X3_TILE(t_begin + 1) : 0;
-  unsigned char on_cur = prow && t_begin < t_end ? prow[(size_t)mt_cur * pstride] : 1;
+  int on_cur = prow && t_begin < t_end ? X3_FLAG(mt_cur) : 1;
   if (t_begin < t_end) X3_STAGE_P(mt_cur, 0);
+  if (PP && t_begin + 1 < t_end) X3_STAGE_P(mt_nxt, 1);
   // resident operand(s) as B operands of the first GEMM: k-step s = channels 16 s + 8 h + e
   const int ires = min(i0 + col, N - 1);
   bf16x8 qh[8], qm[8], ql[8];
@@ -255,17 +319,29 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
 #ifdef MS_TIMING
   unsigned long long tb0 = 0, tdma = 0, tg1 = 0, tew = 0, tb1 = 0, tg2 = 0, tall = __builtin_amdgcn_s_memtime();
 #endif
+  // raw barrier / DMA wait of the ping-pong schedule: no release fence (its vmcnt(0) would make
+  // every wave wait for the DMA it has just issued); the images are only ever written by the DMA
+#define X3_BAR() asm volatile("s_barrier" ::: "memory")
+// s_waitcnt vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait) as the builtin: the
+// compiler's counter tracking sees it and adds no vmcnt(0) of its own before the transpose reads
+// of H2 (which it cannot tell apart from the buffer the DMA writes)
+#define X3_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+  if (PP) {
+    X3_WAIT_VM0();                      // this wave's share of the first two images
+    if (grp) X3_BAR();                  // the trailing waves sit out the first half step
+  }
   for (int e_ = t_begin; e_ < t_end; ++e_) {
     const int mt = mt_cur;
     const int j0 = mt * 32;
     MS_T(U0);
-    __syncthreads();  // image(s) of tile mt landed; every wave is done with tile mt - 1
+    if (PP) X3_BAR();   // H1(k): the image(s) of tile k landed (every wave waited for its share)
+    else __syncthreads();  // image(s) of tile mt landed; every wave is done with tile mt - 1
     MS_T(U1);
-    unsigned char on_nxt = 1;
+    int on_nxt = 1;
     int mt_nn = 0;
     if (e_ + 1 < t_end) {
-      X3_STAGE_P(mt_nxt, cur ^ 1);
-      if (prow) on_nxt = prow[(size_t)mt_nxt * pstride];
+      if (!PP) X3_STAGE_P(mt_nxt, cur ^ 1);
+      if (prow) on_nxt = X3_FLAG(mt_nxt);
       if (e_ + 2 < t_end) mt_nn = X3_TILE(e_ + 2);
     }
     // wave-level skip: this wave's 32 resident indices do not interact with the streamed tile
@@ -275,12 +351,36 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
     // two partial accumulators (small / large terms) per product where registers allow (row
     // pass, one wave per SIMD); the 8-wave passes accumulate small-to-large into one
-    constexpr bool TWO_ACC = PASS == 1;
+    // (ping-pong forward pass: its 240 registers leave room for the second accumulator too —
+    // consecutive k-steps then never chain on one accumulator across the LDS reads between them;
+    // a foreign issue slot between two MFMAs on the SAME accumulator costs ~43 cycles)
+    constexpr bool TWO_ACC = PASS == 1 || (PP && PASS == 0);
     f32x16 sa, ta, sb_, tb_;
 #define sb (*(TWO_ACC ? &sb_ : &sa))
 #define tb (*(TWO_ACC ? &tb_ : &ta))
+    const bool tail = j0 + 32 > N;
+    float kv[16], gs[PASS == 0 ? 1 : 16];
+    // (the forward pass runs two waves per SIMD in 256 registers: the other wave fills the
+    // matrix pipe during the elementwise stage, and the pipelining registers would spill)
+    constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
     if (wave_on && pair_on) {
       // ---- first GEMM: S[streamed][resident] (and T with the second operand) ----
+      // ping-pong issue priorities (s_setprio; the elementwise stages run at 0):
+      //   forward:  first GEMM 2 > second GEMM 0 — the wave in H1 takes the matrix pipe, drops back
+      //             for its stage, and the stage runs under the sibling's second GEMM (without
+      //             priorities the two GEMMs share the pipe, end together, and the stage of H1
+      //             runs with the sibling waiting at the barrier);
+      //   column pass (stage in two halves around k-step 0 of the second GEMM):
+      //             k-step 0 of the second GEMM 3 > first GEMM 2 > k-step 1 0 — the sibling's
+      //             first GEMM runs under the second half of the stage and finishes before
+      //             k-step 1, whose MFMAs then cover the first half of the sibling's stage.
+#define X3_PRIO(P_)                          \
+  if (PP) {                                  \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_setprio(P_);          \
+    __builtin_amdgcn_sched_barrier(0);       \
+  }
+      X3_PRIO(2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         sa[r] = 0.f;
@@ -326,6 +426,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
           X3_MFMA(ta, gh, qh[s]);
         }
       }
+      X3_PRIO(0);
       // large + small partial sums: one accumulator stays live across the barrier
       if (TWO_ACC) {
 #pragma unroll
@@ -348,8 +449,6 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       // ---- elementwise stage on D[streamed = (r&3)+8(r>>2)+4h][resident = col], software
       // in two halves in the backward passes: k-step 0 of the second GEMM only needs D registers
       // 0..7, so the values 8..15 are processed after it (fewer live registers) ----
-      const bool tail = j0 + 32 > N;
-      float kv[16], gs[PASS == 0 ? 1 : 16];
 #define X3_EW_(R, MASKED)                                                          \
   {                                                                                \
     const int row = ((R) & 3) + 8 * ((R) >> 2) + 4 * h;                            \
@@ -387,9 +486,6 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       }                                                                                       \
     }                                                                                         \
   }
-      // (the forward pass runs two waves per SIMD in 256 registers: the other wave fills the
-      // matrix pipe during this stage, and the pipelining registers would spill)
-      constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
       if (PASS == 0 && tail) {  // only the last tile of the forward pass pays for the mask
 #pragma unroll
         for (int r = 0; r < 16; ++r) X3_EW_(r, true);
@@ -407,6 +503,15 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
 #ifdef MS_TIMING
       tew += U6 - U5;
 #endif
+      if (PP) {         // H1(k) | H2(k)
+        MS_T(V0);
+        X3_WAIT_VM0();  // this wave's share of the image(s) of tile k + 1 (issued at the end of H2(k - 1))
+        X3_BAR();
+#ifdef MS_TIMING
+        tb1 += __builtin_amdgcn_s_memtime() - V0;
+#endif
+      }
+      MS_T(U7);
       // ---- second GEMM: out[f][resident] += sum_streamed C[f][streamed] w[streamed][resident];
       //      k-step t = D registers 8t..8t+7 of the first GEMM.  Operands of the next (t, fb)
       //      are fetched from LDS before the MFMAs of the current one. ----
@@ -435,9 +540,11 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       }                                                                                         \
     }                                                                                           \
   }
+      if (PIPE) X3_PRIO(3);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (PIPE && t == 1) {
+          X3_PRIO(0);
           // second half of the stage between the two k-steps (finer interleaving with the MFMAs
           // was measured: it costs registers and gains nothing)
 #pragma unroll
@@ -472,19 +579,37 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       }
 #undef X3_LOAD_C
 #undef X3_TR
+#undef X3_PRIO
 #undef X3_SPLIT_W
 #undef X3_EW
 #undef X3_EW_
 #ifdef MS_TIMING
-      tg2 += __builtin_amdgcn_s_memtime() - U6;
+      tg2 += __builtin_amdgcn_s_memtime() - U7;
 #endif
+    } else if (PP) {    // a wave that skips the pair (or has no rows) still keeps the half steps
+      X3_WAIT_VM0();
+      X3_BAR();
     }
-    cur ^= 1;
+    if (PP) {
+      // the image(s) of tile k + 2 into the buffer of tile k - 1 (its last reader was H2(k - 1) of
+      // the trailing waves, one barrier ago); waited for at the end of this wave's H1(k + 1)
+      const int nb = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3
+      MS_T(V1);
+      if (e_ + 2 < t_end) X3_STAGE_P(mt_nn, nb);
+#ifdef MS_TIMING
+      tdma += __builtin_amdgcn_s_memtime() - V1;
+#endif
+      cur = cur == 2 ? 0 : cur + 1;
+    } else {
+      cur ^= 1;
+    }
     mt_cur = mt_nxt;
     mt_nxt = mt_nn;
     on_cur = on_nxt;
   }
+  if (PP && !grp) X3_BAR();   // the leading waves wait out the last half step of the trailing ones
 #undef X3_TILE
+#undef X3_FLAG
 #ifdef MS_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
     ms_dbg[PASS][0] = tg1;
@@ -1070,6 +1195,29 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
   return best;
 }
 
+// Ping-pong schedule (pn_ms3_kernel<PASS, true>), PN_MS_PINGPONG = 0 off / 1 column pass (default) /
+// 2 column and forward pass.  Measured on cfg5 (B = 4 x 10 000, `profiles/r03_pingpong_ab.txt`): column
+// pass 18 455 -> 16 442 cycles per tile of one workgroup, 1.35 -> 1.28 ms per launch; forward pass
+// 8 172 -> 7 888 cycles but no shorter launches (0.73 ms either way: the chip clocks to its power
+// budget and hands half of a cycle saving back), hence not the default there.  Also measured and
+// not kept: the second GEMM of the forward / row pass over pairs of feature blocks (MFMAs
+// alternating between two accumulators): second GEMM -6 % in cycles, row-pass launches +4 % longer.
+static int x3_pingpong() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PN_MS_PINGPONG");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+#define X3_LAUNCH_PP(PASS, GRID, BLOCK, STREAM, ...)                                                  \
+  {                                                                                                   \
+    if (x3_pingpong() >= ((PASS) == 2 ? 1 : 2))                                                       \
+      hipLaunchKernelGGL((pn_ms3_kernel<PASS, true>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);           \
+    else                                                                                              \
+      hipLaunchKernelGGL((pn_ms3_kernel<PASS, false>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);          \
+  }
+
 // Flat launches (block-sparse plan): one workgroup per CU, a multiple of the 8 XCDs.
 static int x3_flat_grid() {
   static int g = 0;
@@ -1134,7 +1282,7 @@ extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img
   if (pv.flat) {
     {
       PN_PROF("meanshift_fwd", stream);
-      hipLaunchKernelGGL(pn_ms3_kernel<0>, dim3(pv.G), dim3(512), 0, stream, q, nullptr, (const u32x4*)img_x,
+      X3_LAUNCH_PP(0, dim3(pv.G), dim3(512), stream, q, nullptr, (const u32x4*)img_x,
                          nullptr, nullptr, nullptr, bsq, N, ntiles, 0, opart, rpart, pv.pairs, pv.counts, pv.lists,
                          pv.offs, pv.nblk, 0, pv.nb0, B * pv.nb0, pv.cmin, pv.smax);
     }
@@ -1153,7 +1301,7 @@ extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img
   dim3 grid(S, pn_cdiv(N, 256), B);
   {
     PN_PROF("meanshift_fwd", stream);
-    hipLaunchKernelGGL(pn_ms3_kernel<0>, grid, dim3(512), 0, stream, q, nullptr, (const u32x4*)img_x,
+    X3_LAUNCH_PP(0, grid, dim3(512), stream, q, nullptr, (const u32x4*)img_x,
                        nullptr, nullptr, nullptr, bsq, N, ntiles, tps, opart, rpart, nullptr, nullptr, nullptr,
                        nullptr, 0, 0, 0, 0, 0, 0);
   }
@@ -1213,7 +1361,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
     const int* offs_x = pv.offs + (size_t)B * (pv.nb0 + pv.nb1) + 2;
     {
       PN_PROF("meanshift_bwd_rows", stream);
-      hipLaunchKernelGGL(pn_ms3_kernel<1>, dim3(pv.G), dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
+      hipLaunchKernelGGL((pn_ms3_kernel<1, false>), dim3(pv.G), dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
                          (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N, ntiles, 0,
                          opart_q, nullptr, pv.pairs, pv.counts, pv.lists, offs_q, pv.nblk, pv.nb0, pv.nb1,
                          B * pv.nb1, pv.cmin, pv.smax);
@@ -1221,7 +1369,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
     PN_CHECK_LAUNCH();
     {
       PN_PROF("meanshift_bwd_cols", stream);
-      hipLaunchKernelGGL(pn_ms3_kernel<2>, dim3(pv.G), dim3(64 * X3_WAVES(2)), 0, stream, x, nullptr,
+      X3_LAUNCH_PP(2, dim3(pv.G), dim3(64 * X3_WAVES(2)), stream, x, nullptr,
                          (const u32x4*)img_q, (const u32x4*)img_gu, (const float*)cs, (const float*)alpha, bsq, N,
                          ntiles, 0, opart_x, nullptr, pv.pairs, pv.counts, pv.lists, offs_x, pv.nblk,
                          pv.nb0 + pv.nb1, pv.nb2, B * pv.nb2, pv.cmin, pv.smax);
@@ -1247,7 +1395,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
   {
     PN_PROF("meanshift_bwd_rows", stream);
     dim3 grid(S, pn_cdiv(N, 32 * X3_WAVES(1)), B);
-    hipLaunchKernelGGL(pn_ms3_kernel<1>, grid, dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
+    hipLaunchKernelGGL((pn_ms3_kernel<1, false>), grid, dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
                        (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N,
                        ntiles, tps, opart_q, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0);
   }
@@ -1255,7 +1403,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
   {
     PN_PROF("meanshift_bwd_cols", stream);
     dim3 grid2(S2, pn_cdiv(N, 32 * X3_WAVES(2)), B);
-    hipLaunchKernelGGL(pn_ms3_kernel<2>, grid2, dim3(64 * X3_WAVES(2)), 0, stream, x, nullptr,
+    X3_LAUNCH_PP(2, grid2, dim3(64 * X3_WAVES(2)), stream, x, nullptr,
                        (const u32x4*)img_q, (const u32x4*)img_gu, (const float*)cs,
                        (const float*)alpha, bsq, N, ntiles, tps2, opart_x, nullptr, nullptr, nullptr, nullptr,
                        nullptr, 0, 0, 0, 0, 0, 0);

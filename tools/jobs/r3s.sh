@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3, job s: + two accumulators (fwd) and feature-block pairs in the second GEMM (fwd, rows): parity tests, phase timers, bench A/B
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r3s
+mkdir -p $O
+timeout 900 python -m pytest tests/test_meanshift_gpu.py -m gpu -q -x > $O/pytest_pp1.log 2>&1; echo "rc $?" >> $O/pytest_pp1.log
+tail -3 $O/pytest_pp1.log
+export PARSENET_PRETRAIN_CACHE=/tmp/pre_cfg5.pt
+for pp in 1 0 1 0; do
+  PN_MS_PINGPONG=$pp timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dense > $O/bench_pp${pp}_$RANDOM.json 2> $O/bench_pp$pp.err
+done
+PN_EXTRA_HIPCC_FLAGS=-DMS_TIMING python -m parsenet_codebase_amd.build > $O/build.log 2>&1
+for pp in 1 0; do
+PN_MS_PINGPONG=$pp PARSENET_MS_SPARSE=0 timeout 300 python tools/ms_timing.py > $O/timing_dense_pp$pp.txt 2>&1
+grep PASS $O/timing_dense_pp$pp.txt
+done
