@@ -351,10 +351,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
     // two partial accumulators (small / large terms) per product where registers allow (row
     // pass, one wave per SIMD); the 8-wave passes accumulate small-to-large into one
-    // (ping-pong forward pass: its 240 registers leave room for the second accumulator too —
-    // consecutive k-steps then never chain on one accumulator across the LDS reads between them;
-    // a foreign issue slot between two MFMAs on the SAME accumulator costs ~43 cycles)
-    constexpr bool TWO_ACC = PASS == 1 || (PP && PASS == 0);
+    constexpr bool TWO_ACC = PASS == 1;
     f32x16 sa, ta, sb_, tb_;
 #define sb (*(TWO_ACC ? &sb_ : &sa))
 #define tb (*(TWO_ACC ? &tb_ : &ta))
@@ -1200,8 +1197,9 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
 // pass 18 455 -> 16 442 cycles per tile of one workgroup, 1.35 -> 1.28 ms per launch; forward pass
 // 8 172 -> 7 888 cycles but no shorter launches (0.73 ms either way: the chip clocks to its power
 // budget and hands half of a cycle saving back), hence not the default there.  Also measured and
-// not kept: the second GEMM of the forward / row pass over pairs of feature blocks (MFMAs
-// alternating between two accumulators): second GEMM -6 % in cycles, row-pass launches +4 % longer.
+// not kept: two accumulators in the first GEMM of the forward pass and the second GEMM of the
+// forward / row pass over pairs of feature blocks (MFMAs alternating between two accumulators):
+// second GEMM -6 % in cycles, row-pass launches +4 % longer.
 static int x3_pingpong() {
   static int v = -1;
   if (v < 0) {

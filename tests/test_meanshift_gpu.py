@@ -329,6 +329,55 @@ def test_block_sparse_iterations_equal_the_dense_ones(gpu, N, clusters, noise):
         assert pair_frac > 0.99, stats           # nothing can be skipped on an unstructured cloud
 
 
+_SCHEDULE_CHILD = r"""
+import sys, numpy as np, torch
+import parsenet_codebase_amd.mean_shift as MS
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+g = torch.Generator().manual_seed(7)
+N = 4100
+proto = torch.nn.functional.normalize(torch.randn(5, 128, generator=g), dim=1)
+lab = torch.randint(0, 5, (2, N), generator=g)
+X = torch.nn.functional.normalize(proto[lab] + 0.2 * torch.randn(2, N, 128, generator=g) / np.sqrt(128), dim=2).to(dev)
+b = torch.tensor([0.07, 0.11], device=dev)
+w = torch.randn(2, N, 128, generator=g).to(dev)
+MS.ARITH = "bf16x3"
+out = {}
+for sparse in (False, True):
+    MS.SPARSE = sparse
+    x = X.clone().requires_grad_(True)
+    y = MS.mean_shift_iterations(x, b, 4)
+    (y * w).sum().backward()
+    out["y%d" % sparse] = y.detach().cpu().numpy()
+    out["g%d" % sparse] = x.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_pingpong_schedule_is_bit_identical(gpu, tmp_path):
+    """PN_MS_PINGPONG (csrc/meanshift_x3.h) changes WHEN the two waves of a SIMD run their halves
+    of a tile, not what a wave computes or in which order it adds: iterates and gradients of the
+    dense and the planned launches are equal bit for bit under the old schedule (0), the default
+    (1: column pass) and 2 (column and forward pass).  The switch is read once per process: one
+    child process per value (children of this process, never an exec of it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1", "2"):
+        f = str(tmp_path / ("pp%s.npz" % mode))
+        env = dict(os.environ, PN_MS_PINGPONG=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _SCHEDULE_CHILD, f], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = dict(np.load(f))
+    for mode in ("1", "2"):
+        for k, v in res["0"].items():
+            assert np.array_equal(v, res[mode][k]), (mode, k, float(np.abs(v - res[mode][k]).max()))
+    assert np.isfinite(res["0"]["g1"]).all() and float(np.abs(res["0"]["g1"]).max()) > 0
+
+
 def test_tile_caps_contain_their_rows_and_the_plan_keeps_every_heavy_pair(gpu):
     """Rigour of the block-sparse plan, checked by brute force on a clustered cloud whose tiles
     straddle clusters (N not a multiple of 32, natural order = no locality at all for half of it):
