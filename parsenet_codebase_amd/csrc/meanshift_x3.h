@@ -137,6 +137,9 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     const int* __restrict__ offs, int nblk_total, int blk_off, int nbp, int nbB, int cmin, int sstride) {
   constexpr int NIMG = PASS == 2 ? 2 : 1;
   constexpr bool PP = OPT && X3_WAVES(PASS) == 8;   // the row pass runs one wave per SIMD: no ping-pong
+  // row pass: the six DMA pieces of the next image go between the k-steps of the first GEMM instead
+  // of all behind the barrier (780 of 7 860 cycles per tile in which the wave issues no MFMA)
+  constexpr bool SPREAD = OPT && PASS == 1;
   constexpr int NBUF = PP ? 3 : 2;
   __shared__ __attribute__((aligned(16))) u32x4 ldsP[NBUF][NIMG][X3_IMG_U4];
   __shared__ __attribute__((aligned(16))) float lds_sc[NBUF][64];
@@ -340,12 +343,14 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     int on_nxt = 1;
     int mt_nn = 0;
     if (e_ + 1 < t_end) {
-      if (!PP) X3_STAGE_P(mt_nxt, cur ^ 1);
+      if (!PP && !SPREAD) X3_STAGE_P(mt_nxt, cur ^ 1);
       if (prow) on_nxt = X3_FLAG(mt_nxt);
       if (e_ + 2 < t_end) mt_nn = X3_TILE(e_ + 2);
     }
     // wave-level skip: this wave's 32 resident indices do not interact with the streamed tile
     const bool pair_on = on_cur != 0;
+    const bool spread_now = SPREAD && e_ + 1 < t_end;
+    const int mt_st = e_ + 1 < t_end ? mt_nxt : mt;
     MS_T(U2);
     u32x4 wh[2], wm[2], wl[2];                                   // weights of the second GEMM
     u32x4 vh[PASS == 2 ? 2 : 1], vm[PASS == 2 ? 2 : 1], vl[PASS == 2 ? 2 : 1];  // PASS 2: K
@@ -421,6 +426,13 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
           X3_MFMA(ta, gm, qh[s]);
           X3_MFMA(ta, gh, qm[s]);
           X3_MFMA(ta, gh, qh[s]);
+        }
+        if (SPREAD && s < 24 / NW) {
+          // unconditional (a branch here would cut the k-steps into separate scheduling regions):
+          // behind the last tile of a fragment the piece re-reads the current image into the free
+          // buffer, which nobody reads
+          const int q_ = wave * (24 / NW) + s;
+          X3_GLDS16(PAb + (size_t)mt_st * X3_IMG_U4 + q_ * 64 + lane, &ldsP[cur ^ 1][0][q_ * 64]);
         }
       }
       X3_PRIO(0);
@@ -586,6 +598,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     } else if (PP) {    // a wave that skips the pair (or has no rows) still keeps the half steps
       X3_WAIT_VM0();
       X3_BAR();
+    } else if (SPREAD) {
+      if (spread_now) X3_STAGE_P(mt_nxt, cur ^ 1);
     }
     if (PP) {
       // the image(s) of tile k + 2 into the buffer of tile k - 1 (its last reader was H2(k - 1) of
@@ -1192,14 +1206,16 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
   return best;
 }
 
-// Ping-pong schedule (pn_ms3_kernel<PASS, true>), PN_MS_PINGPONG = 0 off / 1 column pass (default) /
-// 2 column and forward pass.  Measured on cfg5 (B = 4 x 10 000, `profiles/r03_pingpong_ab.txt`): column
-// pass 18 455 -> 16 442 cycles per tile of one workgroup, 1.35 -> 1.28 ms per launch; forward pass
-// 8 172 -> 7 888 cycles but no shorter launches (0.73 ms either way: the chip clocks to its power
-// budget and hands half of a cycle saving back), hence not the default there.  Also measured and
-// not kept: two accumulators in the first GEMM of the forward pass and the second GEMM of the
-// forward / row pass over pairs of feature blocks (MFMAs alternating between two accumulators):
-// second GEMM -6 % in cycles, row-pass launches +4 % longer.
+// Round-3 schedules (pn_ms3_kernel<PASS, true>), PN_MS_PINGPONG = 0 off / 1 (default) ping-pong in the
+// column pass + DMA pieces between the k-steps in the row pass / 2 also ping-pong in the forward pass.
+// Measured on cfg5 (B = 4 x 10 000, `profiles/r03_pingpong_ab.txt`): column pass 18 455 -> 16 442
+// cycles per tile of one workgroup, 1.35 -> 1.28 ms per launch; row pass 7 864 -> 7 702 cycles,
+// 1.115 -> 1.07 ms; forward pass 8 172 -> 7 888 cycles but no shorter launches (0.73 ms either
+// way: the chip clocks to its power budget and hands half of a cycle saving back), hence not the
+// default there.  Results are bit-identical in all modes (tests/test_meanshift_gpu.py).  Also
+// measured and not kept: two accumulators in the first GEMM of the forward pass and the second
+// GEMM of the forward / row pass over pairs of feature blocks (MFMAs alternating between two
+// accumulators): second GEMM -6 % in cycles, row-pass launches +4 % longer.
 static int x3_pingpong() {
   static int v = -1;
   if (v < 0) {
@@ -1210,7 +1226,7 @@ static int x3_pingpong() {
 }
 #define X3_LAUNCH_PP(PASS, GRID, BLOCK, STREAM, ...)                                                  \
   {                                                                                                   \
-    if (x3_pingpong() >= ((PASS) == 2 ? 1 : 2))                                                       \
+    if (x3_pingpong() >= ((PASS) == 0 ? 2 : 1))                                                       \
       hipLaunchKernelGGL((pn_ms3_kernel<PASS, true>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);           \
     else                                                                                              \
       hipLaunchKernelGGL((pn_ms3_kernel<PASS, false>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);          \
@@ -1359,7 +1375,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
     const int* offs_x = pv.offs + (size_t)B * (pv.nb0 + pv.nb1) + 2;
     {
       PN_PROF("meanshift_bwd_rows", stream);
-      hipLaunchKernelGGL((pn_ms3_kernel<1, false>), dim3(pv.G), dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
+      X3_LAUNCH_PP(1, dim3(pv.G), dim3(64 * X3_WAVES(1)), stream, q, (const float*)gu,
                          (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N, ntiles, 0,
                          opart_q, nullptr, pv.pairs, pv.counts, pv.lists, offs_q, pv.nblk, pv.nb0, pv.nb1,
                          B * pv.nb1, pv.cmin, pv.smax);
@@ -1393,7 +1409,7 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
   {
     PN_PROF("meanshift_bwd_rows", stream);
     dim3 grid(S, pn_cdiv(N, 32 * X3_WAVES(1)), B);
-    hipLaunchKernelGGL((pn_ms3_kernel<1, false>), grid, dim3(64 * X3_WAVES(1)), 0, stream, q, (const float*)gu,
+    X3_LAUNCH_PP(1, grid, dim3(64 * X3_WAVES(1)), stream, q, (const float*)gu,
                        (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N,
                        ntiles, tps, opart_q, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0);
   }
