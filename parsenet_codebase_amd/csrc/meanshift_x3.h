@@ -127,7 +127,7 @@ __device__ static inline int x3_cflag(const unsigned char* p) {   // one byte vi
 // burst behind the barrier (325 / 1 400 cycles per tile in which no wave issued an MFMA).
 // Vector-memory traffic of the loop is the DMA alone (plan data through scalar loads), and the
 // only vmcnt wait is the explicit one at the end of H1: the DMA has a whole half step to land.
-template <int PASS, bool OPT>
+template <int PASS, int MODE>
 __global__ __launch_bounds__(64 * X3_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void pn_ms3_kernel(
     const float* __restrict__ R, const float* __restrict__ R1, const u32x4* __restrict__ PA,
@@ -136,10 +136,12 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     const unsigned char* __restrict__ pairs, const int* __restrict__ counts, const int* __restrict__ lists,
     const int* __restrict__ offs, int nblk_total, int blk_off, int nbp, int nbB, int cmin, int sstride) {
   constexpr int NIMG = PASS == 2 ? 2 : 1;
-  constexpr bool PP = OPT && X3_WAVES(PASS) == 8;   // the row pass runs one wave per SIMD: no ping-pong
-  // row pass: the six DMA pieces of the next image go between the k-steps of the first GEMM instead
-  // of all behind the barrier (780 of 7 860 cycles per tile in which the wave issues no MFMA)
-  constexpr bool SPREAD = OPT && PASS == 1;
+  // MODE 0: the round-2 schedule; 1: ping-pong (8-wave passes) / spread DMA (row pass)
+  constexpr bool PP = MODE == 1 && X3_WAVES(PASS) == 8;   // the row pass runs one wave per SIMD: no ping-pong
+  // spread DMA: the DMA pieces of the next image go between the k-steps of the first GEMM instead
+  // of all behind the barrier (row pass: 780 of 7 860 cycles per tile in which the wave issues no
+  // MFMA; the same in the 8-wave forward pass without ping-pong: 8 158 -> 8 145 cycles, nothing)
+  constexpr bool SPREAD = PASS == 1 && MODE == 1;
   constexpr int NBUF = PP ? 3 : 2;
   __shared__ __attribute__((aligned(16))) u32x4 ldsP[NBUF][NIMG][X3_IMG_U4];
   __shared__ __attribute__((aligned(16))) float lds_sc[NBUF][64];
@@ -1206,7 +1208,7 @@ static int x3_slices(int B, int N, int ntiles, int blocks_per_cu, int* tps) {
   return best;
 }
 
-// Round-3 schedules (pn_ms3_kernel<PASS, true>), PN_MS_PINGPONG = 0 off / 1 (default) ping-pong in the
+// Round-3 schedules (pn_ms3_kernel<PASS, 1>), PN_MS_PINGPONG = 0 off / 1 (default) ping-pong in the
 // column pass + DMA pieces between the k-steps in the row pass / 2 also ping-pong in the forward pass.
 // Measured on cfg5 (B = 4 x 10 000, `profiles/r03_pingpong_ab.txt`): column pass 18 455 -> 16 442
 // cycles per tile of one workgroup, 1.35 -> 1.28 ms per launch; row pass 7 864 -> 7 702 cycles,
@@ -1227,9 +1229,9 @@ static int x3_pingpong() {
 #define X3_LAUNCH_PP(PASS, GRID, BLOCK, STREAM, ...)                                                  \
   {                                                                                                   \
     if (x3_pingpong() >= ((PASS) == 0 ? 2 : 1))                                                       \
-      hipLaunchKernelGGL((pn_ms3_kernel<PASS, true>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);           \
+      hipLaunchKernelGGL((pn_ms3_kernel<PASS, 1>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);              \
     else                                                                                              \
-      hipLaunchKernelGGL((pn_ms3_kernel<PASS, false>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);          \
+      hipLaunchKernelGGL((pn_ms3_kernel<PASS, 0>), GRID, BLOCK, 0, STREAM, __VA_ARGS__);              \
   }
 
 // Flat launches (block-sparse plan): one workgroup per CU, a multiple of the 8 XCDs.
