@@ -5,15 +5,15 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3x
 mkdir -p $O
 export PARSENET_PRETRAIN_CACHE=/tmp/w150.pt
-timeout 600 python tools/dbg/cmp_x3_commits.py $O/new_a.npz > $O/new_a.log 2>&1
-timeout 600 python tools/dbg/cmp_x3_commits.py $O/new_b.npz > $O/new_b.log 2>&1
-PN_MS_PINGPONG=0 timeout 600 python tools/dbg/cmp_x3_commits.py $O/new_pp0.npz > $O/new_pp0.log 2>&1
+timeout 600 python tools/cmp_x3_commits.py $O/new_a.npz > $O/new_a.log 2>&1
+timeout 600 python tools/cmp_x3_commits.py $O/new_b.npz > $O/new_b.log 2>&1
+PN_MS_PINGPONG=0 timeout 600 python tools/cmp_x3_commits.py $O/new_pp0.npz > $O/new_pp0.log 2>&1
 cp parsenet_codebase_amd/csrc/meanshift_x3.h /tmp/x3_new.h
 # (before the call: git show 5f13491:parsenet_codebase_amd/csrc/meanshift_x3.h > tools/dbg/meanshift_x3_r3o.h.txt)
 cp tools/dbg/meanshift_x3_r3o.h.txt parsenet_codebase_amd/csrc/meanshift_x3.h
 python -m parsenet_codebase_amd.build > $O/build_old.log 2>&1
-timeout 600 python tools/dbg/cmp_x3_commits.py $O/old_a.npz > $O/old_a.log 2>&1
-timeout 600 python tools/dbg/cmp_x3_commits.py $O/old_b.npz > $O/old_b.log 2>&1
+timeout 600 python tools/cmp_x3_commits.py $O/old_a.npz > $O/old_a.log 2>&1
+timeout 600 python tools/cmp_x3_commits.py $O/old_b.npz > $O/old_b.log 2>&1
 tail -2 $O/*.log
 python - <<'P'
 import numpy as np

@@ -10,11 +10,11 @@ PARITY_PRETRAIN=600 timeout 900 python -m pytest tests/test_parity_fullsize_bwd_
 done
 grep -h "parity:\|passed\|failed" $O/pytest_600_*.log | cut -c1-1300
 export PARSENET_PRETRAIN_CACHE=/tmp/w150.pt
-timeout 600 python tools/dbg/cmp_x3_commits.py $O/new_a.npz > $O/new_a.log 2>&1
+timeout 600 python tools/cmp_x3_commits.py $O/new_a.npz > $O/new_a.log 2>&1
 # (before the call: git show 5f13491:parsenet_codebase_amd/csrc/meanshift_x3.h > tools/dbg/meanshift_x3_r3o.h.txt)
 cp tools/dbg/meanshift_x3_r3o.h.txt parsenet_codebase_amd/csrc/meanshift_x3.h
 python -m parsenet_codebase_amd.build > $O/build_old.log 2>&1
-timeout 600 python tools/dbg/cmp_x3_commits.py $O/old_a.npz > $O/old_a.log 2>&1
+timeout 600 python tools/cmp_x3_commits.py $O/old_a.npz > $O/old_a.log 2>&1
 python - <<'P'
 import numpy as np
 O="gpurun_out/r3y/"
