@@ -112,6 +112,13 @@ __device__ static inline int x3_cflag(const unsigned char* p) {   // one byte vi
   return (int)((raw >> ((unsigned)(a & 3) * 8u)) & 0xffu);
 }
 
+// developer switch (-DX3_PACKED_VALU): the elementwise stage of the 8-wave passes with packed fp32
+// VALU instructions as before round 3 (A/B of tools/jobs/r3zb.sh, r3zc.sh)
+#ifdef X3_PACKED_VALU
+#define X3_PACKED true
+#else
+#define X3_PACKED false
+#endif
 #define X3_WAVES(PASS) ((PASS) == 1 ? 4 : 8)  // forward / column pass: 8 waves (2 per SIMD) share the LDS images
 // PP ("ping-pong", 8-wave passes only): the two waves of a SIMD run half a tile apart.  With one
 // barrier per tile both waves of a SIMD enter the elementwise stage (VALU only) of the same tile
@@ -465,7 +472,8 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     const int row = ((R) & 3) + 8 * ((R) >> 2) + 4 * h;                            \
     const float sv = sa[R];                                                        \
     const float dist = __builtin_fmaf(-2.0f, sv, 2.0f);                            \
-    const float a2 = -dist * hl;                                                   \
+    float a2 = -dist * hl;                                                         \
+    if (PASS == 2 && !X3_PACKED) asm("" : "+v"(a2));   /* no v_pk_mul_f32 beside the sibling's MFMAs */ \
     const float a2c = __builtin_amdgcn_fmed3f(a2, -MS_LIM2, MS_LIM2);              \
     float k = __builtin_amdgcn_exp2f(a2c);                                         \
     /* padded points have all-zero image rows: they add nothing in the second GEMM whatever \
@@ -477,23 +485,40 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       const float tv = ta[R];                                                      \
       const float cc = PASS == 1 ? c_res : lds_sc[cur][row];                       \
       const float aa = PASS == 1 ? a_res : lds_sc[cur][32 + row];                  \
-      if (PASS == 2) kv[R] = k * (aa * bsqv); /* weight of the GU term: K / r_i */ \
-      float g = k * ((tv - cc) * aa);                                              \
+      if (PASS == 2) {                                                             \
+        float ab = aa * bsqv;                                                      \
+        if (!X3_PACKED) asm("" : "+v"(ab));                                        \
+        float kk = k * ab;                   /* weight of the GU term: K / r_i */  \
+        if (!X3_PACKED) asm("" : "+v"(kk));                                        \
+        kv[R] = kk;                                                                \
+      }                                                                            \
+      float d_ = (tv - cc) * aa;                                                   \
+      if (PASS == 2 && !X3_PACKED) asm("" : "+v"(d_));                             \
+      float g = k * d_;                                                            \
       asm("" : "+v"(g));          /* keep the select a v_cndmask, not a branch */  \
       gs[PASS == 0 ? 0 : (R)] = a2c == a2 ? g : 0.f;                               \
     }                                                                              \
   }
 #define X3_EW(R) X3_EW_(R, false)
+// (weights of the second GEMM: scalar residual subtractions in the 8-wave passes, packed ones in the
+// row pass — split_common.h, x3_split2_t)
+#define X3_SPLIT_TW(A, B, VH, VM, VL, Q)                       \
+  {                                                            \
+    const X3Pieces _p = x3_split2_t<PASS == 1 || X3_PACKED>(A, B); \
+    VH[Q] = _p.h;                                              \
+    VM[Q] = _p.m;                                              \
+    VL[Q] = _p.l;                                              \
+  }
 #define X3_SPLIT_W(T, Q)                                                                      \
   {                                                                                           \
     if (PASS == 0) {                                                                          \
-      X3_SPLIT_TO(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], wh[T], wm[T], wl[T], Q); \
+      X3_SPLIT_TW(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], wh[T], wm[T], wl[T], Q); \
     } else {                                                                                  \
       const int e = PASS == 0 ? 0 : 8 * (T) + 2 * (Q);                                        \
-      X3_SPLIT_TO(gs[e], gs[e + (PASS == 0 ? 0 : 1)], wh[T], wm[T], wl[T], Q);               \
+      X3_SPLIT_TW(gs[e], gs[e + (PASS == 0 ? 0 : 1)], wh[T], wm[T], wl[T], Q);               \
       if (PASS == 2) {                                                                        \
         const int tt = PASS == 2 ? (T) : 0;                                                   \
-        X3_SPLIT_TO(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], vh[tt], vm[tt], vl[tt], Q); \
+        X3_SPLIT_TW(kv[8 * (T) + 2 * (Q)], kv[8 * (T) + 2 * (Q) + 1], vh[tt], vm[tt], vl[tt], Q); \
       }                                                                                       \
     }                                                                                         \
   }
@@ -592,6 +617,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
 #undef X3_TR
 #undef X3_PRIO
 #undef X3_SPLIT_W
+#undef X3_SPLIT_TW
 #undef X3_EW
 #undef X3_EW_
 #ifdef MS_TIMING

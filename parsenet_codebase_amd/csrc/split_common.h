@@ -61,12 +61,33 @@ __device__ static inline f16x8 h2_as_f16(u32x4 v) { return __builtin_bit_cast(f1
 struct X3Pieces {
   uint32_t h, m, l;
 };
-__device__ static inline X3Pieces x3_split2(float a, float b) {
+// PACKED: the two residuals as v_pk_add_f32 (one instruction per pair); otherwise as SCALAR
+// subtractions (the empty asm keeps the compiler from packing them again): beside MFMAs a packed
+// fp32 VALU instruction costs ~13 cycles more than a plain one (MI355X_MICROARCH.md).  Measured in
+// the mean-shift passes (tools/jobs/r3zb.sh, r3zc.sh; profiles/r03_pingpong_ab.txt): scalar -4 / -11 %
+// cycles per tile in the two 8-wave passes (two waves per SIMD: the VALU work of one runs beside the
+// MFMAs of the other), +2.4 % in the one-wave-per-SIMD row pass (one more issue slot per pair,
+// nothing beside it) — so the callers choose.  Same arithmetic either way.
+template <bool PACKED>
+__device__ static inline X3Pieces x3_split2_t(float a, float b) {
   f32x2 v = {a, b};
   bf16x2 ph = __builtin_convertvector(v, bf16x2);
-  f32x2 r = {a - (float)ph[0], b - (float)ph[1]};
+  f32x2 r, r2;
+  if (PACKED) {
+    r = f32x2{a - (float)ph[0], b - (float)ph[1]};
+  } else {
+    float r0 = a - (float)ph[0], r1 = b - (float)ph[1];
+    asm("" : "+v"(r0));
+    r = f32x2{r0, r1};
+  }
   bf16x2 pm = __builtin_convertvector(r, bf16x2);
-  f32x2 r2 = {r[0] - (float)pm[0], r[1] - (float)pm[1]};
+  if (PACKED) {
+    r2 = f32x2{r[0] - (float)pm[0], r[1] - (float)pm[1]};
+  } else {
+    float s0 = r[0] - (float)pm[0], s1 = r[1] - (float)pm[1];
+    asm("" : "+v"(s0));
+    r2 = f32x2{s0, s1};
+  }
   bf16x2 pl = __builtin_convertvector(r2, bf16x2);
   X3Pieces o;
   o.h = __builtin_bit_cast(uint32_t, ph);
@@ -74,6 +95,7 @@ __device__ static inline X3Pieces x3_split2(float a, float b) {
   o.l = __builtin_bit_cast(uint32_t, pl);
   return o;
 }
+__device__ static inline X3Pieces x3_split2(float a, float b) { return x3_split2_t<true>(a, b); }
 #define X3_SPLIT_TO(A, B, VH, VM, VL, Q) \
   {                                      \
     const X3Pieces _p = x3_split2(A, B); \
