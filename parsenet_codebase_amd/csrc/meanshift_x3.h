@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
 // PA, PB      tile images of the streamed operand(s) (PB: GU, PASS 2 only); both GEMMs read them
 // cs, rs      per-row c_i and alpha_i = 1/(r_i b^2): of the resident row (PASS 1) / streamed (PASS 2)
 // grid (slices, blocks of 128 resident indices, B), 256 threads: wave w owns 32 w .. 32 w + 31.
-// LDS: images double buffered: 48 KiB (PASS 0/1), 96 KiB (PASS 2); one barrier per tile.
+// LDS: images double buffered: 48 KiB (PASS 0/1), 96 KiB (PASS 2); one barrier per tile
+// (MODE 0; the ping-pong schedule of MODE 1: three buffers, two barriers per tile — below).
+
 // Scalar (SMEM) loads of plan data inside the ping-pong loop: the lists and pair flags are
 // read-only for the whole launch, and through the constant address space a uniform address is a
 // s_load_dword tracked by lgkmcnt — the loop then has no vector-memory operation besides the
@@ -124,9 +126,9 @@ __device__ static inline int x3_cflag(const unsigned char* p) {   // one byte vi
 // barrier per tile both waves of a SIMD enter the elementwise stage (VALU only) of the same tile
 // one after the other while the matrix pipe has nothing else to do for the later one (in-kernel
 // timers, column pass: one wave of the SIMD waits 4 000 of 18 500 cycles per tile at the barrier
-// for its sibling, whose stage nobody overlaps).  Here
-// waves 0-3 (one per SIMD) lead and waves 4-7 trail by one half step: a tile is two half steps
-// (H1: first GEMM + stage, H2: second GEMM) separated by workgroup barriers, so that in every
+// for its sibling, whose stage nobody overlaps).  Here one wave of every SIMD leads and the other
+// trails by one half step (`grp`, decided per SIMD at run time): a tile is two half steps
+// (H1: first GEMM + first half of the stage, H2: second GEMM) separated by workgroup barriers, so that in every
 // half step one wave of the SIMD is in H1 and the other in H2 and the stage of either is covered
 // by MFMAs of the other.  An image lives for 3 half steps: three LDS buffers; each wave issues its
 // share of the DMA for tile k + 2 at the END of its own H2(k) — the leading and the trailing
