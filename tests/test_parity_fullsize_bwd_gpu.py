@@ -204,7 +204,8 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     # measured 1.000000) and the flat parameter gradient of the WHOLE loss (below).
     # (the triplet loss divides by the COUNT of active hinge terms, src/segment_loss.py:113-118: one term
     # within 1e-6 of the hinge on either side moves it by 1 / count ~ 1e-3 relative; measured 4e-6 ... 3.5e-4)
-    assert abs(float(el_g.mean()) - float(el_r.mean())) <= 2e-3 * abs(float(el_r.mean())) + 1e-7
+    # (at 600 pre-training steps few hinge terms are still active: measured up to 9.7e-4)
+    assert abs(float(el_g.mean()) - float(el_r.mean())) <= 5e-3 * abs(float(el_r.mean())) + 1e-7
     # (NLL: the feature-space kNN layers see features that agree to 1e-6 between the implementations and
     # the oracle's kNN runs on ITS features — a flipped near-tie neighbour moves that neighbourhood's
     # logits; measured 1.3e-6 ... 2.8e-4 relative over eleven runs)
