@@ -387,8 +387,13 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       //             k-step 0 of the second GEMM 3 > first GEMM 2 > k-step 1 0 — the sibling's
       //             first GEMM runs under the second half of the stage and finishes before
       //             k-step 1, whose MFMAs then cover the first half of the sibling's stage.
+#ifdef X3_NOPRIO   /* developer switch: the ping-pong schedule without issue priorities */
+#define X3_PRIO_ON false
+#else
+#define X3_PRIO_ON true
+#endif
 #define X3_PRIO(P_)                          \
-  if (PP) {                                  \
+  if (PP && X3_PRIO_ON) {                    \
     __builtin_amdgcn_sched_barrier(0);       \
     __builtin_amdgcn_s_setprio(P_);          \
     __builtin_amdgcn_sched_barrier(0);       \
