@@ -387,6 +387,19 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       //             k-step 0 of the second GEMM 3 > first GEMM 2 > k-step 1 0 — the sibling's
       //             first GEMM runs under the second half of the stage and finishes before
       //             k-step 1, whose MFMAs then cover the first half of the sibling's stage.
+// issue priorities of the ping-pong schedule (developer overrides -DX3_P_...: tools/jobs/r3zh.sh)
+#ifndef X3_P_G1
+#define X3_P_G1 2
+#endif
+#ifndef X3_P_EW
+#define X3_P_EW 0
+#endif
+#ifndef X3_P_G2A
+#define X3_P_G2A 3
+#endif
+#ifndef X3_P_G2B
+#define X3_P_G2B 0
+#endif
 #ifdef X3_NOPRIO   /* developer switch: the ping-pong schedule without issue priorities */
 #define X3_PRIO_ON false
 #else
@@ -398,7 +411,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     __builtin_amdgcn_s_setprio(P_);          \
     __builtin_amdgcn_sched_barrier(0);       \
   }
-      X3_PRIO(2);
+      X3_PRIO(X3_P_G1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         sa[r] = 0.f;
@@ -451,7 +464,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
           X3_GLDS16(PAb + (size_t)mt_st * X3_IMG_U4 + q_ * 64 + lane, &ldsP[cur ^ 1][0][q_ * 64]);
         }
       }
-      X3_PRIO(0);
+      X3_PRIO(X3_P_EW);
       // large + small partial sums: one accumulator stays live across the barrier
       if (TWO_ACC) {
 #pragma unroll
@@ -583,11 +596,11 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
       }                                                                                         \
     }                                                                                           \
   }
-      if (PIPE) X3_PRIO(3);
+      if (PIPE) X3_PRIO(X3_P_G2A);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (PIPE && t == 1) {
-          X3_PRIO(0);
+          X3_PRIO(X3_P_G2B);
           // second half of the stage between the two k-steps (finer interleaving with the MFMAs
           // was measured: it costs registers and gains nothing)
 #pragma unroll
