@@ -230,11 +230,14 @@ int pn_transpose_f32(const float* in, float* out, int B, int R, int C, void* str
  * reference builds it with x.transpose(2,1).contiguous(), model.py:42); idx (B,N,k) are
  * per-item indices (the reference's idx_base offset is applied internally).
  * feat (B,N,k,2C): [x_j - x_i | x_i] — the memory behind the (B,2C,N,k) permuted view the
- * reference returns.  The backward scatters a gradient of that shape into gxt (B,N,C). */
+ * reference returns.  The backward reduces a gradient of that shape into gxt (B,N,C): it
+ * transposes the kNN graph (sorted CSR by target point, built in `workspace` of
+ * pn_edgeconv_bwd_workspace(B, N, k) bytes) and every row of gxt is summed by one wave in list
+ * order — no floating-point atomics, bit-reproducible. */
 int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int B, int N, int k, int C,
                             float* feat, void* stream);
 int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N, int k, int C,
-                            float* gxt, void* stream);
+                            float* gxt, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused edge convolution ---------------------------------------------------------
  * Replaces get_graph_feature -> Conv2d 1x1 (no bias) -> GroupNorm / BatchNorm2d ->
@@ -244,7 +247,8 @@ int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N
  * y = P[idx] + Q over the k neighbours.
  *   reduce_fwd : PQ (B,N,2*Cout), idx (B,N,k), gamma (Cout; only its sign is used: max where
  *                gamma >= 0, min otherwise) -> yext, s1 = sum_k y (B,N,Cout) fp32, argk uint8
- *                (B,N,Cout), stats fp64 [(per_sample ? B : 1)][groups][2] = sum y, sum y^2.
+ *                (B,N,Cout), stats fp64 [(per_sample ? B : 1)][groups][2] = sum y, sum y^2
+ *                (per-workgroup partials in `workspace`, combined in index order: no atomics).
  *                per_sample = 1: GroupNorm statistics; 0: BatchNorm statistics (groups = Cout).
  *   moments    : stats -> mean, rstd = 1/sqrt(var + eps) (fp32), n = number of groups in total.
  *   finalize   : out (B,Cout,N) = LeakyReLU(gamma*(yext-mean)*rstd + beta).
@@ -252,12 +256,16 @@ int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N
  *   bwd        : exact Group/BatchNorm gradient on every edge -> dPQ (B,N,2*Cout);
  *                t = gamma*gz, c1c2 fp32 [(per_sample?B:1)][groups][2] = group means of t and
  *                t*yhat over the edge activations; dense = 0 when the statistics were constants
- *                (eval-mode BatchNorm).  The dense term is evaluated by transposing the kNN
- *                graph (CSR by target point, built inside the call in `workspace`) and gathering
- *                rows of Q; only the extreme edge of every (point, channel) uses an atomic. */
+ *                (eval-mode BatchNorm).  Both edge terms are evaluated by transposing the kNN
+ *                graph (CSR by target point, lists sorted by (source, slot), built inside the
+ *                call in `workspace`) and gathering rows of Q, t and argk: every dP row is summed
+ *                by one wave in list order.  No floating-point atomics: two calls on the same
+ *                inputs return the same bits (the reference on one device is deterministic). */
+size_t pn_edgeconv_reduce_workspace(int B, int N, int Cout, int groups);
 int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma, int B,
                                int N, int k, int Cout, int groups, int per_sample, float* yext,
-                               uint8_t* argk, float* s1, double* stats, void* stream);
+                               uint8_t* argk, float* s1, double* stats, void* workspace,
+                               size_t workspace_bytes, void* stream);
 int pn_moments_f32(const double* stats, int n, double count, float eps, float* mean, float* rstd,
                    void* stream);
 int pn_edgeconv_finalize_fwd_f32(const float* yext, const float* mean, const float* rstd,
@@ -297,6 +305,22 @@ int pn_chamfer_nn_ragged_f32(const float* a, const int* offA, int totalA, int ma
                              const int* offB, int totalB, int maxB, int B, float* minA,
                              int64_t* argA, float* minB, int64_t* argB, void* workspace,
                              size_t workspace_bytes, void* stream);
+
+/* Reduced two-sided distance of every item of the ragged batch and its backward (round 4):
+ *   out[s] = (mean_i minA_i + mean_j minB_j) / 2      (src/utils.py:326-358, reduce=True)
+ *   gpred[i] = (pred_i - gt[argA_i]) g_s / nA + sum_{j: argB_j = i} (pred_i - gt_j) g_s / nB
+ * pred / minA / argA are concatenated over the items like the clouds (offA, offB: S+1 ints),
+ * indices local to the item.  Fixed summation order, no atomics. */
+int pn_chamfer_ragged_reduce_f32(const float* minA, const int* offA, const float* minB, const int* offB, int S,
+                                 float* out, void* stream);
+int pn_chamfer_ragged_bwd_f32(const float* pred, const int* offA, int maxA, const float* gt, const int* offB,
+                              const int64_t* argA, const int64_t* argB, const float* g, int S, float* gpred,
+                              void* stream);
+
+/* Gradient of out[b,m,:] = src[b,idx[b,m],:] for rows of 3 floats (the nearest-neighbour gather of
+ * src/utils.py:273-358's min over the broadcast): gsrc[b,i,:] = sum_{m: idx[b,m] = i} g[b,m,:] in
+ * ascending m, gathered per row — no atomics.  g (B,M,3), idx (B,M), gsrc (B,N,3) fully written. */
+int pn_gather_rows3_bwd_f32(const float* g, const int64_t* idx, int B, int M, int N, float* gsrc, void* stream);
 
 /* ---- batched per-segment fitting (pn_weighted_moments, pn_small_lstsq,
  *      pn_bspline_eval) ------------------------------------------------------------------
@@ -380,14 +404,18 @@ int pn_edgeconv_bwd_stats_f32(const float* gout, const float* yext, const float*
  * anchor/positive rows ia[p][:] and negative rows ib[p][:] (row indices into E) and a weight w[p]
  * (1 / (pairs of its shape + 1e-8));  c_ij = relu(|a_i - p_j|^2 - |a_i - n_j|^2 + margin),
  * item_loss[p] = w[p] * (sum_ij c_ij - sum_i c_ii) / (#(c_ij > 0) + 1), loss[0] = sum_p item_loss[p];
- * item_scale[p] = w[p] / (# + 1) is kept for the backward.  _bwd ADDS gout[0] * d loss / d E into gE
- * (rows,D), which the caller zeroes (a point can be sampled more than once: fp32 atomics). */
+ * item_scale[p] = w[p] / (# + 1) is kept for the backward.  _bwd STORES gout[0] * d loss / d E into
+ * the rows of gE (rows,D) that some item names and leaves the others as they are (the caller
+ * zeroes gE).  A point can be sampled more than once: the per-item gradient rows go to `workspace`
+ * (pn_triplet_bwd_workspace bytes) and rows naming the same point are added in item order — no
+ * atomics, bit-reproducible. */
 int pn_triplet_fwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib, const float* w,
                        int P, int num, float margin, float* item_loss, float* item_scale, float* loss,
                        void* stream);
+size_t pn_triplet_bwd_workspace(int P, int num, int D);
 int pn_triplet_bwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib,
                        const float* item_scale, const float* gout, int P, int num, float margin, float* gE,
-                       void* stream);
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Memberships of the fitting stage in one pass: src/residual_utils.py:120 (weights = center @
  * embedding^T), src/fitting_utils.py:306-325 (weights_normalize) and the labels of

@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 9   # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 10  # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -36,9 +36,12 @@ SIGNATURES = {
     "pn_knn_pn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pn_edge_feature_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "pn_edge_feature_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_edge_feature_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
+    "pn_edgeconv_reduce_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pn_edgeconv_reduce_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
     "pn_moments_f32": (c_int, [c_void_p, c_int, c_double, c_float, c_void_p, c_void_p, c_void_p]),
     "pn_edgeconv_finalize_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                              c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
@@ -95,6 +98,10 @@ SIGNATURES = {
     "pn_chamfer_nn_ragged_workspace": (c_size_t, [c_int, c_int]),
     "pn_chamfer_nn_ragged_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_chamfer_ragged_reduce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pn_chamfer_ragged_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_void_p, c_void_p]),
+    "pn_gather_rows3_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_weighted_moments_chunks": (c_int, []),
     "pn_weighted_moments_count": (c_int, []),
     "pn_weighted_moments_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
@@ -116,8 +123,9 @@ SIGNATURES = {
                                   [c_size_t, c_void_p]),
     "pn_triplet_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pn_triplet_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_triplet_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                   c_float, c_void_p, c_void_p]),
+                                   c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_membership_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_float] + [c_void_p] * 5 + [c_void_p]),
     "pn_membership_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 2 + [c_void_p]),
     "pn_nms_occupied_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

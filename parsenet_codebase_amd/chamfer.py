@@ -20,6 +20,23 @@ def _guard_sqrt(x, minimum=1e-5):
     return torch.sqrt(torch.clamp(x, min=minimum))
 
 
+class _GatherRows(torch.autograd.Function):
+    """src (B,N,3), idx (B,M) -> src[b, idx[b,m]] (B,M,3).  torch.gather's backward is scatter_add_
+    (fp32 atomics: several points share a nearest neighbour, and the order of three or more
+    additions changes the bits); here the rows are gathered in ascending m (csrc/chamfer.hip)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = src.shape[1]
+        return torch.gather(src, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return K.gather_rows3_bwd(g.contiguous(), idx, ctx.n), None
+
+
 def nn_sqdist(a, b, side_a=True, side_b=True):
     """a (B,Na,3), b (B,Nb,3) -> (dA (B,Na), dB (B,Nb)): squared distance of every point to its
     nearest neighbour in the other cloud, differentiable w.r.t. both clouds."""
@@ -27,10 +44,10 @@ def nn_sqdist(a, b, side_a=True, side_b=True):
         _, argA, _, argB = K.chamfer_nn(a.detach(), b.detach(), side_a, side_b)
     dA = dB = None
     if side_a:
-        nb = torch.gather(b, 1, argA.unsqueeze(-1).expand(-1, -1, 3))
+        nb = _GatherRows.apply(b, argA)
         dA = torch.sum((a - nb) ** 2, 2)
     if side_b:
-        na = torch.gather(a, 1, argB.unsqueeze(-1).expand(-1, -1, 3))
+        na = _GatherRows.apply(a, argB)
         dB = torch.sum((na - b) ** 2, 2)
     return dA, dB
 

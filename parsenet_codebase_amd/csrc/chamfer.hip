@@ -243,3 +243,161 @@ extern "C" int pn_chamfer_nn_ragged_f32(const float* a, const int* offA, int tot
   }
   return PN_OK;
 }
+
+// ---- reduced two-sided distance and its backward for the ragged batch (round 4) ---------------
+// chamfer_distance_single_shape (src/utils.py:326-358, two-sided, squared, reduce=True) of every
+// item: out[s] = (mean_i minA + mean_j minB) / 2.  One workgroup per item, strided partial sums
+// combined by a fixed tree: the same bits on every run (torch's index_add_ uses fp32 atomics).
+__global__ __launch_bounds__(256) void pn_chamfer_ragged_reduce_kernel(const float* __restrict__ minA,
+                                                                       const int* __restrict__ offA,
+                                                                       const float* __restrict__ minB,
+                                                                       const int* __restrict__ offB,
+                                                                       float* __restrict__ out) {
+  __shared__ float red[2][256];
+  const int s = blockIdx.x, t = threadIdx.x;
+  const int a0 = offA[s], a1 = offA[s + 1], b0 = offB[s], b1 = offB[s + 1];
+  float sa = 0.f, sb = 0.f;
+  for (int i = a0 + t; i < a1; i += 256) sa += minA[i];
+  for (int j = b0 + t; j < b1; j += 256) sb += minB[j];
+  red[0][t] = sa;
+  red[1][t] = sb;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      red[0][t] += red[0][t + o];
+      red[1][t] += red[1][t + o];
+    }
+    __syncthreads();
+  }
+  if (t == 0) out[s] = (red[0][0] / (float)(a1 - a0) + red[1][0] / (float)(b1 - b0)) / 2.0f;
+}
+
+extern "C" int pn_chamfer_ragged_reduce_f32(const float* minA, const int* offA, const float* minB, const int* offB,
+                                            int S, float* out, void* stream_) {
+  PN_CHECK_ARG(minA && offA && minB && offB && out && S > 0, "pn_chamfer_ragged_reduce_f32: bad arguments");
+  hipLaunchKernelGGL(pn_chamfer_ragged_reduce_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream_, minA, offA, minB,
+                     offB, out);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// d out / d pred: every minimum routed to its pair of points,
+//   gpred[i] = (pred_i - gt[argA_i]) * g_s / nA  +  sum_{j : argB_j = i} (pred_i - gt_j) * g_s / nB
+// (the 2 of the square cancels the 1/2).  One wave owns 64 prediction rows of an item and walks the
+// item's targets 64 at a time; the few whose nearest prediction is one of its rows are applied in
+// ascending j — a gather, no atomics.
+__global__ __launch_bounds__(256) void pn_chamfer_ragged_bwd_kernel(
+    const float* __restrict__ pred, const int* __restrict__ offA, const float* __restrict__ gt,
+    const int* __restrict__ offB, const int64_t* __restrict__ argA, const int64_t* __restrict__ argB,
+    const float* __restrict__ g, float* __restrict__ gpred) {
+  const int s = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int a0 = offA[s], nA = offA[s + 1] - a0, b0 = offB[s], nB = offB[s + 1] - b0;
+  const int i0 = (blockIdx.x * 4 + wave) * 64;
+  if (i0 >= nA) return;
+  const int il = i0 + lane;
+  const bool on = il < nA;
+  const float gs = g[s];
+  const float ga = gs / (float)nA, gb = gs / (float)nB;
+  float px = 0.f, py = 0.f, pz = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+  if (on) {
+    const float* p = pred + (size_t)(a0 + il) * 3;
+    px = p[0], py = p[1], pz = p[2];
+    const float* q = gt + (size_t)(b0 + (int)argA[a0 + il]) * 3;
+    ax = (px - q[0]) * ga;
+    ay = (py - q[1]) * ga;
+    az = (pz - q[2]) * ga;
+  }
+  for (int j0 = 0; j0 < nB; j0 += 64) {
+    const int j = j0 + lane;
+    const int rel = j < nB ? (int)argB[b0 + j] - i0 : -1;
+    const bool hit = rel >= 0 && rel < 64;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (hit) {
+      const float* q = gt + (size_t)(b0 + j) * 3;
+      qx = q[0], qy = q[1], qz = q[2];
+    }
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const int r = __shfl(rel, src, 64);
+      const float x = __shfl(qx, src, 64), y = __shfl(qy, src, 64), z = __shfl(qz, src, 64);
+      if (lane == r) {
+        ax += (px - x) * gb;
+        ay += (py - y) * gb;
+        az += (pz - z) * gb;
+      }
+    }
+  }
+  if (on) {
+    float* o = gpred + (size_t)(a0 + il) * 3;
+    o[0] = ax, o[1] = ay, o[2] = az;
+  }
+}
+
+extern "C" int pn_chamfer_ragged_bwd_f32(const float* pred, const int* offA, int maxA, const float* gt,
+                                         const int* offB, const int64_t* argA, const int64_t* argB, const float* g,
+                                         int S, float* gpred, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(pred && offA && gt && offB && argA && argB && g && gpred, "pn_chamfer_ragged_bwd_f32: null pointer");
+  PN_CHECK_ARG(S > 0 && maxA > 0, "pn_chamfer_ragged_bwd_f32: empty batch");
+  PN_PROF("chamfer_ragged_bwd", stream);
+  hipLaunchKernelGGL(pn_chamfer_ragged_bwd_kernel, dim3(pn_cdiv(maxA, 256), S), dim3(256), 0, stream, pred, offA, gt,
+                     offB, argA, argB, g, gpred);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ---- gradient of a row gather with repeated indices (round 4) -----------------------------------
+// out[b,m,:] = src[b,idx[b,m],:] (rows of 3 floats: the nearest neighbours of a Chamfer distance).
+// Backward: gsrc[b,i,:] = sum_{m : idx[b,m] = i} g[b,m,:], summed in ascending m by the wave that
+// owns row i — the tensor library's scatter_add_ uses fp32 atomics, and with three or more
+// contributions to a row their order changes the bits.
+__global__ __launch_bounds__(256) void pn_gather_rows3_bwd_kernel(const float* __restrict__ g,
+                                                                  const int64_t* __restrict__ idx, int M, int N,
+                                                                  float* __restrict__ gsrc) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = (blockIdx.x * 4 + wave) * 64;
+  if (i0 >= N) return;
+  const float* __restrict__ gb = g + (size_t)b * M * 3;
+  const int64_t* __restrict__ ib = idx + (size_t)b * M;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const int m = m0 + lane;
+    const int rel = m < M ? (int)ib[m] - i0 : -1;
+    const bool hit = rel >= 0 && rel < 64;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (hit) {
+      const float* q = gb + (size_t)m * 3;
+      qx = q[0], qy = q[1], qz = q[2];
+    }
+    unsigned long long mask = __ballot(hit);
+    while (mask) {
+      const int src = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int r = __shfl(rel, src, 64);
+      const float x = __shfl(qx, src, 64), y = __shfl(qy, src, 64), z = __shfl(qz, src, 64);
+      if (lane == r) {
+        ax += x;
+        ay += y;
+        az += z;
+      }
+    }
+  }
+  if (i0 + lane < N) {
+    float* o = gsrc + ((size_t)b * N + i0 + lane) * 3;
+    o[0] = ax, o[1] = ay, o[2] = az;
+  }
+}
+
+extern "C" int pn_gather_rows3_bwd_f32(const float* g, const int64_t* idx, int B, int M, int N, float* gsrc,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(g && idx && gsrc && B > 0 && M > 0 && N > 0, "pn_gather_rows3_bwd_f32: bad arguments");
+  PN_PROF("gather_rows_bwd", stream);
+  hipLaunchKernelGGL(pn_gather_rows3_bwd_kernel, dim3(pn_cdiv(N, 256), B), dim3(256), 0, stream, g, idx, M, N, gsrc);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

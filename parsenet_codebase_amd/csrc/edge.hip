@@ -160,42 +160,7 @@ extern "C" int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int 
   return PN_OK;
 }
 
-// backward of the API form: gxt[b,n,:] += sum_kk (g[n,kk,C:2C] - g[n,kk,0:C]);
-// gxt[b,idx[n,kk],:] += g[n,kk,0:C].  gxt (B,N,C) must be zero on entry.
-__global__ __launch_bounds__(256) void pn_edge_feature_bwd_kernel(
-    const float* __restrict__ g, const int64_t* __restrict__ idx, int N, int k, int C,
-    float* __restrict__ gxt) {
-  const int b = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + wave;
-  if (n >= N) return;
-  const int64_t* __restrict__ ib = idx + ((size_t)b * N + n) * k;
-  const float* __restrict__ gb = g + ((size_t)b * N + n) * k * 2 * C;
-  float* __restrict__ gx = gxt + (size_t)b * N * C;
-  for (int c = lane; c < C; c += 64) {
-    float ctr = 0.f;
-    for (int kk = 0; kk < k; ++kk) {
-      const float gd = gb[(size_t)kk * 2 * C + c];
-      const float gc = gb[(size_t)kk * 2 * C + C + c];
-      ctr += gc - gd;
-      atomicAdd(&gx[(size_t)ib[kk] * C + c], gd);
-    }
-    atomicAdd(&gx[(size_t)n * C + c], ctr);
-  }
-}
-
-extern "C" int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N, int k,
-                                       int C, float* gxt, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(gfeat && idx && gxt, "pn_edge_feature_bwd_f32: null pointer");
-  PN_CHECK_HIP(hipMemsetAsync(gxt, 0, (size_t)B * N * C * sizeof(float), stream));
-  PN_PROF("edge_feature_bwd", stream);
-  dim3 grid(pn_cdiv(N, 4), B);
-  hipLaunchKernelGGL(pn_edge_feature_bwd_kernel, grid, dim3(256), 0, stream, gfeat, idx, N, k, C,
-                     gxt);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
+// (the backward of the API form follows the reverse-graph builder further down: it gathers)
 
 // ------------------------------------------------------------------------------------
 // (2) fused edge convolution: gather-reduce over rows of P
@@ -216,12 +181,14 @@ __device__ static inline void st4(float* p, const float4x& a) {
 
 // PQ (B,N,2*COUT): [P | Q] per point.  LPR = COUT/4 lanes cover one row; RPI rows per wave step.
 // Group statistics: Cg channels per group (group g = c / Cg).
-// stats: double [(per_sample ? B : 1)][COUT/Cg][2] accumulated with atomics (zero on entry).
+// part: double [B][gridDim.x][COUT/Cg][2], one partial (sum y, sum y^2) per workgroup and group,
+// combined in index order by pn_stats_reduce_kernel (no atomics: the moments, and with them every
+// activation of the layer, are bit-reproducible run to run).
 template <int COUT>
 __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
     const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ gamma,
     int N, int k, int Cg, int per_sample, float* __restrict__ yext, uint8_t* __restrict__ argk,
-    float* __restrict__ s1out, double* __restrict__ stats) {
+    float* __restrict__ s1out, double* __restrict__ part) {
   constexpr int NCH = COUT <= 256 ? 1 : COUT / 256;  // float4 chunks per lane
   constexpr int LPR = COUT <= 256 ? COUT / 4 : 64;   // lanes per row
   constexpr int RPI = 64 / LPR;                      // rows per wave step
@@ -349,7 +316,7 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
       }
     }
   }
-  // block reduction of the statistics, then one fp64 atomic per (group, moment)
+  // block reduction of the statistics in a fixed order, one partial per (group, moment)
   if (rg == 0) {
 #pragma unroll
     for (int h = 0; h < NCH; ++h)
@@ -366,61 +333,106 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
     double acc = 0.0;
     for (int w = 0; w < EC_WAVES; ++w)
       for (int c = g * Cg; c < (g + 1) * Cg; ++c) acc += s_part[w][which][c];
-    atomicAdd(&stats[((size_t)(per_sample ? b : 0) * G + g) * 2 + which], acc);
+    part[(((size_t)b * gridDim.x + blockIdx.x) * G + g) * 2 + which] = acc;
   }
 }
 
-// generic (any Cout): one thread per (point, channel); used for unusual widths only
-__global__ void pn_edgeconv_reduce_generic_kernel(
+// generic (any Cout): EC_GEN_PTS points per workgroup, one thread per (point, channel) pair at a
+// time; used for unusual widths only.  The per-pair sums go through LDS so that the group partial
+// of the workgroup is formed in a fixed order.
+#define EC_GEN_PTS 16
+__global__ __launch_bounds__(256) void pn_edgeconv_reduce_generic_kernel(
     const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ gamma,
-    int N, int k, int Cout, int Cg, int per_sample, float* __restrict__ yext,
-    uint8_t* __restrict__ argk, float* __restrict__ s1out, double* __restrict__ stats) {
+    int N, int k, int Cout, int Cg, float* __restrict__ yext, uint8_t* __restrict__ argk,
+    float* __restrict__ s1out, double* __restrict__ part) {
+  extern __shared__ float ec_gen_sh[];  // [2][EC_GEN_PTS * Cout]
   const int b = blockIdx.y;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)N * Cout) return;
-  const int i = (int)(t / Cout), c = (int)(t - (long long)i * Cout);
+  const int p0 = blockIdx.x * EC_GEN_PTS;
   const float* PQb = PQ + (size_t)b * N * 2 * Cout;
-  const int64_t* ib = idx + ((size_t)b * N + i) * k;
-  const float q = PQb[(size_t)i * 2 * Cout + Cout + c];
-  const float sg = gamma[c] >= 0.f ? 1.f : -1.f;
-  float best = -__builtin_inff(), s1 = 0.f, s2 = 0.f;
-  int arg = 0;
-  for (int kk = 0; kk < k; ++kk) {
-    const float y = PQb[(size_t)ib[kk] * 2 * Cout + c] + q;
-    const float ys = y * sg;
-    if (ys > best) {
-      best = ys;
-      arg = kk;
+  float* sh1 = ec_gen_sh;
+  float* sh2 = ec_gen_sh + EC_GEN_PTS * Cout;
+  for (int pc = threadIdx.x; pc < EC_GEN_PTS * Cout; pc += 256) {
+    const int pl = pc / Cout, c = pc - pl * Cout, i = p0 + pl;
+    float s1 = 0.f, s2 = 0.f;
+    if (i < N) {
+      const int64_t* ib = idx + ((size_t)b * N + i) * k;
+      const float q = PQb[(size_t)i * 2 * Cout + Cout + c];
+      const float sg = gamma[c] >= 0.f ? 1.f : -1.f;
+      float best = -__builtin_inff();
+      int arg = 0;
+      for (int kk = 0; kk < k; ++kk) {
+        const float y = PQb[(size_t)ib[kk] * 2 * Cout + c] + q;
+        const float ys = y * sg;
+        if (ys > best) {
+          best = ys;
+          arg = kk;
+        }
+        s1 += y;
+        s2 = __builtin_fmaf(y, y, s2);
+      }
+      const size_t o = ((size_t)b * N + i) * Cout + c;
+      yext[o] = best * sg;
+      s1out[o] = s1;
+      argk[o] = (uint8_t)arg;
     }
-    s1 += y;
-    s2 = __builtin_fmaf(y, y, s2);
+    sh1[pc] = s1;
+    sh2[pc] = s2;
   }
-  const size_t o = ((size_t)b * N + i) * Cout + c;
-  yext[o] = best * sg;
-  s1out[o] = s1;
-  argk[o] = (uint8_t)arg;
-  const int G = Cout / Cg, g = c / Cg;
-  atomicAdd(&stats[((size_t)(per_sample ? b : 0) * G + g) * 2 + 0], (double)s1);
-  atomicAdd(&stats[((size_t)(per_sample ? b : 0) * G + g) * 2 + 1], (double)s2);
+  __syncthreads();
+  const int G = Cout / Cg;
+  for (int t = threadIdx.x; t < 2 * G; t += 256) {
+    const int g = t >> 1, which = t & 1;
+    const float* sh = which ? sh2 : sh1;
+    double acc = 0.0;
+    for (int pl = 0; pl < EC_GEN_PTS; ++pl)
+      for (int c = g * Cg; c < (g + 1) * Cg; ++c) acc += (double)sh[pl * Cout + c];
+    part[(((size_t)b * gridDim.x + blockIdx.x) * G + g) * 2 + which] = acc;
+  }
+}
+
+// stats[s][g][which] = sum over the workgroup partials of item s (per_sample) or of all items, in
+// index order: lane l takes partials l, l + 64, ..., then a fixed xor tree.  One wave per result.
+__global__ __launch_bounds__(64) void pn_stats_reduce_kernel(const double* __restrict__ part, int B, int nblk,
+                                                              int G, int per_sample, double* __restrict__ stats) {
+  const int out = blockIdx.x;                 // (s * G + g) * 2 + which
+  const int which = out & 1, g = (out >> 1) % G, s = (out >> 1) / G;
+  const int b0 = per_sample ? s : 0, nb = per_sample ? 1 : B;
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < nb * nblk; e += 64) {
+    const int bb = b0 + e / nblk, blk = e - (e / nblk) * nblk;
+    acc += part[(((size_t)bb * nblk + blk) * G + g) * 2 + which];
+  }
+  acc = pn_wave_sum_d(acc);
+  if (threadIdx.x == 0) stats[out] = acc;
+}
+
+extern "C" size_t pn_edgeconv_reduce_workspace(int B, int N, int Cout, int groups) {
+  (void)Cout;
+  return pn_align_up((size_t)B * pn_cdiv(N, EC_GEN_PTS) * groups * 2 * sizeof(double), 256);
 }
 
 extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma,
                                           int B, int N, int k, int Cout, int groups,
                                           int per_sample, float* yext, uint8_t* argk, float* s1,
-                                          double* stats, void* stream_) {
+                                          double* stats, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(PQ && idx && gamma && yext && argk && s1 && stats,
+  PN_CHECK_ARG(PQ && idx && gamma && yext && argk && s1 && stats && workspace,
                "pn_edgeconv_reduce_fwd_f32: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && k <= 255 && Cout > 0,
                "pn_edgeconv_reduce_fwd_f32: bad sizes (B=%d N=%d k=%d Cout=%d)", B, N, k, Cout);
   PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_reduce_fwd_f32: groups=%d", groups);
+  PN_CHECK_ARG(workspace_bytes >= pn_edgeconv_reduce_workspace(B, N, Cout, groups),
+               "pn_edgeconv_reduce_fwd_f32: workspace too small");
   const int Cg = Cout / groups;
-  PN_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * groups * (per_sample ? B : 1), stream));
+  double* part = (double*)workspace;
+  int nblk;
   PN_PROF("edgeconv_reduce_fwd", stream);
   dim3 grid(pn_cdiv(N, EC_WAVES * EC_PPW), B);
 #define EC_GO(CO)                                                                              \
   hipLaunchKernelGGL(pn_edgeconv_reduce_kernel<CO>, grid, dim3(256), 0, stream, PQ, idx, gamma, \
-                     N, k, Cg, per_sample, yext, argk, s1, stats)
+                     N, k, Cg, per_sample, yext, argk, s1, part)
+  nblk = (int)grid.x;
   if (Cout == 64)
     EC_GO(64);
   else if (Cout == 128)
@@ -430,11 +442,22 @@ extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, c
   else if (Cout == 512)
     EC_GO(512);
   else {
-    dim3 g2(pn_cdiv((long long)N * Cout, 256), B);
-    hipLaunchKernelGGL(pn_edgeconv_reduce_generic_kernel, g2, dim3(256), 0, stream, PQ, idx, gamma,
-                       N, k, Cout, Cg, per_sample, yext, argk, s1, stats);
+    const size_t lds = (size_t)2 * EC_GEN_PTS * Cout * sizeof(float);
+    if (lds > 160 * 1024) {
+      pn_set_error("pn_edgeconv_reduce_fwd_f32: Cout=%d is neither 64/128/256/512 nor <= 1280", Cout);
+      return PN_ERR_UNSUPPORTED;
+    }
+    dim3 g2(pn_cdiv(N, EC_GEN_PTS), B);
+    nblk = (int)g2.x;
+    if (lds > 64 * 1024)
+      PN_CHECK_HIP(hipFuncSetAttribute((const void*)pn_edgeconv_reduce_generic_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pn_edgeconv_reduce_generic_kernel, g2, dim3(256), lds, stream, PQ, idx, gamma,
+                       N, k, Cout, Cg, yext, argk, s1, part);
   }
 #undef EC_GO
+  hipLaunchKernelGGL(pn_stats_reduce_kernel, dim3((per_sample ? B : 1) * groups * 2), dim3(64), 0, stream,
+                     (const double*)part, B, nblk, groups, per_sample, stats);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -555,63 +578,74 @@ extern "C" int pn_edgeconv_bwd_prep_f32(const float* gout, const float* yext, co
 // M = Cg*N*k (x B for batch statistics) edge activations of the group:
 //   dy_e = rstd * ( [e is the extreme edge] * t  -  c1  -  c2 * yhat_e ),  yhat_e = (P[j]+Q[i]-mean)*rstd
 //   dQ[i] = sum_kk dy  = rstd * ( t - k*c1 - c2 * rstd * (s1 - k*mean) )
-//   dP[j] += dy_e      (scatter over the kNN graph, fp32 atomics, rows are contiguous)
-// dPQ (B,N,2*Cout) must be zero on entry.  c1c2: float [(per_sample?B:1)][G][2].
-__global__ __launch_bounds__(256) void pn_edgeconv_bwd_kernel(
-    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ t,
-    const float* __restrict__ s1, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
-    const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cout, int Cg,
-    int per_sample, int dense, float* __restrict__ dPQ) {
-  const int b = blockIdx.y;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= N) return;
-  const int G = Cout / Cg;
-  const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * Cout;
-  float* __restrict__ dPQb = dPQ + (size_t)b * N * 2 * Cout;
-  const int64_t* __restrict__ ib = idx + ((size_t)b * N + i) * k;
-  for (int c = lane; c < Cout; c += 64) {
-    const int sidx = (per_sample ? b : 0) * G + c / Cg;
-    const float mu = mean[sidx], r = rstd[sidx];
-    const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
-    const size_t o = ((size_t)b * N + i) * Cout + c;
-    const float tt = t[o];
-    const float q = PQb[(size_t)i * 2 * Cout + Cout + c];
-    const int ak = argk[o];
-    const float fk = (float)k;
-    dPQb[(size_t)i * 2 * Cout + Cout + c] = r * (tt - fk * c1 - c2 * r * (s1[o] - fk * mu));
-    if (dense) {
-      for (int kk = 0; kk < k; ++kk) {
-        const int j = (int)ib[kk];
-        const float yh = (PQb[(size_t)j * 2 * Cout + c] + q - mu) * r;
-        float dy = -r * (c1 + c2 * yh);
-        if (kk == ak) dy += r * tt;
-        atomicAdd(&dPQb[(size_t)j * 2 * Cout + c], dy);
-      }
-    } else {
-      // statistics are constants (eval-mode BatchNorm): only the extreme edge carries gradient
-      atomicAdd(&dPQb[(size_t)ib[ak] * 2 * Cout + c], r * tt);
-    }
-  }
-}
+//   dP[j] = sum over the edges (i -> j) that END in j of dy_e
+// The second sum runs over the TRANSPOSED kNN graph: it is built once per call as a CSR whose
+// lists are sorted by (source point, neighbour slot), and every dP row is then formed by ONE wave
+// in list order — no floating-point atomics anywhere, the gradient is bit-reproducible run to
+// run (round 4; before, the extreme edges were scattered with fp32 atomics and the order inside
+// a list depended on the wave schedule).  c1c2: float [(per_sample?B:1)][G][2].
 
 // ---- reverse kNN graph (CSR by target point) -----------------------------------------------
-// The dense part of the normalisation gradient needs, for every point j, the sum of Q[i] over
-// the edges (i -> j) that END in j.  Scattering 4*B*N*k*Cout bytes of fp32 atomics costs three
-// times the forward pass; instead the graph is transposed once per backward call (counting
-// sort with int atomics: 2 per edge) and the sum becomes a row gather like the forward.
-__global__ void pn_rev_count_kernel(const int64_t* __restrict__ idx, long long nedges, int N, int k,
-                                    int* __restrict__ deg) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nedges) return;
-  const long long b = e / ((long long)N * k);
-  atomicAdd(&deg[b * N + (int)idx[e]], 1);
+// Counting sort of the B*N*k edges by target with workgroup-private LDS histograms: the edges
+// of one item are dealt to G workgroups in contiguous chunks (chunk g = edges [g*chunk, ...), i.e.
+// ascending source points); each counts its share (ds_add), writes the histogram out, a prefix
+// over the G partial histograms of every target and a scan over the targets give per-workgroup
+// start positions, and the fill pass replays the same edges against LDS cursors (ds_add_rtn).
+// No global atomics.  An entry is (source << 8) | slot.  Inside the bucket of one (workgroup,
+// target) pair the order is the LDS unit's; pn_rev_sort_kernel then sorts every list (the buckets
+// of a list are already in ascending order of their sources, so a long list is sorted bucket by
+// bucket).  Targets beyond REV_LDS_MAXN are handled in windows of that many counters.
+#define REV_G_MIN 64
+#define REV_LDS_MAXN 16384   // 64 KiB of LDS counters
+#define REV_SORT_CAP 1024    // entries a wave sorts at a time (4 KiB of LDS per wave)
+
+static inline int pn_rev_groups(int N) {
+  // a bucket holds at most one entry per source point of its chunk: N / G + 2 <= REV_SORT_CAP
+  const int g = pn_cdiv(N, REV_SORT_CAP - 2);
+  return g > REV_G_MIN ? g : REV_G_MIN;
 }
 
-// one block per item: exclusive scan of deg -> off (N+1 entries), cursor = copy of off
+__global__ __launch_bounds__(256) void pn_rev_count_lds_kernel(const int64_t* __restrict__ idx, int N, int k,
+                                                               int G, int* __restrict__ part) {
+  extern __shared__ int rev_hist[];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const int w0 = blockIdx.z * REV_LDS_MAXN;
+  const int wn = N - w0 < REV_LDS_MAXN ? N - w0 : REV_LDS_MAXN;
+  for (int j = threadIdx.x; j < wn; j += 256) rev_hist[j] = 0;
+  __syncthreads();
+  const long long per = (long long)N * k;
+  const long long chunk = (per + G - 1) / G;
+  const long long e0 = g * chunk, e1 = e0 + chunk < per ? e0 + chunk : per;
+  const int64_t* __restrict__ ib = idx + (size_t)b * per;
+  for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int j = (int)ib[e] - w0;
+    if ((unsigned)j < (unsigned)wn) atomicAdd(&rev_hist[j], 1);
+  }
+  __syncthreads();
+  int* __restrict__ pb = part + ((size_t)b * G + g) * N + w0;
+  for (int j = threadIdx.x; j < wn; j += 256) pb[j] = rev_hist[j];
+}
+
+// per target j: part[g][j] -> start of workgroup g inside the list of j (exclusive prefix over g,
+// in place), deg[j] = length of the list (scanned over j by pn_rev_scan_kernel)
+__global__ __launch_bounds__(256) void pn_rev_binprefix_kernel(int* __restrict__ part, int N, int G,
+                                                               int* __restrict__ deg) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  int* __restrict__ pb = part + (size_t)b * G * N + j;
+  int run = 0;
+#pragma unroll 8
+  for (int g = 0; g < G; ++g) {
+    const int d = pb[(size_t)g * N];
+    pb[(size_t)g * N] = run;
+    run += d;
+  }
+  deg[(size_t)b * N + j] = run;
+}
+
+// one block per item: exclusive scan of deg -> off (N+1 entries)
 __global__ __launch_bounds__(1024) void pn_rev_scan_kernel(const int* __restrict__ deg, int N,
-                                                           int* __restrict__ off,
-                                                           int* __restrict__ cursor) {
+                                                           int* __restrict__ off) {
   __shared__ int part[1024];
   const int b = blockIdx.x, t = threadIdx.x;
   const int per = (N + 1023) / 1024;
@@ -629,95 +663,133 @@ __global__ __launch_bounds__(1024) void pn_rev_scan_kernel(const int* __restrict
   }
   int run = part[t] - s;  // exclusive prefix of this thread's chunk
   int* ob = off + (size_t)b * (N + 1);
-  int* cb = cursor + (size_t)b * N;
   for (int i = lo; i < hi; ++i) {
     ob[i] = run;
-    cb[i] = run;
     run += d[i];
   }
   if (t == 1023) ob[N] = part[1023];
 }
 
-__global__ void pn_rev_fill_kernel(const int64_t* __restrict__ idx, long long nedges, int N, int k,
-                                   int* __restrict__ cursor, int* __restrict__ rev) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nedges) return;
-  const long long per = (long long)N * k;
-  const long long b = e / per;
-  const long long r = e - b * per;  // i*k + kk
-  const int pos = atomicAdd(&cursor[b * N + (int)idx[e]], 1);
-  rev[b * per + pos] = (int)(r / k);  // source point i
-}
-
-// ---- the same transposition with workgroup-private histograms in LDS (N <= REV_LDS_MAXN) ----
-// 2 x 3.2 M same-region global atomics cost 340 us per call at B = 4, N = 10 000, k = 80.  Here the
-// edges of one item are dealt to REV_G workgroups; each counts its share into an LDS histogram
-// (ds_add), writes it out, a prefix over the REV_G partial histograms of every target and a scan
-// over the targets give per-workgroup start positions, and the fill pass replays the same edges against LDS cursors (ds_add_rtn).  No global
-// atomics; the order inside a target's list still depends on the wave schedule (as before).
-#define REV_G 64
-#define REV_LDS_MAXN 16384   // 64 KiB of LDS counters
-__global__ __launch_bounds__(256) void pn_rev_count_lds_kernel(const int64_t* __restrict__ idx, int N, int k,
-                                                               int* __restrict__ part) {
-  extern __shared__ int rev_hist[];
-  const int b = blockIdx.y, g = blockIdx.x;
-  for (int j = threadIdx.x; j < N; j += 256) rev_hist[j] = 0;
-  __syncthreads();
-  const long long per = (long long)N * k;
-  const long long chunk = (per + REV_G - 1) / REV_G;
-  const long long e0 = g * chunk, e1 = e0 + chunk < per ? e0 + chunk : per;
-  const int64_t* __restrict__ ib = idx + (size_t)b * per;
-  for (long long e = e0 + threadIdx.x; e < e1; e += 256) atomicAdd(&rev_hist[(int)ib[e]], 1);
-  __syncthreads();
-  int* __restrict__ pb = part + ((size_t)b * REV_G + g) * N;
-  for (int j = threadIdx.x; j < N; j += 256) pb[j] = rev_hist[j];
-}
-
-// per target j: part[g][j] -> start of workgroup g inside the list of j (exclusive prefix over g,
-// in place), deg[j] = length of the list (scanned over j by pn_rev_scan_kernel)
-__global__ __launch_bounds__(256) void pn_rev_binprefix_kernel(int* __restrict__ part, int N,
-                                                               int* __restrict__ deg) {
-  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N) return;
-  int* __restrict__ pb = part + (size_t)b * REV_G * N + j;
-  int run = 0;
-#pragma unroll 8
-  for (int g = 0; g < REV_G; ++g) {
-    const int d = pb[(size_t)g * N];
-    pb[(size_t)g * N] = run;
-    run += d;
-  }
-  deg[(size_t)b * N + j] = run;
-}
-
 __global__ __launch_bounds__(256) void pn_rev_fill_lds_kernel(const int64_t* __restrict__ idx, int N, int k,
-                                                              const int* __restrict__ part,
+                                                              int G, const int* __restrict__ part,
                                                               const int* __restrict__ off,
-                                                              int* __restrict__ rev) {
+                                                              uint32_t* __restrict__ rev) {
   extern __shared__ int rev_hist[];
   const int b = blockIdx.y, g = blockIdx.x;
-  const int* __restrict__ pb = part + ((size_t)b * REV_G + g) * N;
-  const int* __restrict__ ob = off + (size_t)b * (N + 1);
-  for (int j = threadIdx.x; j < N; j += 256) rev_hist[j] = ob[j] + pb[j];
+  const int w0 = blockIdx.z * REV_LDS_MAXN;
+  const int wn = N - w0 < REV_LDS_MAXN ? N - w0 : REV_LDS_MAXN;
+  const int* __restrict__ pb = part + ((size_t)b * G + g) * N + w0;
+  const int* __restrict__ ob = off + (size_t)b * (N + 1) + w0;
+  for (int j = threadIdx.x; j < wn; j += 256) rev_hist[j] = ob[j] + pb[j];
   __syncthreads();
   const long long per = (long long)N * k;
-  const long long chunk = (per + REV_G - 1) / REV_G;
+  const long long chunk = (per + G - 1) / G;
   const long long e0 = g * chunk, e1 = e0 + chunk < per ? e0 + chunk : per;
   const int64_t* __restrict__ ib = idx + (size_t)b * per;
-  int* __restrict__ rb = rev + (size_t)b * per;
+  uint32_t* __restrict__ rb = rev + (size_t)b * per;
   for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
-    const int pos = atomicAdd(&rev_hist[(int)ib[e]], 1);
-    rb[pos] = (int)(e / k);  // source point i
+    const int j = (int)ib[e] - w0;
+    if ((unsigned)j < (unsigned)wn) {
+      const int pos = atomicAdd(&rev_hist[j], 1);
+      const int i = (int)(e / k);
+      rb[pos] = ((uint32_t)i << 8) | (uint32_t)(e - (long long)i * k);  // (source point, slot)
+    }
   }
 }
 
-// dense term, one wave per target point j:
-//   dP[j,c] = -r*deg_j*(c1 + c2*r*(P[j,c]-mu)) - r^2*c2*sum_{(i->j)} Q[i,c]
+// Rank sort of n <= REV_SORT_CAP distinct entries at p (global), staged in the wave's LDS region.
+// Executed by one whole wave; LDS traffic of a wave is ordered, the fences keep the compiler from
+// moving the reads above the writes.
+__device__ static inline void pn_rev_sort_segment(uint32_t* __restrict__ p, int n, uint32_t* lst, int lane) {
+  if (n > REV_SORT_CAP) return;   // only a graph with repeated neighbours in a row gets here: left as filled
+  const int n4 = (n + 3) & ~3;
+  for (int t = lane; t < n4; t += 64) lst[t] = t < n ? p[t] : 0xffffffffu;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int t = lane; t < n; t += 64) {
+    const uint32_t v = lst[t];
+    int rank = 0;
+    for (int u = 0; u < n4; u += 4) {
+      const uint4 w = *reinterpret_cast<const uint4*>(lst + u);
+      rank += (int)(w.x < v) + (int)(w.y < v) + (int)(w.z < v) + (int)(w.w < v);
+    }
+    p[rank] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one wave per target point: its list in ascending (source, slot) order
+__global__ __launch_bounds__(256) void pn_rev_sort_kernel(const int* __restrict__ off, const int* __restrict__ part,
+                                                          int N, int k, int G, uint32_t* __restrict__ rev) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_lst[4][REV_SORT_CAP];
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= N) return;
+  const int* __restrict__ ob = off + (size_t)b * (N + 1);
+  const int e0 = ob[j], L = ob[j + 1] - e0;
+  if (L <= 1) return;
+  uint32_t* __restrict__ rb = rev + (size_t)b * N * k + e0;
+  if (L <= REV_SORT_CAP) {
+    pn_rev_sort_segment(rb, L, s_lst[wave], lane);
+    return;
+  }
+  const int* __restrict__ pb = part + (size_t)b * G * N + j;
+  int s = 0;  // = pb[0]
+  for (int g = 0; g < G; ++g) {
+    const int nxt = g + 1 < G ? pb[(size_t)(g + 1) * N] : L;
+    if (nxt - s > 1) pn_rev_sort_segment(rb + s, nxt - s, s_lst[wave], lane);
+    s = nxt;
+  }
+}
+
+extern "C" size_t pn_edgeconv_bwd_workspace(int B, int N, int k) {
+  return pn_align_up((size_t)B * N * 4, 256) + pn_align_up((size_t)B * (N + 1) * 4, 256) +
+         pn_align_up((size_t)B * N * k * 4, 256) + pn_align_up((size_t)B * pn_rev_groups(N) * N * 4, 256);
+}
+
+// builds the sorted CSR of the transposed graph in ``workspace``; off (B,N+1), rev (B,N*k)
+static int pn_build_rev_csr(const int64_t* idx, int B, int N, int k, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream, const int** off_out, const uint32_t** rev_out) {
+  PN_CHECK_ARG(N < (1 << 24) && k <= 255, "reverse graph: N=%d (max 2^24 - 1), k=%d (max 255)", N, k);
+  PN_CHECK_ARG(workspace && workspace_bytes >= pn_edgeconv_bwd_workspace(B, N, k),
+               "reverse graph: workspace too small");
+  const int G = pn_rev_groups(N);
+  char* w = (char*)workspace;
+  int* deg = (int*)w;
+  w += pn_align_up((size_t)B * N * 4, 256);
+  int* off = (int*)w;
+  w += pn_align_up((size_t)B * (N + 1) * 4, 256);
+  uint32_t* rev = (uint32_t*)w;
+  w += pn_align_up((size_t)B * N * k * 4, 256);
+  int* part = (int*)w;
+  const int nwin = pn_cdiv(N, REV_LDS_MAXN);
+  const size_t lds = (size_t)(N < REV_LDS_MAXN ? N : REV_LDS_MAXN) * sizeof(int);
+  hipLaunchKernelGGL(pn_rev_count_lds_kernel, dim3(G, B, nwin), dim3(256), lds, stream, idx, N, k, G, part);
+  hipLaunchKernelGGL(pn_rev_binprefix_kernel, dim3(pn_cdiv(N, 256), B), dim3(256), 0, stream, part, N, G, deg);
+  hipLaunchKernelGGL(pn_rev_scan_kernel, dim3(B), dim3(1024), 0, stream, (const int*)deg, N, off);
+  hipLaunchKernelGGL(pn_rev_fill_lds_kernel, dim3(G, B, nwin), dim3(256), lds, stream, idx, N, k, G,
+                     (const int*)part, (const int*)off, rev);
+  hipLaunchKernelGGL(pn_rev_sort_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, (const int*)off,
+                     (const int*)part, N, k, G, rev);
+  PN_CHECK_LAUNCH();
+  *off_out = off;
+  *rev_out = rev;
+  return PN_OK;
+}
+
+// dP row of one target point j, one wave per point, in list order:
+//   dP[j,c] = [dense] ( -r*deg_j*(c1 + c2*r*(P[j,c]-mu)) - r^2*c2*sum_{(i->j)} Q[i,c] )
+//             + r * sum_{(i,slot)->j, argk[i,c] == slot} t[i,c]
+// (the second sum: the edges that are the extreme of their source point in channel c).
 template <int COUT>
 __global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
-    const float* __restrict__ PQ, const int* __restrict__ off, const int* __restrict__ rev,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ c1c2,
-    int N, int k, int Cg, int per_sample, float* __restrict__ dPQ) {
+    const float* __restrict__ PQ, const int* __restrict__ off, const uint32_t* __restrict__ rev,
+    const float* __restrict__ t, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cg, int per_sample,
+    int dense, float* __restrict__ dPQ) {
   constexpr int NCH = COUT <= 256 ? 1 : COUT / 256;
   constexpr int LPR = COUT <= 256 ? COUT / 4 : 64;
   constexpr int RPI = 64 / LPR;
@@ -728,36 +800,51 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
   const int rg = lane / LPR, cl = lane - rg * LPR;
   const int G = COUT / Cg;
   const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * COUT;
+  const float* __restrict__ tb = t + (size_t)b * N * COUT;
+  const uint8_t* __restrict__ ab = argk + (size_t)b * N * COUT;
   const int* __restrict__ ob = off + (size_t)b * (N + 1);
-  const int* __restrict__ rb = rev + (size_t)b * N * k;
+  const uint32_t* __restrict__ rb = rev + (size_t)b * N * k;
   const int e0 = ob[j], e1 = ob[j + 1];
-  float4x acc[NCH];
+  float4x acc[NCH], ext[NCH];
 #pragma unroll
   for (int h = 0; h < NCH; ++h)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[h].v[u] = 0.f;
+    for (int u = 0; u < 4; ++u) acc[h].v[u] = ext[h].v[u] = 0.f;
   // the source list of the point 64 entries at a time in registers (one coalesced load), two row
-  // gathers in flight per trip: same summation order per lane (entries rg, rg + RPI, ... ascending)
+  // gathers in flight per trip: a fixed summation order per lane (entries rg, rg + RPI, ... ascending)
   for (int base = e0; base < e1; base += 64) {
-    const int mine = base + lane < e1 ? rb[base + lane] : j;
+    const uint32_t mine = base + lane < e1 ? rb[base + lane] : ((uint32_t)j << 8) | 0xffu;
     const int cnt = e1 - base < 64 ? e1 - base : 64;
     for (int t0 = 0; t0 < cnt; t0 += 2 * RPI) {
-      const int ta = t0 + rg, tb = ta + RPI;
-      const int sa = __shfl(mine, ta & 63, 64), sb = __shfl(mine, tb & 63, 64);
-      const bool oa = ta < cnt, ob = tb < cnt;
-      const int ia = oa ? sa : j, ib_ = ob ? sb : j;
-      float4x qa[NCH], qb[NCH];
+      const int ta = t0 + rg, tb_ = ta + RPI;
+      const uint32_t sa = (uint32_t)__shfl((int)mine, ta & 63, 64), sb = (uint32_t)__shfl((int)mine, tb_ & 63, 64);
+      const bool oa = ta < cnt, ob_ = tb_ < cnt;
+      const int ia = oa ? (int)(sa >> 8) : j, ib_ = ob_ ? (int)(sb >> 8) : j;
+      const uint32_t ka = oa ? (sa & 255u) : 0x100u, kb = ob_ ? (sb & 255u) : 0x100u;   // 0x100: matches no slot
+      float4x qa[NCH], qb[NCH], va[NCH], vb[NCH];
+      uint32_t aa[NCH], abv[NCH];
 #pragma unroll
       for (int h = 0; h < NCH; ++h) {
-        qa[h] = ld4(PQb + (size_t)ia * 2 * COUT + COUT + (cl + h * 64) * 4);
-        qb[h] = ld4(PQb + (size_t)ib_ * 2 * COUT + COUT + (cl + h * 64) * 4);
+        const int c0 = (cl + h * 64) * 4;
+        if (dense) {
+          qa[h] = ld4(PQb + (size_t)ia * 2 * COUT + COUT + c0);
+          qb[h] = ld4(PQb + (size_t)ib_ * 2 * COUT + COUT + c0);
+        }
+        va[h] = ld4(tb + (size_t)ia * COUT + c0);
+        vb[h] = ld4(tb + (size_t)ib_ * COUT + c0);
+        aa[h] = *reinterpret_cast<const uint32_t*>(ab + (size_t)ia * COUT + c0);
+        abv[h] = *reinterpret_cast<const uint32_t*>(ab + (size_t)ib_ * COUT + c0);
       }
 #pragma unroll
       for (int h = 0; h < NCH; ++h)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (oa) acc[h].v[u] += qa[h].v[u];
-          if (ob) acc[h].v[u] += qb[h].v[u];
+          if (dense) {
+            if (oa) acc[h].v[u] += qa[h].v[u];
+            if (ob_) acc[h].v[u] += qb[h].v[u];
+          }
+          if (((aa[h] >> (8 * u)) & 255u) == ka) ext[h].v[u] += va[h].v[u];
+          if (((abv[h] >> (8 * u)) & 255u) == kb) ext[h].v[u] += vb[h].v[u];
         }
     }
   }
@@ -766,7 +853,10 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
 #pragma unroll
     for (int h = 0; h < NCH; ++h)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[h].v[u] += __shfl_xor(acc[h].v[u], o, 64);
+      for (int u = 0; u < 4; ++u) {
+        acc[h].v[u] += __shfl_xor(acc[h].v[u], o, 64);
+        ext[h].v[u] += __shfl_xor(ext[h].v[u], o, 64);
+      }
   if (rg == 0) {
     const float deg = (float)(e1 - e0);
 #pragma unroll
@@ -779,17 +869,49 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
         const int sidx = (per_sample ? b : 0) * G + (c0 + u) / Cg;
         const float mu = mean[sidx], r = rstd[sidx];
         const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
-        o.v[u] = -r * deg * (c1 + c2 * r * (p.v[u] - mu)) - r * r * c2 * acc[h].v[u];
+        const float dn = dense ? -r * deg * (c1 + c2 * r * (p.v[u] - mu)) - r * r * c2 * acc[h].v[u] : 0.f;
+        o.v[u] = dn + r * ext[h].v[u];
       }
       st4(dPQ + ((size_t)b * N + j) * 2 * COUT + c0, o);
     }
   }
 }
 
-// per source point: dQ[i] (closed form) and the extreme edge's share of dP (sparse atomics)
+// any width: one thread per (target point, channel), the same sums in the same order
+__global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_generic_kernel(
+    const float* __restrict__ PQ, const int* __restrict__ off, const uint32_t* __restrict__ rev,
+    const float* __restrict__ t, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cout, int Cg,
+    int per_sample, int dense, float* __restrict__ dPQ) {
+  const int b = blockIdx.y;
+  const long long tix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= (long long)N * Cout) return;
+  const int j = (int)(tix / Cout), c = (int)(tix - (long long)j * Cout);
+  const int G = Cout / Cg;
+  const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * Cout;
+  const float* __restrict__ tb = t + (size_t)b * N * Cout;
+  const uint8_t* __restrict__ ab = argk + (size_t)b * N * Cout;
+  const int* __restrict__ ob = off + (size_t)b * (N + 1);
+  const uint32_t* __restrict__ rb = rev + (size_t)b * N * k;
+  const int e0 = ob[j], e1 = ob[j + 1];
+  float acc = 0.f, ext = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const uint32_t s = rb[e];
+    const int i = (int)(s >> 8);
+    if (dense) acc += PQb[(size_t)i * 2 * Cout + Cout + c];
+    if ((uint32_t)ab[(size_t)i * Cout + c] == (s & 255u)) ext += tb[(size_t)i * Cout + c];
+  }
+  const int sidx = (per_sample ? b : 0) * G + c / Cg;
+  const float mu = mean[sidx], r = rstd[sidx];
+  const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
+  const float p = PQb[(size_t)j * 2 * Cout + c];
+  const float dn = dense ? -r * (float)(e1 - e0) * (c1 + c2 * r * (p - mu)) - r * r * c2 * acc : 0.f;
+  dPQ[((size_t)b * N + j) * 2 * Cout + c] = dn + r * ext;
+}
+
+// per source point: dQ[i] (closed form)
 __global__ __launch_bounds__(256) void pn_edgeconv_bwd_point_kernel(
-    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ t,
-    const float* __restrict__ s1, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
+    const float* __restrict__ t, const float* __restrict__ s1, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cout, int Cg,
     int per_sample, float* __restrict__ dPQ) {
   const int b = blockIdx.y;
@@ -801,18 +923,8 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_point_kernel(
   const float mu = mean[sidx], r = rstd[sidx];
   const float c1 = c1c2[2 * sidx], c2 = c1c2[2 * sidx + 1];
   const size_t o = ((size_t)b * N + i) * Cout + c;
-  const float tt = t[o];
   const float fk = (float)k;
-  float* __restrict__ dPQb = dPQ + (size_t)b * N * 2 * Cout;
-  dPQb[(size_t)i * 2 * Cout + Cout + c] = r * (tt - fk * c1 - c2 * r * (s1[o] - fk * mu));
-  const int j = (int)idx[((size_t)b * N + i) * k + argk[o]];
-  atomicAdd(&dPQb[(size_t)j * 2 * Cout + c], r * tt);
-}
-
-extern "C" size_t pn_edgeconv_bwd_workspace(int B, int N, int k) {
-  return pn_align_up((size_t)B * N * 4, 256) * 2 + pn_align_up((size_t)B * (N + 1) * 4, 256) +
-         pn_align_up((size_t)B * N * k * 4, 256) +
-         (N <= REV_LDS_MAXN ? pn_align_up((size_t)B * REV_G * N * 4, 256) : 0);
+  dPQ[((size_t)b * N + i) * 2 * Cout + Cout + c] = r * (t[o] - fk * c1 - c2 * r * (s1[o] - fk * mu));
 }
 
 extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t,
@@ -825,67 +937,79 @@ extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const fl
                "pn_edgeconv_bwd_f32: null pointer");
   PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_bwd_f32: groups=%d", groups);
   const int Cg = Cout / groups;
-  const bool fast = dense && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512);
-  if (!fast) {
-    // eval-mode BatchNorm (no dense term) and unusual widths: per-edge atomics
-    PN_CHECK_HIP(hipMemsetAsync(dPQ, 0, (size_t)B * N * 2 * Cout * sizeof(float), stream));
-    PN_PROF("edgeconv_bwd", stream);
-    dim3 grid(pn_cdiv(N, 4), B);
-    hipLaunchKernelGGL(pn_edgeconv_bwd_kernel, grid, dim3(256), 0, stream, PQ, idx, t, s1, argk,
-                       mean, rstd, c1c2, N, k, Cout, Cg, per_sample, dense, dPQ);
-    PN_CHECK_LAUNCH();
-    return PN_OK;
-  }
-  PN_CHECK_ARG(workspace && workspace_bytes >= pn_edgeconv_bwd_workspace(B, N, k),
-               "pn_edgeconv_bwd_f32: workspace too small");
-  char* w = (char*)workspace;
-  int* deg = (int*)w;
-  w += pn_align_up((size_t)B * N * 4, 256);
-  int* cursor = (int*)w;
-  w += pn_align_up((size_t)B * N * 4, 256);
-  int* off = (int*)w;
-  w += pn_align_up((size_t)B * (N + 1) * 4, 256);
-  int* rev = (int*)w;
-  w += pn_align_up((size_t)B * N * k * 4, 256);
-  int* part = (int*)w;
-  const long long nedges = (long long)B * N * k;
-  if (N <= REV_LDS_MAXN) {
-    PN_PROF("edgeconv_bwd_csr", stream);
-    const size_t lds = (size_t)N * sizeof(int);
-    hipLaunchKernelGGL(pn_rev_count_lds_kernel, dim3(REV_G, B), dim3(256), lds, stream, idx, N, k, part);
-    hipLaunchKernelGGL(pn_rev_binprefix_kernel, dim3(pn_cdiv(N, 256), B), dim3(256), 0, stream, part, N, deg);
-    hipLaunchKernelGGL(pn_rev_scan_kernel, dim3(B), dim3(1024), 0, stream, deg, N, off, cursor);
-    hipLaunchKernelGGL(pn_rev_fill_lds_kernel, dim3(REV_G, B), dim3(256), lds, stream, idx, N, k,
-                       (const int*)part, (const int*)off, rev);
-  } else {
-    PN_CHECK_HIP(hipMemsetAsync(deg, 0, (size_t)B * N * 4, stream));
-    PN_PROF("edgeconv_bwd_csr", stream);
-    hipLaunchKernelGGL(pn_rev_count_kernel, dim3(pn_cdiv(nedges, 256)), dim3(256), 0, stream, idx,
-                       nedges, N, k, deg);
-    hipLaunchKernelGGL(pn_rev_scan_kernel, dim3(B), dim3(1024), 0, stream, deg, N, off, cursor);
-    hipLaunchKernelGGL(pn_rev_fill_kernel, dim3(pn_cdiv(nedges, 256)), dim3(256), 0, stream, idx,
-                       nedges, N, k, cursor, rev);
-  }
-  PN_CHECK_LAUNCH();
+  const int* off = nullptr;
+  const uint32_t* rev = nullptr;
   {
-    PN_PROF("edgeconv_bwd", stream);
-    dim3 grid(pn_cdiv(N, 4), B);
+    PN_PROF("edgeconv_bwd_csr", stream);
+    const int rc = pn_build_rev_csr(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
+    if (rc != PN_OK) return rc;
+  }
+  PN_PROF("edgeconv_bwd", stream);
+  dim3 grid(pn_cdiv(N, 4), B);
 #define EC_BG(CO)                                                                               \
   hipLaunchKernelGGL(pn_edgeconv_bwd_gather_kernel<CO>, grid, dim3(256), 0, stream, PQ, off, rev, \
-                     mean, rstd, c1c2, N, k, Cg, per_sample, dPQ)
-    if (Cout == 64)
-      EC_BG(64);
-    else if (Cout == 128)
-      EC_BG(128);
-    else if (Cout == 256)
-      EC_BG(256);
-    else
-      EC_BG(512);
+                     t, argk, mean, rstd, c1c2, N, k, Cg, per_sample, dense, dPQ)
+  dim3 g2(pn_cdiv((long long)N * Cout, 256), B);
+  if (Cout == 64)
+    EC_BG(64);
+  else if (Cout == 128)
+    EC_BG(128);
+  else if (Cout == 256)
+    EC_BG(256);
+  else if (Cout == 512)
+    EC_BG(512);
+  else
+    hipLaunchKernelGGL(pn_edgeconv_bwd_gather_generic_kernel, g2, dim3(256), 0, stream, PQ, off, rev, t, argk,
+                       mean, rstd, c1c2, N, k, Cout, Cg, per_sample, dense, dPQ);
 #undef EC_BG
-    dim3 g2(pn_cdiv((long long)N * Cout, 256), B);
-    hipLaunchKernelGGL(pn_edgeconv_bwd_point_kernel, g2, dim3(256), 0, stream, PQ, idx, t, s1, argk,
-                       mean, rstd, c1c2, N, k, Cout, Cg, per_sample, dPQ);
+  hipLaunchKernelGGL(pn_edgeconv_bwd_point_kernel, g2, dim3(256), 0, stream, t, s1, mean, rstd, c1c2, N, k, Cout,
+                     Cg, per_sample, dPQ);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// backward of the API form of get_graph_feature (gathering over the transposed graph):
+//   gxt[b,j,:] = sum_{(i,slot) -> j} g[b,i,slot,0:C]  +  sum_kk (g[b,j,kk,C:2C] - g[b,j,kk,0:C])
+// one wave per target point, lanes over the channels; list order = (source, slot) ascending.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pn_edge_feature_bwd_kernel(
+    const float* __restrict__ g, const int* __restrict__ off, const uint32_t* __restrict__ rev, int N, int k,
+    int C, float* __restrict__ gxt) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= N) return;
+  const float* __restrict__ gb = g + (size_t)b * N * k * 2 * C;
+  const int* __restrict__ ob = off + (size_t)b * (N + 1);
+  const uint32_t* __restrict__ rb = rev + (size_t)b * N * k;
+  const int e0 = ob[j], e1 = ob[j + 1];
+  for (int c = lane; c < C; c += 64) {
+    float ctr = 0.f;
+    const float* __restrict__ gj = gb + (size_t)j * k * 2 * C;
+    for (int kk = 0; kk < k; ++kk) ctr += gj[(size_t)kk * 2 * C + C + c] - gj[(size_t)kk * 2 * C + c];
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const uint32_t s = rb[e];
+      acc += gb[((size_t)(s >> 8) * k + (s & 255u)) * 2 * C + c];
+    }
+    gxt[((size_t)b * N + j) * C + c] = acc + ctr;
   }
+}
+
+extern "C" int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, int B, int N, int k,
+                                       int C, float* gxt, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(gfeat && idx && gxt, "pn_edge_feature_bwd_f32: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && C > 0, "pn_edge_feature_bwd_f32: empty input");
+  const int* off = nullptr;
+  const uint32_t* rev = nullptr;
+  PN_PROF("edge_feature_bwd", stream);
+  const int rc = pn_build_rev_csr(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
+  if (rc != PN_OK) return rc;
+  dim3 grid(pn_cdiv(N, 4), B);
+  hipLaunchKernelGGL(pn_edge_feature_bwd_kernel, grid, dim3(256), 0, stream, gfeat, off, rev, N, k, C, gxt);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

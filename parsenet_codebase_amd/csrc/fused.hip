@@ -224,17 +224,19 @@ __global__ void pn_triplet_sum_kernel(const float* __restrict__ item_loss, int P
   }
 }
 
-// Backward: gE[row] += g * scale_p * d c_ij / d row for every active (c > 0, i != j) entry:
-//   d/d a_i = 2 (n_j - p_j),  d/d p_j = -2 (a_i - p_j),  d/d n_j = 2 (a_i - n_j)
-// (a_i = P1[i], p_j = P1[j]).  Per item the three sums are formed per row in LDS-resident form
-// and added to gE with fp32 atomics (a point can be sampled several times; the sums per item are
-// ordered, the cross-item order is the atomics').
+// Backward: gE[row] = sum over the items of g * scale_p * d c_ij / d row for every active (c > 0,
+// i != j) entry:  d/d a_i = 2 (n_j - p_j),  d/d p_j = -2 (a_i - p_j),  d/d n_j = 2 (a_i - n_j)
+// (a_i = P1[i], p_j = P1[j]).  A point can be sampled by several items (and by both sides of
+// one): kernel 1 writes the gradient rows of every item to slots[(p * 2 + side) * num + r][D],
+// kernel 2 adds the slots that name the same embedding row IN SLOT ORDER — one workgroup per
+// slot, the first slot of a row does the work — and stores the row.  No atomics: bit-reproducible
+// run to run (round 4).  Rows no item names keep what gE held on entry (the caller zeroes it).
 template <int D>
 __global__ __launch_bounds__(256) void pn_triplet_bwd_kernel(const float* __restrict__ E, const int64_t* __restrict__ ia,
                                                              const int64_t* __restrict__ ib,
                                                              const float* __restrict__ item_scale,
                                                              const float* __restrict__ gout, int num, float margin,
-                                                             float* __restrict__ gE) {
+                                                             float* __restrict__ slots) {
   __shared__ float P1[TRI_MAXNUM][D + 1];
   __shared__ float P2[TRI_MAXNUM][D + 1];
   __shared__ unsigned int act[TRI_MAXNUM];      // act[i] bit j: c_ij > 0 and i != j
@@ -275,10 +277,50 @@ __global__ __launch_bounds__(256) void pn_triplet_bwd_kernel(const float* __rest
         gp -= P1[i][d] - pr;
         gn += P1[i][d] - nr;
       }
-    const float g1 = g2 * (ga + gp), gneg = g2 * gn;
-    if (g1 != 0.f) atomicAdd(&gE[(size_t)ia[(size_t)p * num + r] * D + d], g1);
-    if (gneg != 0.f) atomicAdd(&gE[(size_t)ib[(size_t)p * num + r] * D + d], gneg);
+    slots[((size_t)(p * 2 + 0) * num + r) * D + d] = g2 * (ga + gp);
+    slots[((size_t)(p * 2 + 1) * num + r) * D + d] = g2 * gn;
   }
+}
+
+// slot s = (p * 2 + side) * num + r names row (side ? ib : ia)[p * num + r]
+__device__ static inline int64_t pn_tri_slot_row(const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+                                                 int num, int s) {
+  const int r = s % num, ps = s / num;
+  return (ps & 1) ? ib[(size_t)(ps >> 1) * num + r] : ia[(size_t)(ps >> 1) * num + r];
+}
+
+#define TRI_SCAN 4096     // slot ids staged per pass (16 KiB of LDS)
+template <int D>
+__global__ __launch_bounds__(D) void pn_triplet_combine_kernel(const float* __restrict__ slots,
+                                                                const int64_t* __restrict__ ia,
+                                                                const int64_t* __restrict__ ib, int num, int S,
+                                                                float* __restrict__ gE) {
+  __shared__ unsigned int hit[TRI_SCAN / 32];
+  const int s = blockIdx.x, d = threadIdx.x;
+  const int64_t row = pn_tri_slot_row(ia, ib, num, s);
+  // an earlier slot with the same row owns it
+  int earlier = 0;
+  for (int u = d; u < s; u += D) earlier |= (pn_tri_slot_row(ia, ib, num, u) == row);
+  if (__syncthreads_or(earlier)) return;
+  float acc = slots[(size_t)s * D + d];
+  for (int base = s + 1; base < S; base += TRI_SCAN) {
+    const int cnt = S - base < TRI_SCAN ? S - base : TRI_SCAN;
+    for (int u = d; u < TRI_SCAN / 32; u += D) hit[u] = 0u;
+    __syncthreads();
+    for (int u = d; u < cnt; u += D)
+      if (pn_tri_slot_row(ia, ib, num, base + u) == row) atomicOr(&hit[u >> 5], 1u << (u & 31));
+    __syncthreads();
+    for (int w = 0; w < (cnt + 31) / 32; ++w) {
+      unsigned int m = hit[w];                      // workgroup-uniform
+      while (m) {
+        const int bit = __builtin_ctz(m);
+        m &= m - 1;
+        acc += slots[(size_t)(base + w * 32 + bit) * D + d];
+      }
+    }
+    __syncthreads();
+  }
+  gE[(size_t)row * D + d] = acc;
 }
 
 extern "C" int pn_triplet_fwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib,
@@ -300,19 +342,27 @@ extern "C" int pn_triplet_fwd_f32(const float* E, int rows, int D, const int64_t
   return PN_OK;
 }
 
+extern "C" size_t pn_triplet_bwd_workspace(int P, int num, int D) {
+  return pn_align_up((size_t)P * 2 * num * D * sizeof(float), 256);
+}
+
 extern "C" int pn_triplet_bwd_f32(const float* E, int rows, int D, const int64_t* ia, const int64_t* ib,
                                   const float* item_scale, const float* gout, int P, int num, float margin,
-                                  float* gE, void* stream_) {
+                                  float* gE, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(E && ia && ib && item_scale && gout && gE, "pn_triplet_bwd_f32: null pointer");
+  PN_CHECK_ARG(E && ia && ib && item_scale && gout && gE && workspace, "pn_triplet_bwd_f32: null pointer");
   PN_CHECK_ARG(P > 0 && rows > 0 && num >= 1 && num <= TRI_MAXNUM, "pn_triplet_bwd_f32: P=%d num=%d", P, num);
   if (D != 128) {
     pn_set_error("pn_triplet_bwd_f32: embedding size %d (128 supported)", D);
     return PN_ERR_UNSUPPORTED;
   }
+  PN_CHECK_ARG(workspace_bytes >= pn_triplet_bwd_workspace(P, num, D), "pn_triplet_bwd_f32: workspace too small");
+  float* slots = (float*)workspace;
   PN_PROF("triplet_bwd", stream);
   hipLaunchKernelGGL(pn_triplet_bwd_kernel<128>, dim3(P), dim3(256), 0, stream, E, ia, ib, item_scale, gout, num,
-                     margin, gE);
+                     margin, slots);
+  hipLaunchKernelGGL(pn_triplet_combine_kernel<128>, dim3(P * 2 * num), dim3(128), 0, stream, (const float*)slots, ia,
+                     ib, num, P * 2 * num, gE);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

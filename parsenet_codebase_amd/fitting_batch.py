@@ -257,24 +257,20 @@ class _RaggedChamfer(torch.autograd.Function):
     bit; the backward routes each minimum to its pair of points."""
 
     @staticmethod
-    def forward(ctx, pred, gt, off_a, off_b, item_a, item_b, cnt_a, cnt_b, max_a, max_b):
+    def forward(ctx, pred, gt, off_a, off_b, max_a, max_b):
         minA, argA, minB, argB = K.chamfer_nn_ragged(pred.detach(), off_a, max_a, gt, off_b, max_b)
-        S = cnt_a.shape[0]
-        sa = torch.zeros(S, dtype=torch.float32, device=pred.device).index_add_(0, item_a, minA)
-        sb = torch.zeros(S, dtype=torch.float32, device=pred.device).index_add_(0, item_b, minB)
-        ctx.save_for_backward(pred, gt, argA, argB, off_a, off_b, item_a, item_b, cnt_a, cnt_b)
-        return (sa / cnt_a + sb / cnt_b) / 2.0
+        ctx.save_for_backward(pred, gt, argA, argB, off_a, off_b)
+        ctx.max_a = max_a
+        # per-item means in a fixed order (index_add_ would use fp32 atomics: not reproducible)
+        return K.chamfer_ragged_reduce(minA, off_a, minB, off_b)
 
     @staticmethod
     def backward(ctx, g):
-        pred, gt, argA, argB, off_a, off_b, item_a, item_b, cnt_a, cnt_b = ctx.saved_tensors
-        ga = (g / cnt_a)[item_a]                       # d/d minA_i = g_s / (2 nA): the 2 of the square cancels
-        gb = (g / cnt_b)[item_b]
-        nb = gt[argA + off_b[item_a].long()]
-        gpred = (pred - nb) * ga.unsqueeze(1)
-        ja = argB + off_a[item_b].long()
-        gpred.index_add_(0, ja, (pred[ja] - gt) * gb.unsqueeze(1))
-        return gpred, None, None, None, None, None, None, None, None, None
+        pred, gt, argA, argB, off_a, off_b = ctx.saved_tensors
+        # d/d minA_i = g_s / (2 nA), the 2 of the square cancels; targets whose nearest prediction is
+        # row i are gathered in ascending order (csrc/chamfer.hip)
+        gpred = K.chamfer_ragged_bwd(pred.detach(), off_a, ctx.max_a, gt, off_b, argA, argB, g.contiguous())
+        return gpred, None, None, None, None, None
 
 
 def _host_minor_axis_rotation(cov):
@@ -655,12 +651,11 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         nb = [g.size for g in gt_lists[S_p:]]
         add("off_a", np.concatenate([[0], np.cumsum(na)]))
         add("off_b", np.concatenate([[0], np.cumsum(nb)]))
-        add("item_a", np.repeat(np.arange(S_s), na))
-        add("item_b", np.repeat(np.arange(S_s), nb))
-        add("cnt_a", na, np.float32)
-        add("cnt_b", nb, np.float32)
     add("scale", [lamb if s_["kind"] != "prim" else 1.0 for _, s_ in all_segs], np.float32)
     add("cnt_shape", np.maximum(np.bincount(np.asarray([b for b, _ in all_segs], dtype=np.int64), minlength=B), 1),
+        np.float32)
+    # per-shape sums as a masked row sum (fixed order; index_add_ would use fp32 atomics)
+    add("seg_of_shape", (np.arange(B)[:, None] == np.asarray([b for b, _ in all_segs], dtype=np.int64)[None, :]),
         np.float32)
     dev_tab = h2d(np.concatenate(parts) if parts else np.zeros(1, np.int32), dev)
     T = {k: (dev_tab[o:o + n].view(torch.float32) if k in floats else dev_tab[o:o + n]) for k, (o, n) in where.items()}
@@ -697,8 +692,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         pred = torch.cat(pieces, 0)
         gt_cloud = points.reshape(B * N, 3)[T["gt_flat"][int(gt_off[S_p]):].long()]
         with record_function("fit:chamfer"):
-            d_s = _RaggedChamfer.apply(pred, gt_cloud, T["off_a"], T["off_b"], T["item_a"].long(),
-                                       T["item_b"].long(), T["cnt_a"], T["cnt_b"], max(na), max(nb))
+            d_s = _RaggedChamfer.apply(pred, gt_cloud, T["off_a"], T["off_b"], max(na), max(nb))
         dists.append(d_s)
 
     # ---- losses, metrics, ONE download ----------------------------------------------------
@@ -709,8 +703,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
     if S_all:
         d_all = torch.cat(dists)
         d_used = torch.where(d_all.detach() > 1, torch.full_like(d_all, 0.1), d_all)   # degenerate case -> constant
-        loss_b = torch.zeros(B, dtype=torch.float32, device=dev).index_add_(0, T["seg_shape"].long(),
-                                                                              d_used * T["scale"])
+        loss_b = (T["seg_of_shape"].reshape(B, S_all) * (d_used * T["scale"]).unsqueeze(0)).sum(1)
         loss_b = loss_b / T["cnt_shape"]
         tail = [d_all.detach().double()]
         if S_p:

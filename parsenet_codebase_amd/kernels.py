@@ -120,9 +120,12 @@ def edge_feature_bwd(gfeat, idx):
     B, N, k, C2 = gfeat.shape
     C = C2 // 2
     gxt = torch.empty((B, N, C), dtype=torch.float32, device=gfeat.device)
+    lib = _lib.load()
+    wsz = lib.pn_edgeconv_bwd_workspace(B, N, k)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=gfeat.device)
     with _lib.on_device(gfeat.device):
-        rc = _lib.load().pn_edge_feature_bwd_f32(ptr(gfeat), ptr(idx), B, N, k, C, ptr(gxt),
-                                                 current_stream(gfeat.device))
+        rc = lib.pn_edge_feature_bwd_f32(ptr(gfeat), ptr(idx), B, N, k, C, ptr(gxt), ptr(ws), wsz,
+                                         current_stream(gfeat.device))
     check(rc, "pn_edge_feature_bwd_f32")
     return gxt
 
@@ -142,10 +145,13 @@ def edgeconv_reduce_fwd(PQ, idx, gamma, groups, per_sample):
     s1 = torch.empty((B, N, Cout), dtype=torch.float32, device=dev)
     argk = torch.empty((B, N, Cout), dtype=torch.uint8, device=dev)
     stats = torch.empty((B if per_sample else 1, groups, 2), dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    wsz = lib.pn_edgeconv_reduce_workspace(B, N, Cout, groups)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
     with _lib.on_device(dev):
-        rc = _lib.load().pn_edgeconv_reduce_fwd_f32(ptr(PQ), ptr(idx), ptr(gamma), B, N, k, Cout, groups,
-                                                    int(per_sample), ptr(yext), ptr(argk), ptr(s1),
-                                                    ptr(stats), current_stream(dev))
+        rc = lib.pn_edgeconv_reduce_fwd_f32(ptr(PQ), ptr(idx), ptr(gamma), B, N, k, Cout, groups,
+                                            int(per_sample), ptr(yext), ptr(argk), ptr(s1),
+                                            ptr(stats), ptr(ws), wsz, current_stream(dev))
     check(rc, "pn_edgeconv_reduce_fwd_f32")
     return yext, argk, s1, stats
 
@@ -561,6 +567,46 @@ def chamfer_nn_ragged(a, off_a, max_a, b, off_b, max_b, side_a=True, side_b=True
     return minA, argA, minB, argB
 
 
+def chamfer_ragged_reduce(minA, off_a, minB, off_b):
+    """(mean minA + mean minB) / 2 per item of the ragged batch, fixed summation order -> (S,)."""
+    require_cuda(minA, minB)
+    S = off_a.shape[0] - 1
+    out = torch.empty(S, dtype=torch.float32, device=minA.device)
+    with _lib.on_device(minA.device):
+        rc = _lib.load().pn_chamfer_ragged_reduce_f32(ptr(_f32c(minA, "minA")), ptr(_i32c(off_a, "off_a")),
+                                                      ptr(_f32c(minB, "minB")), ptr(_i32c(off_b, "off_b")), S,
+                                                      ptr(out), current_stream(minA.device))
+    check(rc, "pn_chamfer_ragged_reduce_f32")
+    return out
+
+
+def chamfer_ragged_bwd(pred, off_a, max_a, gt, off_b, argA, argB, g):
+    """Gradient of chamfer_ragged_reduce with respect to the predictions (TA,3); g (S,)."""
+    require_cuda(pred, gt, g)
+    pred, gt, g = _f32c(pred, "pred"), _f32c(gt, "gt"), _f32c(g, "g")
+    S = off_a.shape[0] - 1
+    gpred = torch.empty_like(pred)
+    with _lib.on_device(pred.device):
+        rc = _lib.load().pn_chamfer_ragged_bwd_f32(ptr(pred), ptr(_i32c(off_a, "off_a")), int(max_a), ptr(gt),
+                                                   ptr(_i32c(off_b, "off_b")), ptr(_i64c(argA, "argA")),
+                                                   ptr(_i64c(argB, "argB")), ptr(g), S, ptr(gpred),
+                                                   current_stream(pred.device))
+    check(rc, "pn_chamfer_ragged_bwd_f32")
+    return gpred
+
+
+def gather_rows3_bwd(g, idx, N):
+    """g (B,M,3), idx (B,M) int64 -> (B,N,3): rows of g added into the rows idx names, ascending m."""
+    require_cuda(g, idx)
+    g, idx = _f32c(g, "g"), _i64c(idx, "idx")
+    B, M, _ = g.shape
+    out = torch.empty((B, N, 3), dtype=torch.float32, device=g.device)
+    with _lib.on_device(g.device):
+        rc = _lib.load().pn_gather_rows3_bwd_f32(ptr(g), ptr(idx), B, M, N, ptr(out), current_stream(g.device))
+    check(rc, "pn_gather_rows3_bwd_f32")
+    return out
+
+
 # ---- batched primitive fits (csrc/fitbatch.hip) ---------------------------------------------
 PRIM_PLANE, PRIM_SPHERE, PRIM_CYLINDER, PRIM_CONE = 0, 1, 2, 3
 FIT_NPAR = 16
@@ -727,10 +773,13 @@ def triplet_bwd(E, ia, ib, item_scale, gout, margin):
     require_cuda(E, gout)
     P, num = ia.shape
     gE = torch.zeros_like(E)
+    lib = _lib.load()
+    wsz = lib.pn_triplet_bwd_workspace(P, num, E.shape[1])
+    ws = torch.empty(wsz, dtype=torch.uint8, device=E.device)
     with _lib.on_device(E.device):
-        rc = _lib.load().pn_triplet_bwd_f32(ptr(E), E.shape[0], E.shape[1], ptr(ia), ptr(ib), ptr(item_scale),
-                                            ptr(_f32c(gout.reshape(1), "gout")), P, num, float(margin), ptr(gE),
-                                            current_stream(E.device))
+        rc = lib.pn_triplet_bwd_f32(ptr(E), E.shape[0], E.shape[1], ptr(ia), ptr(ib), ptr(item_scale),
+                                    ptr(_f32c(gout.reshape(1), "gout")), P, num, float(margin), ptr(gE),
+                                    ptr(ws), wsz, current_stream(E.device))
     check(rc, "pn_triplet_bwd_f32")
     return gE
 

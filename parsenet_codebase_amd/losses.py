@@ -130,9 +130,11 @@ def evaluate_miou(gt_labels, pred_labels):
     return total / N
 
 
-_nll = torch.nn.NLLLoss()
-
-
 def primitive_loss(pred, gt):
-    """src/segment_loss.py:151-152."""
-    return _nll(pred, gt)
+    """src/segment_loss.py:151-152: nn.NLLLoss() (mean) of pred (B,K,N) log-probabilities at gt (B,N).
+    Written as gather + mean: torch's nll_loss2d forward accumulates with atomics on the GPU (its
+    result is not reproducible run to run); every target selects one entry, so the gather's backward
+    has no collisions and the mean is a fixed-order reduction."""
+    if pred.dim() == 3 and pred.is_cuda:
+        return -torch.gather(pred, 1, gt.long().unsqueeze(1)).mean()
+    return F.nll_loss(pred, gt)

@@ -206,11 +206,13 @@ def test_ragged_chamfer_and_bspline_kernels(gpu):
     # autograd form against the per-pair API
     from parsenet_codebase_amd.chamfer import chamfer_distance_single_shape
     pred = torch.cat(A).to(gpu).requires_grad_(True)
-    item = lambda c: torch.tensor(np.repeat(np.arange(len(c)), c), device=gpu)   # noqa: E731
-    cnt = lambda c: torch.tensor(c, dtype=torch.float32, device=gpu)            # noqa: E731
-    vals = _RaggedChamfer.apply(pred, torch.cat(Bc).to(gpu), off(na), off(nb), item(na), item(nb), cnt(na), cnt(nb),
-                                max(na), max(nb))
+    vals = _RaggedChamfer.apply(pred, torch.cat(Bc).to(gpu), off(na), off(nb), max(na), max(nb))
     (vals * torch.arange(1, 5, device=gpu)).sum().backward()
+    # fixed summation order: a second evaluation returns the same bits, values and gradient
+    pred2 = torch.cat(A).to(gpu).requires_grad_(True)
+    vals2 = _RaggedChamfer.apply(pred2, torch.cat(Bc).to(gpu), off(na), off(nb), max(na), max(nb))
+    (vals2 * torch.arange(1, 5, device=gpu)).sum().backward()
+    assert torch.equal(vals, vals2) and torch.equal(pred.grad, pred2.grad)
     o = 0
     for k, (a, b) in enumerate(zip(A, Bc)):
         ag = a.to(gpu).requires_grad_(True)
