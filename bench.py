@@ -84,6 +84,11 @@ class StubStep:
         self.data = torch.randn(self.pool, 8, generator=g).to(device)
         self.cursor = 0
         self.pretrain_loss = None
+        # PN_STUB_FAIL="rank:step": that rank's status check raises in its step-th call (counted from the
+        # start of the timed region) — the CPU suite's stand-in for a degenerate segment on one rank
+        fail = os.environ.get("PN_STUB_FAIL", "")
+        self.fail_at = int(fail.split(":")[1]) if fail and int(fail.split(":")[0]) == rank else -1
+        self.calls, self.skipped_steps = 0, 0
 
         def train():
             for _ in range(pretrain):
@@ -100,8 +105,16 @@ class StubStep:
         self.bucket.zero()
         loss = (self.model(x) ** 2).mean()
         loss.backward()
-        self.bucket.all_reduce_mean()
-        self.opt.step()
+        if not self.bucket.collective:             # rank 0's pre-training: nobody to agree with
+            self.opt.step()
+            return loss
+        self.calls += 1
+
+        def finish():
+            if self.calls == self.fail_at:
+                raise RuntimeError("injected: degenerate segment on this rank")
+        _, _, took = self.bucket.finish_or_skip(finish, self.opt)
+        self.skipped_steps += 0 if took else 1
         return loss
 
 
@@ -586,6 +599,10 @@ def main():
             "cpu_baseline": cpu,
             "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(table.items())},
         }
+        if getattr(step, "skipped_steps", 0):
+            # a rank's fitting stage raised: the step was dropped on EVERY rank (no reduction, no
+            # optimizer move; train_parsenet_e2e.py:243-257) — counted over all runs of this process
+            out["skipped_steps"] = step.skipped_steps
         if elapsed_dense is not None:
             # same weights, same shapes, same RNG stream, every mean-shift launch dense
             out["value_dense"] = shapes / elapsed_dense

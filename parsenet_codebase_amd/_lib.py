@@ -229,13 +229,20 @@ class _PinnedRing:
     40 ms holes in front of the first kernel after an upload), and the sizes of a step's tables
     change with the number of segments, which defeats torch's caching host allocator.  A ring of
     fixed-size slots allocated once: a slot is reused only after the event recorded behind its last
-    copy has completed (normally long before its turn comes round again)."""
+    copy has completed (normally long before its turn comes round again).
+
+    Uploads are done with a slot once that event has completed.  A DOWNLOAD is not: the host reads
+    the slot after the event, possibly much later (the fit status of a step is read after the
+    backward pass has been queued) — such a slot is taken with ``hold=True`` and stays out of the
+    rotation until the reader calls ``release`` (round-3 advisor finding: 32 further takes handed
+    the slot to an upload whose host-side copy overwrote unread results)."""
 
     def __init__(self, slots=32, nbytes=1 << 20):
         self.nbytes, self.nslots, self.slots, self.next = nbytes, slots, None, 0
 
-    def take(self, nbytes):
-        """(uint8 pinned view of ``nbytes``, slot) or (None, None) when the request exceeds a slot."""
+    def take(self, nbytes, hold=False):
+        """(uint8 pinned view of ``nbytes``, slot) or (None, None) when the request exceeds a slot or
+        every slot is held by a host reader."""
         if nbytes > self.nbytes:
             return None, None
         if self.slots is None:
@@ -243,13 +250,24 @@ class _PinnedRing:
             # over the first dozens of uploads — i.e. over somebody's timed steps)
             whole = torch.empty(self.nslots * self.nbytes, dtype=torch.uint8).pin_memory()
             self.slots = [{"buf": whole[i * self.nbytes:(i + 1) * self.nbytes], "event": torch.cuda.Event(),
-                           "armed": False} for i in range(self.nslots)]
-        i = self.next
-        self.next = (i + 1) % self.nslots
-        slot = self.slots[i]
-        if slot["armed"]:
-            slot["event"].synchronize()
-        return slot["buf"][:max(nbytes, 1)], slot
+                           "armed": False, "held": False} for i in range(self.nslots)]
+        for _ in range(self.nslots):
+            i = self.next
+            self.next = (i + 1) % self.nslots
+            slot = self.slots[i]
+            if slot["held"]:
+                continue
+            if slot["armed"]:
+                slot["event"].synchronize()
+            slot["held"] = bool(hold)
+            return slot["buf"][:max(nbytes, 1)], slot
+        return None, None
+
+    @staticmethod
+    def release(slot):
+        """The host has read (or copied out) what the download left in the slot."""
+        if slot is not None:
+            slot["held"] = False
 
     @staticmethod
     def arm(slot):
@@ -261,23 +279,42 @@ class _PinnedRing:
 _RING = _PinnedRing()
 
 
+_SPIN_SECONDS = None
+
+
 def wait_event(event):
-    """Block the host until ``event`` has completed — by polling.  hipEventSynchronize puts the
-    thread to sleep, and on a busy host (the pool's boxes are shared) the wake-up alone costs up to
-    milliseconds while the device sits idle behind the very copy the host waits for; the three waits
-    of a training step are short, a spinning core is cheap."""
-    while not event.query():
-        pass
+    """Block the host until ``event`` has completed — by polling, for a bounded time.
+    hipEventSynchronize puts the thread to sleep, and on a busy host (the pool's boxes are shared)
+    the wake-up alone costs up to milliseconds while the device sits idle behind the very copy the
+    host waits for; the three waits of a training step are short.  One process per GPU means one
+    spinning core PER RANK next to its OMP threads, so with several ranks (WORLD_SIZE > 1) the
+    spin is bounded — 300 us by default, PARSENET_SPIN_US overrides, 0 = always sleep — and the
+    blocking wait takes over; a single rank spins up to 50 ms (a step's wait is 1-20 ms)."""
+    global _SPIN_SECONDS
+    if _SPIN_SECONDS is None:
+        us = os.environ.get("PARSENET_SPIN_US")
+        if us is None:
+            us = 300 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 50000
+        _SPIN_SECONDS = float(us) * 1e-6
+    if event.query():
+        return
+    import time
+    deadline = time.perf_counter() + _SPIN_SECONDS
+    while time.perf_counter() < deadline:
+        if event.query():
+            return
+    event.synchronize()
 
 
-def pinned_like(shape, dtype):
+def pinned_like(shape, dtype, hold=False):
     """A pinned host tensor of ``shape`` / ``dtype`` from the ring (plus its slot, to be armed after
-    the copy that fills or drains it), or a freshly pinned one (slot None) when it does not fit."""
+    the copy that fills or drains it), or a freshly pinned one (slot None) when it does not fit.
+    ``hold=True`` for downloads: the slot is the caller's until _PinnedRing.release(slot)."""
     n = 1
     for d in shape:
         n *= int(d)
     nbytes = n * torch.empty((), dtype=dtype).element_size()
-    raw, slot = _RING.take(nbytes)
+    raw, slot = _RING.take(nbytes, hold)
     if raw is None:
         return torch.empty(tuple(shape), dtype=dtype).pin_memory(), None
     return raw[:nbytes].view(dtype).reshape(tuple(shape)), slot

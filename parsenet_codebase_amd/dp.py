@@ -51,6 +51,7 @@ class FlatGradBucket:
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
         self.collective = True      # False: steps that only one rank runs (workloads.train_on_rank0_then_broadcast)
+        self._side = None           # host-side (gloo) group for the step-status flag, created on first use
         o = 0
         for p in self.params:
             n = p.numel()
@@ -60,9 +61,45 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def _multi(self):
+        return self.collective and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def any_rank_failed(self, failed):
+        """True if ``failed`` is set on ANY rank.  A rank whose fitting stage raises must not skip the
+        gradient all-reduce alone (the others would sit in RCCL until the watchdog fires) and the
+        others must not enter it without that rank: the status is agreed upon with a one-element
+        all-reduce on a HOST-side gloo group — no device synchronisation, the backward pass keeps
+        running underneath — and every rank then takes the same branch.  A collective: all ranks of
+        a step call it, in the same place.  Single rank / collective off: returns ``failed``."""
+        if not self._multi():
+            return bool(failed)
+        if self._side is None:
+            # new_group is itself collective: every rank reaches its first status check together
+            self._side = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        t = torch.tensor([1 if failed else 0], dtype=torch.int32)
+        dist.all_reduce(t, group=self._side)
+        return bool(int(t.item()) > 0)
+
+    def finish_or_skip(self, finish, optimizer):
+        """Tail of a data-parallel step whose status arrives late (ParsenetE2EStep: the fit status of
+        the batched fitting stage rides in a deferred download; train_parsenet_e2e.py:243-257 drops
+        the batch on such an exception).  Runs ``finish()``; if it raised on ANY rank, nobody reduces
+        and nobody moves the weights (returns (None, exception or None, False)); otherwise ONE
+        gradient all-reduce and the optimizer step (returns (finish's result, None, True))."""
+        err, out = None, None
+        try:
+            out = finish()
+        except Exception as e:          # the status of the step: agreed upon below, re-raised by the caller
+            err = e
+        if self.any_rank_failed(err is not None):
+            return None, err, False
+        self.all_reduce_mean()
+        optimizer.step()
+        return out, None, True
+
     def all_reduce_mean(self):
         """Average gradients over ranks with one all-reduce (no-op on a single rank)."""
-        if self.collective and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self._multi():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
         return self.flat

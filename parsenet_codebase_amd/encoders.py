@@ -75,15 +75,16 @@ _ACT = {"none": 0, "relu": 1, "leaky": 2}
 def _frozen_affine(conv, bn, x):
     """(scale, shift) of ``bn(conv(.) )`` as a per-channel affine map after the bias-free GEMM, or
     None unless ``bn`` is a frozen evaluation-mode BatchNorm (running statistics, no tensor of it
-    or the convolution's bias wants a gradient) on the GPU.  Cached on the module until one of its
-    tensors changes."""
+    or the convolution's bias wants a gradient) on the GPU.  Cached (graph.frozen_cache: outside the
+    module, validated by data_ptr / _version of its tensors; after an edit through ``.data`` call
+    graph.invalidate_frozen_caches) until one of its tensors changes."""
     frozen = not (bn.training or bn.running_mean is None) and x.is_cuda and not (
         torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (bn.weight, bn.bias, conv.bias)))
     if not frozen:
         return None
     src = (bn.running_mean, bn.running_var, bn.weight, bn.bias, conv.bias)
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
-    hit = bn.__dict__.get("_pn_affine")
+    hit = graph.frozen_cache(bn).get("affine")
     if hit is None or hit[0] != key:
         with torch.no_grad():
             scale = torch.rsqrt(bn.running_var + bn.eps)
@@ -94,7 +95,7 @@ def _frozen_affine(conv, bn, x):
             if conv.bias is not None:
                 shift = shift + conv.bias * scale
         hit = (key, scale.contiguous(), shift.contiguous())
-        bn.__dict__["_pn_affine"] = hit
+        graph.frozen_cache(bn)["affine"] = hit
     return hit[1], hit[2]
 
 

@@ -328,14 +328,16 @@ def standardize_segments(P2, w):
         mean = (P2 * wsel.unsqueeze(2)).sum(1) / (wsel.sum(1, keepdim=True) + EPS)
         Pc = P2 - mean.unsqueeze(1)
         cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
-        cov_h, slot = pinned_like(cov.shape, cov.dtype)          # host step of the reference: download ...
+        cov_h, slot = pinned_like(cov.shape, cov.dtype, hold=True)   # host step of the reference: download ...
         cov_h.copy_(cov, non_blocking=True)
         if slot is not None:
             _PinnedRing.arm(slot)
             wait_event(slot["event"])
         else:
             torch.cuda.current_stream(cov.device).synchronize()
-        R = h2d(host_minor_axis_rotations(cov_h), P2.device)       # ... batched geev, upload
+        rot = host_minor_axis_rotations(cov_h)                     # ... batched geev ...
+        _PinnedRing.release(slot)
+        R = h2d(rot, P2.device)                                    # ... upload
         Pr = torch.bmm(Pc, R.transpose(1, 2))
         wp = Pr * w.unsqueeze(2)
         big = torch.full_like(wp, float("inf"))
@@ -535,19 +537,26 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             memory + an event: the host blocks on THIS copy only, whatever else is queued behind it."""
             dev_pack = torch.cat([head, st["labels"].reshape(-1), st["cid"].reshape(-1), st["ncl"], bwflag,
                                   st["nocc"], st["nflag"]]).to(torch.int32)
-            host, slot = pinned_like(dev_pack.shape, torch.int32)      # staging ring: no pinned allocation per step
+            # staging ring: no pinned allocation per step; HELD until the host has copied the ids out
+            host, slot = pinned_like(dev_pack.shape, torch.int32, hold=True)
             host.copy_(dev_pack, non_blocking=True)
             if slot is not None:
                 _PinnedRing.arm(slot)
-                return host, slot["event"]
+                return host, slot["event"], slot
             done = torch.cuda.Event()
             done.record()
-            return host, done
+            return host, done, None
+
+        def collect(pend):
+            """Wait for a started download and copy it out of its ring slot (the slot goes back into
+            the rotation: the uploads of the host stage below — or of another group — may take it)."""
+            wait_event(pend[1])
+            out = pend[0].numpy().copy()
+            _PinnedRing.release(pend[2])
+            return out
 
         def download(st):
-            host, done = start_download(st)
-            wait_event(done)
-            return host.numpy()
+            return collect(start_download(st))
         pending = start_download(state)
         yield                                                    # (a pipelined caller queues the next group here)
         # numpy RNG: one shuffle per mean_shift call of the reference (src/mean_shift.py:121-122), i.e. one
@@ -560,8 +569,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             np.random.shuffle(np.arange(N))
         # ... and so is everything the matching needs from the ground truth alone
         gt_pre = [precompute_ground_truth(labels[b], primitives[b]) for b in range(B)]
-        wait_event(pending[1])                                   # download: cluster ids
-        pack = pending[0].numpy()
+        pack = collect(pending)                                  # download: cluster ids
         if pack[0] > 0:
             MSM.auto_report(B, N, (float(pack[0]) - 1.0) * 1e-6)
         if int(pack[-2 * B:-B].max()) > state["width"]:
@@ -713,13 +721,14 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         loss_b = torch.zeros(B, dtype=torch.float32, device=dev)
         tail_dev = ptype.reshape(-1).double()
     pf = params_p.float() if S_p else None
-    tail_host = tail_event = None
+    tail_host = tail_event = tail_slot = None
     if defer_metrics and tail_dev.is_cuda:
         # stream-ordered copy into pinned memory right here, behind the forward kernels: finish()
         # then waits for THIS copy only — not for the backward pass and the optimizer step the
         # caller queues in between — and the host is free to queue the next step meanwhile
-        tail_host, slot = pinned_like(tail_dev.shape, tail_dev.dtype)
+        tail_host, slot = pinned_like(tail_dev.shape, tail_dev.dtype, hold=True)     # held until finish() has read it
         tail_host.copy_(tail_dev, non_blocking=True)
+        tail_slot = slot
         if slot is not None:
             _PinnedRing.arm(slot)
             tail_event = slot["event"]
@@ -733,7 +742,8 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         backward pass, so the device never waits for the host between the two."""
         if tail_event is not None:
             wait_event(tail_event)
-            host = tail_host.numpy()
+            host = tail_host.numpy().copy()
+            _PinnedRing.release(tail_slot)
         else:
             host = tail_dev.cpu().numpy()                                                      # sync 3
         d_h = host[:S_all]

@@ -4,10 +4,38 @@ Public names mirror the reference (src/model.py:9-53, src/PointNet.py:9-140); ev
 numerically heavy is a HIP kernel reached through ``kernels`` (C ABI).  Only tiny
 per-channel reductions and the point-level GEMM are left to torch (rocBLAS).
 """
+import weakref
+
 import numpy as np
 import torch
 
 from . import kernels as K
+
+# Folded constants of FROZEN layers (the SplineNets of the fitting stage: W -> [Wa | Wb - Wa],
+# rsqrt(running_var + eps), the affine map of an evaluation-mode BatchNorm1d), keyed by the layer
+# object and validated by (data_ptr, _version) of the tensors they were built from.  They live HERE,
+# not in the module's __dict__: torch.save(module) / copy.deepcopy do not carry them along.  An
+# in-place edit through ``.data`` (``p.data.copy_(...)``) does not bump ``_version`` — call
+# invalidate_frozen_caches(module) after such an edit; load_state_dict / optimizer steps / ``copy_``
+# on the parameter itself are seen without help.
+_FROZEN = weakref.WeakKeyDictionary()
+
+
+def frozen_cache(layer):
+    """The cache dictionary of one layer object (created on first use)."""
+    d = _FROZEN.get(layer)
+    if d is None:
+        d = _FROZEN[layer] = {}
+    return d
+
+
+def invalidate_frozen_caches(module=None):
+    """Forget the folded constants of ``module`` and its sub-modules (all layers if None)."""
+    if module is None:
+        _FROZEN.clear()
+        return
+    for m in module.modules():
+        _FROZEN.pop(m, None)
 
 
 # --------------------------------------------------------------------------------------
@@ -134,7 +162,7 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
         raise ValueError("edge conv weight expects %d input channels, got %d" % (2 * C, w.shape[1]))
     # W [xj - xi ; xi] = Wa xj + (Wb - Wa) xi: one GEMM on points
     frozen = not (weight.requires_grad and torch.is_grad_enabled())
-    hit = norm.__dict__.get("_pn_wcat") if frozen else None
+    hit = frozen_cache(norm).get("wcat") if frozen else None
     key = (weight.data_ptr(), weight._version, C)
     if hit is not None and hit[0] == key:
         wcat_t = hit[1]                                    # frozen layer (the SplineNets of the fitting stage)
@@ -143,7 +171,7 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
         wcat_t = torch.cat([wa, wb - wa], 0).t()           # (C, 2Cout)
         if frozen:
             wcat_t = wcat_t.detach().contiguous()
-            norm.__dict__["_pn_wcat"] = (key, wcat_t)
+            frozen_cache(norm)["wcat"] = (key, wcat_t)
     # batched with stride 0 on the weight: no transposing copy of x (see encoders.weight_bmm)
     PQ = torch.bmm(x.transpose(1, 2), wcat_t.unsqueeze(0).expand(B, -1, -1))   # (B,N,2Cout)
     if isinstance(norm, torch.nn.GroupNorm):
@@ -170,10 +198,10 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
                     norm.running_var.mul_(1 - mom).add_((var * (M / max(M - 1.0, 1.0))).float(), alpha=mom)
             return out
         rkey = (norm.running_var.data_ptr(), norm.running_var._version, norm.eps)
-        rhit = norm.__dict__.get("_pn_rstd")
+        rhit = frozen_cache(norm).get("rstd")
         if rhit is None or rhit[0] != rkey:
             rhit = (rkey, torch.rsqrt(norm.running_var + norm.eps))
-            norm.__dict__["_pn_rstd"] = rhit
+            frozen_cache(norm)["rstd"] = rhit
         out, _ = _EdgeConvNormMax.apply(PQ, idx, gamma, beta, Cout, False, norm.eps, slope,
                                         (norm.running_mean, rhit[1]))
         return out

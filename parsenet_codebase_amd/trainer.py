@@ -332,12 +332,31 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000, mod
     return history
 
 
+class StepSkipped(Exception):
+    """Raised by a micro-batch whose fitting loss or backward pass failed — the part of the step the
+    reference guards with its bare ``try`` (train_parsenet_e2e.py:232-257).  Carries the formatted
+    traceback of the original exception."""
+
+
+def guarded(fn, *args, **kwargs):
+    """``fn(*args, **kwargs)`` with any exception turned into StepSkipped: wrap exactly the calls the
+    reference's ``try`` covers — evaluation.fitting_loss(...) and loss.backward()."""
+    try:
+        return fn(*args, **kwargs)
+    except Exception as e:
+        raise StepSkipped(traceback.format_exc()) from e
+
+
 def accumulate_or_skip(bucket, optimizer, num_iter, micro, world=1, device=None, on_step=None, model=None,
                        on_exception=None):
     """One optimizer step of train_parsenet_e2e.py:174-277: zero the gradients, run ``micro(i)`` —
-    forward + backward of micro-batch i, accumulating into the bucket — ``num_iter`` times; an
-    exception in ANY micro-batch drops the whole step ("mistake", :243-257): the partial sums stay
-    in the bucket until the next step zeroes them and the optimizer does not move.  With several
+    forward + backward of micro-batch i, accumulating into the bucket — ``num_iter`` times; a
+    StepSkipped from ANY micro-batch (its fitting loss or backward pass failed: ``guarded``) drops
+    the whole step ("mistake", :243-257): the partial sums stay in the bucket until the next step
+    zeroes them and the optimizer does not move.  Everything else — StopIteration from a finite
+    data iterator, an out-of-memory error or a programming error in the forward pass — propagates:
+    the reference's ``try`` does not cover those either (round-3 advisor finding: a blanket
+    ``except Exception`` recorded them as "mistakes" and silently skipped every following step).  With several
     ranks the drop is collective — a one-element all-reduce of the flag, so that no rank enters the
     gradient all-reduce alone — and a completed step averages the accumulated gradients over the
     ranks with the bucket's single all-reduce.  ``on_step(model, flat)`` sees the accumulated,
@@ -347,9 +366,9 @@ def accumulate_or_skip(bucket, optimizer, num_iter, micro, world=1, device=None,
     for i in range(num_iter):
         try:
             micro(i)
-        except Exception:       # degenerate segment: the reference drops the step
+        except StepSkipped as e:       # degenerate segment: the reference drops the step
             if on_exception is not None:
-                on_exception(traceback.format_exc())
+                on_exception(str(e))
             mistake = True
             break
     if world > 1:   # a skipped step must be skipped by every rank (the all-reduce is collective)
@@ -407,12 +426,11 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
                 embedding, log_prob, embed_loss = _seg_forward(model, pts, nrm, labels, cfg.normals)
                 embed_loss = torch.mean(embed_loss)
                 p_loss = primitive_loss(log_prob, prim)
-                res_loss, _ = evaluation.fitting_loss(embedding.permute(0, 2, 1), pts, nrm, labels, primitives_,
-                                                      log_prob, quantile=0.025, iterations=10, lamb=lamb,
-                                                      eval=False)
+                res_loss, _ = guarded(evaluation.fitting_loss, embedding.permute(0, 2, 1), pts, nrm, labels,
+                                      primitives_, log_prob, quantile=0.025, iterations=10, lamb=lamb, eval=False)
                 s_iou, iou = res_loss[3:]
                 loss = embed_loss + p_loss + 1 * res_loss[0]
-                loss.backward()
+                guarded(loss.backward)
                 acc["res"] += res_loss[0].item() / num_iter
                 if res_loss[1] is not None:
                     res_g.append(res_loss[1])
@@ -424,9 +442,8 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
                 acc["iou"] += iou / num_iter
                 acc["emb"] += embed_loss.item() / num_iter
 
-            def report(tb):
-                if rank == 0:
-                    log("exception in training: " + tb.splitlines()[-1])
+            def report(tb):       # on the rank that raised (another rank's log would not have it)
+                log("exception in training (rank %d): %s" % (rank, tb.strip().splitlines()[-1]))
             if not accumulate_or_skip(bucket, optimizer, num_iter, micro, world, device, on_step, model, report):
                 skipped += 1
                 continue

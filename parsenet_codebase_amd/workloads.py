@@ -162,6 +162,7 @@ class ParsenetE2EStep(ParsenetSegStep):
         self.overlap = True       # (shape-by-shape mode) clustering of shape b+1 on a side stream
         self.side = torch.cuda.Stream(device=device)
         self._warmed = False
+        self.skipped_steps, self.last_error = 0, None    # steps dropped because a rank's fitting stage raised
 
     def _pretrain(self, seed, first_shape, lr):
         """See the class docstring.  PARSENET_PRETRAIN_CACHE=<file> keeps the pre-trained weights
@@ -249,21 +250,37 @@ class ParsenetE2EStep(ParsenetSegStep):
         res_total = 0
         self.evaluation.batched = self.batched
         if self.batched:
-            loss_b, finish = self.evaluation.fitting_losses_pipelined(
-                emb, self.points, self.normals, self.labels, self.prim_np, log_prob, quantile=0.025, iterations=10,
-                lamb=0.1, chunks=self.chunks)
+            try:
+                loss_b, finish = self.evaluation.fitting_losses_pipelined(
+                    emb, self.points, self.normals, self.labels, self.prim_np, log_prob, quantile=0.025,
+                    iterations=10, lamb=0.1, chunks=self.chunks)
+            except Exception as e:
+                # the host part of the stage (matching, segment tables) can raise before anything is
+                # queued: with several ranks this rank still has to join the status agreement below
+                if not self.bucket._multi():
+                    raise
+                stage_error = e
+
+                def finish():
+                    raise stage_error
+                loss_b = [0.0] * self.batch
             res_total = sum(loss_b[b] for b in range(self.batch))     # the association of the per-shape sum
             loss = loss + res_total / self.batch
             loss.backward()
             # The fit status (lstsq failure, non-finite residual) rides in the deferred download: it
-            # is read BEFORE the optimizer step, so a degenerate segment raises with the weights
+            # is read BEFORE the optimizer step, so a degenerate segment leaves the weights
             # untouched, like the reference's skipped batch (train_parsenet_e2e.py:243-257).  The
             # copy was queued behind the forward kernels; the device is still busy with the backward
-            # pass while the host waits for it.
-            self.last_metrics = finish()
-            self.bucket.all_reduce_mean()
-            self.opt.step()
+            # pass while the host waits for it.  With several ranks the status is agreed upon first
+            # (dp.FlatGradBucket.finish_or_skip): either every rank reduces and steps or none does —
+            # a rank that raised alone would leave the others in the gradient all-reduce for good.
+            self.last_metrics, err, took = self.bucket.finish_or_skip(finish, self.opt)
             self.last_res = res_total
+            if not took:
+                self.skipped_steps += 1
+                self.last_error = err
+                if err is not None and not self.bucket._multi():
+                    raise err                 # one rank: the caller decides (the reference's loop catches it)
             return loss
         main = torch.cuda.current_stream(self.device)
         handles, events = {}, {}

@@ -305,3 +305,42 @@ def test_pipelined_groups_equal_the_whole_batch(gpu):
         assert all(np.array_equal(a, b) for a, b in zip(out[chunks][2], out[1][2]))
         assert float((out[chunks][0] - out[1][0]).abs().max()) <= 1e-6 * float(out[1][0].abs().max())
         assert float((out[chunks][1] - out[1][1]).abs().max()) <= 1e-5 * float(out[1][1].abs().max())
+
+
+def test_sixteen_groups_do_not_recycle_a_download_slot_before_it_is_read(gpu):
+    """Round-3 advisor finding: the pinned staging ring has 32 slots and a group of the pipelined
+    stage takes about five; with 16 groups the ring wraps before group 0's deferred results (the
+    fit status and distances read in finish()) and the last group's cluster ids are read — an upload
+    of a later group then overwrote them.  Download slots are now held until the host has copied
+    them out: 16 groups of one shape must give what one group of 16 shapes gives."""
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.encoders import DGCNNControlPoints
+    from parsenet_codebase_amd.fitting import Evaluation
+    torch.cuda.set_device(gpu)
+    torch.manual_seed(0)
+    B, N = 16, 1500
+    pts, nrm, lab, prim = synthetic.make_batch(40, B, N, min_segments=3, max_segments=4)
+    g = torch.Generator().manual_seed(2)
+    embs = []
+    for b in range(B):
+        S = int(lab[b].max()) + 1
+        proto = torch.nn.functional.normalize(torch.randn(S, 128, generator=g), dim=1)
+        embs.append(proto[torch.from_numpy(lab[b])] + 0.15 * torch.randn(N, 128, generator=g) / np.sqrt(128))
+    emb0 = torch.stack(embs).to(gpu)
+    logp = torch.log_softmax(torch.randn(B, 10, N, generator=g), 1).to(gpu)
+    P, Nr = torch.from_numpy(pts).to(gpu), torch.from_numpy(nrm).to(gpu)
+    ev = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1),
+                    open_path=DGCNNControlPoints(20, num_points=10, mode=0))
+    out = {}
+    for chunks in (1, 16):
+        e = emb0.clone().requires_grad_(True)
+        np.random.seed(7)
+        loss_b, finish = ev.fitting_losses_pipelined(e, P, Nr, lab, prim, logp, quantile=0.025, iterations=10,
+                                                     lamb=0.1, chunks=chunks)
+        loss_b.sum().backward()
+        res = finish()
+        out[chunks] = (loss_b.detach().clone(), [r[1][1] for r in res], [r[0][1] for r in res], [r[0][3] for r in res])
+    assert all(np.array_equal(a, b) for a, b in zip(out[16][1], out[1][1]))           # cluster ids
+    assert float((out[16][0] - out[1][0]).abs().max()) <= 1e-6 * float(out[1][0].abs().max())
+    for a, b in zip(out[16][2] + out[16][3], out[1][2] + out[1][3]):                    # metrics from the deferred download
+        assert (a is None and b is None) or abs(a - b) <= 1e-6 * max(abs(b), 1e-12)

@@ -201,6 +201,108 @@ def test_bench_whole_control_flow_on_two_gloo_ranks():
     assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 1
 
 
+def test_bench_step_is_dropped_on_every_rank_when_one_rank_raises():
+    """bench.py --workload stub on two gloo ranks with a failure injected into rank 1's status check
+    (PN_STUB_FAIL): the step is dropped on BOTH ranks — nobody enters the gradient all-reduce alone —
+    and the run continues to its JSON line, which counts the skipped step."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PN_STUB_FAIL"] = "1:4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub",
+                        "--steps", "6", "--warmup", "2", "--pretrain", "3"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["skipped_steps"] == 1 and rec["value"] > 0
+
+
+def _status_worker(rank, w, port, out):
+    import torch
+    import torch.distributed as dist
+    from parsenet_codebase_amd.dp import FlatGradBucket
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=w)
+    torch.manual_seed(0)
+    net = torch.nn.Linear(3, 1, bias=False)
+    bucket = FlatGradBucket(net.parameters())
+    opt = torch.optim.SGD(net.parameters(), lr=0.5)
+    w0 = net.weight.detach().clone()
+    x = torch.ones(1, 3) * (rank + 1)
+
+    def one(fail):
+        bucket.zero()
+        net(x).sum().backward()
+
+        def finish():
+            if fail:
+                raise RuntimeError("degenerate segment")
+            return "metrics"
+        return bucket.finish_or_skip(finish, opt)
+    res, err, took = one(rank == 1)                      # rank 1 raises: BOTH drop the step
+    ok = (not took) and res is None and torch.equal(net.weight.detach(), w0) and ((err is not None) == (rank == 1))
+    res, err, took = one(False)                          # next step: mean over ranks, one optimizer move
+    ok = ok and took and res == "metrics" and err is None
+    ok = ok and torch.allclose(net.weight.detach(), w0 - 0.5 * torch.full((1, 3), 1.5))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_step_status_is_agreed_upon_before_the_gradient_all_reduce():
+    """dp.FlatGradBucket.finish_or_skip on two gloo ranks (workloads.ParsenetE2EStep.step's tail): a
+    status check that raises on ONE rank drops the step on both, the next step reduces and moves."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_status_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
+def test_pinned_ring_never_hands_out_a_slot_a_host_reader_still_holds():
+    """_lib._PinnedRing: a download slot (hold=True) stays out of the rotation until released, however
+    many uploads come by; when every slot is held the caller gets (None, None) and allocates."""
+    from parsenet_codebase_amd import _lib
+
+    class Ev:
+        def synchronize(self):
+            pass
+
+        def record(self):
+            pass
+    ring = _lib._PinnedRing(slots=4, nbytes=64)
+    ring.slots = [{"buf": torch.zeros(64, dtype=torch.uint8), "event": Ev(), "armed": False, "held": False}
+                  for _ in range(4)]
+    _, held = ring.take(8, hold=True)
+    seen = [ring.take(8)[1] for _ in range(40)]
+    assert all(s is not held for s in seen) and len({id(s) for s in seen}) == 3
+    _lib._PinnedRing.release(held)
+    assert any(ring.take(8)[1] is held for _ in range(4))
+    taken = [ring.take(8, hold=True)[1] for _ in range(4)]
+    assert all(t is not None for t in taken) and ring.take(8) == (None, None)
+    for t in taken:
+        _lib._PinnedRing.release(t)
+    assert ring.take(8)[1] is not None
+
+
+def test_wait_event_spins_for_a_bounded_time_then_blocks(monkeypatch):
+    from parsenet_codebase_amd import _lib
+
+    class Ev:
+        def __init__(self, ready_after):
+            self.n, self.ready_after, self.blocked = 0, ready_after, False
+
+        def query(self):
+            self.n += 1
+            return self.n > self.ready_after
+
+        def synchronize(self):
+            self.blocked = True
+    monkeypatch.setattr(_lib, "_SPIN_SECONDS", 1e-3)
+    quick, never = Ev(3), Ev(10 ** 12)
+    _lib.wait_event(quick)
+    _lib.wait_event(never)
+    assert not quick.blocked and never.blocked
+
+
 def _pretrain_worker(rank, w, port, out):
     import torch
     import torch.distributed as dist
@@ -240,7 +342,7 @@ def _accum_worker(rank, w, port, out):
     import torch
     import torch.distributed as dist
     from parsenet_codebase_amd.dp import FlatGradBucket
-    from parsenet_codebase_amd.trainer import accumulate_or_skip
+    from parsenet_codebase_amd.trainer import accumulate_or_skip, guarded
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=w)
     torch.manual_seed(0)
@@ -252,9 +354,12 @@ def _accum_worker(rank, w, port, out):
     seen = []
 
     def micro_factory(first, fail_at):
-        def micro(i):
+        def fitting_loss(i):
             if i == fail_at:
                 raise RuntimeError("degenerate segment")
+
+        def micro(i):
+            guarded(fitting_loss, i)                # what the reference's try covers
             net(data[first + i:first + i + 1]).sum().backward()
         return micro
     # step 1: rank 1 fails in its third micro-batch -> EVERY rank drops the step, no optimizer move
@@ -269,6 +374,30 @@ def _accum_worker(rank, w, port, out):
     ok = ok and torch.allclose(net.weight.detach().reshape(-1), w0.reshape(-1) - 0.5 * want)
     out[rank] = bool(ok)
     dist.destroy_process_group()
+
+
+def test_only_the_guarded_part_of_a_micro_batch_can_skip_a_step():
+    """trainer.accumulate_or_skip drops a step on StepSkipped (fitting loss / backward, like the
+    reference's try at train_parsenet_e2e.py:232-257) and lets everything else through: an exhausted
+    data iterator or a programming error must not be recorded as a "mistake" step after step."""
+    import torch
+    from parsenet_codebase_amd.dp import FlatGradBucket
+    from parsenet_codebase_amd.trainer import accumulate_or_skip, guarded
+    net = torch.nn.Linear(2, 1)
+    bucket, opt = FlatGradBucket(net.parameters()), torch.optim.SGD(net.parameters(), lr=0.1)
+    it = iter([torch.ones(1, 2)])
+    seen = []
+
+    def micro(i):
+        x = next(it)                                   # StopIteration in the second micro-batch
+        guarded(lambda: net(x).sum().backward())
+    with pytest.raises((StopIteration, RuntimeError)):
+        accumulate_or_skip(bucket, opt, 2, micro)
+
+    def bad(i):
+        guarded(lambda: (_ for _ in ()).throw(ValueError("no full-rank ridge system")))
+    assert accumulate_or_skip(bucket, opt, 2, bad, on_exception=seen.append) is False
+    assert seen and "no full-rank ridge system" in seen[0]
 
 
 def test_e2e_accumulation_skip_and_rank_mean_on_two_gloo_ranks():

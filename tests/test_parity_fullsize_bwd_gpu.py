@@ -16,15 +16,14 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 # Segmentation steps the whole-step / training-loop tests spend on THEIR OWN shapes before the compared
-# step.  The comparison is chaotic in the partition (a `distance < b` merge decision on modes that agree
-# to 1e-6 between the implementations), and the pre-training is not bit-reproducible (fp32 atomics in
-# two backward kernels): every run sees another network.  With 150 steps (diffuse modes, 10-30 per
-# shape) the outcome scattered from run to run — accumulated-gradient cosines of the loop test
-# 0.9991-0.9999 in seven runs, then 0.62 / 0.71 / 0.84 / 0.97 / 0.996 in five (same kernels, bit for
-# bit: tools/jobs/r3x.sh, r3y.sh) —, with 600 steps (modes close to the segments) 0.99909 / 0.99962 /
-# 0.99992 (tools/jobs/r3y.sh), with 800 steps 0.99977 / 0.99986 / 0.999999 (r3z.sh; there the network
-# terms have converged so far that the residual term is 30-90 x their gradient).  PARITY_PRETRAIN
-# overrides (developer knob).
+# step.  Since round 4 every backward kernel sums in a fixed order (no floating-point atomics), so the
+# pre-training — and with it the network both sides are compared on — is the same bit for bit in every
+# run: the numbers quoted at the asserts below are THE outcome of this recipe on an MI355X, not samples
+# of a distribution (rounds 2-3: fp32 atomics in two backward kernels made every run train another
+# network, accumulated-gradient cosines scattered between 0.62 and 0.9999 at 150 steps, and the bars
+# were floors).  What remains ill-posed between two IMPLEMENTATIONS is the partition (a `distance < b`
+# merge decision on modes that agree to 1e-6); with 600 steps the modes sit close to the segments and
+# the partitions agree to 5 points in 10 000.  PARITY_PRETRAIN overrides (developer knob).
 PRETRAIN = int(os.environ.get("PARITY_PRETRAIN", "600"))
 
 
@@ -218,8 +217,14 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     # how far the network terms have converged (|res grad| / |net grad| 0.05 ... 90 between runs):
     # measured 0.99986 / 0.999999 (600 steps), 0.8507 / 0.99889 / 0.99812 (800 steps, residual term
     # 30-90 x the network terms, one flipped shape in the first) — a floor only.
-    assert float(np.median(cos_res)) > 0.9, cos_res
-    assert cos_all > 0.8, cos_all
+    # Round 4 (deterministic backward, the same network in every run): clusters 12 / 7 / 12 / 11 on both
+    # sides, agreement 1.0 / 1.0 / 0.9998 / 0.9995, residual rel 0 / 1e-4 / 6e-4 / 6e-7, cos(d res / d emb)
+    # 0.99994 / 1.00000 / 0.86016 / 1.00000 (the third shape: two points change modes), all shapes 0.99897,
+    # network terms 1.000000, WHOLE gradient 0.999989.
+    assert float(np.median(cos_res)) > 0.9999, cos_res
+    assert cos_res_all > 0.995, cos_res_all
+    assert cos_net > 0.99999, cos_net
+    assert cos_all > 0.9999, cos_all
     # Segmentations and per-shape residuals of THIS embedding (measured at 150 training steps: diffuse modes) are
     # not: mean-shift with quantile 0.025 finds 10-27 modes on these 4-5 segment shapes, and whether
     # two of them merge in the NMS is a `distance < b` comparison between shifted points that agree
@@ -235,11 +240,13 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     # 0.9998 / 0.941 / 0.9996 / 0.725, 0.929 / 0.988 / 0.927 / 0.968, 0.844 / 0.940 / 0.998 / 0.834 (this last
     # one under a 0.9 bar on the median: the floor is what every run has shown, not a typical value);
     # cluster counts apart by at most 2)
-    assert max(abs(a - b) for a, b in zip(ncl_g, [len(np.unique(i)) for i in ids_r])) <= 3
-    assert float(np.median(agree)) > 0.8 and min(agree) > 0.5, agree
+    # (round 4: the bars below are what the now-reproducible run shows, with a margin for another host's
+    # CPU arithmetic in the oracle; rounds 2-3 could only hold floors of 0.8 / 0.5 / 5e-2 here)
+    assert ncl_g == [len(np.unique(i)) for i in ids_r]
+    assert min(agree) > 0.99, agree
     for b in range(B):
-        if agree[b] > 0.9995:
-            assert rel_res[b] < 5e-2, (b, rel_res[b])
+        if agree[b] > 0.999:
+            assert rel_res[b] < 1e-2, (b, rel_res[b])
 
 
 def test_e2e_training_loop_against_the_oracle(gpu, tmp_path):
@@ -356,11 +363,13 @@ def test_e2e_training_loop_against_the_oracle(gpu, tmp_path):
     # the larger values are single NMS merge flips —, accumulated gradient cos 0.99914 ... 0.99986)
     # (one micro-batch may carry a flipped merge — its residual then differs by any factor; 0.32 in one of
     # the three runs at 600 pre-training steps — so the bar is on the second largest)
-    assert sorted(res_rel)[-2] < 0.25 and float(np.median(res_rel)) < 5e-2, res_rel
+    # (round 4, reproducible: residual rel 1.4e-1 / 1.9e-3 / 1.9e-3 / 1.4e-5 / 6.8e-2 — the first and the last
+    # micro-batch carry a flipped merge —, accumulated gradient cos 0.999552)
+    assert sorted(res_rel)[-2] < 0.1 and float(np.median(res_rel)) < 1e-2, res_rel
     # (600 / 800 pre-training steps, seven runs: 0.98774 — with all five residual losses within 6e-4, i.e. no
     # flipped merge: the gradient of a fit near the edge of its conditioning —, 0.99909 ... 0.999999; a dropped
     # or doubled micro-batch would show as ~0.9)
-    assert cos > 0.95, (cos, rel)
+    assert cos > 0.999, (cos, rel)
     # parameters after the step: Adam's first step is lr * sign(g) per element — elements whose
     # gradient is fp32 noise around zero move either way (2 lr apart), all others agree
     pg = torch.cat([p.detach().cpu().reshape(-1) for p in model_g.parameters()])
