@@ -188,6 +188,14 @@ def main():
             w = torch.rand(1, 256, generator=torch.Generator().manual_seed(5))
             out["splinenet%d_w" % mode] = w.numpy()
             out["splinenet%d_yw" % mode] = net(x[:1], w).numpy()
+    # cfg1 of BASELINE.json at its stated size: open SplineNet, ONE 700-point patch
+    # (configs/config_open_splines.yml:22-43, train_open_splines.py:152), with and without memberships
+    net = deterministic_init(ref_model.DGCNNControlPoints(20, num_points=10, mode=0)).eval()
+    pts, _ = synthetic.make_spline_patches(3, 1, 700, closed=False)
+    x = torch.from_numpy(pts.transpose(0, 2, 1).copy())
+    with torch.no_grad():
+        w = torch.rand(1, 700, generator=torch.Generator().manual_seed(6))
+        out.update(cfg1_x=x.numpy(), cfg1_y=net(x).numpy(), cfg1_w=w.numpy(), cfg1_yw=net(x, w).numpy())
     loss_obj = ref_sl.EmbeddingLoss(margin=1.0, if_mean_shift=False)
     net = deterministic_init(ref_pn.PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True,
                                                                num_primitives=10,
@@ -202,6 +210,27 @@ def main():
                parsenet_logp=logp.detach().numpy(), parsenet_embed_loss=eloss.detach().numpy(),
                parsenet_grad_seg2=net.mlp_seg_prob2.weight.grad.numpy().copy())
     save("networks", **out)
+
+    # ---- metrics and the torus distance: reference functions without another pin ----------------
+    # evaluate_miou (src/segment_loss.py:127-148) and ComputePrimitiveDistance.distance_from_torus
+    # (src/primitives.py:58-87; no caller in the training scripts, kept for API completeness)
+    rng = np.random.RandomState(12)
+    gt_l = rng.randint(0, 10, (3, 500))
+    pred_l = rng.randn(3, 500, 10).astype(np.float32)
+    pred_l[np.arange(3)[:, None], np.arange(500)[None], gt_l] += 1.5        # mostly right
+    gq = torch.Generator().manual_seed(13)
+    tp = torch.randn(400, 3, generator=gq)
+    axis = torch.tensor([0.3, -0.5, 0.8]).requires_grad_(True)
+    cen = torch.tensor([[0.1, 0.2, -0.3]]).requires_grad_(True)
+    R_, r_ = torch.tensor(0.9).requires_grad_(True), torch.tensor(0.25).requires_grad_(True)
+    d_red = ref_prim.ComputePrimitiveDistance(reduce=True).distance_from_torus(tp, [axis, cen, R_, r_])
+    d_red.backward()
+    d_pts = ref_prim.ComputePrimitiveDistance(reduce=False).distance_from_torus(tp, [axis, cen, R_, r_], sqrt=True)
+    save("metrics", miou_gt=gt_l.astype(np.int32), miou_pred=pred_l, miou=np.float64(ref_sl.evaluate_miou(gt_l, pred_l)),
+         torus_points=tp.numpy(), torus_axis=axis.detach().numpy(), torus_center=cen.detach().numpy(),
+         torus_R=np.float32(0.9), torus_r=np.float32(0.25), torus_mean=np.float32(d_red.item()),
+         torus_sqrt_per_point=d_pts.detach().numpy(), torus_g_axis=axis.grad.numpy(), torus_g_center=cen.grad.numpy(),
+         torus_g_R=np.float32(R_.grad.item()), torus_g_r=np.float32(r_.grad.item()))
 
     # ---- mean shift ---------------------------------------------------------------------------
     # 2500 points in 6 well separated clusters: K = int(0.025 * 10000) = 250 stays inside a cluster.
@@ -448,7 +477,13 @@ def main():
     # replaced by the oracle's restatement of that published algorithm — the one step of this
     # fixture that is not the reference's own arithmetic (oracle/ref_fitting.py says so).
     from oracle import ref_fitting as RF
-    ref_pf.remove_outliers = RF.remove_outliers
+    removed = []
+
+    def counted_remove_outliers(points, viz=False):
+        kept = RF.remove_outliers(points)
+        removed.append((int(points.shape[0]), int(kept.shape[0])))
+        return kept
+    ref_pf.remove_outliers = counted_remove_outliers
     # predicted primitive types: piecewise-constant per ground-truth segment so that spline and
     # analytic branches are both taken
     seg_types = np.array([2, 1, 9, 4, 5, 3, 0, 8])
@@ -470,6 +505,13 @@ def main():
     for k in sorted(kinds_e):
         if kinds_e[k] in ("open-spline", "closed-spline"):
             arrays["recon_%d" % k] = params_e[k][1].detach().numpy().astype(np.float32)
+    # Which arrays passed through the restated open3d step: the spline segments' reconstructions, the
+    # spline mean and the total loss.  Cluster ids, segment kinds, both IoUs and the geometric mean
+    # (analytic primitives: src/primitive_forward.py:1000-1018 never calls remove_outliers) are the
+    # reference's own arithmetic end to end.  ``outlier_step`` records (points in, points kept) per call.
+    arrays["depends_on_restated_open3d"] = np.array(sorted(k for k in arrays if k.startswith("recon_")) +
+                                                    ["spline", "loss"])
+    arrays["outlier_step"] = np.array(removed, dtype=np.int32).reshape(-1, 2)
     save("e2e_eval", **arrays)
 
     # ---- data layer: the reference's generators and augmentation on synthetic arrays --------------

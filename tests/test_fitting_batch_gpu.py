@@ -319,7 +319,10 @@ def test_sixteen_groups_do_not_recycle_a_download_slot_before_it_is_read(gpu):
     torch.cuda.set_device(gpu)
     torch.manual_seed(0)
     B, N = 16, 1500
-    pts, nrm, lab, prim = synthetic.make_batch(40, B, N, min_segments=3, max_segments=4)
+    # planes, spheres and cones only: a SplineNet segment run at another batch size carries kNN near-tie
+    # flips (tests/golden/reference_noise_e2e.txt; measured here: one of 16 shapes 3.5e-2 apart), which
+    # would hide what this test is about
+    pts, nrm, lab, prim = synthetic.make_batch_ids(list(synthetic.ANALYTIC_WELL_POSED_IDS), N)
     g = torch.Generator().manual_seed(2)
     embs = []
     for b in range(B):
@@ -341,6 +344,10 @@ def test_sixteen_groups_do_not_recycle_a_download_slot_before_it_is_read(gpu):
         res = finish()
         out[chunks] = (loss_b.detach().clone(), [r[1][1] for r in res], [r[0][1] for r in res], [r[0][3] for r in res])
     assert all(np.array_equal(a, b) for a, b in zip(out[16][1], out[1][1]))           # cluster ids
-    assert float((out[16][0] - out[1][0]).abs().max()) <= 1e-6 * float(out[1][0].abs().max())
+    relerr = ((out[16][0] - out[1][0]).abs() / out[1][0].abs().clamp_min(1e-12)).cpu().numpy()
+    print("16 groups vs 1: per-shape loss rel", np.array2string(relerr, precision=2))
+    # (groups of one shape run the SplineNets on other batch sizes than the whole batch does: the
+    # batched-vs-shape-by-shape bar of test_batched_stage_equals_shape_by_shape applies)
+    assert float(relerr.max()) <= 2e-5
     for a, b in zip(out[16][2] + out[16][3], out[1][2] + out[1][3]):                    # metrics from the deferred download
-        assert (a is None and b is None) or abs(a - b) <= 1e-6 * max(abs(b), 1e-12)
+        assert (a is None and b is None) or abs(a - b) <= 2e-5 * max(abs(b), 1e-12)

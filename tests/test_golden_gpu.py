@@ -73,6 +73,78 @@ def test_networks(gpu):
     assert rel(net.mlp_seg_prob2.weight.grad, g["parsenet_grad_seg2"]) < 1e-3
 
 
+def test_cfg1_open_splinenet_single_700_point_patch(gpu):
+    """cfg1 of BASELINE.json at its stated size (configs/config_open_splines.yml:22-43,
+    train_open_splines.py:152): ONE 700-point patch through the open SplineNet in evaluation mode,
+    with and without per-point memberships (src/model.py:165-167), against the reference's output —
+    control points at the north star's 1e-5.  Also through the frozen fast path of the fitting stage."""
+    from src.model import DGCNNControlPoints
+    from tests.golden.common import deterministic_init
+    g = load("networks")
+    net = deterministic_init(DGCNNControlPoints(20, num_points=10, mode=0)).eval().to(gpu)
+    x, w = torch.from_numpy(g["cfg1_x"]).to(gpu), torch.from_numpy(g["cfg1_w"]).to(gpu)
+    assert tuple(x.shape) == (1, 3, 700)
+    with torch.no_grad():
+        y, yw = net(x), net(x, w)
+    assert tuple(y.shape) == (1, 400, 3)
+    assert rel(y, g["cfg1_y"]) < 1e-5 and rel(yw, g["cfg1_yw"]) < 1e-5
+    for p_ in net.parameters():                 # frozen network: fused affine / weighted-max head
+        p_.requires_grad = False
+    wg = w.clone().requires_grad_(True)
+    ywf = net(x, wg)
+    assert rel(ywf, g["cfg1_yw"]) < 1e-5
+    ywf.sum().backward()
+    assert torch.isfinite(wg.grad).all() and float(wg.grad.abs().sum()) > 0
+
+
+def test_torus_distance_against_the_reference(gpu):
+    """ComputePrimitiveDistance.distance_from_torus (src/primitives.py:58-87): value, per-point form
+    and the gradient with respect to axis / centre / radii against the reference's own."""
+    from src.primitives import ComputePrimitiveDistance
+    g = load("metrics")
+    P = torch.from_numpy(g["torus_points"]).to(gpu)
+    axis = torch.from_numpy(g["torus_axis"]).to(gpu).requires_grad_(True)
+    cen = torch.from_numpy(g["torus_center"]).to(gpu).requires_grad_(True)
+    R_ = torch.tensor(float(g["torus_R"]), device=gpu, requires_grad=True)
+    r_ = torch.tensor(float(g["torus_r"]), device=gpu, requires_grad=True)
+    d = ComputePrimitiveDistance(reduce=True).distance_from_torus(P, [axis, cen, R_, r_])
+    d.backward()
+    assert abs(float(d) - float(g["torus_mean"])) <= 1e-5 * float(g["torus_mean"])
+    assert rel(axis.grad, g["torus_g_axis"]) < 1e-4 and rel(cen.grad, g["torus_g_center"]) < 1e-4
+    assert abs(float(R_.grad) - float(g["torus_g_R"])) <= 1e-4 * abs(float(g["torus_g_R"]))
+    assert abs(float(r_.grad) - float(g["torus_g_r"])) <= 1e-4 * abs(float(g["torus_g_r"]))
+    per = ComputePrimitiveDistance(reduce=False).distance_from_torus(P, [axis.detach(), cen.detach(), R_.detach(),
+                                                                        r_.detach()], sqrt=True)
+    assert rel(per, g["torus_sqrt_per_point"]) < 1e-5
+
+
+def test_statistical_outlier_removal_on_a_hand_computable_cloud(gpu):
+    """remove_outliers stands for open3d 0.9's remove_statistical_outlier(nb_neighbors=20, std_ratio=0.5)
+    (src/fitting_utils.py:704-710; open3d is absent: parity unpinned for this one step).  Its documented
+    semantics on a cloud whose answer is computed by hand: 40 points on the integer lattice of a line
+    plus two stragglers.  Mean distance to the 20 nearest neighbours INCLUDING the point itself:
+    interior points (0 + 2 (1 + ... + 9) + 10) / 20 = 5, growing to (0 + 1 + ... + 19) / 20 = 9.5 at the
+    two ends; the stragglers far above.  Threshold = mean + 0.5 std (Bessel) of those means."""
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd.fitting import remove_outliers
+    line = np.stack([np.arange(40.0), np.zeros(40), np.zeros(40)], 1)
+    cloud = np.concatenate([line, [[200.0, 0, 0], [0.0, 300.0, 0]]]).astype(np.float32)
+    # by hand: the mean neighbour distance of lattice point i (its 20 nearest lattice points, itself included)
+    avg = []
+    for i in range(40):
+        d = np.sort(np.abs(np.arange(40) - i))[:20]
+        avg.append(d.sum() / 20.0)
+    avg.append(np.sort(np.abs(200.0 - np.arange(40)))[:19].sum() / 20.0)             # itself + 19 lattice points
+    avg.append(np.sort(np.sqrt(300.0 ** 2 + np.arange(40.0) ** 2))[:19].sum() / 20.0)
+    avg = np.array(avg)
+    assert avg[20] == 5.0 and avg[0] == 9.5
+    thr = avg.mean() + 0.5 * avg.std(ddof=1)
+    want = cloud[avg < thr]
+    assert 0 < want.shape[0] < 42 and not (want == cloud[40]).all(1).any() and not (want == cloud[41]).all(1).any()
+    assert np.array_equal(RF.remove_outliers(cloud).astype(np.float32), want)
+    assert np.array_equal(remove_outliers(torch.from_numpy(cloud).to(gpu)).cpu().numpy(), want)
+
+
 def test_mean_shift(gpu):
     from src.mean_shift import MeanShift
     g = load("mean_shift")
@@ -251,7 +323,10 @@ def test_end_to_end_fitting_loss_eval_mode(gpu):
             if "recon_%d" % k in g.files:
                 assert rel(params[k][1], g["recon_%d" % k]) < 2e-4, k
     assert abs(loss[0].item() - float(g["loss"])) / float(g["loss"]) < tol
-    assert abs(loss[1] - float(g["geo"])) / float(g["geo"]) < tol
+    # the analytic primitives never pass through the restated open3d step (the fixture lists what does:
+    # g["depends_on_restated_open3d"]): the reference's own arithmetic, held to 1e-4
+    assert "geo" not in set(g["depends_on_restated_open3d"].tolist())
+    assert abs(loss[1] - float(g["geo"])) / float(g["geo"]) < (1e-4 if same_numbering else tol)
     assert abs(loss[2] - float(g["spline"])) / float(g["spline"]) < tol
 
 

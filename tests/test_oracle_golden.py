@@ -55,6 +55,31 @@ def test_networks():
     assert rel(net.mlp_seg_prob2.weight.grad, g["parsenet_grad_seg2"]) < 1e-4
 
 
+def test_cfg1_single_patch_and_metrics():
+    """cfg1 at its stated size (1 x 700 points, open SplineNet) on the oracle, and the reference's
+    evaluate_miou (src/segment_loss.py:127-148) against the product's host-side restatement."""
+    from oracle import ref_torch as R
+    from parsenet_codebase_amd.losses import evaluate_miou
+    from tests.golden.common import deterministic_init
+    g = load("networks")
+    net = deterministic_init(R.DGCNNControlPoints(20, num_points=10, mode=0)).eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["cfg1_x"]))
+        yw = net(torch.from_numpy(g["cfg1_x"]), torch.from_numpy(g["cfg1_w"]))
+    assert tuple(y.shape) == (1, 400, 3)
+    assert rel(y, g["cfg1_y"]) < 1e-5 and rel(yw, g["cfg1_yw"]) < 1e-5
+    m = load("metrics")
+    got = evaluate_miou(m["miou_gt"].astype(np.int64), m["miou_pred"])
+    assert abs(got - float(m["miou"])) < 1e-12
+    e = load("e2e_eval")
+    # the fixture names what passed through the restated open3d step: spline reconstructions, the spline
+    # mean and the total; everything else in it is the reference's own arithmetic
+    dep = set(e["depends_on_restated_open3d"].tolist())
+    assert {"spline", "loss"} <= dep and all(k in dep for k in e.files if k.startswith("recon_"))
+    assert not {"geo", "s_iou", "p_iou", "cluster_ids", "seg_kinds"} & dep
+    assert (e["outlier_step"][:, 1] <= e["outlier_step"][:, 0]).all()
+
+
 def test_mean_shift():
     from oracle import ref_torch as R
     g = load("mean_shift")
