@@ -158,14 +158,15 @@ customsvd = CustomSVD.apply
 
 
 def weights_normalize(weights, bw):
-    """src/fitting_utils.py:306-325: soft memberships (C,N) from centre/point dot products."""
-    prob = guard_exp(weights / (bw ** 2) / 2)
-    prob = prob / torch.sum(prob, 0, keepdim=True)
-    if weights.shape[0] == 1:
-        return prob
-    prob = prob - torch.min(prob, 1, keepdim=True)[0]
-    prob = prob / (torch.max(prob, 1, keepdim=True)[0] + EPS)
-    return prob
+    """src/fitting_utils.py:306-325: soft memberships (C,N) from centre/point dot products.
+    One item of the padded batch form the training path uses (fitting_batch.weights_normalize_batch:
+    exponent, column normalisation over the clusters, per-cluster min-shift / max-scale)."""
+    from .fitting_batch import weights_normalize_batch
+    C = weights.shape[0]
+    dev = weights.device
+    bwt = bw if torch.is_tensor(bw) else torch.tensor(float(bw), device=dev)
+    ncl = torch.full((1,), C, dtype=torch.int64, device=dev)
+    return weights_normalize_batch(weights.unsqueeze(0), bwt.reshape(1).to(weights.dtype), ncl)[0]
 
 
 def to_one_hot(target, maxx=50, device_id=0):
@@ -250,26 +251,16 @@ def pca_torch(X):
 
 def standardize_point_torch(point, weights):
     """src/fitting_utils.py:512-553: centre on the confident points, rotate the minor PCA axis to
-    +x, scale by the weighted extent.  Returns (point, std (1,3), mean (3), R (3,3))."""
-    higher_indices = weights[:, 0] > 0.8
-    if torch.sum(higher_indices) < 400:
-        if weights.shape[0] >= 7500:
-            _, higher_indices = torch.topk(weights[:, 0], weights.shape[0] // 4)
-        else:
-            _, higher_indices = torch.topk(weights[:, 0], weights.shape[0] // 2)
-    weighted_points = point[higher_indices] * weights[higher_indices]
-    mean = torch.sum(weighted_points, 0) / (torch.sum(weights[higher_indices]) + EPS)
-    point = point - mean
-    S, U = pca_torch(point[higher_indices])
-    smallest_ev = U[:, torch.min(S[:, 0], 0)[1]].numpy()
-    R = rotation_matrix_a_to_b(smallest_ev, np.array([1, 0, 0])).astype(np.float32)
-    R = torch.from_numpy(R).to(point.device).detach()
-    point = torch.transpose(R @ torch.transpose(point, 1, 0), 1, 0)
-    weighted_points = point[higher_indices] * weights[higher_indices]
-    std = torch.abs(torch.max(weighted_points, 0)[0] - torch.min(weighted_points, 0)[0])
-    std = std.reshape((1, 3)).detach()
-    point = point / (std + EPS)
-    return point, std, mean, R
+    +x, scale by the weighted extent.  point (n,3), weights (n,1) -> (point, std (1,3), mean (3),
+    R (3,3)).  The batched stage's routine with one segment (fitting_batch.standardize_segments:
+    selection mask, weighted mean, covariance on the device, the reference's host geev for the
+    axis sign, extent of the weighted selected points); every caller of the reference runs it
+    under no_grad (src/primitive_forward.py:39-40, :358-359), so do the results here."""
+    from .fitting_batch import standardize_segments
+    require_cuda(point, weights)
+    pts, std, mean, R = standardize_segments(point.detach().reshape(1, -1, 3).float(),
+                                             weights.detach().reshape(1, -1).float())
+    return pts[0], std[0].reshape((1, 3)), mean[0], R[0]
 
 
 def standardize_points_torch(points, weights):
@@ -435,47 +426,47 @@ def _restore(points_std, scale, R, mean):
     return torch.transpose(tmp, 1, 0) + mean
 
 
+def _spline_segment(input_points_, control_decoder, nu, nv, weights, wrap):
+    """The spline branch of the batched fitting stage with ONE segment (fitting_batch.py: standardise,
+    SplineNet, pn_bspline_eval_f32 with the de-standardisation x * std -> R^-1 -> + mean folded into
+    its affine map and, for closed surfaces, the first sample row appended again).  Returns
+    (samples (1, G*G or (G+1)*G, 3), control grid (1,20,20,3) in the standardised frame, the affine
+    map (1,3,4))."""
+    from .fitting_batch import _BSplineEval, standardize_segments
+    require_cuda(input_points_, weights)
+    if input_points_.shape[0] != 1:
+        raise ValueError("spline forward pass: one segment per call (got a batch of %d)" % input_points_.shape[0])
+    dev = input_points_.device
+    nu, nv = nu.to(dev), nv.to(dev)
+    w = weights.reshape(1, -1)
+    pts_std, std, mean, R = standardize_segments(input_points_.detach().float(), w.detach().float())
+    affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
+    ctrl = control_decoder(pts_std.permute(0, 2, 1).contiguous(), w).reshape(1, 20, 20, 3)
+    return _BSplineEval.apply(ctrl, nu, nv, affine, wrap), ctrl, affine
+
+
 def forward_pass_open_spline(input_points_, control_decoder, nu, nv, viz=False, weights=None,
                              if_optimize=True):
-    """Standardise -> SplineNet (open, 20x20 grid) -> evaluate on (nu, nv) -> de-standardise.
-    input_points_ (1,n,3), weights (n,1).  Returns (samples, samples) like the reference."""
-    nu, nv = nu.to(input_points_.device), nv.to(input_points_.device)
-    with torch.no_grad():
-        points_, scales, means, RS = standardize_points_torch(input_points_, weights)
-    batch_size = points_.shape[0]
-    output = control_decoder(points_.permute(0, 2, 1), weights.T)
-    reconstructed_points = sample_points_from_control_points_(nu, nv, output, batch_size)
-    output = output.view(1, 400, 3)
-    rec = torch.stack([_restore(reconstructed_points[b].clone(), scales[b], RS[b], means[b])
-                       for b in range(batch_size)], 0)
+    """src/primitive_forward.py:34-85: standardise -> SplineNet (open, 20 x 20 grid) -> evaluate on
+    (nu, nv) -> de-standardise.  input_points_ (1,n,3), weights (n,1).  Returns (samples, samples)."""
+    rec, ctrl, affine = _spline_segment(input_points_, control_decoder, nu, nv, weights, False)
     if if_optimize:
-        ctrl = torch.stack([_restore(output[b], scales[b], RS[b], means[b]) for b in range(batch_size)], 0)
-        rec = optimize_open_spline_kronecker(rec, input_points_, ctrl, deform=True)
+        grid = ctrl.reshape(1, 400, 3) @ affine[:, :, :3].transpose(1, 2) + affine[:, :, 3].unsqueeze(1)
+        rec = optimize_open_spline_kronecker(rec, input_points_, grid, deform=True)
     return rec, rec
 
 
 def forward_closed_splines(input_points_, control_decoder, nu, nv, viz=False, weights=None,
                            if_optimize=True):
-    """Closed (u-periodic) variant: the first sample row is appended again (31 x 30 = 930 points).
-    Returns (samples (1,930,3), None, samples)."""
-    batch_size = input_points_.shape[0]
-    nu, nv = nu.to(input_points_.device), nv.to(input_points_.device)
-    with torch.no_grad():
-        points_, scales, means, RS = standardize_points_torch(input_points_, weights)
-    output = control_decoder(points_.permute(0, 2, 1), weights.T)
-    reconstructed_points = sample_points_from_control_points_(nu, nv, output, batch_size)
-    closed = []
-    for b in range(batch_size):
-        tmp = _restore(reconstructed_points[b].clone(), scales[b], RS[b], means[b]).reshape((30, 30, 3))
-        closed.append(torch.cat([tmp, tmp[0:1]], 0))
-    rec = torch.stack(closed, 0).reshape((1, 930, 3))
+    """src/primitive_forward.py:347-397, closed (u-periodic) variant: the first sample row is appended
+    again (31 x 30 = 930 points).  Returns (samples (1,930,3), None, samples)."""
+    rec, ctrl, affine = _spline_segment(input_points_, control_decoder, nu, nv, weights, True)
     if if_optimize and input_points_.shape[1] > 200:
-        # src/primitive_forward.py:389-410: the control grid is closed in u the same way
-        # (21 x 20) and restored to the input frame before the refit
-        ctrl = output.view(batch_size, 20, 20, 3)
-        ctrl = torch.cat([ctrl, ctrl[:, 0:1]], 1).reshape(batch_size, 21 * 20, 3)
-        ctrl = torch.stack([_restore(ctrl[b], scales[b], RS[b], means[b]) for b in range(batch_size)], 0)
-        rec = optimize_close_spline_kronecker(rec, input_points_, ctrl)
+        # :389-410: the control grid is closed in u the same way (21 x 20) and restored to the input
+        # frame before the refit
+        grid = torch.cat([ctrl, ctrl[:, 0:1]], 1).reshape(1, 21 * 20, 3)
+        grid = grid @ affine[:, :, :3].transpose(1, 2) + affine[:, :, 3].unsqueeze(1)
+        rec = optimize_close_spline_kronecker(rec, input_points_, grid)
     return rec, None, rec
 
 
@@ -584,61 +575,79 @@ def initialize_closed_spline_model(modelname, mode):
 # ---------------------------------------------------------------------------------------
 # weighted primitive fits (src/primitive_forward.py:708-843)
 # ---------------------------------------------------------------------------------------
+class _PrimitiveFit(torch.autograd.Function):
+    """Closed-form fit of ONE analytic primitive to a weighted cloud: the batched stage's kernels
+    (csrc/fitbatch.hip: 60 weighted moments in one pass over the points, the 3 x 3 algebra of
+    src/primitive_forward.py:708-843 on dual numbers in fp64, the cone's second pass) with a table
+    of one segment.  W (n,) weights -> params (16,) fp64; backward: the stored Jacobian
+    d params / d moments folded into the adjoint moment pass.  Points and normals are data."""
+
+    @staticmethod
+    def forward(ctx, W, P, Nrm, code):
+        dev = P.device
+        n = P.shape[0]
+        P3, N3, W3 = P.reshape(1, n, 3).contiguous(), Nrm.reshape(1, n, 3).contiguous(), W.reshape(1, 1, n).contiguous()
+        zero = torch.zeros(1, dtype=torch.int32, device=dev)
+        typ = torch.full((1,), int(code), dtype=torch.int32, device=dev)
+        rows = torch.full((1,), n, dtype=torch.int32, device=dev)
+        partial = K.weighted_moments(P3, N3, W3, zero, zero, 1, 0.0)
+        params, jac, status = K.primitive_fit(partial, typ, rows)
+        cone_direct = K.cone_angle(P3, W3, zero, zero, typ, status, params, jac, 1, 0.0)
+        ctx.save_for_backward(P3, N3, W3, zero, typ, params, jac, cone_direct)
+        ctx.mark_non_differentiable(status)
+        return params[0], status
+
+    @staticmethod
+    def backward(ctx, gparams, _gs):
+        P3, N3, W3, zero, typ, params, jac, cone_direct = ctx.saved_tensors
+        one = torch.ones(1, dtype=torch.float32, device=P3.device)
+        gW = K.weighted_moments_bwd(P3, N3, W3, zero, zero, typ, one, gparams.reshape(1, -1).double().contiguous(), jac,
+                                    params, cone_direct, 1, 0.0)
+        return gW.reshape(-1), None, None, None
+
+
 class Fit:
+    """src/primitive_forward.py:700-843.  points (n,3), normals (n,3), weights (n,1); the results are
+    differentiable with respect to the weights (the only differentiable input on every path of the
+    reference: points and normals are data)."""
+
     def __init__(self):
         self.lstsq = LeastSquares().lstsq
         self.parameters = {}
 
+    @staticmethod
+    def _fit(code, points, normals, weights):
+        require_cuda(points, weights)
+        if points.requires_grad or (normals is not None and normals.requires_grad):
+            raise RuntimeError("Fit: points / normals are data on this path (no gradient with respect to them); "
+                               "detach them")
+        nrm = points if normals is None else normals
+        params, status = _PrimitiveFit.apply(weights.reshape(-1).float(), points.detach().float(),
+                                             nrm.detach().float(), code)
+        if int(status.item()) & 1:
+            raise RuntimeError("lstsq: non-finite design matrix / no full-rank ridge system")
+        return params.float()
+
     def fit_plane_torch(self, points, normals, weights, ids=0, show_warning=False):
-        """points (n,3), weights (n,1) -> unit normal a (1,3), offset d: a.x = d."""
-        weights_sum = torch.sum(weights) + EPS
-        X = points - torch.sum(weights * points, 0).reshape((1, 3)) / weights_sum
-        U, s, V = customsvd(weights * X)
-        a = torch.reshape(V[:, -1], (1, 3))
-        d = torch.sum(weights * (a @ points.permute(1, 0)).permute(1, 0)) / weights_sum
-        return a, d
+        """-> unit normal a (1,3), offset d: a.x = d."""
+        p = self._fit(K.PRIM_PLANE, points, normals, weights)
+        return p[0:3].reshape((1, 3)), p[3]
 
     def fit_sphere_torch(self, points, normals, weights, ids=0, show_warning=False):
-        N = weights.shape[0]
-        sum_weights = torch.sum(weights) + EPS
-        A = 2 * (-points + torch.sum(points * weights, 0) / sum_weights)
-        dot_points = weights * torch.sum(points * points, 1, keepdim=True)
-        normalization = torch.sum(dot_points) / sum_weights
-        Y = (dot_points - normalization).reshape((N, 1))
-        A = weights * A
-        Y = weights * Y
-        center = -self.lstsq(A, Y, 0.01).reshape((1, 3))
-        radius_square = torch.sum(weights[:, 0] * torch.sum((points - center) ** 2, 1)) / sum_weights
-        radius_square = torch.clamp(radius_square, min=1e-3)
-        return center, guard_sqrt(radius_square)
+        """-> centre (1,3), radius."""
+        p = self._fit(K.PRIM_SPHERE, points, normals, weights)
+        return p[0:3].reshape((1, 3)), p[3]
 
     def fit_cylinder_torch(self, points, normals, weights, ids=0, show_warning=False):
-        U, s, V = customsvd(weights * normals)
-        a = torch.reshape(V[:, -1], (3, 1))
-        a = a / (torch.norm(a, 2) + EPS)
-        prj_circle = points - ((points @ a).permute(1, 0) * a).permute(1, 0)
-        center, radius = self.fit_sphere_torch(prj_circle, normals, weights)
-        return a, center, radius
+        """-> axis (3,1), centre (1,3) on the axis, radius."""
+        p = self._fit(K.PRIM_CYLINDER, points, normals, weights)
+        return p[0:3].reshape((3, 1)), p[3:6].reshape((1, 3)), p[6]
 
     def fit_cone_torch(self, points, normals, weights, ids=0, show_warning=False):
-        N = points.shape[0]
-        A = weights * normals
-        Y = weights * torch.sum(normals * points, 1).reshape((N, 1))
-        sv, _ = _gram_spectrum(A)
-        if float(sv[0] / torch.clamp(sv[-1], min=1e-300)) > 1e5:
-            # ill-conditioned: the reference returns a null cone
-            dev = points.device
-            return (torch.zeros((1, 3), device=dev), torch.tensor([[1.0, 0.0, 0.0]], device=dev),
-                    torch.zeros(1, device=dev))
-        c = self.lstsq(A, Y, lamb=1e-3)
-        a, _ = self.fit_plane_torch(normals, None, weights)
-        # normals point outside, the axis inside the cone
-        a = torch.where(torch.sum(normals @ a.transpose(1, 0)) > 0, -a, a)
-        diff = torch.nn.functional.normalize(points - c.transpose(1, 0), p=2, dim=1)
-        diff = torch.clamp(torch.abs(diff @ a.transpose(1, 0)), max=0.999)
-        theta = torch.sum(weights * torch.acos(diff)) / (torch.sum(weights) + EPS)
-        theta = torch.clamp(theta, min=1e-3, max=3.142 / 2 - 1e-3)
-        return c, a, theta
+        """-> apex (3,1), axis (1,3), half angle; an ill-conditioned normal system gives the
+        reference's null cone (apex 0, axis +x, angle 0)."""
+        p = self._fit(K.PRIM_CONE, points, normals, weights)
+        return p[0:3].reshape((3, 1)), p[3:6].reshape((1, 3)), p[6]
 
 
 class FittingModule:
@@ -694,81 +703,67 @@ def _mask_index(mask, device):
     return h2d(np.nonzero(np.asarray(mask))[0], device)
 
 
+_CLOSED_TYPES, _OPEN_TYPES = (0, 9, 6, 7), (2, 8)
+# analytic types -> FittingModule method (src/primitive_forward.py:1000-1018)
+_ANALYTIC = {1: "forward_pass_plane", 3: "forward_pass_cone", 4: "forward_pass_cylinder", 5: "forward_pass_sphere"}
+# evaluation mode re-samples a spline segment into the range its SplineNet was trained on (:989-996, :1030-1036)
+_RESAMPLE = {"closed": (1400, 1800), "open": (1000, 1500)}
+
+
 def fit_one_shape_torch(data, fitter, weights, bw, eval=False, sample_points=False, if_optimize=False,
                         if_visualize=False):
-    """src/primitive_forward.py:925-1047.
-    Training mode: per matched segment pick the weight column, keep every 2nd point (every 4th for
-    analytic primitives), at most 4 splines per shape, skip segments under 20 (splines: 100)
-    points, dispatch on the ground-truth primitive type.
-    Evaluation mode: the segment's own points with its (hard) weights; spline segments have their
-    statistical outliers removed and are re-sampled to 1400-1800 (closed) / 1000-1500 (open)
-    points before the SplineNet; ``if_optimize`` adds the LS refit."""
+    """src/primitive_forward.py:925-1047, one matched segment after the other (the training loops use
+    the stage-wise form of the same rules, fitting_batch.build_segment_table).
+    Training mode: the segment's weight column over ALL points of the shape; every 2nd point is kept,
+    every 4th for analytic primitives; at most 4 spline segments per shape; segments under 20 points
+    (splines: 100) are recorded as None; the ground-truth modal type selects the fit.
+    Evaluation mode: the segment's own points with their (hard) weights; spline segments lose their
+    statistical outliers and are re-sampled into the SplineNet's range; ``if_optimize`` adds the LS
+    refit (closed: only for segments of more than 200 points)."""
     if sample_points or if_visualize:
         raise NotImplementedError("sample_points / if_visualize build open3d meshes for the viewer: out of "
                                   "scope of the hot path (SURVEY section 8)")
-    reconstructed_shape = []
     fitter.fitting.parameters = {}
-    gt_points = {}
-    spline_count = 0
-
-    def skip(label_index):
-        reconstructed_shape.append(None)
-        gt_points[label_index] = None
-        fitter.fitting.parameters[label_index] = None
-
-    for d in data:
-        points, normals, labels, gpoints, segment_indices, part_index = d
-        part_index, label_index = part_index
-        labels = int(labels)
-        Z = points.shape[0]
-        if not eval:
-            weight = weights[:, part_index:part_index + 1] + EPS
-            points, normals, weight = points[0::2], normals[0::2], weight[0::2]
-            if labels in [0, 2, 6, 7, 9, 8]:
-                spline_count += 1
-                if spline_count > 4:
-                    skip(label_index)
-                    continue
-            else:
-                points, normals, weight = points[0::2], normals[0::2], weight[0::2]
-        else:
+    gt_points, reconstructed_shape = {}, []
+    splines_seen = 0
+    for points, normals, seg_type, gpoints, segment_indices, (part_index, label_index) in data:
+        seg_type = int(seg_type)
+        kind = "closed" if seg_type in _CLOSED_TYPES else "open" if seg_type in _OPEN_TYPES else "analytic"
+        if kind == "analytic" and seg_type not in _ANALYTIC:
+            raise ValueError("unknown primitive type %r" % (seg_type,))
+        size_in = points.shape[0]
+        if eval:
             weight = weights[_mask_index(segment_indices, weights.device), part_index:part_index + 1] + EPS
-        if points.shape[0] < 20:
-            skip(label_index)
-            continue
-        if labels in [0, 9, 6, 7]:
-            if points.shape[0] < 100:
-                skip(label_index)
-                continue
-            if eval:
-                Z = points.shape[0]
-                points = remove_outliers(points)
-                weight = weight[0:points.shape[0]]
-                points, weight = up_sample_points_in_range(points, weight, 1400, 1800)
-            recon_points = fitter.forward_pass_closed_spline(points, weights=weight, ids=label_index,
-                                                             if_optimize=if_optimize and (Z > 200))
-        elif labels == 1:
-            recon_points = fitter.forward_pass_plane(points, normals, weight, ids=label_index)
-        elif labels == 3:
-            recon_points = fitter.forward_pass_cone(points, normals, weight, ids=label_index)
-        elif labels == 4:
-            recon_points = fitter.forward_pass_cylinder(points, normals, weight, ids=label_index)
-        elif labels == 5:
-            recon_points = fitter.forward_pass_sphere(points, normals, weight, ids=label_index)
-        elif labels in [2, 8]:
-            if points.shape[0] < 100:
-                skip(label_index)
-                continue
-            if eval:
-                points = remove_outliers(points)
-                weight = weight[0:points.shape[0]]
-                points, weight = up_sample_points_in_range(points, weight, 1000, 1500)
-            recon_points = fitter.forward_pass_open_spline(points, weights=weight, ids=label_index,
-                                                           if_optimize=if_optimize)
+            keep = None
         else:
-            raise ValueError("unknown primitive type %r" % (labels,))
+            weight = weights[:, part_index:part_index + 1] + EPS
+            keep = slice(0, None, 2 if kind != "analytic" else 4)
+        dropped = False
+        if not eval and kind != "analytic":
+            splines_seen += 1
+            dropped = splines_seen > 4                          # memory guard of the reference (:957-963)
+        if keep is not None and not dropped:
+            points, normals, weight = points[keep], normals[keep], weight[keep]
+        if dropped or points.shape[0] < (20 if kind == "analytic" else 100):
+            reconstructed_shape.append(None)
+            gt_points[label_index] = None
+            fitter.fitting.parameters[label_index] = None
+            continue
+        if kind == "analytic":
+            rec = getattr(fitter, _ANALYTIC[seg_type])(points, normals, weight, ids=label_index)
+        else:
+            if eval:
+                size_in = points.shape[0]
+                points = remove_outliers(points)
+                points, weight = up_sample_points_in_range(points, weight[0:points.shape[0]], *_RESAMPLE[kind])
+            if kind == "closed":
+                rec = fitter.forward_pass_closed_spline(points, weights=weight, ids=label_index,
+                                                        if_optimize=if_optimize and (size_in > 200))
+            else:
+                rec = fitter.forward_pass_open_spline(points, weights=weight, ids=label_index,
+                                                      if_optimize=if_optimize)
         gt_points[label_index] = gpoints
-        reconstructed_shape.append(recon_points)
+        reconstructed_shape.append(rec)
     return gt_points, reconstructed_shape
 
 
