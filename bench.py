@@ -165,6 +165,7 @@ def kernel_roofline(step, nprof):
     from parsenet_codebase_amd import mean_shift as _ms
     _lib.prof_reset()
     _lib.prof_enable(True)
+    _lib.meanshift_exec_tiles()                # clear the executed-work counters of the mean-shift kernels
     os.environ["PARSENET_MS_STATS"] = "1"      # active fractions of the block-sparse mean-shift plans
     plan_stats = []                            # one entry per profiled step: mean over its 10 iterations
     for _ in range(nprof):
@@ -176,6 +177,7 @@ def kernel_roofline(step, nprof):
     torch.cuda.synchronize()
     os.environ.pop("PARSENET_MS_STATS", None)
     _lib.prof_enable(False)
+    exec_pairs = dict(zip(("meanshift_fwd", "meanshift_bwd_rows", "meanshift_bwd_cols"), _lib.meanshift_exec_tiles()))
     res = _lib.prof_results()
     if not res:
         return None, {}
@@ -213,6 +215,15 @@ def kernel_roofline(step, nprof):
         ach = flops / avg_s / 1e12
         sparse = None
         executed = 1.0
+        UNITS = {"meanshift_fwd": 2, "meanshift_bwd_rows": 3, "meanshift_bwd_cols": 4}
+        PAIR_FLOP = 2.0 * 32 * 32 * 128              # one (resident tile, streamed tile) pair, one GEMM unit
+
+        def executed_tflops(fam):
+            """Piece-product FLOPs the launches of ``fam`` EXECUTED (counted by the kernels themselves:
+            csrc/meanshift_x3.h pn_ms3_exec) over the event time of the same launches."""
+            if fam not in table or not exec_pairs.get(fam):
+                return None
+            return exec_pairs[fam] * PAIR_FLOP * UNITS[fam] * 6.0 / (table[fam]["ms_total"] * 1e-3) / 1e12
         if _ms.ARITH == "bf16x3" and plan_stats:
             # block-sparse launches: the waves run the GEMMs of the tile pairs the plan keeps; the
             # others are rigorously below 1e-9 of the smallest row sum (csrc/meanshift_x3.h)
@@ -225,7 +236,10 @@ def kernel_roofline(step, nprof):
                       "steps_sampled": len(plan_stats),
                       "note": "fractions of the dense N^2 tile pairs, per profiled step (mean over its 10 "
                               "iterations); the profiled steps visit every batch of the timed pool once"}
-            executed = sparse["tile_pairs_executed"]["mean"]
+        if _ms.ARITH == "bf16x3" and exec_pairs.get(dom):
+            # share of the dense work the profiled launches executed: counted pairs / dense pairs
+            nt = (N + 31) // 32
+            executed = exec_pairs[dom] / float(table[dom]["calls"] * shapes_per_launch * nt * nt)
         if _ms.ARITH in ("bf16x3", "fp16x2"):
             # every fp32 product is formed from 6 bf16 (3 fp16) piece products on the 16-bit matrix
             # cores (fp32 accumulate).  `achieved` / `frac`: the piece-product FLOPs the launch EXECUTES
@@ -234,6 +248,8 @@ def kernel_roofline(step, nprof):
             # reference's dense fp32 iteration that this launch stands for is reported separately.
             pieces = 6.0 if _ms.ARITH == "bf16x3" else 3.0
             ach_exec = pieces * ach * executed
+            if _ms.ARITH == "bf16x3" and executed_tflops(dom) is not None:
+                ach_exec = executed_tflops(dom)          # counter-backed: executed work / the same launches' time
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach_exec, "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach_exec / MFMA_BF16_PEAK_TFLOPS,
                     "traffic": pmc_traffic(dom, _ms.ARITH, shapes_per_launch, planned=bool(plan_stats)),
@@ -246,6 +262,18 @@ def kernel_roofline(step, nprof):
                         "ratio": ach * pieces / MFMA_BF16_PEAK_TFLOPS,
                         "note": "SURVEY 8d work of the reference's dense iteration (units x 2 N^2 d per shape) / "
                                 "launch duration; exceeds 1 when the plan skips tile pairs — not a roofline fraction"}}
+            if _ms.ARITH == "bf16x3":
+                # all three passes, each from its own counter and its own launches' event time
+                roof["passes"] = {fam: {"frac": executed_tflops(fam) / MFMA_BF16_PEAK_TFLOPS,
+                                        "executed_tflops": executed_tflops(fam),
+                                        "avg_launch_ms": table[fam]["avg_ms"], "launches": table[fam]["calls"],
+                                        "tile_pairs_executed": exec_pairs[fam],
+                                        "share_of_dense_pairs": exec_pairs[fam] / float(
+                                            table[fam]["calls"] * shapes_per_launch * ((N + 31) // 32) ** 2)}
+                                  for fam in UNITS if executed_tflops(fam) is not None}
+                roof["executed_work"] = ("tile pairs counted inside the kernels (pn_meanshift_x3_exec_tiles) x 2*32*32*128 "
+                                         "FLOP x GEMM units (2/3/4) x 6 piece products / HIP-event time of the same "
+                                         "launches; = SQ_VALU_MFMA_BUSY_CYCLES / 32 x 32768 FLOP of a counter run")
             if sparse:
                 roof["block_sparse"] = sparse
         else:
@@ -418,6 +446,12 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="cfg5: skip the second timed run with dense mean-shift launches")
     ap.add_argument("--pretrain", type=int, default=2000,
                     help="cfg5: deterministic seg-only steps before the timed region (see workloads.ParsenetE2EStep)")
+    ap.add_argument("--profile-only", action="store_true",
+                    help="no timed runs: pre-train (or load PARSENET_PRETRAIN_CACHE), then ONLY the profiled pass over "
+                         "the pool with mean-shift launches of one kind (PARSENET_MS_SPARSE=1 planned / 0 dense; auto "
+                         "counts as planned) and print the line with `value` null — the process to put under "
+                         "rocprofv3: its kernel trace then holds the launches the roofline is quoted on, not the "
+                         "warm-up pass on a synthetic embedding or the other launch kind")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -482,20 +516,22 @@ def main():
     # batches of the pool have different segment counts, i.e. different tensor shapes in the fitting
     # stage, and the first visit of a shape pays for allocator growth and library heuristics that
     # belong to no steady-state step (the W warm-up steps the caller asks for follow as usual).
-    if hasattr(step, "warm_paths"):
+    if hasattr(step, "warm_paths") and not args.profile_only:
         step.warm_paths()
+    elif hasattr(step, "_warmed"):
+        step._warmed = True            # --profile-only: no warm-up pass on the synthetic embedding in the trace
     # everything allocated so far (modules, pools, compiled wrappers) is permanent: take it out of the
     # cyclic collector's generations so that a full collection in the middle of a step stays short
     import gc
     gc.collect()
     gc.freeze()
     start = snapshot()
-    if hasattr(step, "pool") and not stub:
+    if hasattr(step, "pool") and not stub and not args.profile_only:
         for _ in range(max(1, step.pool // step.batch)):
             step.step()
         sync()
         restore(start)
-    elapsed = timed_run()
+    elapsed = None if args.profile_only else timed_run()
 
     # cfg5: the same steps once more with every mean-shift launch dense (PARSENET_MS_SPARSE=0 at run
     # time): the block-sparse plans are data dependent, the dense value is their floor
@@ -507,7 +543,9 @@ def main():
         if _ms.ARITH == "bf16x3":
             ms_mode = _ms.SPARSE
             calls_timed = dict(_ms.CALLS)
-    if (ms_mode not in (None, False) and not args.no_dense) or stub:
+            if args.profile_only:          # no timed steps to take the kind from: the environment decides
+                calls_timed = {"planned": 0 if ms_mode is False else 1, "dense": 1 if ms_mode is False else 0}
+    if ((ms_mode not in (None, False) and not args.no_dense) or stub) and not args.profile_only:
         restore(start)
         if ms_mode is not None:
             _ms.SPARSE = False
@@ -567,7 +605,7 @@ def main():
         for _ in range(nprof):
             step.step()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub and not args.profile_only:
         cpu = cpu_baseline(args.workload, start["model"] if args.workload == "cfg5" else None,
                            "the GPU side's pre-trained state_dict" if args.workload == "cfg5" else "random-init weights")
     if world > 1:
@@ -581,13 +619,13 @@ def main():
         out = {
             "metric": ("shapes/sec fwd+bwd on 10k-pt clouds" if args.workload in ("cfg4", "cfg5")
                        else "shapes/sec fwd+bwd on 700-pt spline patches"),
-            "value": shapes / elapsed,
+            "value": None if elapsed is None else shapes / elapsed,
             "unit": "shapes/s",
             "n_gpus": world,
             "world_size_observed": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": None if elapsed is None else 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

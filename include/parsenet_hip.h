@@ -137,6 +137,13 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
  *              neighbours on the sphere).  Only a heuristic for locality; never affects results.
  */
 int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int* rank, void* stream);
+/* Executed work of the bf16 x 3 mean-shift launches, counted by the launches themselves: every wave
+ * counts the (resident 32-row tile, streamed 32-row tile) pairs whose GEMMs it runs (all pairs in a
+ * dense launch, the pairs the plan keeps in a planned one).  out3[0..2] = pairs executed by the
+ * forward / row-pass / column-pass launches since the previous call; reading clears the counters
+ * and synchronises with the device.  One pair is 2 * 32 * 32 * 128 FLOP per GEMM unit (2 / 3 / 4
+ * units) x 6 piece products on the bf16 matrix cores. */
+int pn_meanshift_x3_exec_tiles(unsigned long long* out3);
 size_t pn_meanshift_x3_plan_bytes(int B, int N);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, void* stream);
 int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,

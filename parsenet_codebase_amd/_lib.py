@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 10  # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 11  # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -62,6 +62,7 @@ SIGNATURES = {
     "pn_meanshift_x3_split_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_iter_fwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "pn_meanshift_x3_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
+    "pn_meanshift_x3_exec_tiles": (c_int, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "pn_meanshift_x3_plan_bytes": (c_size_t, [c_int, c_int]),
     "pn_meanshift_chain_order_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_tileinfo_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -337,6 +338,14 @@ def h2d(array, device):
     out = host.to(device, non_blocking=True)
     _PinnedRing.arm(slot)
     return out
+
+
+def meanshift_exec_tiles():
+    """(forward, row pass, column pass) tile pairs the bf16 x 3 mean-shift launches executed since the
+    last call — counted inside the kernels; reading clears the counters (and synchronises)."""
+    out = (ctypes.c_ulonglong * 3)()
+    check(load().pn_meanshift_x3_exec_tiles(out), "pn_meanshift_x3_exec_tiles")
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def prof_enable(on=True):

@@ -136,6 +136,15 @@ __device__ static inline int x3_cflag(const unsigned char* p) {   // one byte vi
 // burst behind the barrier (325 / 1 400 cycles per tile in which no wave issued an MFMA).
 // Vector-memory traffic of the loop is the DMA alone (plan data through scalar loads), and the
 // only vmcnt wait is the explicit one at the end of H1: the DMA has a whole half step to land.
+// Executed work, counted by the launches themselves: every wave counts the (resident 32-row tile,
+// streamed tile) pairs whose GEMMs it actually runs — all of them in a dense launch, the pairs its
+// plan keeps in a planned one — and adds the count to pn_ms3_exec[PASS] when it retires (one integer
+// atomic per wave and launch).  One pair = 2 * 32 * 32 * 128 FLOP per GEMM unit (forward 2, row pass
+// 3, column pass 4 units) x 6 bf16 piece products: bench.py divides this by the event time of the
+// same launches (pn_meanshift_x3_exec_tiles reads and clears the counters), and
+// SQ_VALU_MFMA_BUSY_CYCLES / 32 x 32 768 FLOP of a counter run reproduces it.
+__device__ unsigned long long pn_ms3_exec[3];
+
 template <int PASS, int MODE>
 __global__ __launch_bounds__(64 * X3_WAVES(PASS))
 __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void pn_ms3_kernel(
@@ -199,6 +208,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     fblk = lo;
     S = sstride;
   }
+  int nexec = 0;   // tile pairs this wave executes (wave-uniform)
   for (bool first_seg = true;; first_seg = false) {   // list fragments (exactly one without a flat plan)
   int b = blockIdx.z, rblk = blockIdx.y, slice = blockIdx.x;
   // block-sparse plan (pn_meanshift_x3_plan_f32): the streamed tiles this workgroup's resident
@@ -377,6 +387,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
     // matrix pipe during the elementwise stage, and the pipelining registers would spill)
     constexpr bool PIPE = PASS != 0;      // elementwise stage in two halves around k-step 0
     if (wave_on && pair_on) {
+      ++nexec;
       // ---- first GEMM: S[streamed][resident] (and T with the second operand) ----
       // ping-pong issue priorities (s_setprio; the elementwise stages run at 0):
       //   forward:  first GEMM 2 > second GEMM 0 — the wave in H1 takes the matrix pipe, drops back
@@ -700,6 +711,17 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
   ++fblk;
   while (offs[fblk + 1] <= e_lo) ++fblk;  // empty lists
   }
+  if (lane == 0 && nexec) atomicAdd(&pn_ms3_exec[PASS], (unsigned long long)nexec);
+}
+
+// executed tile pairs of the forward / row / column launches since the last call (read and cleared;
+// synchronises with the device)
+extern "C" int pn_meanshift_x3_exec_tiles(unsigned long long* out3) {
+  PN_CHECK_ARG(out3, "pn_meanshift_x3_exec_tiles: null pointer");
+  const unsigned long long zero[3] = {0, 0, 0};
+  PN_CHECK_HIP(hipMemcpyFromSymbol(out3, HIP_SYMBOL(pn_ms3_exec), sizeof(zero)));
+  PN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pn_ms3_exec), zero, sizeof(zero)));
+  return PN_OK;
 }
 
 extern "C" size_t pn_meanshift_x3_image_bytes(int B, int N) {
