@@ -636,6 +636,9 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels": {k: round(v["avg_ms"], 4) for k, v in sorted(table.items())},
+            # the same families as GPU milliseconds per step (avg launch x launches per step; launches in brackets)
+            "kernel_ms_per_step": {k: [round(v["ms_total"] / max(nprof, 1), 3), round(v["calls"] / max(nprof, 1), 1)]
+                                   for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_total"])},
         }
         if getattr(step, "skipped_steps", 0):
             # a rank's fitting stage raised: the step was dropped on EVERY rank (no reduction, no

@@ -724,6 +724,17 @@ extern "C" int pn_meanshift_x3_exec_tiles(unsigned long long* out3) {
   return PN_OK;
 }
 
+#include "meanshift_rows2.h"
+
+// PN_MS_ROWS2=1: the row pass with the tile split between the two waves of a SIMD
+// (meanshift_rows2.h) — built and measured in round 4, SLOWER than the one-wave kernel
+// (profiles/r04_rows2_ab.txt: 1.96 against 1.47 ms per launch of 4 shapes; a first version that
+// duplicated the elementwise stage 1.59), hence not the default (0).  Same results to fp32 rounding.
+static int x3_rows2() {   // read at every call (tests switch it within one process)
+  const char* e = getenv("PN_MS_ROWS2");
+  return e ? atoi(e) : 0;
+}
+
 extern "C" size_t pn_meanshift_x3_image_bytes(int B, int N) {
   const int Np = (int)pn_align_up(N, 64);
   return (size_t)B * (Np / 32) * X3_IMG_U4 * 16;
@@ -1445,6 +1456,11 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
     const int* offs_x = pv.offs + (size_t)B * (pv.nb0 + pv.nb1) + 2;
     {
       PN_PROF("meanshift_bwd_rows", stream);
+      if (x3_rows2())
+        hipLaunchKernelGGL(pn_ms3_rows2_kernel, dim3(pv.G), dim3(64 * R2_WAVES), 0, stream, q, (const float*)gu,
+                           (const u32x4*)img_x, (const float*)cs, (const float*)alpha, bsq, N, ntiles, 0, opart_q,
+                           pv.pairs, pv.lists, offs_q, pv.nblk, pv.nb0, pv.nb1, B * pv.nb1, pv.cmin, pv.smax);
+      else
       X3_LAUNCH_PP(1, dim3(pv.G), dim3(64 * X3_WAVES(1)), stream, q, (const float*)gu,
                          (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N, ntiles, 0,
                          opart_q, nullptr, pv.pairs, pv.counts, pv.lists, offs_q, pv.nblk, pv.nb0, pv.nb1,
@@ -1479,6 +1495,11 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
   {
     PN_PROF("meanshift_bwd_rows", stream);
     dim3 grid(S, pn_cdiv(N, 32 * X3_WAVES(1)), B);
+    if (x3_rows2())
+      hipLaunchKernelGGL(pn_ms3_rows2_kernel, grid, dim3(64 * R2_WAVES), 0, stream, q, (const float*)gu,
+                         (const u32x4*)img_x, (const float*)cs, (const float*)alpha, bsq, N, ntiles, tps, opart_q,
+                         nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0);
+    else
     X3_LAUNCH_PP(1, grid, dim3(64 * X3_WAVES(1)), stream, q, (const float*)gu,
                        (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N,
                        ntiles, tps, opart_q, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0);

@@ -378,6 +378,38 @@ def test_pingpong_schedule_is_bit_identical(gpu, tmp_path):
     assert np.isfinite(res["0"]["g1"]).all() and float(np.abs(res["0"]["g1"]).max()) > 0
 
 
+@pytest.mark.parametrize("N,B", [(4100, 2), (10000, 1), (2049, 3)])
+def test_paired_row_pass_equals_the_one_wave_kernel(gpu, N, B, monkeypatch):
+    """csrc/meanshift_rows2.h (round 4, opt-in: measured slower than the one-wave kernel): the row pass
+    of the backward with a resident tile split between the two waves of a SIMD — one forms S, the other
+    T, they swap halves through LDS, each evaluates half of the elementwise stage and runs one k-step
+    of the second GEMM.  The same products in another fixed order: ten differentiated iterations agree
+    with the one-wave kernel to fp32 rounding and are reproducible bit for bit, with planned and with
+    dense launches; N not a multiple of 128: resident tiles without rows."""
+    import parsenet_codebase_amd.mean_shift as MS
+    torch.cuda.set_device(gpu)
+    g = torch.Generator().manual_seed(N)
+    proto = torch.nn.functional.normalize(torch.randn(7, 128, generator=g), dim=1)
+    lab = torch.randint(0, 7, (B, N), generator=g)
+    X = torch.nn.functional.normalize(proto[lab] + 0.3 * torch.randn(B, N, 128, generator=g) / np.sqrt(128), dim=2).to(gpu)
+    W = torch.randn(B, N, 128, generator=g).to(gpu)
+    bw = torch.full((B,), 0.17, device=gpu)
+    for sparse in (True, False):
+        monkeypatch.setattr(MS, "SPARSE", sparse)
+        got = {}
+        for mode in ("0", "1", "1b"):
+            monkeypatch.setenv("PN_MS_ROWS2", mode[0])
+            x = X.clone().requires_grad_(True)
+            y = MS.mean_shift_iterations(x, bw, 10)
+            (y * W).sum().backward()
+            got[mode] = (y.detach().clone(), x.grad.clone())
+        assert torch.equal(got["0"][0], got["1"][0])                       # the forward pass is untouched
+        assert torch.equal(got["1"][1], got["1b"][1])                      # reproducible
+        gmax = float(got["0"][1].abs().max())
+        assert float((got["0"][1] - got["1"][1]).abs().max()) <= 2e-6 * gmax
+        assert torch.isfinite(got["1"][1]).all() and gmax > 0
+
+
 def test_tile_caps_contain_their_rows_and_the_plan_keeps_every_heavy_pair(gpu):
     """Rigour of the block-sparse plan, checked by brute force on a clustered cloud whose tiles
     straddle clusters (N not a multiple of 32, natural order = no locality at all for half of it):
