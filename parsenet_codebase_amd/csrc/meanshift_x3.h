@@ -762,9 +762,14 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 //   any pair (q in tile A, x in tile B):  cos(min(pi, th + rA + rB)) <= q.x <= cos(max(0, th - rA - rB)),
 //   th = angle(c_A, c_B).
 // For a row tile A of the resident side, L_A = max_B cos(th + rA + rB) bounds every row's BEST
-// dot product from below, hence r_i >= exp((L_A - 1) / b^2) for all its rows; tile B is needed iff
-//   U_AB >= L_A - b^2 * log(N / 1e-9)      (N terms of at most exp((U-1)/b^2) against r_i).
-// The tile that attains L_A always passes, so no row sum can vanish.  pairs[tQ][tX] holds the
+// dot product from below, hence r_i >= exp((L_A - 1) / b^2) for all its rows.  What may be dropped
+// for A is any set D of caps whose terms together stay below rel_eps of that:
+//   sum_{B in D} 32 exp((U_AB - L_A) / b^2) <= rel_eps        (a cap holds at most 32 rows).
+// Round 4: D = the caps with U_AB < t_A for the LARGEST threshold t_A that satisfies this (found per
+// cap A by bisection over the row of U values, pn_ms3_thr_kernel) — the mass actually dropped, not
+// "all N points at the bound of the nearest dropped cap" (rounds 2-3: U_AB >= L_A - b^2 log(N / rel_eps)),
+// which keeps 4-6 points of a hundred fewer tile pairs on the benchmark's embedding
+// (tools/plan_mass_probe.py).  The cap that attains L_A always passes, so no row sum can vanish.  pairs[tQ][tX] holds the
 // predicate; the lists hold, per resident block of every pass, the streamed tiles with at least
 // one pair set (pass 0 / 1: blocks of 8 / 4 q tiles against x tiles; pass 2: blocks of 8 x tiles
 // against q tiles).
@@ -932,7 +937,8 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
                                                           const float* __restrict__ rhoX,
                                                           const float* __restrict__ bsq, int ntiles,
                                                           float logterm, float* __restrict__ pm,
-                                                          unsigned char* __restrict__ pairs) {
+                                                          unsigned char* __restrict__ pairs,
+                                                          float* __restrict__ utab, const float* __restrict__ thr) {
   const int b = blockIdx.z, qb = blockIdx.y, xb = blockIdx.x, lane = threadIdx.x;
   const int col = lane & 31, h = lane >> 5;
   const int ncap = 2 * ntiles, nxb = gridDim.x;
@@ -961,11 +967,9 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
   // lane col keeps radius and L of q cap qb * 32 + col; the rows of a lane fetch them by shuffle
   const int qmine = qb * 32 + col;
   const float rq_mine = qmine < ncap ? rhoQ[(size_t)b * ncap + qmine] : -1.f;
-  float L_mine = -2.f;
-  if (SWEEP == 1 && qmine < ncap) {
-    const float* pq = pm + ((size_t)b * ncap + qmine) * nxb;
-    for (int e = 0; e < nxb; ++e) L_mine = fmaxf(L_mine, pq[e]);
-  }
+  // sweep 1: the drop threshold t of the q cap (pn_ms3_thr_kernel)
+  const float L_mine = SWEEP == 1 && qmine < ncap ? thr[(size_t)b * ncap + qmine] : 2.f;
+  (void)cutoff;
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     bool on = false;
@@ -981,11 +985,17 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if (col == 0 && qi < ncap) pm[((size_t)b * ncap + qi) * nxb + xb] = m;
+        // the upper bound U of the pair's dot products (from the LOWER bound of the centre angle, like
+        // sweep 1 recomputes it) for the threshold search; -2: a cap without rows (no mass)
+        const float th_lo = acosf(fminf(fmaxf(acc[r + k] + X3_DOT_ERR, -1.f), 1.f));
+        const float lo = th_lo - rq - rx;
+        if (qi < ncap && ux < ncap)
+          utab[((size_t)b * ncap + qi) * ncap + ux] = (rq >= 0.f && rx >= 0.f) ? (lo <= 0.f ? 1.f : cosf(lo)) : -2.f;
       } else {
-        const float L = __shfl(L_mine, qi - qb * 32, 64);
+        const float t = __shfl(L_mine, qi - qb * 32, 64);
         const float lo = th - rq - rx;
         const float U = lo <= 0.f ? 1.f : cosf(lo);
-        on |= rq >= 0.f && rx >= 0.f && U >= L - cutoff;
+        on |= rq >= 0.f && rx >= 0.f && U >= t;
       }
     }
     if (SWEEP == 1) {
@@ -997,6 +1007,47 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
     }
   }
 }
+
+// Drop threshold of every q cap (one wave per cap): the largest t with
+//   sum_{x caps with U < t} 32 exp((U - L) / b^2) <= 0.9 rel_eps
+// (0.9: the fp32 summation of <= 2 ntiles positive terms), by bisection over the cap's row of the U
+// table; L = the cap's lower bound of the best dot product (sweep 0).  Caps with U >= t are kept.
+__global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict__ utab, const float* __restrict__ pm,
+                                                        const float* __restrict__ rhoQ, const float* __restrict__ bsq,
+                                                        int ncap, int nxb, float rel_eps, float* __restrict__ thr) {
+  const int b = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
+  const size_t row = (size_t)b * ncap + a;
+  if (rhoQ[row] < 0.f) {          // a cap without rows: its pairs are never set
+    if (lane == 0) thr[row] = 2.f;
+    return;
+  }
+  float L = -2.f;
+  for (int e = lane; e < nxb; e += 64) L = fmaxf(L, pm[row * nxb + e]);
+  L = pn_wave_max(L);
+  const float ib = 1.0f / bsq[b];
+  constexpr int MAXV = 32;        // 64 x 32 = 2048 caps = 32 768 points (the plan's N limit is 65 535: see below)
+  float u[MAXV], m[MAXV];
+  const int nv = (ncap + 63) / 64;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int i = lane + 64 * v;
+    const float uu = (v < nv && i < ncap) ? utab[row * ncap + i] : -2.f;
+    u[v] = uu;
+    m[v] = uu > -1.5f ? 32.f * __expf(fminf((uu - L) * ib, 80.f)) : 0.f;
+  }
+  float lo = -1.5f, hi = L;       // f(lo) = 0 <= budget; the cap attaining L has mass >= 32 > budget
+  const float budget = 0.9f * rel_eps;
+  for (int it = 0; it < 32; ++it) {
+    const float t = 0.5f * (lo + hi);
+    float f = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) f += u[v] < t ? m[v] : 0.f;
+    f = pn_wave_sum(f);
+    if (f <= budget) lo = t; else hi = t;
+  }
+  if (lane == 0) thr[row] = lo;
+}
+
 
 // compact lists; one wave per resident block: [0,nb0) pass 0, [nb0,nb0+nb1) pass 1, then pass 2
 __global__ __launch_bounds__(64) void pn_ms3_lists_kernel(const unsigned char* __restrict__ pairs, int ntiles,
@@ -1123,8 +1174,13 @@ __global__ __launch_bounds__(256) void pn_ms3_combine_bwd_kernel(
   *g = o;
 }
 
-static size_t x3_plan_scratch(int B, int ntiles) {
+// scratch of the plan kernels behind the lists: [pm: 2 nt x nt / 16 floats | thresholds: 2 nt | U table: (2 nt)^2] per item
+static size_t x3_plan_scratch_pm(int B, int ntiles) {
   return pn_align_up((size_t)B * 2 * ntiles * pn_cdiv(2 * ntiles, 32) * sizeof(float), 256);
+}
+static size_t x3_plan_scratch(int B, int ntiles) {
+  return x3_plan_scratch_pm(B, ntiles) + pn_align_up((size_t)B * 2 * ntiles * sizeof(float), 256) +
+         pn_align_up((size_t)B * 2 * ntiles * 2 * ntiles * sizeof(float), 256);
 }
 static void x3_plan_layout(int B, int N, int* ntiles, int* nb0, int* nb1, int* nb2, size_t* off_counts,
                            size_t* off_lists, size_t* total) {
@@ -1229,13 +1285,19 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   int* counts = (int*)((char*)plan + oc);
   int* lists = (int*)((char*)plan + ol);
   const float logterm = logf((float)N / rel_eps);
-  // (the scratch of the first sweep — 2 nt x nt / 16 floats per item — sits behind the lists)
-  float* pm = (float*)((char*)plan + tot - x3_plan_scratch(B, nt));
+  PN_CHECK_ARG(2 * nt <= 2048, "pn_meanshift_x3_plan_f32: N=%d (the threshold search holds <= 2048 caps: N <= 32768)", N);
+  // (the scratch of the sweeps sits behind the lists)
+  char* scratch = (char*)plan + tot - x3_plan_scratch(B, nt);
+  float* pm = (float*)scratch;
+  float* thr = (float*)(scratch + x3_plan_scratch_pm(B, nt));
+  float* utab = (float*)(scratch + x3_plan_scratch_pm(B, nt) + pn_align_up((size_t)B * 2 * nt * sizeof(float), 256));
   const dim3 pgrid(pn_cdiv(2 * nt, 32), pn_cdiv(2 * nt, 32), B);
   hipLaunchKernelGGL(pn_ms3_pairs_kernel<0>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
-                     pairs);
+                     pairs, utab, (const float*)thr);
+  hipLaunchKernelGGL(pn_ms3_thr_kernel, dim3(2 * nt, B), dim3(64), 0, stream, (const float*)utab, (const float*)pm,
+                     rhoQ, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr);
   hipLaunchKernelGGL(pn_ms3_pairs_kernel<1>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
-                     pairs);
+                     pairs, utab, (const float*)thr);
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms3_lists_kernel, dim3(nb0 + nb1 + nb2, B), dim3(64), 0, stream, pairs, nt, nb0, nb1, nb2,
                      counts, lists);

@@ -51,7 +51,7 @@ AUTO_STAT = None            # device scalar of the most recent planned call in a
 # pairs at 1e-9 / 1e-6 / 1e-5.  PARSENET_MS_REL_EPS overrides (1e-9: the round-2/3 setting).
 PLAN_REL_EPS = float(os.environ.get("PARSENET_MS_REL_EPS", "1e-6"))
 SPARSE_MIN_N = 2048
-SPARSE_MAX_N = 65535        # block numbers of the plan are 16-bit safe; the T x T predicate stays small
+SPARSE_MAX_N = 32768        # the plan's threshold search holds one row of <= 2048 cap bounds in registers
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
 
 

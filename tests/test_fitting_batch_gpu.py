@@ -279,7 +279,9 @@ def test_pipelined_groups_equal_the_whole_batch(gpu):
     torch.cuda.set_device(gpu)
     torch.manual_seed(0)
     B, N = 3, 3000
-    pts, nrm, lab, prim = synthetic.make_batch(20, B, N, min_segments=4, max_segments=5)
+    # planes, spheres and cones only: a SplineNet run on another batch size (the groups) carries kNN
+    # near-tie flips of its own (tests/golden/reference_noise_e2e.txt), which is not what is compared here
+    pts, nrm, lab, prim = synthetic.make_batch_ids(list(synthetic.ANALYTIC_WELL_POSED_IDS[4:7]), N)
     g = torch.Generator().manual_seed(1)
     embs = []
     for b in range(B):

@@ -220,12 +220,13 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     # Round 4 (deterministic backward, the same network in every run).  With the plans' bound at 1e-9:
     # clusters 12 / 7 / 12 / 11 on both sides, agreement 1.0 / 1.0 / 0.9998 / 0.9995, residual rel 0 / 1e-4 /
     # 6e-4 / 6e-7, cos(d res / d emb) 0.99994 / 1.00000 / 0.86016 / 1.00000 (the third shape: two points
-    # change modes), all shapes 0.99897, network terms 1.000000, WHOLE gradient 0.999989.  With the default
-    # bound of 1e-6 (mean_shift.PLAN_REL_EPS) the first shape's NMS keeps one more mode (13 against 12,
-    # agreement 0.9798, its residual 1.9e-2 apart, cos 0.96583) and everything else is unchanged: all
-    # shapes 0.99896, WHOLE gradient 0.999990 — which shape carries a flipped merge is decided by
-    # perturbations far below the arithmetic's noise, so the per-shape bars apply where the
-    # partitions coincide.
+    # change modes), all shapes 0.99897, network terms 1.000000, WHOLE gradient 0.999989 — the same with
+    # the default bound of 1e-6 and the mass criterion of the plans (mean_shift.PLAN_REL_EPS).  With the
+    # older "N points at the bound" criterion at 1e-6 the first shape's NMS kept one more mode (13
+    # against 12, agreement 0.9798, its residual 1.9e-2 apart, cos 0.96583) and everything else was
+    # unchanged (all shapes 0.99896, WHOLE gradient 0.999990): which shape carries a flipped merge is
+    # decided by perturbations far below the arithmetic's noise, so the per-shape bars
+    # apply where the partitions coincide.
     exact = [b for b in range(B) if agree[b] == 1.0]
     assert len(exact) >= 1 and all(cos_res[b] > 0.9999 for b in exact), (agree, cos_res)
     assert float(np.median(cos_res)) > 0.95, cos_res
