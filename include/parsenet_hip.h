@@ -145,9 +145,11 @@ int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int* rank, void
  * units) x 6 piece products on the bf16 matrix cores. */
 int pn_meanshift_x3_exec_tiles(unsigned long long* out3);
 size_t pn_meanshift_x3_plan_bytes(int B, int N);
-int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, void* stream);
+int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
+                                 void* stream);
 int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,
-                             const float* bsq, int B, int N, float rel_eps, void* plan, void* stream);
+                             const float* cntX, const float* bsq, int B, int N, float rel_eps, void* plan,
+                             void* stream);
 int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img_x, const float* bsq, int B, int N,
                                       int D, float* opart, float* rpart, float* y, float* rsum,
                                       float* unorm, const void* plan, void* stream);

@@ -762,14 +762,18 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 //   any pair (q in tile A, x in tile B):  cos(min(pi, th + rA + rB)) <= q.x <= cos(max(0, th - rA - rB)),
 //   th = angle(c_A, c_B).
 // For a row tile A of the resident side, L_A = max_B cos(th + rA + rB) bounds every row's BEST
-// dot product from below, hence r_i >= exp((L_A - 1) / b^2) for all its rows.  What may be dropped
-// for A is any set D of caps whose terms together stay below rel_eps of that:
-//   sum_{B in D} 32 exp((U_AB - L_A) / b^2) <= rel_eps        (a cap holds at most 32 rows).
+// dot product from below; every data cap B contributes at least n_B exp((Lo_AB - 1) / b^2) to every
+// row sum of A (n_B rows, Lo_AB = cos(th + rA + rB) <= every dot product of the pair), hence
+//   r_i >= exp((L_A - 1) / b^2) R_A,   R_A = sum_B n_B exp((Lo_AB - L_A) / b^2)  (>= 1: the cap attaining L_A).
+// What may be dropped for A is any set D of caps whose terms together stay below rel_eps of that:
+//   sum_{B in D} n_B exp((U_AB - L_A) / b^2) <= rel_eps R_A.
 // Round 4: D = the caps with U_AB < t_A for the LARGEST threshold t_A that satisfies this (found per
 // cap A by bisection over the row of U values, pn_ms3_thr_kernel) — the mass actually dropped, not
-// "all N points at the bound of the nearest dropped cap" (rounds 2-3: U_AB >= L_A - b^2 log(N / rel_eps)),
-// which keeps 4-6 points of a hundred fewer tile pairs on the benchmark's embedding
-// (tools/plan_mass_probe.py).  The cap that attains L_A always passes, so no row sum can vanish.  pairs[tQ][tX] holds the
+// "all N points at the bound of the nearest dropped cap" against a row sum of ONE term (rounds 2-3:
+// U_AB >= L_A - b^2 log(N / rel_eps)).  On the benchmark's embedding the plans keep 0.51 instead of
+// 0.70 of the tile pairs at the same rel_eps (a row of a cluster has hundreds of terms near its
+// best one: R_A ~ 200; tools/plan_mass_probe.py, profiles/r04_plan_eps_probe.txt).  The cap that
+// attains L_A always passes, so no row sum can vanish.  pairs[tQ][tX] holds the
 // predicate; the lists hold, per resident block of every pass, the streamed tiles with at least
 // one pair set (pass 0 / 1: blocks of 8 / 4 q tiles against x tiles; pass 2: blocks of 8 x tiles
 // against q tiles).
@@ -790,13 +794,15 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 // the start of the next): one cap around all 32 rows would then be wide enough to meet every
 // other tile.  The rows are dealt to two seeds (s1 = the row farthest from the mean direction,
 // s2 = the row farthest from s1; a row goes with the seed it has the larger dot product with) and
-// each group gets its own cap.  cen (B,ntiles,2,D), rho (B,ntiles,2); rho < 0: empty group.
+// each group gets its own cap.  cen (B,ntiles,2,D), rho (B,ntiles,2); rho < 0: empty group;
+// cnt (B,ntiles,2): the number of rows of each group (the plan weighs the caps of the data with them).
 // (Measured on the cfg5 embedding: active tile pairs 0.29 -> 0.23, visited list entries of the
 // row pass 0.40 -> 0.28 of all.)
 // (four waves per tile, eight rows each: the dot products of a round are wave-wide sums, and one
 // wave per tile left the SIMDs with a single wave of serial reductions: 53 us per call)
 __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __restrict__ z, int N, int ntiles,
-                                                              float* __restrict__ cen, float* __restrict__ rho) {
+                                                              float* __restrict__ cen, float* __restrict__ rho,
+                                                              float* __restrict__ cnt_out) {
   __shared__ float part[4][2][MS_D];
   __shared__ float sd[3][32];
   __shared__ float smin[4][2];
@@ -806,11 +812,13 @@ __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __res
   const int j0 = t * 32, cnt = min(32, N - j0);
   float* co = cen + ((size_t)b * ntiles + t) * 2 * MS_D;
   float* ro = rho + ((size_t)b * ntiles + t) * 2;
+  float* no = cnt_out ? cnt_out + ((size_t)b * ntiles + t) * 2 : nullptr;   // rows of the two caps
   if (cnt <= 0) {   // padding tile: interacts with everything (its image rows are zero)
     if (tid < 2 * MS_D) co[tid] = 0.f;
     if (tid == 0) {
       ro[0] = 3.2f;
       ro[1] = -1.f;
+      if (no) no[0] = no[1] = 0.f;
     }
     return;
   }
@@ -917,6 +925,10 @@ __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __res
     if (lane == 0) {
       ro[0] = r[0];
       ro[1] = r[1];
+      if (no) {
+        no[1] = (float)__popc(second);
+        no[0] = (float)(cnt - __popc(second));
+      }
     }
   }
 #undef X3_TI_DOTS
@@ -938,7 +950,8 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
                                                           const float* __restrict__ bsq, int ntiles,
                                                           float logterm, float* __restrict__ pm,
                                                           unsigned char* __restrict__ pairs,
-                                                          float* __restrict__ utab, const float* __restrict__ thr) {
+                                                          float* __restrict__ utab, float* __restrict__ lotab,
+                                                          const float* __restrict__ thr) {
   const int b = blockIdx.z, qb = blockIdx.y, xb = blockIdx.x, lane = threadIdx.x;
   const int col = lane & 31, h = lane >> 5;
   const int ncap = 2 * ntiles, nxb = gridDim.x;
@@ -989,8 +1002,12 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
         // sweep 1 recomputes it) for the threshold search; -2: a cap without rows (no mass)
         const float th_lo = acosf(fminf(fmaxf(acc[r + k] + X3_DOT_ERR, -1.f), 1.f));
         const float lo = th_lo - rq - rx;
-        if (qi < ncap && ux < ncap)
-          utab[((size_t)b * ncap + qi) * ncap + ux] = (rq >= 0.f && rx >= 0.f) ? (lo <= 0.f ? 1.f : cosf(lo)) : -2.f;
+        if (qi < ncap && ux < ncap) {
+          const bool both = rq >= 0.f && rx >= 0.f;
+          utab[((size_t)b * ncap + qi) * ncap + ux] = both ? (lo <= 0.f ? 1.f : cosf(lo)) : -2.f;
+          // ... and the lower bound Lo of ALL of them (what `m` maximises): the row-sum bound R
+          lotab[((size_t)b * ncap + qi) * ncap + ux] = both ? (hi >= 3.14159f ? -1.f : cosf(hi)) : -2.f;
+        }
       } else {
         const float t = __shfl(L_mine, qi - qb * 32, 64);
         const float lo = th - rq - rx;
@@ -1009,11 +1026,13 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
 }
 
 // Drop threshold of every q cap (one wave per cap): the largest t with
-//   sum_{x caps with U < t} 32 exp((U - L) / b^2) <= 0.9 rel_eps
-// (0.9: the fp32 summation of <= 2 ntiles positive terms), by bisection over the cap's row of the U
-// table; L = the cap's lower bound of the best dot product (sweep 0).  Caps with U >= t are kept.
-__global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict__ utab, const float* __restrict__ pm,
-                                                        const float* __restrict__ rhoQ, const float* __restrict__ bsq,
+//   sum_{x caps with U < t} n_x exp((U - L) / b^2) <= 0.9 rel_eps R,   R = sum_x n_x exp((Lo - L) / b^2)
+// (0.9: the fp32 summation of <= 2 ntiles positive terms on either side), by bisection over the cap's
+// rows of the U and Lo tables; L = the cap's lower bound of the best dot product (sweep 0), n_x the
+// rows of data cap x.  Caps with U >= t are kept.
+__global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict__ utab, const float* __restrict__ lotab,
+                                                        const float* __restrict__ pm, const float* __restrict__ rhoQ,
+                                                        const float* __restrict__ cntX, const float* __restrict__ bsq,
                                                         int ncap, int nxb, float rel_eps, float* __restrict__ thr) {
   const int b = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
   const size_t row = (size_t)b * ncap + a;
@@ -1025,18 +1044,25 @@ __global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict_
   for (int e = lane; e < nxb; e += 64) L = fmaxf(L, pm[row * nxb + e]);
   L = pn_wave_max(L);
   const float ib = 1.0f / bsq[b];
-  constexpr int MAXV = 32;        // 64 x 32 = 2048 caps = 32 768 points (the plan's N limit is 65 535: see below)
+  constexpr int MAXV = 32;        // 64 x 32 = 2048 caps = 32 768 points
   float u[MAXV], m[MAXV];
   const int nv = (ncap + 63) / 64;
+  float R = 0.f;
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
     const int i = lane + 64 * v;
-    const float uu = (v < nv && i < ncap) ? utab[row * ncap + i] : -2.f;
+    const bool in = v < nv && i < ncap;
+    const float uu = in ? utab[row * ncap + i] : -2.f;
+    const float ll = in ? lotab[row * ncap + i] : -2.f;
+    const float n = in ? (cntX ? cntX[(size_t)b * ncap + i] : 32.f) : 0.f;
     u[v] = uu;
-    m[v] = uu > -1.5f ? 32.f * __expf(fminf((uu - L) * ib, 80.f)) : 0.f;
+    m[v] = uu > -1.5f ? n * __expf(fminf((uu - L) * ib, 80.f)) : 0.f;
+    // without counts every non-empty cap is known to hold one row
+    R += ll > -1.5f ? (cntX ? n : 1.f) * __expf(fminf((ll - L) * ib, 0.f)) : 0.f;
   }
-  float lo = -1.5f, hi = L;       // f(lo) = 0 <= budget; the cap attaining L has mass >= 32 > budget
-  const float budget = 0.9f * rel_eps;
+  R = fmaxf(pn_wave_sum(R), 1.f);
+  float lo = -1.5f, hi = L;       // f(lo) = 0 <= budget; the cap attaining L has mass >= its share of R > budget
+  const float budget = 0.9f * rel_eps * R;
   for (int it = 0; it < 32; ++it) {
     const float t = 0.5f * (lo + hi);
     float f = 0.f;
@@ -1047,7 +1073,6 @@ __global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict_
   }
   if (lane == 0) thr[row] = lo;
 }
-
 
 // compact lists; one wave per resident block: [0,nb0) pass 0, [nb0,nb0+nb1) pass 1, then pass 2
 __global__ __launch_bounds__(64) void pn_ms3_lists_kernel(const unsigned char* __restrict__ pairs, int ntiles,
@@ -1174,13 +1199,13 @@ __global__ __launch_bounds__(256) void pn_ms3_combine_bwd_kernel(
   *g = o;
 }
 
-// scratch of the plan kernels behind the lists: [pm: 2 nt x nt / 16 floats | thresholds: 2 nt | U table: (2 nt)^2] per item
+// scratch of the plan kernels behind the lists: [pm: 2 nt x nt / 16 floats | thresholds: 2 nt | U and Lo tables: 2 x (2 nt)^2] per item
 static size_t x3_plan_scratch_pm(int B, int ntiles) {
   return pn_align_up((size_t)B * 2 * ntiles * pn_cdiv(2 * ntiles, 32) * sizeof(float), 256);
 }
 static size_t x3_plan_scratch(int B, int ntiles) {
   return x3_plan_scratch_pm(B, ntiles) + pn_align_up((size_t)B * 2 * ntiles * sizeof(float), 256) +
-         pn_align_up((size_t)B * 2 * ntiles * 2 * ntiles * sizeof(float), 256);
+         2 * pn_align_up((size_t)B * 2 * ntiles * 2 * ntiles * sizeof(float), 256);
 }
 static void x3_plan_layout(int B, int N, int* ntiles, int* nb0, int* nb1, int* nb2, size_t* off_counts,
                            size_t* off_lists, size_t* total) {
@@ -1203,13 +1228,13 @@ extern "C" size_t pn_meanshift_x3_plan_bytes(int B, int N) {
 }
 
 // cen (B,ntiles,2,D), rho (B,ntiles,2) with ntiles = align_up(N,64)/32
-extern "C" int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho,
+extern "C" int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
                                             void* stream) {
   PN_CHECK_ARG(z && cen && rho && B > 0 && N > 0, "pn_meanshift_x3_tileinfo_f32: bad arguments");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
   const int ntiles = (int)pn_align_up(N, 64) / 32;
   hipLaunchKernelGGL(pn_ms3_tileinfo_kernel, dim3(ntiles, B), dim3(256), 0, (hipStream_t)stream, z, N, ntiles, cen,
-                     rho);
+                     rho, cnt);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -1273,8 +1298,8 @@ extern "C" int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int*
 // plan of one iteration from the tile caps of the iterate (Q) and of the data (X); rel_eps: the
 // skipped mass relative to the smallest row sum (1e-9)
 extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX,
-                                        const float* rhoX, const float* bsq, int B, int N, float rel_eps,
-                                        void* plan, void* stream_) {
+                                        const float* rhoX, const float* cntX, const float* bsq, int B, int N,
+                                        float rel_eps, void* plan, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(cenQ && rhoQ && cenX && rhoX && bsq && plan && B > 0 && N > 0 && rel_eps > 0.f,
                "pn_meanshift_x3_plan_f32: bad arguments");
@@ -1291,13 +1316,16 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   float* pm = (float*)scratch;
   float* thr = (float*)(scratch + x3_plan_scratch_pm(B, nt));
   float* utab = (float*)(scratch + x3_plan_scratch_pm(B, nt) + pn_align_up((size_t)B * 2 * nt * sizeof(float), 256));
+  float* lotab = utab + pn_align_up((size_t)B * 2 * nt * 2 * nt * sizeof(float), 256) / sizeof(float);
   const dim3 pgrid(pn_cdiv(2 * nt, 32), pn_cdiv(2 * nt, 32), B);
   hipLaunchKernelGGL(pn_ms3_pairs_kernel<0>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
-                     pairs, utab, (const float*)thr);
-  hipLaunchKernelGGL(pn_ms3_thr_kernel, dim3(2 * nt, B), dim3(64), 0, stream, (const float*)utab, (const float*)pm,
-                     rhoQ, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr);
+                     pairs, utab, lotab, (const float*)thr);
+  // cntX (rows of every data cap, pn_meanshift_x3_tileinfo_f32) may be NULL: one row per non-empty cap in the
+  // row-sum bound, 32 in the dropped mass — still rigorous, keeps more pairs
+  hipLaunchKernelGGL(pn_ms3_thr_kernel, dim3(2 * nt, B), dim3(64), 0, stream, (const float*)utab, (const float*)lotab,
+                     (const float*)pm, rhoQ, cntX, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr);
   hipLaunchKernelGGL(pn_ms3_pairs_kernel<1>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
-                     pairs, utab, (const float*)thr);
+                     pairs, utab, lotab, (const float*)thr);
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms3_lists_kernel, dim3(nb0 + nb1 + nb2, B), dim3(64), 0, stream, pairs, nt, nb0, nb1, nb2,
                      counts, lists);

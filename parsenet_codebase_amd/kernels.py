@@ -345,19 +345,21 @@ def meanshift_x3_split(x):
 
 
 def meanshift_x3_tileinfo(z):
-    """z (B,N,128) unit rows -> (centres (B,T,2,128), angular radii (B,T,2)) of the two bounding
-    caps of every 32-row tile, T = align_up(N, 64) / 32 (radius < 0: empty cap): the geometry the
-    block-sparse plan is derived from."""
+    """z (B,N,128) unit rows -> (centres (B,T,2,128), angular radii (B,T,2), row counts (B,T,2)) of
+    the two bounding caps of every 32-row tile, T = align_up(N, 64) / 32 (radius < 0: empty cap): the
+    geometry the block-sparse plan is derived from."""
     require_cuda(z)
     z = _f32c(z, "z")
     B, N, D = z.shape
     T = (N + 63) // 64 * 2
     cen = torch.empty((B, T, 2, D), dtype=torch.float32, device=z.device)
     rho = torch.empty((B, T, 2), dtype=torch.float32, device=z.device)
+    cnt = torch.empty((B, T, 2), dtype=torch.float32, device=z.device)
     with _lib.on_device(z.device):
-        rc = _lib.load().pn_meanshift_x3_tileinfo_f32(ptr(z), B, N, D, ptr(cen), ptr(rho), current_stream(z.device))
+        rc = _lib.load().pn_meanshift_x3_tileinfo_f32(ptr(z), B, N, D, ptr(cen), ptr(rho), ptr(cnt),
+                                                      current_stream(z.device))
     check(rc, "pn_meanshift_x3_tileinfo_f32")
-    return cen, rho
+    return cen, rho, cnt
 
 
 def meanshift_chain_order(sim):
@@ -376,13 +378,14 @@ def meanshift_chain_order(sim):
 def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
     """Block-sparse plan of one iteration (which tile pairs can contribute more than ``rel_eps`` of
     the smallest row sum): an opaque byte tensor for meanshift_x3_iter_fwd / _bwd."""
-    cq, rq = q_info
-    cx, rx = x_info
+    cq, rq = q_info[0], q_info[1]
+    cx, rx = x_info[0], x_info[1]
+    nx = x_info[2] if len(x_info) > 2 else None      # rows of the data caps (None: conservative bounds)
     B = cq.shape[0]
     lib = _lib.load()
     plan = torch.empty(lib.pn_meanshift_x3_plan_bytes(B, N), dtype=torch.uint8, device=cq.device)
     with _lib.on_device(cq.device):
-        rc = lib.pn_meanshift_x3_plan_f32(ptr(cq), ptr(rq), ptr(cx), ptr(rx), ptr(bsq), B, N, float(rel_eps),
+        rc = lib.pn_meanshift_x3_plan_f32(ptr(cq), ptr(rq), ptr(cx), ptr(rx), ptr(nx), ptr(bsq), B, N, float(rel_eps),
                                           ptr(plan), current_stream(cq.device))
     check(rc, "pn_meanshift_x3_plan_f32")
     return plan

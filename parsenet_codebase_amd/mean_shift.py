@@ -48,7 +48,8 @@ AUTO_STAT = None            # device scalar of the most recent planned call in a
 # (tools/plan_eps_probe.py, profiles/r04_plan_eps_probe.txt): the ten-iteration result differs
 # from the dense launches' by 7e-6 ... 7e-5 (summation order: the locality permutation) and does
 # not move between rel_eps = 1e-9 and 1e-4, while the plans keep 0.81 / 0.70 / 0.66 of the tile
-# pairs at 1e-9 / 1e-6 / 1e-5.  PARSENET_MS_REL_EPS overrides (1e-9: the round-2/3 setting).
+# pairs at 1e-9 / 1e-6 / 1e-5 (with the round-2/3 criterion; with the mass / row-sum criterion of
+# round 4, csrc/meanshift_x3.h: 0.51 at 1e-6).  PARSENET_MS_REL_EPS overrides (1e-9: rounds 2-3).
 PLAN_REL_EPS = float(os.environ.get("PARSENET_MS_REL_EPS", "1e-6"))
 SPARSE_MIN_N = 2048
 SPARSE_MAX_N = 32768        # the plan's threshold search holds one row of <= 2048 cap bounds in registers

@@ -269,7 +269,7 @@ def test_deferred_metrics_are_the_same_results(gpu):
         assert sorted(a[1][0].keys()) == sorted(b[1][0].keys())
 
 
-def test_pipelined_groups_equal_the_whole_batch(gpu):
+def test_pipelined_groups_equal_the_whole_batch(gpu, monkeypatch):
     """fitting_losses_pipelined (clustering of every group of shapes queued before the host turns to
     the first group's matching) against the one-group stage: same numpy RNG consumption, losses and
     gradient with respect to the embedding; chunk counts that do not divide the batch included."""
@@ -282,6 +282,12 @@ def test_pipelined_groups_equal_the_whole_batch(gpu):
     # planes, spheres and cones only: a SplineNet run on another batch size (the groups) carries kNN
     # near-tie flips of its own (tests/golden/reference_noise_e2e.txt), which is not what is compared here
     pts, nrm, lab, prim = synthetic.make_batch_ids(list(synthetic.ANALYTIC_WELL_POSED_IDS[4:7]), N)
+    # dense mean-shift launches: a planned launch of three shapes and three planned launches of one cut the
+    # concatenated lists differently, the iterates then differ by 2e-7 (tools/dbg: whole vs alone), and one
+    # such difference is enough to flip a near-tie further down (measured: one shape's loss 1.1 % apart) —
+    # the grouping, not the launch kind, is what this test compares
+    from parsenet_codebase_amd import mean_shift as MSM
+    monkeypatch.setattr(MSM, "SPARSE", False)
     g = torch.Generator().manual_seed(1)
     embs = []
     for b in range(B):

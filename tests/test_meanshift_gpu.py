@@ -426,8 +426,9 @@ def test_tile_caps_contain_their_rows_and_the_plan_keeps_every_heavy_pair(gpu):
     lab[:, :N // 2] = torch.sort(lab[:, :N // 2], dim=1)[0]          # first half grouped, second half mixed
     X = torch.nn.functional.normalize(proto[lab] + 0.15 * torch.randn(B, N, 128, generator=g) / np.sqrt(128), dim=2)
     Xg = X.to(gpu)
-    cen, rho = K.meanshift_x3_tileinfo(Xg)
+    cen, rho, cnt = K.meanshift_x3_tileinfo(Xg)
     T = cen.shape[1]
+    assert cnt.shape == rho.shape and float(cnt.sum()) == B * N
     assert cen.shape == (B, T, 2, 128) and rho.shape == (B, T, 2) and T == (N + 63) // 64 * 2
     cen_c, rho_c = cen.cpu().double(), rho.cpu().double()
     Xd = X.double()
@@ -441,9 +442,12 @@ def test_tile_caps_contain_their_rows_and_the_plan_keeps_every_heavy_pair(gpu):
             inside = (ang <= rho_c[b, t][None, :]) & (rho_c[b, t][None, :] >= 0)
             assert bool(inside.any(1).all()), (b, t)
     bsq = torch.tensor([0.08 ** 2, 0.12 ** 2], device=gpu)
-    plan = K.meanshift_x3_plan((cen, rho), (cen, rho), bsq, N)
+    plan = K.meanshift_x3_plan((cen, rho), (cen, rho, cnt), bsq, N)
     pairs = plan[:B * T * T].reshape(B, T, T).cpu().bool()
     assert 0.05 < pairs.float().mean() < 0.9
+    # without the counts of the data caps the bounds are more conservative: a superset of the pairs
+    loose = K.meanshift_x3_plan((cen, rho), (cen, rho), bsq, N)[:B * T * T].reshape(B, T, T).cpu().bool()
+    assert bool((loose | ~pairs).all()) and loose.float().mean() >= pairs.float().mean()
     S = Xd @ Xd.transpose(1, 2)                                                  # (B,N,N) exact enough in fp64
     for b in range(B):
         Kmat = torch.exp((S[b] - 1.0) / float(bsq[b]))

@@ -24,7 +24,7 @@ for start in (0, 4, 8, 12):
         bw, _ = bandwidth_batch(e, 0.025)
         perm = MSM.locality_order(e, 2)
         x = torch.gather(e, 1, perm.unsqueeze(2).expand(-1, -1, 128))
-        cen, rho = K.meanshift_x3_tileinfo(x)            # (B,T,2,128), (B,T,2)
+        cen, rho, _cnt = K.meanshift_x3_tileinfo(x)            # (B,T,2,128), (B,T,2)
         B, T = rho.shape[:2]
         c = cen.reshape(B, 2 * T, 128).double()
         r = rho.reshape(B, 2 * T).double()
@@ -51,4 +51,14 @@ for start in (0, 4, 8, 12):
             def tiles(kp):
                 k4 = kp.reshape(B, T, 2, T, 2)
                 return k4.any(4).any(2).float().mean().item()
-            print("batch %d eps %.0e: tile pairs kept: N-bound %.4f  mass-bound %.4f" % (start, eps, tiles(keep_now), tiles(keep_mass)))
+            # row-sum bound: r_i >= exp((L-1)/b^2) * R with R = sum over x caps of n_x exp((Lo - L)/b^2), Lo = lower
+            # bound of every dot product of the cap pair (pm); n_x = 1 (rigorous without counts) or 16 (typical)
+            res = []
+            for nx in (1.0, 16.0):
+                Rrow = (torch.where(ok, nx * torch.exp(((pm - L.unsqueeze(2)) / bsq).clamp(max=0.0)), torch.zeros_like(pm))).sum(2)
+                Rrow = Rrow.clamp_min(1.0)
+                drop_sorted2 = csum <= eps * Rrow.unsqueeze(2)
+                drop2 = torch.zeros_like(drop_sorted2).scatter_(2, order, drop_sorted2)
+                res.append((tiles(ok & ~drop2), float(Rrow.median()), float(Rrow.mean())))
+            print("batch %d eps %.0e: tile pairs kept: N-bound %.4f  mass-bound %.4f  + row-sum bound n=1: %.4f (R median %.1f mean %.1f)  n=16: %.4f (R median %.1f)"
+                  % (start, eps, tiles(keep_now), tiles(keep_mass), res[0][0], res[0][1], res[0][2], res[1][0], res[1][1]))
