@@ -122,9 +122,11 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     """HBM-side bytes per launch of a mean-shift kernel from the committed PMC run of the same
     launch configuration (profiles/: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH
     doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
-    the file is not there — bench.py never profiles counters itself.  The round-3 files were
-    collected inside ``bench.py --workload cfg5`` (batched launches of 4 shapes): one for planned
-    launches (256 workgroups), one for dense ones; the round-1 files are per shape."""
+    the file is not there — bench.py never profiles counters itself (rocprofv3 does, in passes of
+    their own: tools/evidence_round4.sh).  The round-3 / round-4 files were collected inside
+    ``bench.py --workload cfg5`` (batched launches of 4 shapes; round 4: ``--profile-only``, i.e. only
+    the launches the roofline is quoted on): one for planned launches (256 workgroups), one for dense
+    ones; the round-1 files are per shape."""
     import csv
     files = {"fp16x2": ("r01_meanshift_h2_pmc.csv", "pn_msh_kernel<%d>"),
              "bf16x3": ("r01_meanshift_x3_pmc.csv", "pn_ms3_kernel<%d>"),
@@ -132,8 +134,12 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     scale = float(shapes_per_launch)
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     if arith == "bf16x3" and shapes_per_launch == 4:
-        cand = (["r03_meanshift_x3_planned_cfg5_pmc.csv", "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
-                ["r03_meanshift_x3_dense_cfg5_pmc.csv", "r02_meanshift_x3_batch4_pmc.csv"])
+        cand = (["r04_meanshift_x3_planned_cfg5_pmc.csv", "r03_meanshift_x3_planned_cfg5_pmc.csv",
+                 "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
+                ["r04_meanshift_x3_dense_cfg5_pmc.csv", "r03_meanshift_x3_dense_cfg5_pmc.csv",
+                 "r02_meanshift_x3_batch4_pmc.csv"])
+        cand = [c for c in cand if os.path.exists(os.path.join(prof, c)) and
+                "FETCH_SIZE" in open(os.path.join(prof, c)).read()] or cand
         files["bf16x3"] = (next((c for c in cand if os.path.exists(os.path.join(prof, c))), cand[-1]),
                            "pn_ms3_kernel<%d>")
         scale = 1.0
@@ -573,7 +579,7 @@ def main():
         _ms.SPARSE = mostly_planned
     try:
         roof, table = (None, {}) if stub else kernel_roofline(step, nprof)
-        if ms_mode is not None and not mostly_planned:
+        if ms_mode is not None and not mostly_planned and not args.profile_only:
             # the plans of the timed pool all the same (one planned pass, not timed, not profiled):
             # how much of the dense work a planned launch WOULD execute on this embedding
             restore(start)

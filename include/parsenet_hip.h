@@ -117,15 +117,22 @@ int pn_meanshift_x3_iter_bwd_f32(const float* gy, const float* y, const float* q
                                  float* gx, void* stream);
 
 /* Block-sparse variant.  K_ij = exp((q_i . x_j - 1) / b^2) of src/mean_shift.py:58-64 decays fast
- * on a clustered embedding; a (32-row tile of q) x (32-row tile of x) pair is skipped when a
- * rigorous bound from the tiles' bounding caps on the unit sphere shows that ALL its N^2/T^2
- * terms together stay below rel_eps (1e-9) of the SMALLEST row sum of the q tile — far below the
- * rounding of the fp32 sums, so the result is the dense one to fp32 noise.  The caller orders
- * the points so that tiles are local (any order is valid; mean-shift is permutation-equivariant).
+ * on a clustered embedding; the (32-row tile of q) x (32-row tile of x) pairs a plan skips are
+ * chosen, from rigorous bounds on the tiles' bounding caps on the unit sphere, such that for EVERY
+ * row of q all skipped terms together stay below rel_eps of that row's sum (the caller's choice;
+ * the host side uses 1e-6, below the rounding of an fp32 sum of N terms) — the result is the dense
+ * one to fp32 noise.  Per q cap A: L_A = lower bound of its rows' best dot product, R_A = sum over
+ * the data caps B of n_B exp((Lo_AB - L_A) / b^2) (n_B rows, Lo_AB <= every dot product of the
+ * pair) bounds every row sum from below by exp((L_A - 1) / b^2) R_A, and the data caps with the
+ * smallest upper bounds U_AB are dropped as long as sum n_B exp((U_AB - L_A) / b^2) <= rel_eps R_A.
+ * The caller orders the points so that tiles are local (any order is valid; mean-shift is
+ * permutation-equivariant).
  *   tileinfo : z (B,N,D) unit rows -> two bounding caps per tile (its rows dealt to two far-apart
  *              seeds): cen (B,T,2,D) normalised means, rho (B,T,2) angular radii (+1e-3 slack;
- *              < 0: empty cap), T = align_up(N,64)/32.
- *   plan     : caps of the iterate q and of the data x -> plan (pn_meanshift_x3_plan_bytes):
+ *              < 0: empty cap), cnt (B,T,2) rows per cap (may be NULL), T = align_up(N,64)/32.
+ *   plan     : caps of the iterate q and of the data x (cntX: the data caps' row counts; NULL: one
+ *              row per non-empty cap in R, 32 in the dropped mass — rigorous, keeps more pairs)
+ *              -> plan (pn_meanshift_x3_plan_bytes), N <= 32768:
  *              the pair predicate (T x T bytes), per resident block of each pass the compact
  *              list of streamed tiles with at least one pair set, and the prefix sums of the list
  *              lengths (the launches cut the concatenated lists into one equal range per CU).
