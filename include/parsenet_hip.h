@@ -151,6 +151,18 @@ int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int* rank, void
  * and synchronises with the device.  One pair is 2 * 32 * 32 * 128 FLOP per GEMM unit (2 / 3 / 4
  * units) x 6 piece products on the bf16 matrix cores. */
 int pn_meanshift_x3_exec_tiles(unsigned long long* out3);
+/* Nearest candidate of every query — arg-max_j xq_i . xc_j, the first step of MeanShift.nms
+ * (src/mean_shift.py:146-149) — by EXACT pruning: xq, xc (B,N,D) unit rows in one common order that
+ * keeps neighbours together (the locality order of the iterations), their tile caps from
+ * pn_meanshift_x3_tileinfo_f32.  A candidate tile whose upper bound lies below the query tile's
+ * guaranteed best cannot hold a maximum; only the remaining tile pairs are evaluated, as fp32 fma
+ * chains over the channels in order (the arithmetic of pn_dot_select_f32, bit for bit).  perm (B,N)
+ * position -> original index (NULL: identity): nearest (B,N) is indexed by the query's ORIGINAL
+ * index and holds the candidate's ORIGINAL index, ties to the smaller one.  workspace:
+ * pn_meanshift_x3_plan_bytes(B, N). */
+int pn_meanshift_x3_nearest_f32(const float* xq, const float* xc, const float* cenQ, const float* rhoQ,
+                                const float* cenC, const float* rhoC, const int64_t* perm, int B, int N, int D,
+                                int64_t* nearest, void* workspace, size_t workspace_bytes, void* stream);
 size_t pn_meanshift_x3_plan_bytes(int B, int N);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
                                  void* stream);

@@ -1043,6 +1043,14 @@ __global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict_
   float L = -2.f;
   for (int e = lane; e < nxb; e += 64) L = fmaxf(L, pm[row * nxb + e]);
   L = pn_wave_max(L);
+  if (rel_eps < 0.f) {
+    // EXACT pruning (pn_meanshift_x3_nearest_f32: the arg-max of a dot product): every row of the cap has
+    // a candidate with dot >= L, so a candidate cap whose upper bound lies below L cannot hold a row's
+    // maximum — minus the rounding of the fp32 chains the two values are compared in (each within
+    // X3_DOT_ERR of the real dot product of unit rows)
+    if (lane == 0) thr[row] = L - 4.f * X3_DOT_ERR;
+    return;
+  }
   const float ib = 1.0f / bsq[b];
   constexpr int MAXV = 32;        // 64 x 32 = 2048 caps = 32 768 points
   float u[MAXV], m[MAXV];
@@ -1301,7 +1309,7 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
                                         const float* rhoX, const float* cntX, const float* bsq, int B, int N,
                                         float rel_eps, void* plan, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  PN_CHECK_ARG(cenQ && rhoQ && cenX && rhoX && bsq && plan && B > 0 && N > 0 && rel_eps > 0.f,
+  PN_CHECK_ARG(cenQ && rhoQ && cenX && rhoX && bsq && plan && B > 0 && N > 0 && rel_eps != 0.f,
                "pn_meanshift_x3_plan_f32: bad arguments");
   int nt, nb0, nb1, nb2;
   size_t oc, ol, tot;
@@ -1309,7 +1317,7 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   unsigned char* pairs = (unsigned char*)plan;
   int* counts = (int*)((char*)plan + oc);
   int* lists = (int*)((char*)plan + ol);
-  const float logterm = logf((float)N / rel_eps);
+  const float logterm = rel_eps > 0.f ? logf((float)N / rel_eps) : 0.f;   // (rel_eps < 0: exact pruning, see pn_ms3_thr_kernel)
   PN_CHECK_ARG(2 * nt <= 2048, "pn_meanshift_x3_plan_f32: N=%d (the threshold search holds <= 2048 caps: N <= 32768)", N);
   // (the scratch of the sweeps sits behind the lists)
   char* scratch = (char*)plan + tot - x3_plan_scratch(B, nt);
@@ -1332,6 +1340,120 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   PN_CHECK_LAUNCH();
   int* offs = counts + pn_align_up((size_t)B * (nb0 + nb1 + nb2) * 4, 256) / 4;
   hipLaunchKernelGGL(pn_ms3_offsets_kernel, dim3(3), dim3(256), 0, stream, counts, B, nb0, nb1, nb2, offs);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ---- nearest candidate of every query by EXACT pruning (round 4) ---------------------------------
+// MeanShift.nms starts from the nearest shifted point of every point: arg-max_j x_i . c_j over all N
+// candidates (src/mean_shift.py:146-149), an INDEX, held bit-exact against the oracle: fp32 fma chain
+// over the channels in order, ties to the smaller index.  The engine of knn_mfma.hip evaluates all
+// N^2 chains on the fp32 matrix cores (1.1 ms per launch of 4 shapes x 10 000 points).  With the points
+// in the locality order of the iterations, the caps of the query tiles and of the candidate tiles say
+// which tile pairs can hold a maximum at all (pn_ms3_thr_kernel, exact mode: no tolerance involved), and
+// the chains of those pairs alone are evaluated here — by plain fma instructions, in the same order.
+// One workgroup per query tile: thread (q = tid & 31, g = tid >> 5) holds query q's 128 channels in
+// registers and takes candidates g, g + 8, g + 16, g + 24 of every kept tile (staged in LDS, read as
+// wave-uniform 16-byte broadcasts).  perm (position -> original index, or NULL): results are written at
+// the query's ORIGINAL index and name the candidate's ORIGINAL index; ties go to the smaller original index.
+__global__ __launch_bounds__(256) void pn_ms3_nearest_kernel(const float* __restrict__ xq, const float* __restrict__ xc,
+                                                             const unsigned char* __restrict__ pairs,
+                                                             const long long* __restrict__ perm, int N, int ntiles,
+                                                             long long* __restrict__ nearest) {
+  __shared__ __attribute__((aligned(16))) float ct[32][MS_D];
+  __shared__ float bv[8][32];
+  __shared__ int bi[8][32];
+  const int b = blockIdx.y, tq = blockIdx.x, tid = threadIdx.x;
+  const int q = tid & 31, g = tid >> 5;
+  const int qi = tq * 32 + q;
+  if (tq * 32 >= N) return;
+  const int qc = min(qi, N - 1);
+  float qv[MS_D];
+  {
+    const float4* src = reinterpret_cast<const float4*>(xq + ((size_t)b * N + qc) * MS_D);
+#pragma unroll
+    for (int e = 0; e < MS_D / 4; ++e) {
+      const float4 v = src[e];
+      qv[4 * e] = v.x, qv[4 * e + 1] = v.y, qv[4 * e + 2] = v.z, qv[4 * e + 3] = v.w;
+    }
+  }
+  const unsigned char* __restrict__ prow = pairs + ((size_t)b * ntiles + tq) * ntiles;
+  const long long* __restrict__ pb = perm ? perm + (size_t)b * N : nullptr;
+  float best = -__builtin_inff();
+  int besti = 0x7fffffff;
+  for (int t = 0; t < ntiles; ++t) {
+    if (!prow[t]) continue;                      // workgroup-uniform
+    const int j0 = t * 32;
+    if (j0 >= N) break;
+    __syncthreads();                             // everyone is done with the previous tile
+    for (int e = tid; e < 32 * MS_D / 4; e += 256) {
+      const int r = e / (MS_D / 4), c4 = e - r * (MS_D / 4);
+      const int j = min(j0 + r, N - 1);
+      reinterpret_cast<float4*>(&ct[r][0])[c4] = reinterpret_cast<const float4*>(xc + ((size_t)b * N + j) * MS_D)[c4];
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int e = 0; e < MS_D / 4; ++e) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float4 c = reinterpret_cast<const float4*>(&ct[g + 8 * m][0])[e];
+        float a = acc[m];
+        a = __builtin_fmaf(qv[4 * e], c.x, a);
+        a = __builtin_fmaf(qv[4 * e + 1], c.y, a);
+        a = __builtin_fmaf(qv[4 * e + 2], c.z, a);
+        a = __builtin_fmaf(qv[4 * e + 3], c.w, a);
+        acc[m] = a;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int j = j0 + g + 8 * m;
+      if (j < N) {
+        const int jo = pb ? (int)pb[j] : j;
+        if (acc[m] > best || (acc[m] == best && jo < besti)) {
+          best = acc[m];
+          besti = jo;
+        }
+      }
+    }
+  }
+  bv[g][q] = best;
+  bi[g][q] = besti;
+  __syncthreads();
+  if (g == 0 && qi < N) {
+    float v = bv[0][q];
+    int ix = bi[0][q];
+#pragma unroll
+    for (int w = 1; w < 8; ++w)
+      if (bv[w][q] > v || (bv[w][q] == v && bi[w][q] < ix)) {
+        v = bv[w][q];
+        ix = bi[w][q];
+      }
+    nearest[(size_t)b * N + (pb ? (int)pb[qi] : qi)] = (long long)ix;
+  }
+}
+
+// queries xq and candidates xc (B,N,D) unit rows in ONE common (locality) order with their tile caps
+// (pn_meanshift_x3_tileinfo_f32); workspace: pn_meanshift_x3_plan_bytes(B, N).
+extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX,
+                                        const float* rhoX, const float* cntX, const float* bsq, int B, int N,
+                                        float rel_eps, void* plan, void* stream_);
+extern "C" int pn_meanshift_x3_nearest_f32(const float* xq, const float* xc, const float* cenQ, const float* rhoQ,
+                                           const float* cenC, const float* rhoC, const int64_t* perm, int B, int N,
+                                           int D, int64_t* nearest, void* workspace, size_t workspace_bytes,
+                                           void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(xq && xc && cenQ && rhoQ && cenC && rhoC && nearest && workspace, "pn_meanshift_x3_nearest_f32: null pointer");
+  PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
+  PN_CHECK_ARG(workspace_bytes >= pn_meanshift_x3_plan_bytes(B, N), "pn_meanshift_x3_nearest_f32: workspace too small");
+  // the pair predicate of the exact mode (bsq is not read: any valid pointer)
+  const int rc = pn_meanshift_x3_plan_f32(cenQ, rhoQ, cenC, rhoC, nullptr, rhoQ, B, N, -1.0f, workspace, stream_);
+  if (rc != PN_OK) return rc;
+  const int ntiles = (int)pn_align_up(N, 64) / 32;
+  PN_PROF("sel_pruned_argmax", stream);
+  hipLaunchKernelGGL(pn_ms3_nearest_kernel, dim3(pn_cdiv(N, 32), B), dim3(256), 0, stream, xq, xc,
+                     (const unsigned char*)workspace, (const long long*)perm, N, ntiles, (long long*)nearest);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

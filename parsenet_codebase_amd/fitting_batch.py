@@ -24,6 +24,8 @@ by STAGE over all shapes and segments instead of by shape and segment:
 
 The reference's serial path costs ~250 launches and ~10 host synchronisations per segment; this
 one ~60 launches per shape and 4 synchronisations per STEP (one per shape at batch 4)."""
+import os
+
 import numpy as np
 import torch
 from torch.profiler import record_function
@@ -93,7 +95,7 @@ def bandwidth_batch(X, quantile, num_samples=10000):
     return torch.clamp(bw, min=0.003), (flags != 0).sum(1)
 
 
-def nms_batch(new_X, X, bw, width=None, labels=True):
+def nms_batch(new_X, X, bw, width=None, labels=True, nearest=None):
     """MeanShift.nms (src/mean_shift.py:139-179) for all shapes at once.  new_X, X (B,N,128)
     detached, bw (B,).  Returns a dict: labels (B,N) int64 (None with ``labels=False``: the caller
     takes them from the membership kernel it runs anyway), cid (B,CMAX) int64 ascending centre ids
@@ -113,13 +115,25 @@ def nms_batch(new_X, X, bw, width=None, labels=True):
     occupied / voted centres and the vote itself are three small kernels (csrc/fused.hip:
     pn_nms_occupied_f32, pn_nms_vote_f32) around one GEMM."""
     B, N, D = X.shape
-    res = K.dot_select(X, new_X, 1, want_value=False)
-    if res is None:
-        return None
-    idx, flags = res
-    nflag = (flags != 0).sum(1)
+    if nearest is not None:
+        # (B,N) from the planned iterations (kernels.meanshift_x3_nearest): the same indices as the
+        # selection engine's, evaluated on the tile pairs that can hold a maximum only; nothing to flag
+        member = nearest
+        nflag = torch.zeros(B, dtype=torch.int64, device=X.device)
+        if os.environ.get("PARSENET_CHECK_NEAREST") == "1":       # developer check against the selection engine
+            ref, fl = K.dot_select(X, new_X, 1, want_value=False)
+            bad = (ref[:, :, 0] != nearest) & (fl == 0)
+            if bool(bad.any()):
+                raise AssertionError("pruned nearest differs from dot_select in %d rows (B=%d N=%d)" % (int(bad.sum()), B, N))
+    else:
+        res = K.dot_select(X, new_X, 1, want_value=False)
+        if res is None:
+            return None
+        idx, flags = res
+        member = idx[:, :, 0]
+        nflag = (flags != 0).sum(1)
     cap = N if width is None else min(int(width), N)
-    counts, uq, nocc = K.nms_occupied(idx[:, :, 0], cap)
+    counts, uq, nocc = K.nms_occupied(member, cap)
     U = cap
     if width is None:
         U = max(int(nocc.max().item()), 1)                                    # sync: sizes the next launches
@@ -506,14 +520,21 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
     if bwres is not None and D == 128:
         bw, bwflag = bwres
         with record_function("fit:meanshift_fwd"):
-            new_X = MSM.mean_shift_iterations(emb, bw, iterations)
+            # (a planned call also returns every point's nearest shifted point, the first step of the NMS:
+            # the iterations hold both sides in the locality order its exact pruning needs)
+            MSM.WANT_NEAREST = os.environ.get("PARSENET_MS_NEAREST", "1") != "0"
+            try:
+                new_X = MSM.mean_shift_iterations(emb, bw, iterations)
+            finally:
+                MSM.WANT_NEAREST = False
+            nearest, MSM.LAST_NEAREST = MSM.LAST_NEAREST, None
 
         def cluster(width):
             """NMS down to the padded list of centres, then — still on the device, before anything is
             downloaded — the memberships of ALL CMAX padded centre rows (rows >= ncl are masked in
             the kernel), whose first output are the cluster labels the host is waiting for."""
             with torch.no_grad(), record_function("fit:nms"):
-                st = nms_batch(new_X.detach(), emb.detach(), bw, width, labels=False)
+                st = nms_batch(new_X.detach(), emb.detach(), bw, width, labels=False, nearest=nearest)
             if st is not None:
                 with record_function("fit:memberships"):
                     cen_all = torch.gather(new_X, 1, st["cid"].unsqueeze(2).expand(-1, -1, D))       # (B,CMAX,D)

@@ -391,6 +391,29 @@ def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
     return plan
 
 
+def meanshift_x3_nearest(xq, xc, q_info, c_info, perm=None):
+    """arg-max_j xq_i . xc_j for unit rows xq, xc (B,N,128) given in one common locality order, with
+    their tile caps (meanshift_x3_tileinfo); perm (B,N) int64 position -> original index.  Returns
+    (B,N) int64 indexed by / naming ORIGINAL indices: exactly dot_select(xq, xc, 1) of the unpermuted
+    tensors (fp32 fma chains, ties to the smaller index), evaluated on the tile pairs that can hold
+    a maximum only."""
+    require_cuda(xq, xc)
+    xq, xc = _f32c(xq, "xq"), _f32c(xc, "xc")
+    B, N, D = xq.shape
+    lib = _lib.load()
+    out = torch.empty((B, N), dtype=torch.int64, device=xq.device)
+    wsz = lib.pn_meanshift_x3_plan_bytes(B, N)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=xq.device)
+    if perm is not None:
+        perm = _i64c(perm, "perm")
+    with _lib.on_device(xq.device):
+        rc = lib.pn_meanshift_x3_nearest_f32(ptr(xq), ptr(xc), ptr(q_info[0]), ptr(q_info[1]), ptr(c_info[0]),
+                                             ptr(c_info[1]), ptr(perm), B, N, D, ptr(out), ptr(ws), wsz,
+                                             current_stream(xq.device))
+    check(rc, "pn_meanshift_x3_nearest_f32")
+    return out
+
+
 def meanshift_x3_plan_stats(plan, B, N):
     """(active fraction of tile pairs, of pass-0 / pass-1 / pass-2 block x tile pairs) — diagnostics."""
     T = (N + 63) // 64 * 2

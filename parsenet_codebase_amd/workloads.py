@@ -61,6 +61,7 @@ class ParsenetSegStep:
         self.bucket = FlatGradBucket(self.model.parameters())
         self.opt = _adam(self.model.parameters(), lr)
         self.rng_seed = seed
+        self.shape_ids = None if shape_ids is None else list(shape_ids)
         if shape_ids is not None:
             self.load_pool(first_shape, len(shape_ids), ids=shape_ids)
         else:
@@ -171,9 +172,12 @@ class ParsenetE2EStep(ParsenetSegStep):
         import os
         held_out = self.pretrain_pool is not None
         cache = os.environ.get("PARSENET_PRETRAIN_CACHE")
-        tag = "seed%d_first%d_B%d_N%d_steps%d_pool%s_lr%g" % (
+        # (the ids of an explicit shape list belong to the recipe: two steps that differ in nothing else must
+        # not load each other's weights — round 4: a test run with the cache variable set did exactly that)
+        tag = "seed%d_first%d_B%d_N%d_steps%d_pool%s_lr%g_ids%s" % (
             seed, PRETRAIN_FIRST_SHAPE if held_out else first_shape, self.batch, self.num_points,
-            self.pretrain_steps, self.pretrain_pool, lr)
+            self.pretrain_steps, self.pretrain_pool, lr,
+            "-".join(str(int(i)) for i in self.shape_ids) if self.shape_ids is not None else "pool")
 
         def train():
             state = torch.load(cache, map_location=self.device) if cache and os.path.exists(cache) else None
