@@ -1351,86 +1351,145 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
 // N^2 chains on the fp32 matrix cores (1.1 ms per launch of 4 shapes x 10 000 points).  With the points
 // in the locality order of the iterations, the caps of the query tiles and of the candidate tiles say
 // which tile pairs can hold a maximum at all (pn_ms3_thr_kernel, exact mode: no tolerance involved), and
-// the chains of those pairs alone are evaluated here — by plain fma instructions, in the same order.
-// One workgroup per query tile: thread (q = tid & 31, g = tid >> 5) holds query q's 128 channels in
-// registers and takes candidates g, g + 8, g + 16, g + 24 of every kept tile (staged in LDS, read as
-// wave-uniform 16-byte broadcasts).  perm (position -> original index, or NULL): results are written at
-// the query's ORIGINAL index and name the candidate's ORIGINAL index; ties go to the smaller original index.
+// the chains of those pairs alone are evaluated here, in the same arithmetic.
+// One workgroup per query tile, four waves; wave w takes the kept candidate tiles w, w + 4, ... of the
+// tile's list and evaluates each 32 x 32 block of chains on the fp32 matrix cores exactly like the engine
+// (v_mfma_f32_32x32x2_f32: k-step m = channels 2m, 2m + 1 — an fma chain over the channels in order): the
+// queries are the resident operand (64 registers), the candidate tile goes through the wave's own LDS
+// region (rows padded to 129 floats: the column read of a k-step is conflict-free), the next tile's
+// rows are in flight while the current one is evaluated.  Every lane keeps the best candidate of ITS
+// query among the rows it sees; lanes, halves and waves are combined once at the end.  perm (position ->
+// original index, or NULL): results are written at the query's ORIGINAL index and name the candidate's
+// ORIGINAL index; ties go to the smaller original index (decided explicitly: the visiting order is free).
+#define NR_PAD 129
 __global__ __launch_bounds__(256) void pn_ms3_nearest_kernel(const float* __restrict__ xq, const float* __restrict__ xc,
                                                              const unsigned char* __restrict__ pairs,
                                                              const long long* __restrict__ perm, int N, int ntiles,
                                                              long long* __restrict__ nearest) {
-  __shared__ __attribute__((aligned(16))) float ct[32][MS_D];
-  __shared__ float bv[8][32];
-  __shared__ int bi[8][32];
+  __shared__ float ctw[4][32 * NR_PAD];
+  __shared__ float bvw[4][32];
+  __shared__ int biw[4][32];
+  __shared__ unsigned short tl[2048];          // the kept candidate tiles of this query tile, ascending
+  __shared__ int tl_n;
+  __shared__ int wcnt[4];
   const int b = blockIdx.y, tq = blockIdx.x, tid = threadIdx.x;
-  const int q = tid & 31, g = tid >> 5;
-  const int qi = tq * 32 + q;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, h = lane >> 5;
   if (tq * 32 >= N) return;
-  const int qc = min(qi, N - 1);
-  float qv[MS_D];
+  // compact the pair row into a list (one coalesced pass, ballot scan per wave, waves in order)
   {
-    const float4* src = reinterpret_cast<const float4*>(xq + ((size_t)b * N + qc) * MS_D);
-#pragma unroll
-    for (int e = 0; e < MS_D / 4; ++e) {
-      const float4 v = src[e];
-      qv[4 * e] = v.x, qv[4 * e + 1] = v.y, qv[4 * e + 2] = v.z, qv[4 * e + 3] = v.w;
+    const unsigned char* __restrict__ prow = pairs + ((size_t)b * ntiles + tq) * ntiles;
+    const int nreal = (N + 31) / 32;            // tiles that hold rows
+    if (tid == 0) tl_n = 0;
+    __syncthreads();
+    for (int base = 0; base < nreal; base += 256) {
+      const int t = base + tid;
+      const bool on = t < nreal && prow[t] != 0;
+      const unsigned long long m = __ballot(on);
+      if (lane == 0) wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = tl_n;
+      for (int w = 0; w < wave; ++w) off += wcnt[w];
+      if (on) tl[off + pn_mbcnt(m)] = (unsigned short)t;
+      __syncthreads();
+      if (tid == 0) tl_n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      __syncthreads();
     }
   }
-  const unsigned char* __restrict__ prow = pairs + ((size_t)b * ntiles + tq) * ntiles;
+  const int ntk = tl_n;
   const long long* __restrict__ pb = perm ? perm + (size_t)b * N : nullptr;
-  float best = -__builtin_inff();
-  int besti = 0x7fffffff;
-  for (int t = 0; t < ntiles; ++t) {
-    if (!prow[t]) continue;                      // workgroup-uniform
-    const int j0 = t * 32;
-    if (j0 >= N) break;
-    __syncthreads();                             // everyone is done with the previous tile
-    for (int e = tid; e < 32 * MS_D / 4; e += 256) {
-      const int r = e / (MS_D / 4), c4 = e - r * (MS_D / 4);
-      const int j = min(j0 + r, N - 1);
-      reinterpret_cast<float4*>(&ct[r][0])[c4] = reinterpret_cast<const float4*>(xc + ((size_t)b * N + j) * MS_D)[c4];
-    }
-    __syncthreads();
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int e = 0; e < MS_D / 4; ++e) {
+  const float* __restrict__ xcb = xc + (size_t)b * N * MS_D;
+  // resident queries: B[k = h][j = col] of k-step m = channel 2m + h of query tq * 32 + col
+  const int qi = tq * 32 + col;
+  float bq[MS_D / 2];
+  {
+    const float* __restrict__ src = xq + ((size_t)b * N + min(qi, N - 1)) * MS_D + h;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float4 c = reinterpret_cast<const float4*>(&ct[g + 8 * m][0])[e];
-        float a = acc[m];
-        a = __builtin_fmaf(qv[4 * e], c.x, a);
-        a = __builtin_fmaf(qv[4 * e + 1], c.y, a);
-        a = __builtin_fmaf(qv[4 * e + 2], c.z, a);
-        a = __builtin_fmaf(qv[4 * e + 3], c.w, a);
-        acc[m] = a;
-      }
-    }
+    for (int m = 0; m < MS_D / 2; ++m) bq[m] = src[2 * m];
+  }
+  float bestv = -__builtin_inff();
+  int bestj = -1;                                // position in the common order
+  float* __restrict__ cw = ctw[wave];
+  // staging: lane l takes 16-byte chunks l, l + 64, ... of the 32 x 128 tile (chunk c = row c / 32, columns 4 (c % 32)..)
+  float4 stage[16];
+#define NR_FETCH(T_)                                                                               \
+  {                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                               \
+      const int c_ = u * 64 + lane;                                                                \
+      const int j_ = min((T_) * 32 + (c_ >> 5), N - 1);                                            \
+      stage[u] = reinterpret_cast<const float4*>(xcb + (size_t)j_ * MS_D)[c_ & 31];                \
+    }                                                                                              \
+  }
+  if (wave < ntk) NR_FETCH((int)tl[wave]);
+  for (int k = wave; k < ntk; k += 4) {
+    const int j0 = (int)tl[k] * 32;
+    // (wave-local: LDS traffic of a wave is ordered; the fences keep the compiler from reordering)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int j = j0 + g + 8 * m;
-      if (j < N) {
-        const int jo = pb ? (int)pb[j] : j;
-        if (acc[m] > best || (acc[m] == best && jo < besti)) {
-          best = acc[m];
-          besti = jo;
+    for (int u = 0; u < 16; ++u) {
+      const int c_ = u * 64 + lane;
+      float* d_ = cw + (c_ >> 5) * NR_PAD + 4 * (c_ & 31);
+      d_[0] = stage[u].x, d_[1] = stage[u].y, d_[2] = stage[u].z, d_[3] = stage[u].w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (k + 4 < ntk) NR_FETCH((int)tl[k + 4]);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A[i = col][k = h]: candidate j0 + col, channel 2m + h
+    const float* __restrict__ ar = cw + col * NR_PAD + h;
+#pragma unroll
+    for (int m = 0; m < MS_D / 2; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * m], bq[m], acc, 0, 0, 0);
+    // D[i = candidate (r & 3) + 8 (r >> 2) + 4 h][j = query col]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = acc[r];
+      if (j < N && v >= bestv) {
+        bool take = v > bestv || bestj < 0;
+        if (!take) take = pb ? pb[j] < pb[bestj] : j < bestj;     // equal values: the smaller ORIGINAL index
+        if (take) {
+          bestv = v;
+          bestj = j;
         }
       }
     }
   }
-  bv[g][q] = best;
-  bi[g][q] = besti;
+#undef NR_FETCH
+  // the other half of the rows (lane col + 32), then the four waves
+  {
+    const float ov = __shfl_xor(bestv, 32, 64);
+    const int oj = __shfl_xor(bestj, 32, 64);
+    bool take = oj >= 0 && (bestj < 0 || ov > bestv);
+    if (!take && oj >= 0 && bestj >= 0 && ov == bestv) take = pb ? pb[oj] < pb[bestj] : oj < bestj;
+    if (take) {
+      bestv = ov;
+      bestj = oj;
+    }
+  }
+  if (h == 0) {
+    bvw[wave][col] = bestv;
+    biw[wave][col] = bestj;
+  }
   __syncthreads();
-  if (g == 0 && qi < N) {
-    float v = bv[0][q];
-    int ix = bi[0][q];
+  if (wave == 0 && h == 0 && qi < N) {
+    float v = bvw[0][col];
+    int ix = biw[0][col];
 #pragma unroll
-    for (int w = 1; w < 8; ++w)
-      if (bv[w][q] > v || (bv[w][q] == v && bi[w][q] < ix)) {
-        v = bv[w][q];
-        ix = bi[w][q];
+    for (int w = 1; w < 4; ++w) {
+      const float ov = bvw[w][col];
+      const int oj = biw[w][col];
+      bool take = oj >= 0 && (ix < 0 || ov > v);
+      if (!take && oj >= 0 && ix >= 0 && ov == v) take = pb ? pb[oj] < pb[ix] : oj < ix;
+      if (take) {
+        v = ov;
+        ix = oj;
       }
-    nearest[(size_t)b * N + (pb ? (int)pb[qi] : qi)] = (long long)ix;
+    }
+    nearest[(size_t)b * N + (pb ? (int)pb[qi] : qi)] = pb ? pb[ix] : (long long)ix;
   }
 }
 
