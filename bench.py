@@ -532,6 +532,10 @@ def main():
     gc.collect()
     gc.freeze()
     start = snapshot()
+    # (numpy's generator feeds the triplet sampling: seeded here too, so that the pass over the pool — whose
+    # steps are counted in clusters_per_shape — does not depend on whether the pre-training ran in this
+    # process or came from PARSENET_PRETRAIN_CACHE)
+    np.random.seed(999 + rank)
     if hasattr(step, "pool") and not stub and not args.profile_only:
         for _ in range(max(1, step.pool // step.batch)):
             step.step()
