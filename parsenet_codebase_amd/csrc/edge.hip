@@ -973,27 +973,55 @@ extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const fl
 //   gxt[b,j,:] = sum_{(i,slot) -> j} g[b,i,slot,0:C]  +  sum_kk (g[b,j,kk,C:2C] - g[b,j,kk,0:C])
 // one wave per target point, lanes over the channels; list order = (source, slot) ascending.
 // ------------------------------------------------------------------------------------
+// CW = lanes per row (the power of two >= min(C, 64)); the 64 / CW lane groups of a wave take the list
+// entries (and the neighbour slots of the centre term) t = group, group + 64 / CW, ... in ascending order,
+// two row loads in flight per lane, and are added by a fixed xor tree at the end: a fixed summation order.
+template <int CW>
 __global__ __launch_bounds__(256) void pn_edge_feature_bwd_kernel(
     const float* __restrict__ g, const int* __restrict__ off, const uint32_t* __restrict__ rev, int N, int k,
     int C, float* __restrict__ gxt) {
+  constexpr int G = 64 / CW;
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + wave;
   if (j >= N) return;
+  const int grp = lane / CW, cl = lane - grp * CW;
   const float* __restrict__ gb = g + (size_t)b * N * k * 2 * C;
   const int* __restrict__ ob = off + (size_t)b * (N + 1);
   const uint32_t* __restrict__ rb = rev + (size_t)b * N * k;
   const int e0 = ob[j], e1 = ob[j + 1];
-  for (int c = lane; c < C; c += 64) {
-    float ctr = 0.f;
-    const float* __restrict__ gj = gb + (size_t)j * k * 2 * C;
-    for (int kk = 0; kk < k; ++kk) ctr += gj[(size_t)kk * 2 * C + C + c] - gj[(size_t)kk * 2 * C + c];
+  const float* __restrict__ gj = gb + (size_t)j * k * 2 * C;
+  for (int c0 = 0; c0 < C; c0 += CW) {
+    const int c = c0 + cl;
+    const bool cin = c < C;
+    const int cc = cin ? c : 0;
     float acc = 0.f;
-    for (int e = e0; e < e1; ++e) {
-      const uint32_t s = rb[e];
-      acc += gb[((size_t)(s >> 8) * k + (s & 255u)) * 2 * C + c];
+    // centre term: sum_kk (g[j,kk,C+c] - g[j,kk,c])
+    for (int kk = grp; kk < k; kk += 2 * G) {
+      const int kb = kk + G;
+      const float a1 = gj[(size_t)kk * 2 * C + C + cc], a0 = gj[(size_t)kk * 2 * C + cc];
+      const bool ob2 = kb < k;
+      const float b1 = ob2 ? gj[(size_t)kb * 2 * C + C + cc] : 0.f, b0 = ob2 ? gj[(size_t)kb * 2 * C + cc] : 0.f;
+      acc += a1 - a0;
+      if (ob2) acc += b1 - b0;
     }
-    gxt[((size_t)b * N + j) * C + c] = acc + ctr;
+    // incoming edges: 64 list entries at a time in registers
+    for (int base = e0; base < e1; base += 64) {
+      const uint32_t mine = base + lane < e1 ? rb[base + lane] : 0u;
+      const int cnt = e1 - base < 64 ? e1 - base : 64;
+      for (int t0 = 0; t0 < cnt; t0 += 2 * G) {          // (wave-uniform trips: the shuffles are executed by every lane)
+        const int ta = t0 + grp, tb = ta + G;
+        const uint32_t sa = (uint32_t)__shfl((int)mine, ta & 63, 64), sb = (uint32_t)__shfl((int)mine, tb & 63, 64);
+        const bool oa2 = ta < cnt, ob2 = tb < cnt;
+        const float va = oa2 ? gb[((size_t)(sa >> 8) * k + (sa & 255u)) * 2 * C + cc] : 0.f;
+        const float vb = ob2 ? gb[((size_t)(sb >> 8) * k + (sb & 255u)) * 2 * C + cc] : 0.f;
+        if (oa2) acc += va;
+        if (ob2) acc += vb;
+      }
+    }
+#pragma unroll
+    for (int o = CW; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (grp == 0 && cin) gxt[((size_t)b * N + j) * C + c] = acc;
   }
 }
 
@@ -1009,7 +1037,19 @@ extern "C" int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, i
   const int rc = pn_build_rev_csr(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
   if (rc != PN_OK) return rc;
   dim3 grid(pn_cdiv(N, 4), B);
-  hipLaunchKernelGGL(pn_edge_feature_bwd_kernel, grid, dim3(256), 0, stream, gfeat, off, rev, N, k, C, gxt);
+#define EF_BWD(CW_) \
+  hipLaunchKernelGGL(pn_edge_feature_bwd_kernel<CW_>, grid, dim3(256), 0, stream, gfeat, off, rev, N, k, C, gxt)
+  if (C <= 4)
+    EF_BWD(4);
+  else if (C <= 8)
+    EF_BWD(8);
+  else if (C <= 16)
+    EF_BWD(16);
+  else if (C <= 32)
+    EF_BWD(32);
+  else
+    EF_BWD(64);
+#undef EF_BWD
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

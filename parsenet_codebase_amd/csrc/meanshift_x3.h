@@ -1030,6 +1030,7 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
 // (0.9: the fp32 summation of <= 2 ntiles positive terms on either side), by bisection over the cap's
 // rows of the U and Lo tables; L = the cap's lower bound of the best dot product (sweep 0), n_x the
 // rows of data cap x.  Caps with U >= t are kept.
+template <int MAXV>   // 64 MAXV >= the number of caps (the cap's rows of bounds live in registers)
 __global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict__ utab, const float* __restrict__ lotab,
                                                         const float* __restrict__ pm, const float* __restrict__ rhoQ,
                                                         const float* __restrict__ cntX, const float* __restrict__ bsq,
@@ -1052,7 +1053,6 @@ __global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict_
     return;
   }
   const float ib = 1.0f / bsq[b];
-  constexpr int MAXV = 32;        // 64 x 32 = 2048 caps = 32 768 points
   float u[MAXV], m[MAXV];
   const int nv = (ncap + 63) / 64;
   float R = 0.f;
@@ -1330,8 +1330,18 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
                      pairs, utab, lotab, (const float*)thr);
   // cntX (rows of every data cap, pn_meanshift_x3_tileinfo_f32) may be NULL: one row per non-empty cap in the
   // row-sum bound, 32 in the dropped mass — still rigorous, keeps more pairs
-  hipLaunchKernelGGL(pn_ms3_thr_kernel, dim3(2 * nt, B), dim3(64), 0, stream, (const float*)utab, (const float*)lotab,
-                     (const float*)pm, rhoQ, cntX, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr);
+#define X3_THR(MV)                                                                                              \
+  hipLaunchKernelGGL(pn_ms3_thr_kernel<MV>, dim3(2 * nt, B), dim3(64), 0, stream, (const float*)utab,           \
+                     (const float*)lotab, (const float*)pm, rhoQ, cntX, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr)
+  if (2 * nt <= 512)
+    X3_THR(8);
+  else if (2 * nt <= 768)       // N <= 12 288: the benchmark's 626 caps
+    X3_THR(12);
+  else if (2 * nt <= 1024)
+    X3_THR(16);
+  else
+    X3_THR(32);
+#undef X3_THR
   hipLaunchKernelGGL(pn_ms3_pairs_kernel<1>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
                      pairs, utab, lotab, (const float*)thr);
   PN_CHECK_LAUNCH();
