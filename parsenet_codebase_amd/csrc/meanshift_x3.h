@@ -86,6 +86,79 @@ __global__ __launch_bounds__(256) void pn_ms3_prep_bwd_kernel(
   }
 }
 
+// The backward prologue in ONE launch (round 4; three before: pn_ms3_prep_bwd_kernel + two
+// pn_ms3_split_kernel): one workgroup per 32-row tile computes gu, c and alpha of its rows (the same
+// arithmetic, one wave per row, eight rows per wave), keeps the gu rows in LDS and writes the tile
+// images of q and of gu.
+__global__ __launch_bounds__(256) void pn_ms3_prologue_bwd_kernel(
+    const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ q,
+    const float* __restrict__ rsum, const float* __restrict__ unorm, const float* __restrict__ bsq, int N, int ntiles,
+    float* __restrict__ gu, float* __restrict__ cs, float* __restrict__ alpha, u32x4* __restrict__ img_q,
+    u32x4* __restrict__ img_gu) {
+  __shared__ __attribute__((aligned(16))) float gt[32][MS_D];
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j0 = tile * 32;
+  for (int r = wave; r < 32; r += 4) {
+    const int i = j0 + r;
+    float u0 = 0.f, u1 = 0.f;
+    if (i < N) {
+      const size_t base = ((size_t)b * N + i) * MS_D;
+      const float y0 = y[base + lane], y1 = y[base + lane + 64];
+      const float g0 = gy[base + lane], g1 = gy[base + lane + 64];
+      const float nn = unorm[(size_t)b * N + i], rr = rsum[(size_t)b * N + i];
+      const float yg = pn_wave_sum(y0 * g0 + y1 * g1);
+      u0 = (g0 - y0 * yg) / nn;
+      u1 = (g1 - y1 * yg) / nn;
+      const float c = pn_wave_sum(u0 * (y0 * nn) + u1 * (y1 * nn));
+      gu[base + lane] = u0;
+      gu[base + lane + 64] = u1;
+      if (lane == 0) {
+        cs[(size_t)b * N + i] = c;
+        alpha[(size_t)b * N + i] = 1.0f / (rr * bsq[b]);
+      }
+    }
+    gt[r][lane] = u0;            // rows >= N: zero image rows
+    gt[r][lane + 64] = u1;
+  }
+  __syncthreads();
+  const float* __restrict__ qb = q + (size_t)b * N * MS_D;
+  u32x4* __restrict__ Pq = img_q + ((size_t)b * ntiles + tile) * X3_IMG_U4;
+  u32x4* __restrict__ Pg = img_gu + ((size_t)b * ntiles + tile) * X3_IMG_U4;
+  for (int it = threadIdx.x; it < 512; it += 256) {
+    const int j = it >> 4, c = it & 15;  // row j, chunk c = channels 8c..8c+7
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (j0 + j < N) {
+      const float* src = qb + (size_t)(j0 + j) * MS_D + 8 * c;
+      v0 = *reinterpret_cast<const float4*>(src);
+      v1 = *reinterpret_cast<const float4*>(src + 4);
+    }
+    const float4 w0 = *reinterpret_cast<const float4*>(&gt[j][8 * c]);
+    const float4 w1 = *reinterpret_cast<const float4*>(&gt[j][8 * c + 4]);
+    const int slot = j * 16 + (c ^ x3_swz(j));
+    {
+      u32x4 h, m, l;
+      X3_SPLIT_TO(v0.x, v0.y, h, m, l, 0);
+      X3_SPLIT_TO(v0.z, v0.w, h, m, l, 1);
+      X3_SPLIT_TO(v1.x, v1.y, h, m, l, 2);
+      X3_SPLIT_TO(v1.z, v1.w, h, m, l, 3);
+      Pq[slot] = h;
+      Pq[X3_PIECE_U4 + slot] = m;
+      Pq[2 * X3_PIECE_U4 + slot] = l;
+    }
+    {
+      u32x4 h, m, l;
+      X3_SPLIT_TO(w0.x, w0.y, h, m, l, 0);
+      X3_SPLIT_TO(w0.z, w0.w, h, m, l, 1);
+      X3_SPLIT_TO(w1.x, w1.y, h, m, l, 2);
+      X3_SPLIT_TO(w1.z, w1.w, h, m, l, 3);
+      Pg[slot] = h;
+      Pg[X3_PIECE_U4 + slot] = m;
+      Pg[2 * X3_PIECE_U4 + slot] = l;
+    }
+  }
+}
+
 // six-term product of two split operands into two accumulators (large and small terms apart)
 #define X3_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
 
@@ -1723,13 +1796,8 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
   const int ntiles = (int)pn_align_up(N, 64) / 32;
   const X3Plan pv = x3_plan_view(plan, B, N, ntiles);
   float* alpha = cs + (size_t)B * N;
-  hipLaunchKernelGGL(pn_ms3_prep_bwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, gy, y, rsum,
-                     unorm, bsq, N, gu, cs, alpha);
-  PN_CHECK_LAUNCH();
-  dim3 sgrid(ntiles, B);
-  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, q, N, ntiles, (u32x4*)img_q);
-  hipLaunchKernelGGL(pn_ms3_split_kernel, sgrid, dim3(256), 0, stream, (const float*)gu, N, ntiles,
-                     (u32x4*)img_gu);
+  hipLaunchKernelGGL(pn_ms3_prologue_bwd_kernel, dim3(ntiles, B), dim3(256), 0, stream, gy, y, q, rsum, unorm, bsq, N,
+                     ntiles, gu, cs, alpha, (u32x4*)img_q, (u32x4*)img_gu);
   PN_CHECK_LAUNCH();
   const long long ND4 = (long long)N * MS_D / 4;
   if (pv.flat) {

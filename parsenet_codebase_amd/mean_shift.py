@@ -158,9 +158,11 @@ class _MeanShiftIterations(torch.autograd.Function):
         iterates, rsums, norms, plans = [x], [], [], []
         x_info = K.meanshift_x3_tileinfo(x) if sparse else None
         q = x
-        for _ in range(iterations):
+        for it in range(iterations):
             if sparse:
-                plan = K.meanshift_x3_plan(K.meanshift_x3_tileinfo(q), x_info, bsq, N, PLAN_REL_EPS)
+                # (the first iterate IS the data: its caps are x_info)
+                plan = K.meanshift_x3_plan(x_info if it == 0 else K.meanshift_x3_tileinfo(q), x_info, bsq, N,
+                                           PLAN_REL_EPS)
                 plans.append(plan)
                 q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan)
             elif x3 is not None:
