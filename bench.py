@@ -293,6 +293,9 @@ def kernel_roofline(step, nprof):
     return roof, table
 
 
+_HOST_THREADS_AT_START = 0
+
+
 def cpu_baseline(name, state=None, state_note="random-init weights"):
     """The torch-CPU oracle (restatement of the reference's algorithm) on ONE shape of the same
     workload (shape 0 of rank 0's timed pool), all host cores; ``state`` = the state_dict the GPU
@@ -303,7 +306,11 @@ def cpu_baseline(name, state=None, state_note="random-init weights"):
     from parsenet_codebase_amd import synthetic
     torch.manual_seed(0)
     np.random.seed(0)
-    cores = torch.get_num_threads()
+    # the GPU legs run with one host thread (dp.limit_host_threads); the oracle gets the CPUs the process
+    # may really use: the cgroup quota, not the visible cores (128 threads on a 16-CPU quota are throttled)
+    from parsenet_codebase_amd import dp as _dp
+    cores = min(_HOST_THREADS_AT_START or torch.get_num_threads(), _dp.usable_cpus())
+    torch.set_num_threads(cores)
     if name in ("cfg2", "cfg3"):
         return cpu_baseline_splinenet(name, cores)
     model = R.PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True, num_primitives=10,
@@ -458,6 +465,9 @@ def main():
                          "counts as planned) and print the line with `value` null — the process to put under "
                          "rocprofv3: its kernel trace then holds the launches the roofline is quoted on, not the "
                          "warm-up pass on a synthetic embedding or the other launch kind")
+    ap.add_argument("--host-threads", type=int, default=int(os.environ.get("PARSENET_HOST_THREADS", "1")),
+                    help="torch intra-op CPU threads while the GPU legs run (default 1, see dp.limit_host_threads; 0: "
+                         "torch's default of one per visible core); the CPU baseline gets the usable CPUs")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -470,6 +480,9 @@ def main():
         return launch_selftest()
 
     from parsenet_codebase_amd import dp
+    global _HOST_THREADS_AT_START
+    os.environ["PARSENET_HOST_THREADS"] = str(args.host_threads)     # init_from_env applies it
+    _HOST_THREADS_AT_START = torch.get_num_threads()
     stub = args.workload == "stub"
     rank, world, device = dp.init_from_env(backend="gloo" if stub else None)
     if device.type != "cuda" and not stub:
@@ -641,6 +654,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if stub else _dtype_label(args.workload),
             "data": "synthetic",
+            # host side of the GPU legs: torch intra-op threads / CPUs the cgroup grants / cores visible
+            "host": {"threads": args.host_threads or _HOST_THREADS_AT_START, "usable_cpus": dp.usable_cpus(),
+                     "visible_cores": os.cpu_count()},
             "config": dict(cfg, parallelism="dp%d" % world, global_batch=step.shapes_per_step() * world,
                            **({"meanshift_products": _ms_arith()} if args.workload == "cfg5" else {})),
             "roofline": roof,

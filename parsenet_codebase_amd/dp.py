@@ -8,8 +8,57 @@ import torch
 import torch.distributed as dist
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the smaller of the visible cores and the cgroup's CFS quota.
+    The boxes of this pool show 256 cores and grant 16 (``cpu.max`` = 1600000 100000)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read().split()[0])
+            if quota != "max" and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def limit_host_threads(n=None):
+    """torch's intra-op CPU pool down to ``n`` threads (default 1; PARSENET_HOST_THREADS overrides, 0 = leave
+    torch's default of one thread per visible core).  Returns the count it found.
+
+    The product computes nothing on the CPU: the host thread queues launches and runs the small
+    host steps of the reference (Hungarian matching, a batched 3x3 geev).  With the default pool
+    every one of those steps that enters an OpenMP region wakes ~128 threads that spin afterwards;
+    under a CFS quota (round 4: 16 CPUs on a 256-core box) the process is throttled for tens of
+    milliseconds and the GPU idles: measured on one box 70.4 / 75.3 shapes/s with the default pool against
+    94.4 / 92.6 with one thread (cfg5, `profiles/r04_host_threads_ab.txt`; `nr_throttled` +20 per
+    run against +2), and the batched geev step alone 0.15 ms against a bimodal 0.5 / 4.7 ms.  With
+    one process per GPU the default pool is also 8 x oversubscribed on a node."""
+    before = torch.get_num_threads()
+    want = os.environ.get("PARSENET_HOST_THREADS")
+    if n is None:
+        n = int(want) if want not in (None, "") else 1
+    if n > 0 and n != before:
+        torch.set_num_threads(n)
+    return before
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment; returns (rank, world, device)."""
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, device).
+    Also caps the host's intra-op thread pool (``limit_host_threads``)."""
+    limit_host_threads()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -605,3 +605,35 @@ def test_workload_pool_rotation_on_the_host():
     assert step.pool == 2 and np.array_equal(step.labels, synthetic.make_batch_ids(ids, 1500)[2])
     with pytest.raises(ValueError):
         workloads.ParsenetSegStep(torch.device("cpu"), batch=4, num_points=1500, nn_nb=8, pool=6)
+
+
+def test_host_thread_cap_and_usable_cpus(monkeypatch):
+    """dp.limit_host_threads: one intra-op thread by default (the GPU legs compute nothing on the CPU; the
+    default pool gets the process throttled under a CFS quota), PARSENET_HOST_THREADS overrides, 0 leaves
+    torch alone; dp.usable_cpus never exceeds the visible cores and honours the cgroup quota."""
+    import torch
+    from parsenet_codebase_amd import dp
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("PARSENET_HOST_THREADS", raising=False)
+        assert dp.limit_host_threads() == before
+        assert torch.get_num_threads() == 1
+        monkeypatch.setenv("PARSENET_HOST_THREADS", "2")
+        dp.limit_host_threads()
+        assert torch.get_num_threads() == 2
+        monkeypatch.setenv("PARSENET_HOST_THREADS", "0")
+        dp.limit_host_threads()
+        assert torch.get_num_threads() == 2          # 0: untouched
+        dp.limit_host_threads(3)
+        assert torch.get_num_threads() == 3          # an explicit count wins
+    finally:
+        torch.set_num_threads(before)
+    n = dp.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        if q != "max":
+            assert n <= max(1, int(float(q) / float(p)))
+    except OSError:
+        pass
