@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
 // ---------------------------------------------------------------------------------------
 struct KnnPlan {
   bool fast;
-  int ksteps, qsets, Cp, Nqp, Ncp, S, tiles_per_slice, subcap;
+  int ksteps, qsets, Cp, Nqp, Ncp, S, tiles_per_slice, subcap, B;
 };
 
 static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool want_value) {
@@ -513,6 +513,7 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
   memset(&p, 0, sizeof(p));
   p.Nqp = (int)pn_align_up(Nq, 64);
   p.Ncp = (int)pn_align_up(Nc, 64);
+  p.B = B;
   if (mode == 1) {
     p.ksteps = 4;
   } else if (C <= 4) {
@@ -576,9 +577,14 @@ static int knn_x3_level() {
   const char* e = getenv("PN_KNN_X3");
   return e ? atoi(e) : 2;
 }
-static bool knn_x3_pass1(const KnnPlan& p, int mode) {
+// 256 channels (ksteps 128; round 4): the squared-distance form only — kNN graphs of the widest edge-conv
+// layers (closed SplineNet) —, and only when the 128-query workgroups (one per CU: the resident queries take
+// 192 registers) fill the chip: measured (tools/kbench.py knnwide, N = 2 500, k = 10) 12 segments 0.85 ms
+// against 0.96 ms on the fp32 engine, 6 segments (120 workgroups) 0.73 against 0.55 ms.
+static bool knn_x3_pass1(const KnnPlan& p, int mode, bool dot_form = false) {
   const int on = knn_x3_level();
-  return on && p.fast && (mode == 0 || (mode == 2 && on >= 3)) && (p.ksteps == 32 || p.ksteps == 64) &&
+  const bool wide256 = p.ksteps == 128 && mode == 0 && !dot_form && (long long)p.B * pn_cdiv(p.Nqp, 128) >= 192;
+  return on && p.fast && (mode == 0 || (mode == 2 && on >= 3)) && (p.ksteps == 32 || p.ksteps == 64 || wide256) &&
          p.Ncp >= 2048;
 }
 #define KX_MAX_SLICES 16   // of the collecting pass (2 x 16 sub-lists per query)
@@ -667,7 +673,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     if (!self) knn_prep_launch(stream, q, B, C, Nq, p.Cp, p.Nqp, mode, q_pm, perm_q, xq, xxq);
   }
   PN_CHECK_LAUNCH();
-  const bool x3p1 = !argmax && (approx_value ? knn_x3_pass1(p, 0) : knn_x3_pass1(p, mode));
+  const bool x3p1 = !argmax && (approx_value ? knn_x3_pass1(p, 0, true) : knn_x3_pass1(p, mode));
   if (approx_value && !(x3p1 && mode == 2 && out_val && !out_idx)) {
     pn_set_error("select_run: the bf16 x 3 value selection needs C <= 128 and Nc >= 2048");
     return PN_ERR_UNSUPPORTED;
@@ -686,8 +692,11 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
     if (p.ksteps == 32)
       hipLaunchKernelGGL(pn_knn_x3_image_kernel<8>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
                          xpm, xxo);
-    else
+    else if (p.ksteps == 64)
       hipLaunchKernelGGL(pn_knn_x3_image_kernel<16>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
+                         xpm, xxo);
+    else
+      hipLaunchKernelGGL(pn_knn_x3_image_kernel<32>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
                          xpm, xxo);
     PN_CHECK_LAUNCH();
   }
@@ -717,8 +726,10 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
                      img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP, (const unsigned*)xxmax)
         if (mode == 0 && p.ksteps == 32)
           KX_GO(8, 2, 0, 2, 0, g1, tps1, 0);
-        else if (mode == 0)
+        else if (mode == 0 && p.ksteps == 64)
           KX_GO(16, 1, 0, 1, 0, g1, tps1, 0);
+        else if (mode == 0)
+          KX_GO(32, 1, 0, 1, 0, g1, tps1, 0);
         else if (p.ksteps == 32)
           KX_GO(8, 2, 2, 2, 0, g1, tps1, 0);
         else
@@ -773,8 +784,10 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         PN_PROF(p.ksteps == 32 ? "knn_x3_pass2_c64" : "knn_x3_pass2_wide", stream);
         if (p.ksteps == 32)
           KX_GO(8, 2, 0, 2, 1, g2, tps2, subcap2);
-        else
+        else if (p.ksteps == 64)
           KX_GO(16, 1, 0, 1, 1, g2, tps2, subcap2);
+        else
+          KX_GO(32, 1, 0, 1, 1, g2, tps2, subcap2);
       }
       PN_CHECK_LAUNCH();
       {
@@ -783,8 +796,12 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<64>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
                              x3A, out_idx, flags, anyflag);
-        else
+        else if (p.ksteps == 64)
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<128>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                             p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
+                             x3A, out_idx, flags, anyflag);
+        else
+          hipLaunchKernelGGL(pn_knn_final_x3_kernel<256>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
                              x3A, out_idx, flags, anyflag);
       }
@@ -865,7 +882,7 @@ extern "C" int pn_dot_kth_x3_f32(const float* q, int Nq, const float* c, int Nc,
   PN_CHECK_ARG(B > 0 && C > 0 && Nq > 0 && Nc > 0 && k >= 1 && k <= Nc,
                "pn_dot_kth_x3_f32: bad sizes (B=%d C=%d Nq=%d Nc=%d k=%d)", B, C, Nq, Nc, k);
   const KnnPlan p = knn_mfma_plan(2, B, C, Nq, Nc, k, true);
-  if (!p.fast || !knn_x3_pass1(p, 0)) {
+  if (!p.fast || !knn_x3_pass1(p, 0, true)) {
     pn_set_error("pn_dot_kth_x3_f32: shape outside the bf16 x 3 path (C <= 128, Nc >= 2048, Nc/16 >= 2k)");
     return PN_ERR_UNSUPPORTED;
   }

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
 // A step of the loop handles TPS consecutive tiles (one barrier, one batch of LDS DMA).
 #define KX_NW 4
 // (the 128-channel dot-product variant needs 165 registers: three workgroups per CU)
-#define KX_WPE(NCH, MODE) ((NCH) == 16 && (MODE) == 2 ? 3 : 2)
+// (256 channels, NCH = 32: the resident queries alone are 192 registers — one wave per SIMD with the whole
+// register file, one 4-wave workgroup and 96 KiB of LDS per CU)
+#define KX_WPE(NCH, MODE) ((NCH) == 32 ? 1 : ((NCH) == 16 && (MODE) == 2 ? 3 : 2))
 // KIND 0: tile maxima; KIND 1: collect the candidates with v~ >= tau (tau already lowered by the
 // margin) into the sub-list of (query, slice, half) like pass 2 of the fp32 engine — the keys carry
 // APPROXIMATE values, pn_knn_final_x3_kernel repairs what the approximation cannot decide.
@@ -182,13 +184,19 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
           // two accumulators per query set: the h.h products alone (their C accumulations carry
           // the rounding that matters: the error bound below counts C ulps, not 6 C) and the five
           // products that are 2^-8 and smaller
-          f32x16 acc[QSETS], acs[QSETS];
+          // (NCH = 32 runs one wave per SIMD with one query set: four of the six MFMAs of a k-step in a
+          // row would wait for each other on the one small accumulator, so the small products alternate
+          // between two — same bound: each holds a subset of the 5 C terms, one more rounding of a
+          // 2^-7 |q||c| quantity at the end)
+          f32x16 acc[QSETS], acs[QSETS], act[QSETS];
+          f32x16(&sm2)[QSETS] = NCH == 32 ? act : acs;
 #pragma unroll
           for (int u = 0; u < QSETS; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               acc[u][r] = 0.f;
               acs[u][r] = 0.f;
+              act[u][r] = 0.f;
             }
           const u32x4* __restrict__ lp = ldsP[cur] + i * IMG;
 #pragma unroll
@@ -202,11 +210,15 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     ACC[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[u][s], ACC[u], 0, 0, 0)
             KX_P(acs, al, qh);
             KX_P(acc, ah, qh);
-            KX_P(acs, ah, ql);
+            KX_P(sm2, ah, ql);
             KX_P(acs, am, qm);
-            KX_P(acs, am, qh);
+            KX_P(sm2, am, qh);
             KX_P(acs, ah, qm);
 #undef KX_P
+          }
+          if (NCH == 32) {
+#pragma unroll
+            for (int u = 0; u < QSETS; ++u) acs[u] += act[u];
           }
           // D[candidate = (r&3) + 8(r>>2) + 4h][query = col]
           float xxj[16];
@@ -315,6 +327,31 @@ __global__ void pn_knn_x3_margin_kernel(float* __restrict__ tau, const float* __
   tau[(size_t)b * Nqp + q] = t - eps - 0x1p-22f * fabsf(t);
 }
 
+// the oracle's dot product of two point-major fp32 rows: ONE fma chain over the channels in order.  The
+// candidate row is fetched in blocks of at most 128 channels (a whole block first: one memory latency per
+// block, not one per float4; 256 channels in one block would be 256 registers)
+template <int CP>
+__device__ static inline float knx_exact_dot(const float* __restrict__ xq, const float* __restrict__ xcrow) {
+  constexpr int CB = CP > 128 ? 128 : CP;
+  float dot = 0.f;
+#pragma clang loop unroll(disable)
+  for (int c0 = 0; c0 < CP; c0 += CB) {
+    const float4* xc = reinterpret_cast<const float4*>(xcrow + c0);
+    float4 cv[CB / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < CB / 4; ++c4) cv[c4] = xc[c4];
+#pragma unroll
+    for (int c4 = 0; c4 < CB / 4; ++c4) {
+      const float4 qv = *reinterpret_cast<const float4*>(xq + c0 + 4 * c4);
+      dot = __builtin_fmaf(qv.x, cv[c4].x, dot);
+      dot = __builtin_fmaf(qv.y, cv[c4].y, dot);
+      dot = __builtin_fmaf(qv.z, cv[c4].z, dot);
+      dot = __builtin_fmaf(qv.w, cv[c4].w, dot);
+    }
+  }
+  return dot;
+}
+
 // K4 for approximate keys (feature metric, kNN graph of one set): one wave per query.
 //   1. gather the sub-lists (keys: approximate value, candidate index -> ORIGINAL index);
 //   2. keep every candidate whose approximate value is within 2 eps of the k-th largest one — a
@@ -391,19 +428,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
     // the exact selection and sort of the fp32 engine.
     for (int e = lane; e < m; e += 64) {
       const int j = (int)knn_key_index(keys[e]);
-      const float4* xc = reinterpret_cast<const float4*>(xpm + ((size_t)b * N + j) * CP);
-      float4 cv[CP / 4];
-#pragma unroll
-      for (int c4 = 0; c4 < CP / 4; ++c4) cv[c4] = xc[c4];
-      float dot = 0.f;
-#pragma unroll
-      for (int c4 = 0; c4 < CP / 4; ++c4) {
-        const float4 qv = *reinterpret_cast<const float4*>(xq + 4 * c4);
-        dot = __builtin_fmaf(qv.x, cv[c4].x, dot);
-        dot = __builtin_fmaf(qv.y, cv[c4].y, dot);
-        dot = __builtin_fmaf(qv.z, cv[c4].z, dot);
-        dot = __builtin_fmaf(qv.w, cv[c4].w, dot);
-      }
+      const float dot = knx_exact_dot<CP>(xq, xpm + ((size_t)b * N + j) * CP);
       const float t = __builtin_fmaf(2.0f, dot, -xxo[(size_t)b * N + j]);
       keys[e] = knn_key(__fsub_rn(t, nq), j);
     }
@@ -460,19 +485,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
       u64& key = half ? k1 : k0;
       if (need) {
         const int j = (int)knn_key_index(key);
-        const float4* xc = reinterpret_cast<const float4*>(xpm + ((size_t)b * N + j) * CP);
-        float4 cv[CP / 4];   // the whole row first: one memory latency, not CP / 4
-#pragma unroll
-        for (int c4 = 0; c4 < CP / 4; ++c4) cv[c4] = xc[c4];
-        float dot = 0.f;
-#pragma unroll
-        for (int c4 = 0; c4 < CP / 4; ++c4) {
-          const float4 qv = *reinterpret_cast<const float4*>(xq + 4 * c4);
-          dot = __builtin_fmaf(qv.x, cv[c4].x, dot);
-          dot = __builtin_fmaf(qv.y, cv[c4].y, dot);
-          dot = __builtin_fmaf(qv.z, cv[c4].z, dot);
-          dot = __builtin_fmaf(qv.w, cv[c4].w, dot);
-        }
+        const float dot = knx_exact_dot<CP>(xq, xpm + ((size_t)b * N + j) * CP);
         const float t = __builtin_fmaf(2.0f, dot, -xxo[(size_t)b * N + j]);
         const float v = __fsub_rn(t, nq);
         key = knn_key(v, j);

@@ -120,10 +120,11 @@ def test_near_ties_under_the_bf16_passes(gpu, x3_level, monkeypatch):
     assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
 
 
-@pytest.mark.parametrize("B,C,N,k", [(1, 128, 3000, 80), (3, 40, 2100, 128), (2, 100, 2049, 20), (1, 64, 4097, 1)])
+@pytest.mark.parametrize("B,C,N,k", [(1, 128, 3000, 80), (3, 40, 2100, 128), (2, 100, 2049, 20), (1, 64, 4097, 1),
+                                     (10, 256, 2500, 10), (12, 200, 2111, 80), (12, 256, 2049, 1)])
 @pytest.mark.parametrize("x3_level", ["1", "2"])
 def test_bf16_passes_on_odd_shapes(gpu, B, C, N, k, x3_level, monkeypatch):
-    """The split passes (64- and 128-channel images, padded channels, tails of the last tile,
+    """The split passes (64-, 128- and 256-channel images, padded channels, tails of the last tile,
     k = 1 and k = 128) against the C oracle."""
     from oracle import cbind
     monkeypatch.setenv("PN_KNN_X3", x3_level)

@@ -34,6 +34,32 @@ def bench_knn():
         print("knn B=%d C=%d N=%d k=%d %s: %.3f ms  %.1f TFLOP/s" % (B, C, N, k, metric, ms, flops / ms / 1e9))
 
 
+def bench_knnwide():
+    """The wide layers of the SplineNets inside a cfg5 step (segments of 2 500 sub-sampled points) and of a
+    cfg3 step, bf16 x 3 passes on (PN_KNN_X3 = 2, default) and off (0: the fp32 matrix-core engine)."""
+    import os
+    from parsenet_codebase_amd import _lib
+    dev = torch.device("cuda:0")
+    for (B, C, N, k) in [(6, 256, 2500, 10), (12, 256, 2500, 10), (6, 128, 2500, 10), (12, 128, 2500, 10), (32, 256, 700, 10)]:
+        x = torch.randn(B, C, N, device=dev) * (0.5 + torch.rand(B, C, 1, device=dev))
+        out = {}
+        for lvl in ("2", "0"):
+            os.environ["PN_KNN_X3"] = lvl
+            ms = timeit(lambda: kernels.knn(x, k, "feature"))
+            out[lvl] = (ms, kernels.knn(x, k, "feature"))
+            _lib.prof_enable(True)
+            _lib.prof_reset()
+            for _ in range(5):
+                kernels.knn(x, k, "feature")
+            torch.cuda.synchronize()
+            print("    PN_KNN_X3=%s: " % lvl + "  ".join("%s %.3f" % (kn, t / calls) for kn, (t, calls) in sorted(_lib.prof_results().items())))
+            _lib.prof_enable(False)
+        os.environ.pop("PN_KNN_X3")
+        same = bool((out["2"][1] == out["0"][1]).all())
+        print("knn B=%d C=%d N=%d k=%d: bf16x3 passes %.3f ms, fp32 engine %.3f ms, same graph: %s"
+              % (B, C, N, k, out["2"][0], out["0"][0], same))
+
+
 def bench_knn64():
     """cfg4's 64-channel layer and the bandwidth selection of cfg5, with the per-kernel timers."""
     from parsenet_codebase_amd import _lib
