@@ -163,6 +163,23 @@ int pn_meanshift_x3_exec_tiles(unsigned long long* out3);
 int pn_meanshift_x3_nearest_f32(const float* xq, const float* xc, const float* cenQ, const float* rhoQ,
                                 const float* cenC, const float* rhoC, const int64_t* perm, int B, int N, int D,
                                 int64_t* nearest, void* workspace, size_t workspace_bytes, void* stream);
+/* Mean-shift backward restricted to R <= 64 rows per batch item (csrc/meanshift_rows.hip).  A step of
+ * src/mean_shift.py:45-79 maps row i of the iterate to a function of that row and of the data alone, and
+ * the training path reads the final iterate only at the cluster centres (src/mean_shift.py:36-43): the
+ * gradient is zero outside those rows in every step on the way back.  One call = one step: gy, y, q
+ * (B,R,D) are the R rows of the incoming gradient, of the step's result and of its input iterate, rsum,
+ * unorm (B,R) the saved row sums and pre-normalisation norms of those rows, x (B,N,D) the data, bsq (B)
+ * the squared bandwidths.  Writes gq (B,R,D), the gradient w.r.t. the input rows, and ADDS the step's
+ * gradient w.r.t. the data into gx (B,N,D).  D = 128.  No atomics.  workspace:
+ * pn_meanshift_rows_bwd_workspace(B, N) bytes. */
+size_t pn_meanshift_rows_bwd_workspace(int B, int N);
+int pn_meanshift_rows_bwd_f32(const float* gy, const float* y, const float* q, const float* rsum, const float* unorm,
+                              const float* x, const float* bsq, int B, int N, int D, int R, float* gq, float* gx,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* gx[b, rows[b,r], :] += g[b, r, :], r ascending (rows (B,R) int64 may repeat; entries outside [0, N)
+ * are skipped): the first iterate of the mean-shift iterations IS the data. */
+int pn_meanshift_rows_scatter_add_f32(const float* g, const int64_t* rows, int B, int N, int D, int R, float* gx,
+                                      void* stream);
 size_t pn_meanshift_x3_plan_bytes(int B, int N);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
                                  void* stream);

@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 13  # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 14  # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -64,6 +64,10 @@ SIGNATURES = {
     "pn_meanshift_x3_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "pn_meanshift_x3_exec_tiles": (c_int, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "pn_meanshift_x3_nearest_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_meanshift_rows_bwd_workspace": (c_size_t, [c_int, c_int]),
+    "pn_meanshift_rows_bwd_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_size_t, c_void_p]),
+    "pn_meanshift_rows_scatter_add_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_plan_bytes": (c_size_t, [c_int, c_int]),
     "pn_meanshift_chain_order_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_tileinfo_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -41,6 +41,8 @@ OPEN_TYPES = (2, 8)
 PRIM_CODE = {1: K.PRIM_PLANE, 5: K.PRIM_SPHERE, 4: K.PRIM_CYLINDER, 3: K.PRIM_CONE}
 PRIM_NAME = {K.PRIM_PLANE: "plane", K.PRIM_SPHERE: "sphere", K.PRIM_CYLINDER: "cylinder", K.PRIM_CONE: "cone"}
 CMAX = 64          # padded list of cluster centres (the guard retries above 49 anyway)
+# mean-shift backward through the centre rows only (mean_shift._CentreRows; 0: dense passes over all rows)
+ROWS_BWD = os.environ.get("PARSENET_MS_ROWS_BWD", "1") != "0"
 
 
 # -------------------------------------------------------------------------------------------
@@ -524,7 +526,13 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             # the iterations hold both sides in the locality order its exact pruning needs)
             MSM.WANT_NEAREST = os.environ.get("PARSENET_MS_NEAREST", "1") != "0"
             try:
-                new_X = MSM.mean_shift_iterations(emb, bw, iterations)
+                # (no autograd graph through the N rows: the gradient enters at the centre rows only —
+                # MSM.centre_rows below — and the backward then runs those rows alone; PARSENET_MS_ROWS_BWD=0:
+                # the dense backward passes over all rows, same gradient up to the summation order)
+                if ROWS_BWD:
+                    new_X, ms_state = MSM.mean_shift_iterations_state(emb, bw, iterations)
+                else:
+                    new_X, ms_state = MSM.mean_shift_iterations(emb, bw, iterations), None
             finally:
                 MSM.WANT_NEAREST = False
             nearest, MSM.LAST_NEAREST = MSM.LAST_NEAREST, None
@@ -537,7 +545,10 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
                 st = nms_batch(new_X.detach(), emb.detach(), bw, width, labels=False, nearest=nearest)
             if st is not None:
                 with record_function("fit:memberships"):
-                    cen_all = torch.gather(new_X, 1, st["cid"].unsqueeze(2).expand(-1, -1, D))       # (B,CMAX,D)
+                    if ms_state is not None:
+                        cen_all = MSM.centre_rows(emb, ms_state, st["cid"])                            # (B,CMAX,D)
+                    else:
+                        cen_all = torch.gather(new_X, 1, st["cid"].unsqueeze(2).expand(-1, -1, D))
                     st["cen"] = cen_all
                     st["Wn"], st["Wraw"], st["labels"] = _Membership.apply(cen_all, emb, bw, torch.clamp(st["ncl"], max=CMAX))
             return st

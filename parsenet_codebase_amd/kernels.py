@@ -435,11 +435,19 @@ def meanshift_x3_plan_visited(plans, B, N):
     return torch.stack([p[:n].float().mean() for p in plans]).mean()
 
 
-def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None):
+def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None, out=None):
+    """``out`` = (y (B,N,D), rsum (B,N), unorm (B,N)) contiguous fp32 tensors to write into (slices of
+    the buffers that keep all iterates of a call together), or None: allocated here."""
     B, N, D = q.shape
-    y = torch.empty_like(q)
-    rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
-    unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
+    if out is not None:
+        y, rsum, unorm = out
+        for t, shp in ((y, (B, N, D)), (rsum, (B, N)), (unorm, (B, N))):
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != q.device:
+                raise ValueError("meanshift_x3_iter_fwd: out tensors must be contiguous fp32 of shapes (B,N,D), (B,N), (B,N)")
+    else:
+        y = torch.empty_like(q)
+        rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
     with _lib.on_device(q.device):
         rc = _lib.load().pn_meanshift_x3_iter_fwd_plan_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
                                                            ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
@@ -465,6 +473,53 @@ def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx, plan=N
                                                    ptr(gx), ptr(plan), current_stream(x.device))
     check(rc, "pn_meanshift_x3_iter_bwd_plan_f32")
     return gq
+
+
+def meanshift_rows_bwd(gy, y, q, rsum, unorm, x, bsq, gx, ws=None):
+    """One step of the mean-shift backward restricted to R <= 64 rows per batch item (csrc/meanshift_rows.hip;
+    src/mean_shift.py:45-79 maps every row on its own): gy, y, q (B,R,128), rsum, unorm (B,R), x (B,N,128),
+    bsq (B).  Returns gq (B,R,128); ADDS the step's gradient w.r.t. the data into gx (B,N,128)."""
+    require_cuda(gy, y, q, rsum, unorm, x, bsq, gx)
+    gy, y, q, x = _f32c(gy, "gy"), _f32c(y, "y"), _f32c(q, "q"), _f32c(x, "x")
+    rsum, unorm, bsq = _f32c(rsum, "rsum"), _f32c(unorm, "unorm"), _f32c(bsq, "bsq")
+    B, N, D = x.shape
+    R = q.shape[1]
+    if tuple(gy.shape) != (B, R, D) or tuple(y.shape) != (B, R, D) or tuple(q.shape) != (B, R, D):
+        raise ValueError("meanshift_rows_bwd: gy, y, q must be (B,R,D)")
+    if tuple(rsum.shape) != (B, R) or tuple(unorm.shape) != (B, R) or tuple(gx.shape) != (B, N, D):
+        raise ValueError("meanshift_rows_bwd: rsum, unorm (B,R), gx (B,N,D)")
+    if gx.dtype != torch.float32 or not gx.is_contiguous():
+        raise TypeError("meanshift_rows_bwd: gx must be contiguous fp32")
+    lib = _lib.load()
+    wsz = lib.pn_meanshift_rows_bwd_workspace(B, N)
+    if ws is None or ws.numel() < wsz:
+        ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
+    gq = torch.empty_like(q)
+    with _lib.on_device(x.device):
+        rc = lib.pn_meanshift_rows_bwd_f32(ptr(gy), ptr(y), ptr(q), ptr(rsum), ptr(unorm), ptr(x), ptr(bsq), B, N, D, R,
+                                           ptr(gq), ptr(gx), ptr(ws), ws.numel(), current_stream(x.device))
+    check(rc, "pn_meanshift_rows_bwd_f32")
+    return gq
+
+
+def meanshift_rows_workspace(B, N, device):
+    return torch.empty(_lib.load().pn_meanshift_rows_bwd_workspace(B, N), dtype=torch.uint8, device=device)
+
+
+def meanshift_rows_scatter_add(gx, rows, g):
+    """gx[b, rows[b,r], :] += g[b, r, :], r ascending, in place (rows (B,R) int64, repeats allowed)."""
+    require_cuda(gx, rows, g)
+    g = _f32c(g, "g")
+    rows = _i64c(rows, "rows")
+    B, N, D = gx.shape
+    R = rows.shape[1]
+    if tuple(g.shape) != (B, R, D) or gx.dtype != torch.float32 or not gx.is_contiguous():
+        raise ValueError("meanshift_rows_scatter_add: g (B,R,D), gx contiguous fp32 (B,N,D)")
+    with _lib.on_device(gx.device):
+        rc = _lib.load().pn_meanshift_rows_scatter_add_f32(ptr(g), ptr(rows), B, N, D, R, ptr(gx),
+                                                           current_stream(gx.device))
+    check(rc, "pn_meanshift_rows_scatter_add_f32")
+    return gx
 
 
 def meanshift_h2_split(x):

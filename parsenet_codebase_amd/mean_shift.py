@@ -132,62 +132,92 @@ _SPLIT = {"fp16x2": (K.meanshift_h2_split, K.meanshift_h2_iter_fwd, K.meanshift_
           "bf16x3": (K.meanshift_x3_split, K.meanshift_x3_iter_fwd, K.meanshift_x3_iter_bwd)}
 
 
+def _run_iterations(X, bsq, iterations, stacked=False):
+    """The forward pass of the iterations (no autograd).  Returns a dict: the operands in the order the
+    kernels ran on (``x``: the data, locality-ordered when the launches are planned; ``perm`` / ``inv``),
+    the iterates / row sums / norms of every step and the plans.  ``stacked``: the iterates, row sums and
+    norms of all steps live in ONE buffer each (``iterates_all`` (T+1,B,N,D), ``rsums_all`` / ``norms_all``
+    (T,B,N)) — what the row-restricted backward gathers its rows from in three launches."""
+    x = X.contiguous()
+    B, N, D = x.shape
+    if ARITH not in _SPLIT and ARITH != "f32":
+        raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
+    kern = _SPLIT.get(ARITH) if iterations > 0 else None
+    sparse = kern is not None and ARITH == "bf16x3" and SPARSE_MIN_N <= N <= SPARSE_MAX_N and use_sparse(B, N)
+    if kern is not None and ARITH == "bf16x3":
+        CALLS["planned" if sparse else "dense"] += 1
+    perm = inv = None
+    if sparse:   # everything below runs on the locality-ordered points; undone on the way out
+        perm = locality_order(x, int(os.environ.get("PARSENET_MS_LLOYD", "2")))
+        inv = torch.empty_like(perm).scatter_(1, perm, torch.arange(N, device=x.device).expand(B, N))
+        x = torch.gather(x, 1, perm.unsqueeze(2).expand(-1, -1, D))
+    x3 = kern[0](x) if kern is not None else None
+    # streamed copy of X: pre-split tile images (16-bit pieces) or channel-first fp32 (exact path)
+    xt = x3 if x3 is not None else K.meanshift_pack(x)
+    ws = K.MeanShiftWorkspace(B, N, D, x.device)
+    direct = stacked and ARITH == "bf16x3" and x3 is not None       # the bf16 x 3 kernels write into the buffers
+    it_all = rs_all = nr_all = None
+    if direct:
+        it_all = torch.empty((iterations + 1, B, N, D), dtype=torch.float32, device=x.device)
+        rs_all = torch.empty((iterations, B, N), dtype=torch.float32, device=x.device)
+        nr_all = torch.empty((iterations, B, N), dtype=torch.float32, device=x.device)
+        it_all[0].copy_(x)
+        x = it_all[0]
+    iterates, rsums, norms, plans = [x], [], [], []
+    x_info = K.meanshift_x3_tileinfo(x) if sparse else None
+    q = x
+    for it in range(iterations):
+        out = (it_all[it + 1], rs_all[it], nr_all[it]) if direct else None
+        if sparse:
+            # (the first iterate IS the data: its caps are x_info)
+            plan = K.meanshift_x3_plan(x_info if it == 0 else K.meanshift_x3_tileinfo(q), x_info, bsq, N,
+                                       PLAN_REL_EPS)
+            plans.append(plan)
+            q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan, out=out)
+        elif x3 is not None and ARITH == "bf16x3":
+            q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, None, out=out)
+        elif x3 is not None:
+            q, r, n = kern[1](q, x3, bsq, ws)
+        else:
+            q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
+        iterates.append(q)
+        rsums.append(r)
+        norms.append(n)
+    global LAST_PLAN_STATS, AUTO_STAT, LAST_NEAREST
+    LAST_NEAREST = None
+    if sparse and WANT_NEAREST and iterations > 0:
+        LAST_NEAREST = K.meanshift_x3_nearest(x, q, x_info, K.meanshift_x3_tileinfo(q), perm)
+    if sparse and os.environ.get("PARSENET_MS_STATS") == "1":
+        LAST_PLAN_STATS = [K.meanshift_x3_plan_stats(p, B, N) for p in plans]
+    if sparse and SPARSE == "auto" and plans:
+        AUTO_STAT = K.meanshift_x3_plan_visited(plans, B, N)
+    if stacked and not direct:
+        it_all = torch.stack(iterates)
+        rs_all = torch.stack(rsums) if rsums else torch.empty((0, B, N), device=x.device)
+        nr_all = torch.stack(norms) if norms else torch.empty((0, B, N), device=x.device)
+    return {"x": x, "xt": xt, "x3": x3, "kern": kern, "sparse": sparse, "perm": perm, "inv": inv, "q": q,
+            "iterates": iterates, "rsums": rsums, "norms": norms, "plans": plans,
+            "iterates_all": it_all, "rsums_all": rs_all, "norms_all": nr_all}
+
+
 class _MeanShiftIterations(torch.autograd.Function):
     """X (B,N,D) unit rows, bsq (B) squared bandwidths -> iterate after ``iterations`` steps.
     Saves only the iterates, row sums and norms (O(T N D)); the backward recomputes the kernel."""
 
     @staticmethod
     def forward(ctx, X, bsq, iterations):
-        x = X.contiguous()
-        B, N, D = x.shape
-        if ARITH not in _SPLIT and ARITH != "f32":
-            raise ValueError("PARSENET_MS_ARITH must be fp16x2, bf16x3 or f32, not %r" % ARITH)
-        kern = _SPLIT.get(ARITH) if iterations > 0 else None
-        sparse = kern is not None and ARITH == "bf16x3" and SPARSE_MIN_N <= N <= SPARSE_MAX_N and use_sparse(B, N)
-        if kern is not None and ARITH == "bf16x3":
-            CALLS["planned" if sparse else "dense"] += 1
-        perm = inv = None
-        if sparse:   # everything below runs on the locality-ordered points; undone on the way out
-            perm = locality_order(x, int(os.environ.get("PARSENET_MS_LLOYD", "2")))
-            inv = torch.empty_like(perm).scatter_(1, perm, torch.arange(N, device=x.device).expand(B, N))
-            x = torch.gather(x, 1, perm.unsqueeze(2).expand(-1, -1, D))
-        x3 = kern[0](x) if kern is not None else None
-        # streamed copy of X: pre-split tile images (16-bit pieces) or channel-first fp32 (exact path)
-        xt = x3 if x3 is not None else K.meanshift_pack(x)
-        ws = K.MeanShiftWorkspace(B, N, D, x.device)
-        iterates, rsums, norms, plans = [x], [], [], []
-        x_info = K.meanshift_x3_tileinfo(x) if sparse else None
-        q = x
-        for it in range(iterations):
-            if sparse:
-                # (the first iterate IS the data: its caps are x_info)
-                plan = K.meanshift_x3_plan(x_info if it == 0 else K.meanshift_x3_tileinfo(q), x_info, bsq, N,
-                                           PLAN_REL_EPS)
-                plans.append(plan)
-                q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan)
-            elif x3 is not None:
-                q, r, n = kern[1](q, x3, bsq, ws)
-            else:
-                q, r, n = K.meanshift_iter_fwd(q, x, xt, bsq, ws)
-            iterates.append(q)
-            rsums.append(r)
-            norms.append(n)
-        global LAST_PLAN_STATS, AUTO_STAT, LAST_NEAREST
-        LAST_NEAREST = None
-        if sparse and WANT_NEAREST and iterations > 0:
-            LAST_NEAREST = K.meanshift_x3_nearest(x, q, x_info, K.meanshift_x3_tileinfo(q), perm)
-        if sparse and os.environ.get("PARSENET_MS_STATS") == "1":
-            LAST_PLAN_STATS = [K.meanshift_x3_plan_stats(p, B, N) for p in plans]
-        if sparse and SPARSE == "auto" and plans:
-            AUTO_STAT = K.meanshift_x3_plan_visited(plans, B, N)
+        D = X.shape[2]
+        st = _run_iterations(X, bsq, iterations)
+        sparse, q = st["sparse"], st["q"]
         ctx.iterations = iterations
-        ctx.x3 = x3
-        ctx.kern = kern
+        ctx.x3 = st["x3"]
+        ctx.kern = st["kern"]
         ctx.sparse = sparse
-        ctx.save_for_backward(xt, bsq, *iterates, *rsums, *norms, *plans, *([perm, inv] if sparse else []))
+        ctx.save_for_backward(st["xt"], bsq, *st["iterates"], *st["rsums"], *st["norms"], *st["plans"],
+                              *([st["perm"], st["inv"]] if sparse else []))
         if iterations == 0:
-            return x.clone()
-        return torch.gather(q, 1, inv.unsqueeze(2).expand(-1, -1, D)) if sparse else q
+            return st["x"].clone()
+        return torch.gather(q, 1, st["inv"].unsqueeze(2).expand(-1, -1, D)) if sparse else q
 
     @staticmethod
     def backward(ctx, gy):
@@ -233,6 +263,83 @@ def mean_shift_iterations(X, b, iterations):
     bsq = (bt.detach() ** 2).contiguous()
     out = _MeanShiftIterations.apply(Xb, bsq, int(iterations))
     return out[0] if squeeze else out
+
+
+class MeanShiftState:
+    """What a forward pass of the iterations leaves behind for the row-restricted backward
+    (``mean_shift_iterations_state`` / ``centre_rows``)."""
+    __slots__ = ("x", "bsq", "iterates", "rsums", "norms", "inv", "iterations", "new_X")
+
+
+def mean_shift_iterations_state(X, b, iterations):
+    """The iterations WITHOUT an autograd graph: returns (new_X (B,N,D) detached, state).  The training
+    path reads the final iterate at the cluster centres only; ``centre_rows(X, state, ids)`` returns those
+    rows WITH the gradient path back to X."""
+    require_cuda(X)
+    if X.dim() != 3:
+        raise ValueError("mean_shift_iterations_state expects (B,N,D)")
+    B, N, D = X.shape
+    bt = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(-1)
+    if bt.numel() == 1:
+        bt = bt.expand(B)
+    bsq = (bt.detach() ** 2).contiguous()
+    with torch.no_grad():
+        st = _run_iterations(X.detach(), bsq, int(iterations), stacked=True)
+        q = st["q"]
+        new_X = torch.gather(q, 1, st["inv"].unsqueeze(2).expand(-1, -1, D)) if st["sparse"] else q
+        if iterations == 0:
+            new_X = new_X.clone()
+    state = MeanShiftState()
+    state.x, state.bsq, state.inv, state.iterations, state.new_X = st["x"], bsq, st["inv"], int(iterations), new_X
+    state.iterates, state.rsums, state.norms = st["iterates_all"], st["rsums_all"], st["norms_all"]
+    return new_X, state
+
+
+class _CentreRows(torch.autograd.Function):
+    """rows ``ids`` (B,R <= 64) of the final iterate, differentiable w.r.t. the data X.
+
+    A step of src/mean_shift.py:45-79 maps row i of the iterate to a function of that row and of X alone,
+    so a gradient that enters the final iterate at R rows (centres = new_X[indices],
+    src/mean_shift.py:36-43) is zero in every other row of every earlier iterate: the backward runs the R
+    rows against the N data points, step by step (csrc/meanshift_rows.hip), instead of N x N."""
+
+    @staticmethod
+    def forward(ctx, X, state, ids):
+        B, N, D = state.x.shape
+        T = state.iterations
+        ids = ids.long()
+        rows = torch.gather(state.inv, 1, ids) if state.inv is not None else ids      # positions in the kernels' order
+        R = rows.shape[1]
+        Qc = torch.gather(state.iterates, 2, rows.view(1, B, R, 1).expand(T + 1, B, R, D))          # (T+1,B,R,D)
+        rc = torch.gather(state.rsums, 2, rows.view(1, B, R).expand(T, B, R))
+        nc = torch.gather(state.norms, 2, rows.view(1, B, R).expand(T, B, R))
+        ctx.T = T
+        ctx.has_inv = state.inv is not None
+        ctx.save_for_backward(Qc, rc, nc, rows, state.x, state.bsq, *([state.inv] if state.inv is not None else []))
+        return Qc[T].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        Qc, rc, nc, rows, x, bsq = ctx.saved_tensors[:6]
+        B, N, D = x.shape
+        gX = torch.zeros_like(x)
+        g = g.contiguous()
+        ws = K.meanshift_rows_workspace(B, N, x.device)
+        for t in reversed(range(ctx.T)):
+            g = K.meanshift_rows_bwd(g, Qc[t + 1], Qc[t], rc[t], nc[t], x, bsq, gX, ws)
+        K.meanshift_rows_scatter_add(gX, rows, g)            # the first iterate is X itself
+        if ctx.has_inv:
+            inv = ctx.saved_tensors[6]
+            gX = torch.gather(gX, 1, inv.unsqueeze(2).expand(-1, -1, D))
+        return gX, None, None
+
+
+def centre_rows(X, state, ids):
+    """Rows ``ids`` (B,R) of the final iterate of ``mean_shift_iterations_state(X, ...)`` with the gradient
+    path to X (R <= 64; ids may repeat)."""
+    if ids.shape[1] > 64:
+        raise ValueError("centre_rows: at most 64 rows per batch item, got %d" % ids.shape[1])
+    return _CentreRows.apply(X, state, ids)
 
 
 def _first_argmax(vals, dim):

@@ -523,3 +523,77 @@ def test_pruned_nearest_equals_the_selection_engine(gpu, N, B, dups, monkeypatch
     top2 = d.topk(2, dim=2)[0]
     clear = (top2[:, :, 0] - top2[:, :, 1]) > 1e-5
     assert torch.equal(got[clear], d.argmax(2)[clear])
+
+
+@pytest.mark.parametrize("N,B,sparse", [(10000, 2, True), (4100, 3, True), (3001, 2, False), (700, 4, False)])
+def test_centre_rows_backward_equals_the_dense_backward(gpu, N, B, sparse, monkeypatch):
+    """The training path reads the final iterate at the cluster centres only (src/mean_shift.py:36-43) and a
+    step maps every row on its own (src/mean_shift.py:45-79): the backward restricted to those rows
+    (mean_shift.centre_rows, csrc/meanshift_rows.hip) returns the gradient of the dense passes — rows picked
+    at random, repeats among them (the padded centre lists repeat), planned and dense launches — and is
+    bit-reproducible."""
+    import parsenet_codebase_amd.mean_shift as MS
+    torch.cuda.set_device(gpu)
+    monkeypatch.setattr(MS, "ARITH", "bf16x3")
+    monkeypatch.setattr(MS, "SPARSE", sparse)
+    g = torch.Generator().manual_seed(N + B)
+    proto = torch.nn.functional.normalize(torch.randn(7, 128, generator=g), dim=1)
+    lab = torch.randint(0, 7, (B, N), generator=g)
+    X = torch.nn.functional.normalize(proto[lab] + 0.25 * torch.randn(B, N, 128, generator=g) / np.sqrt(128), dim=2).to(gpu)
+    b = (0.15 + 0.1 * torch.rand(B, generator=g)).to(gpu)
+    R = 64
+    ids = torch.randint(0, N, (B, R), generator=g)
+    ids[:, 40:] = ids[:, :1]                       # the padded tail repeats a row ...
+    w = torch.randn(B, R, 128, generator=g)
+    w[:, 40:] = 0.0                                # ... with zero gradient, like the masked centre rows
+    ids[:, 5] = ids[:, 4]                          # and a genuine repeat with gradient in both
+    ids, w = ids.to(gpu), w.to(gpu)
+    x0 = X.clone().requires_grad_(True)
+    y = MS.mean_shift_iterations(x0, b, 10)
+    (torch.gather(y, 1, ids.unsqueeze(2).expand(-1, -1, 128)) * w).sum().backward()
+    grads = []
+    for _ in range(2):
+        x1 = X.clone().requires_grad_(True)
+        new_X, state = MS.mean_shift_iterations_state(x1, b, 10)
+        assert not new_X.requires_grad
+        assert torch.equal(new_X, y.detach())
+        c = MS.centre_rows(x1, state, ids)
+        assert torch.equal(c, torch.gather(new_X, 1, ids.unsqueeze(2).expand(-1, -1, 128)))
+        (c * w).sum().backward()
+        grads.append(x1.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert _rel(grads[0], x0.grad) < 2e-5
+    # rows without gradient anywhere: exactly zero unless the data row itself was picked or is reached
+    assert torch.isfinite(grads[0]).all()
+
+
+def test_centre_rows_backward_against_the_fp64_reference(gpu, monkeypatch):
+    """... and against the reference's own formula evaluated in float64 with autograd (src/mean_shift.py:45-79)."""
+    import parsenet_codebase_amd.mean_shift as MS
+    torch.cuda.set_device(gpu)
+    monkeypatch.setattr(MS, "ARITH", "bf16x3")
+    B, N, T = 2, 1500, 10
+    g = torch.Generator().manual_seed(5)
+    proto = torch.nn.functional.normalize(torch.randn(5, 128, generator=g), dim=1)
+    lab = torch.randint(0, 5, (B, N), generator=g)
+    X = torch.nn.functional.normalize(proto[lab] + 0.3 * torch.randn(B, N, 128, generator=g) / np.sqrt(128), dim=2)
+    b = torch.tensor([0.2, 0.3])
+    ids = torch.randint(0, N, (B, 12), generator=g)
+    w = torch.randn(B, 12, 128, generator=g)
+    xr = X.double().requires_grad_(True)
+    outs = []
+    for i in range(B):
+        new = xr[i].clone()
+        for _ in range(T):
+            dist = 2.0 - 2.0 * new @ xr[i].t()
+            Kmat = torch.exp(torch.clamp(-dist / (b[i].double() ** 2) / 2, max=75, min=-75))
+            new = new + ((Kmat @ xr[i]) / Kmat.sum(1, keepdim=True) - new)
+            new = new / torch.norm(new, dim=1, p=2, keepdim=True)
+        outs.append(new[ids[i]])
+    (torch.stack(outs) * w.double()).sum().backward()
+    xg = X.to(gpu).requires_grad_(True)
+    new_X, state = MS.mean_shift_iterations_state(xg, b.to(gpu), T)
+    c = MS.centre_rows(xg, state, ids.to(gpu))
+    (c * w.to(gpu)).sum().backward()
+    assert _rel(c, torch.stack(outs)) < 1e-5
+    assert _rel(xg.grad, xr.grad) < 5e-5
