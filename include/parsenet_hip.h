@@ -163,6 +163,19 @@ int pn_meanshift_x3_exec_tiles(unsigned long long* out3);
 int pn_meanshift_x3_nearest_f32(const float* xq, const float* xc, const float* cenQ, const float* rhoQ,
                                 const float* cenC, const float* rhoC, const int64_t* perm, int B, int N, int D,
                                 int64_t* nearest, void* workspace, size_t workspace_bytes, void* stream);
+/* fp32-grade GEMM of the per-point layers (nn.Conv1d(kernel_size=1): src/model.py:56-180,
+ * src/PointNet.py:143-289) on the bf16 matrix cores (csrc/gemm_x3.hip): operands split error-free into
+ * three bf16 pieces, six piece products per fp32 product, fp32 accumulation.
+ * pn_gemm_x3_weight_image_f32: the pre-split image of a weight W (M,K) row-major for y = W x
+ * (transposed = 0) or of W^T for gx = W^T gy (transposed = 1; the image then belongs to a (K,M) operand);
+ * img: pn_gemm_x3_weight_image_bytes(M, K) resp. (K, M) bytes.
+ * pn_gemm_x3_f32: out (B,M,N) = A x (+ bias (M) or NULL), img_a the image of the (M,K) operand A,
+ * x (B,K,N) channel-first; workspace: pn_gemm_x3_points_image_bytes(B, K, N) bytes. */
+size_t pn_gemm_x3_weight_image_bytes(int M, int K);
+size_t pn_gemm_x3_points_image_bytes(int B, int C, int N);
+int pn_gemm_x3_weight_image_f32(const float* w, int M, int K, int transposed, void* img, void* stream);
+int pn_gemm_x3_f32(const void* img_a, const float* x, const float* bias, int B, int M, int K, int N, float* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
 /* Mean-shift backward restricted to R <= 64 rows per batch item (csrc/meanshift_rows.hip).  A step of
  * src/mean_shift.py:45-79 maps row i of the iterate to a function of that row and of the data alone, and
  * the training path reads the final iterate only at the cluster centres (src/mean_shift.py:36-43): the

@@ -64,6 +64,11 @@ SIGNATURES = {
     "pn_meanshift_x3_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "pn_meanshift_x3_exec_tiles": (c_int, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "pn_meanshift_x3_nearest_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_gemm_x3_weight_image_bytes": (c_size_t, [c_int, c_int]),
+    "pn_gemm_x3_points_image_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pn_gemm_x3_weight_image_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_gemm_x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
     "pn_meanshift_rows_bwd_workspace": (c_size_t, [c_int, c_int]),
     "pn_meanshift_rows_bwd_f32": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_size_t, c_void_p]),

@@ -8,6 +8,9 @@ unchanged (with or without DataParallel's ``module.`` prefix):
 Edge-conv layers run through graph.edge_conv_norm_max (kNN + fused gather-reduce kernels);
 the per-point heads are dense GEMMs left to rocBLAS via torch.
 """
+import os
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -17,21 +20,95 @@ from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
-def weight_bmm(w, x):
-    """w (Co,Ci) applied to x (B,Ci,N) -> (B,Co,N) as a strided-batched GEMM with batch stride 0
-    on the weight.  torch.matmul would fold the batch into the rows instead, which costs a
-    transposing copy of the activations on the way in and on the way out (13 % of a cfg4 step)."""
-    return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers;
+# PARSENET_GEMM_X3=0: everything through rocBLAS.  Below GEMM_X3_MIN_FLOP the split images do not pay.
+GEMM_X3 = os.environ.get("PARSENET_GEMM_X3", "1") != "0"
+GEMM_X3_MIN_FLOP = float(os.environ.get("PARSENET_GEMM_X3_MIN_GFLOP", "2")) * 1e9
+GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "512"))
+_W_IMAGES = {}          # id(frozen parameter) -> {view: ((version, data_ptr), image)}; entries die with the parameter
+
+
+def _weight_image(w, transposed):
+    """Split image of w (or of w^T).  A TRAINABLE weight gets a fresh image on every call (two small launches;
+    nothing to go stale when the optimizer moves it).  The image of a frozen one (requires_grad False: the
+    SplineNets inside an e2e step) is kept with the parameter object — not with its address, which the allocator
+    hands to the next module — and rebuilt when the parameter's version counter or storage changes."""
+    from . import kernels as K
+    base = w._base if w._base is not None else w
+    if base.requires_grad:
+        return K.gemm_x3_weight_image(w.detach(), transposed)
+    ent = _W_IMAGES.get(id(base))
+    if ent is None:
+        ent = _W_IMAGES[id(base)] = {}
+        weakref.finalize(base, _W_IMAGES.pop, id(base), None)
+    key = (transposed, w.storage_offset(), tuple(w.shape), tuple(w.stride()))
+    state = (base._version, base.data_ptr())
+    hit = ent.get(key)
+    if hit is None or hit[0] != state:
+        hit = ent[key] = (state, K.gemm_x3_weight_image(w.detach(), transposed))
+    return hit[1]
+
+
+class _WeightGemmX3(torch.autograd.Function):
+    """w (Co,Ci) applied to x (B,Ci,N) (+ bias) on the bf16 matrix cores; the gradient w.r.t. x the same way
+    with the image of w^T, the gradient w.r.t. w as a rocBLAS product over the points."""
+
+    @staticmethod
+    def forward(ctx, w, x, bias):
+        from . import kernels as K
+        ctx.save_for_backward(w, x)
+        ctx.has_bias = bias is not None
+        return K.gemm_x3(_weight_image(w, False), w.shape[0], x, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import kernels as K
+        w, x = ctx.saved_tensors
+        gy = gy.contiguous()
+        gw = gx = gb = None
+        if ctx.needs_input_grad[1]:
+            if _gemm_x3_rows_pay(w.shape[1]):
+                gx = K.gemm_x3(_weight_image(w, True), w.shape[1], gy, None)
+            else:
+                gx = torch.bmm(w.t().unsqueeze(0).expand(gy.shape[0], -1, -1), gy)
+        if ctx.needs_input_grad[0]:
+            gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2))
+        return gw, gx, gb
+
+
+def _gemm_x3_rows_pay(M):
+    """The split image of the activations costs ~10 bytes per element of x whatever M is, the matrix-core GEMM
+    saves ~40 % of 2 M K N / 100 TFLOP/s: measured (tools/kbench.py gemm) even at M = 256, 1.2-1.3 x at
+    M >= 512."""
+    return M >= GEMM_X3_MIN_ROWS
+
+
+def _gemm_x3_pays(w, x):
+    return (GEMM_X3 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and
+            _gemm_x3_rows_pay(w.shape[0]) and w.shape[1] >= 64 and
+            2.0 * w.shape[0] * w.shape[1] * x.shape[0] * x.shape[2] >= GEMM_X3_MIN_FLOP)
+
+
+def weight_bmm(w, x, bias=None):
+    """w (Co,Ci) applied to x (B,Ci,N) -> (B,Co,N) (+ bias (Co)).  Large products: bf16 x 3 on the matrix
+    cores (_WeightGemmX3).  Otherwise a strided-batched rocBLAS GEMM with batch stride 0 on the weight:
+    torch.matmul would fold the batch into the rows instead, which costs a transposing copy of the
+    activations on the way in and on the way out (13 % of a cfg4 step)."""
+    if _gemm_x3_pays(w, x):
+        return _WeightGemmX3.apply(w, x, bias)
+    y = torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1)
+    return y
 
 
 def conv1x1(x, conv):
     """nn.Conv1d(kernel_size=1) applied as a plain GEMM (rocBLAS) instead of a MIOpen convolution:
     same arithmetic, no per-shape algorithm search (the fitting stage feeds a new point count for
     every segment)."""
-    y = weight_bmm(conv.weight[:, :, 0], x)
-    if conv.bias is not None:
-        y = y + conv.bias.view(1, -1, 1)
-    return y
+    return weight_bmm(conv.weight[:, :, 0], x, conv.bias)
 
 
 def batch_norm_1d(x, bn):

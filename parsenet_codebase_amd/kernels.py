@@ -475,6 +475,48 @@ def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx, plan=N
     return gq
 
 
+def gemm_x3_weight_image(w, transposed=False):
+    """Pre-split bf16 x 3 image of a weight w (M,K) for gemm_x3 (transposed: of w^T, for the gradient
+    w.r.t. the activations).  Returns a uint8 tensor."""
+    require_cuda(w)
+    w = _f32c(w, "w")
+    if w.dim() != 2:
+        raise ValueError("gemm_x3_weight_image expects (M,K), got %s" % (tuple(w.shape),))
+    M, Kd = w.shape
+    lib = _lib.load()
+    nbytes = lib.pn_gemm_x3_weight_image_bytes(Kd, M) if transposed else lib.pn_gemm_x3_weight_image_bytes(M, Kd)
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    with _lib.on_device(w.device):
+        rc = lib.pn_gemm_x3_weight_image_f32(ptr(w), M, Kd, 1 if transposed else 0, ptr(img), current_stream(w.device))
+    check(rc, "pn_gemm_x3_weight_image_f32")
+    return img
+
+
+def gemm_x3(img_a, M, x, bias=None):
+    """out (B,M,N) = A x (+ bias): img_a = gemm_x3_weight_image of the (M,K) operand A, x (B,K,N) fp32
+    channel-first.  fp32-grade products on the bf16 matrix cores (csrc/gemm_x3.hip)."""
+    require_cuda(img_a, x)
+    x = _f32c(x, "x")
+    if x.dim() != 3:
+        raise ValueError("gemm_x3 expects x (B,K,N), got %s" % (tuple(x.shape),))
+    B, Kd, N = x.shape
+    lib = _lib.load()
+    if img_a.numel() != lib.pn_gemm_x3_weight_image_bytes(M, Kd):
+        raise ValueError("gemm_x3: the weight image does not belong to a (%d,%d) operand" % (M, Kd))
+    if bias is not None:
+        bias = _f32c(bias, "bias")
+        if bias.numel() != M:
+            raise ValueError("gemm_x3: bias must have %d elements" % M)
+    out = torch.empty((B, M, N), dtype=torch.float32, device=x.device)
+    wsz = lib.pn_gemm_x3_points_image_bytes(B, Kd, N)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
+    with _lib.on_device(x.device):
+        rc = lib.pn_gemm_x3_f32(ptr(img_a), ptr(x), ptr(bias), B, M, Kd, N, ptr(out), ptr(ws), wsz,
+                                current_stream(x.device))
+    check(rc, "pn_gemm_x3_f32")
+    return out
+
+
 def meanshift_rows_bwd(gy, y, q, rsum, unorm, x, bsq, gx, ws=None):
     """One step of the mean-shift backward restricted to R <= 64 rows per batch item (csrc/meanshift_rows.hip;
     src/mean_shift.py:45-79 maps every row on its own): gy, y, q (B,R,128), rsum, unorm (B,R), x (B,N,128),

@@ -6,7 +6,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
-from parsenet_codebase_amd import workloads
+from parsenet_codebase_amd import dp, workloads
+
+dp.limit_host_threads()       # as bench.py and the trainer run: one intra-op CPU thread
 
 dev = torch.device("cuda:0")
 step = workloads.ParsenetE2EStep(dev, batch=4, num_points=10000, pretrain_steps=2000, pool=16, pretrain_pool=64)

@@ -34,6 +34,35 @@ def bench_knn():
         print("knn B=%d C=%d N=%d k=%d %s: %.3f ms  %.1f TFLOP/s" % (B, C, N, k, metric, ms, flops / ms / 1e9))
 
 
+def bench_gemm():
+    """Per-point layers: y = W x on the bf16 matrix cores (csrc/gemm_x3.hip: split image of x + GEMM) against the
+    rocBLAS fp32 product it replaces (torch.bmm with batch stride 0 on the weight), forward shapes of cfg3 / cfg5."""
+    from parsenet_codebase_amd import _lib
+    dev = torch.device("cuda:0")
+    for (B, M, Kd, N, what) in [(32, 1024, 1152, 700, "cfg3 conv5"), (32, 1152, 1024, 700, "cfg3 conv5, gradient w.r.t. x"),
+                                (4, 1024, 256, 10000, "cfg5 mlp1"), (4, 512, 256, 10000, "cfg5 conv1 (local part)"),
+                                (4, 256, 512, 10000, "cfg5 conv2"), (4, 256, 256, 10000, "cfg5 seg_prob1"),
+                                (4, 128, 256, 10000, "cfg5 seg_prob2"), (10, 1024, 512, 2500, "cfg5 open SplineNet conv5"),
+                                (10, 1024, 1152, 2500, "cfg5 closed SplineNet conv5"), (32, 1024, 256, 700, "cfg3 layer 4 half")]:
+        w = torch.randn(M, Kd, device=dev)
+        x = torch.randn(B, Kd, N, device=dev)
+        img = kernels.gemm_x3_weight_image(w)
+        t_x3 = timeit(lambda: kernels.gemm_x3(img, M, x))
+        we = w.unsqueeze(0).expand(B, -1, -1)
+        t_bl = timeit(lambda: torch.bmm(we, x))
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        for _ in range(5):
+            kernels.gemm_x3(img, M, x)
+        torch.cuda.synchronize()
+        pr = {kn: t / calls for kn, (t, calls) in _lib.prof_results().items()}
+        _lib.prof_enable(False)
+        gf = 2.0 * M * Kd * B * N / 1e9
+        print("%-34s M=%d K=%d points=%d: bf16x3 %.3f ms (image %.3f + GEMM %.3f = %.0f TFLOP/s fp32-equivalent, %.2f of the "
+              "bf16 peak), rocBLAS fp32 %.3f ms (%.0f TFLOP/s)" % (what, M, Kd, B * N, t_x3, pr.get("gemm_x3_image", 0),
+              pr.get("gemm_x3", 0), gf / pr.get("gemm_x3", 1), 6 * gf / pr.get("gemm_x3", 1) / 2500.0, t_bl, gf / t_bl))
+
+
 def bench_knnwide():
     """The wide layers of the SplineNets inside a cfg5 step (segments of 2 500 sub-sampled points) and of a
     cfg3 step, bf16 x 3 passes on (PN_KNN_X3 = 2, default) and off (0: the fp32 matrix-core engine)."""
