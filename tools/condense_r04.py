@@ -69,25 +69,30 @@ def copy(name, dst, head=None, drop=("amdgpu.ids", "UserWarning", "_warn_once", 
 
 PO = "PARSENET_MS_SPARSE=%s rocprofv3 --kernel-trace --stats -- python3 bench.py --profile-only"
 for tag, name, cmd, note in (
-        ("s5", "cfg5_profile_only", PO % "1", "the pre-trained network from the cache, then ONLY the profiled pass over the pool, planned launches"),
-        ("s5d", "cfg5_profile_only_dense", PO % "0", "as above with dense mean-shift launches"),
+        ("s5", "cfg5_profile_only", PO % "1", "the pre-trained network from the cache, then ONLY the profiled pass over the pool, planned launches; the DEFAULT: mean-shift backward through the centre rows only"),
+        ("s5b", "cfg5_profile_only_dense_backward", "PARSENET_MS_ROWS_BWD=0 " + PO % "1", "as above with the dense backward passes over all rows (callers with a dense gradient), planned launches"),
+        ("s5d", "cfg5_profile_only_dense", "PARSENET_MS_ROWS_BWD=0 " + PO % "0", "dense backward passes AND dense mean-shift launches"),
         ("s4", "cfg4", "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0", "pool pass, warm-up and timed steps"),
         ("s_cfg2", "cfg2", "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0", "warm-up and timed steps"),
         ("s_cfg3", "cfg3", "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload cfg3 --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0", "warm-up and timed steps")):
     f = find(tag, "b_kernel_stats.csv")
     if f:
         stats(f, os.path.join(P, "r04_%s_kernel_stats.csv" % name), cmd, note)
-for j in ("bench_cfg5", "bench_cfg5_b", "bench_cfg5_c", "bench_cfg4", "bench_cfg2", "bench_cfg3", "po_stats", "po_stats_dense"):
+for j in ("bench_cfg5", "bench_cfg5_b", "bench_cfg5_c", "bench_cfg4", "bench_cfg2", "bench_cfg3", "po_stats", "po_stats_bwd", "po_stats_dense"):
     src = os.path.join(SRC, j + ".json")
     if os.path.exists(src):
         lines = [ln for ln in open(src).read().splitlines() if ln.startswith("{")]
         if lines:
-            out = {"po_stats": "bench_cfg5_profile_only_under_rocprofv3", "po_stats_dense": "bench_cfg5_profile_only_dense_under_rocprofv3"}.get(j, j)
+            out = {"po_stats": "bench_cfg5_profile_only_under_rocprofv3",
+                   "po_stats_bwd": "bench_cfg5_profile_only_dense_backward_under_rocprofv3",
+                   "po_stats_dense": "bench_cfg5_profile_only_dense_under_rocprofv3"}.get(j, j)
             open(os.path.join(P, "r04_" + out + ".json"), "w").write(lines[-1] + "\n")
 pmc(["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], os.path.join(P, "r04_meanshift_x3_planned_cfg5_pmc.csv"), ("pn_ms3_kernel",))
 pmc(["pmc_FETCH_SIZE_dense", "pmc_WRITE_SIZE_dense", "pmc_SQ_dense"], os.path.join(P, "r04_meanshift_x3_dense_cfg5_pmc.csv"), ("pn_ms3_kernel",))
 copy("roofline_check.txt", "r04_roofline_check.txt")
+copy("roofline_check_bwd.txt", "r04_roofline_check_dense_backward.txt")
 copy("roofline_check_dense.txt", "r04_roofline_check_dense.txt")
+copy("timeline.txt", "r04_cfg5_step_timeline.txt")
 copy("breakdown.txt", "r04_cfg5_step_breakdown.txt")
 copy("torch_sites.txt", "r04_cfg5_torch_sites.txt", head=48)
 copy("host_cprofile.txt", "r04_cfg5_host_cprofile.txt", head=70)
@@ -119,10 +124,10 @@ for j in ("bench_cfg5", "bench_cfg5_b", "bench_cfg5_c"):
             d = json.loads(lines[-1])
             r = d.get("roofline") or {}
             rep.append("%s: value %.2f shapes/s (%.2f ms per step), value_dense %s, pretrain_final_loss %r, clusters_per_shape %s, "
-                       "tile pairs executed (share of dense, column pass) %s, frac %s" % (
+                       "tile pairs executed (forward pass) %s, frac %s" % (
                            j, d["value"], d["ms_per_step"], d.get("value_dense"), d["config"].get("pretrain_final_loss"),
                            d["config"].get("clusters_per_shape"),
-                           (r.get("passes") or {}).get("meanshift_bwd_cols", {}).get("tile_pairs_executed"), r.get("frac")))
+                           (r.get("passes") or {}).get("meanshift_fwd", {}).get("tile_pairs_executed"), r.get("frac")))
 if rep:
     open(os.path.join(P, "r04_bench_reproducibility.txt"), "w").write(
         "# three processes of `python bench.py` on one box: the pre-training, the clustering and the executed work are the\n"
