@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
 // ---------------------------------------------------------------------------------------
 struct KnnPlan {
   bool fast;
-  int ksteps, qsets, Cp, Nqp, Ncp, S, tiles_per_slice, subcap, B;
+  int ksteps, qsets, Cp, Nqp, Ncp, S, tiles_per_slice, subcap, B, k;
 };
 
 static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool want_value) {
@@ -514,6 +514,7 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
   p.Nqp = (int)pn_align_up(Nq, 64);
   p.Ncp = (int)pn_align_up(Nc, 64);
   p.B = B;
+  p.k = k;
   if (mode == 1) {
     p.ksteps = 4;
   } else if (C <= 4) {
@@ -584,7 +585,10 @@ static int knn_x3_level() {
 static bool knn_x3_pass1(const KnnPlan& p, int mode, bool dot_form = false) {
   const int on = knn_x3_level();
   const bool wide256 = p.ksteps == 128 && mode == 0 && !dot_form && (long long)p.B * pn_cdiv(p.Nqp, 128) >= 192;
-  return on && p.fast && (mode == 0 || (mode == 2 && on >= 3)) && (p.ksteps == 32 || p.ksteps == 64 || wide256) &&
+  // 128 channels with a small k (the SplineNets' graphs, k = 10): the final sort on approximate keys costs
+  // more than the passes save (12 segments of 2 500 points: 0.61 against 0.52 ms on the fp32 engine)
+  const bool wide128 = p.ksteps == 64 && (mode != 0 || dot_form || p.k >= 32);
+  return on && p.fast && (mode == 0 || (mode == 2 && on >= 3)) && (p.ksteps == 32 || wide128 || wide256) &&
          p.Ncp >= 2048;
 }
 #define KX_MAX_SLICES 16   // of the collecting pass (2 x 16 sub-lists per query)

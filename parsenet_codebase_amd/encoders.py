@@ -20,9 +20,13 @@ from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
-# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers;
-# PARSENET_GEMM_X3=0: everything through rocBLAS.  Below GEMM_X3_MIN_FLOP the split images do not pay.
-GEMM_X3 = os.environ.get("PARSENET_GEMM_X3", "1") != "0"
+# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers: OPT-IN
+# (PARSENET_GEMM_X3=1).  As accurate as the rocBLAS fp32 product (tests/test_gemm_gpu.py), 1.2-1.6 x faster per
+# product, but worth +2 % on a cfg3 step and nothing on a cfg5 step so far (profiles/r04_gemm_x3_ab.txt), and a
+# change of the products' rounding trains ANOTHER network over hundreds of steps: the whole-step parity bars
+# (tests/test_parity_fullsize_bwd_gpu.py) and the benchmark's pre-trained state are pinned to the rocBLAS
+# arithmetic.  Below GEMM_X3_MIN_FLOP / GEMM_X3_MIN_ROWS the split images do not pay.
+GEMM_X3 = os.environ.get("PARSENET_GEMM_X3", "0") == "1"
 GEMM_X3_MIN_FLOP = float(os.environ.get("PARSENET_GEMM_X3_MIN_GFLOP", "2")) * 1e9
 GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "512"))
 _W_IMAGES = {}          # id(frozen parameter) -> {view: ((version, data_ptr), image)}; entries die with the parameter

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # dp.init_from_env() caps torch's intra-op CPU pool at one thread for a training process; inside the test
+    # process that would leave the CPU oracle with one thread from the first trainer test on (measured: the GPU
+    # suite 1 016 s instead of 481 s, and other oracle roundings than the bars were measured with)
+    os.environ.setdefault("PARSENET_HOST_THREADS", "0")
 
 
 @pytest.fixture(scope="session")

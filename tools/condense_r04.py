@@ -92,8 +92,8 @@ pmc(["pmc_FETCH_SIZE_dense", "pmc_WRITE_SIZE_dense", "pmc_SQ_dense"], os.path.jo
 copy("roofline_check.txt", "r04_roofline_check.txt")
 copy("roofline_check_bwd.txt", "r04_roofline_check_dense_backward.txt")
 copy("roofline_check_dense.txt", "r04_roofline_check_dense.txt")
-copy("timeline.txt", "r04_cfg5_step_timeline.txt")
-copy("breakdown.txt", "r04_cfg5_step_breakdown.txt")
+pass  # r04_cfg5_step_timeline.txt: timed steps of tools/jobs/r4r.sh
+pass  # r04_cfg5_step_breakdown.txt: assembled by hand from tools/jobs/r4r.sh (timed steps) and the evidence pass
 copy("torch_sites.txt", "r04_cfg5_torch_sites.txt", head=48)
 copy("host_cprofile.txt", "r04_cfg5_host_cprofile.txt", head=70)
 copy("host.txt", "r04_host.txt")
