@@ -18,12 +18,19 @@
 // Arithmetic: plain fp32 fma on the vector ALUs (the whole backward of a cfg5 step is 26 GFLOP this
 // way; the dense passes it replaces executed 2 x 10 launches of ~1 TFLOP each).
 //
+// pn_ms_rows_prep_kernel: gu, c, alpha, 1 / r of the R rows, once per step.
 // pn_ms_rows_bwd_kernel: one workgroup per block of 64 data points j and batch item: stages the 64
-// x rows, the R q rows and the R gu rows (computed here from y, gy) in LDS, forms the 64 x 64 blocks of
+// x rows, the R q rows and the R gu rows in LDS, forms the 64 x 64 blocks of
 // q.x and gu.x, the kernel values, gs and K / r, then its own 64 rows of gX (exclusive owner: read,
 // add, write) and its partial of gq, which pn_ms_rows_reduce_kernel adds over the blocks in fixed
 // order.  No atomics: results are bit-reproducible.
+// Measured in round 4 (cfg5: 4 shapes x 10 000 points, 64 rows, same box, alternating): 96 us per step of the backward.  The
+// same block on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 for all four products: 20 000 instead of
+// 50 000 cycles of arithmetic per workgroup) took 101 us: with 150 KiB of staged operands there is one
+// 4-wave workgroup per CU and nothing hides its load -> barrier -> product -> barrier -> read-add-write chain;
+// the matrix-core version was removed again.
 #include "common.h"
+#include <cstdlib>
 
 #define MR_D 128
 #define MR_R 64        // rows per batch item (zero padded)
@@ -35,10 +42,46 @@
 
 __device__ static inline float4 mr_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// gu, c, alpha and 1 / r of the R rows, one wave per row (as pn_ms_prep_bwd_kernel): once per step, not once
+// per workgroup of the main kernel (there the sixteen rows of a wave were sixteen dependent round trips to
+// memory: 60 % of the launch)
+__global__ __launch_bounds__(256) void pn_ms_rows_prep_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                              const float* __restrict__ rsum, const float* __restrict__ unorm,
+                                                              const float* __restrict__ bsq, int R, float* __restrict__ gu,
+                                                              float* __restrict__ scal) {
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= MR_R) return;
+  float u0 = 0.f, u1 = 0.f, c = 0.f, al = 0.f, ri = 0.f;
+  if (r < R) {
+    const size_t base = ((size_t)b * R + r) * MR_D;
+    const float y0 = y[base + lane], y1 = y[base + lane + 64];
+    const float g0 = gy[base + lane], g1 = gy[base + lane + 64];
+    const float nn = unorm[(size_t)b * R + r], rr = rsum[(size_t)b * R + r];
+    const float yg = pn_wave_sum(y0 * g0 + y1 * g1);
+    u0 = (g0 - y0 * yg) / nn;
+    u1 = (g1 - y1 * yg) / nn;
+    c = pn_wave_sum(u0 * (y0 * nn) + u1 * (y1 * nn));
+    al = 1.0f / (rr * bsq[b]);
+    ri = 1.0f / rr;
+  }
+  float* g = gu + ((size_t)b * MR_R + r) * MR_D;
+  g[lane] = u0;
+  g[lane + 64] = u1;
+  if (lane == 0) {
+    float* sp = scal + ((size_t)b * MR_R + r) * 4;
+    sp[0] = c;
+    sp[1] = al;
+    sp[2] = ri;
+    sp[3] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void pn_ms_rows_bwd_kernel(
-    const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ q,
-    const float* __restrict__ rsum, const float* __restrict__ unorm, const float* __restrict__ x,
-    const float* __restrict__ bsq, int N, int R, int nblk, float* __restrict__ gx, float* __restrict__ gq_part) {
+    const float* __restrict__ gu, const float* __restrict__ scal, const float* __restrict__ q,
+    const float* __restrict__ x, const float* __restrict__ bsq, int N, int R, int nblk, float* __restrict__ gx,
+    float* __restrict__ gq_part) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Xs = lds;                          // [64][MR_LD]
   float* Qs = Xs + MR_CB * MR_LD;           // [64][MR_LD]
@@ -50,7 +93,7 @@ __global__ __launch_bounds__(256) void pn_ms_rows_bwd_kernel(
   float* sa = sc + MR_R;                    // alpha_i
   float* sr = sa + MR_R;                    // 1 / r_i
   const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+
   const int j0 = blk * MR_CB;
   const float bs = bsq[b];
   const float hl = (0.5f / bs) * MR_LOG2E;
@@ -66,27 +109,15 @@ __global__ __launch_bounds__(256) void pn_ms_rows_bwd_kernel(
     if (r < R) w = mr_ld4(q + ((size_t)b * R + r) * MR_D + 4 * c4);
     *reinterpret_cast<float4*>(Qs + r * MR_LD + 4 * c4) = w;
   }
-  for (int r = wave; r < MR_R; r += 4) {      // one wave per row (as pn_ms_prep_bwd_kernel)
-    float u0 = 0.f, u1 = 0.f, c = 0.f, al = 0.f, ri = 0.f;
-    if (r < R) {
-      const size_t base = ((size_t)b * R + r) * MR_D;
-      const float y0 = y[base + lane], y1 = y[base + lane + 64];
-      const float g0 = gy[base + lane], g1 = gy[base + lane + 64];
-      const float nn = unorm[(size_t)b * R + r], rr = rsum[(size_t)b * R + r];
-      const float yg = pn_wave_sum(y0 * g0 + y1 * g1);
-      u0 = (g0 - y0 * yg) / nn;
-      u1 = (g1 - y1 * yg) / nn;
-      c = pn_wave_sum(u0 * (y0 * nn) + u1 * (y1 * nn));
-      al = 1.0f / (rr * bs);
-      ri = 1.0f / rr;
-    }
-    Us[r * MR_LD + lane] = u0;
-    Us[r * MR_LD + lane + 64] = u1;
-    if (lane == 0) {
-      sc[r] = c;
-      sa[r] = al;
-      sr[r] = ri;
-    }
+  for (int it = tid; it < MR_R * (MR_D / 4); it += 256) {      // gu rows and the per-row scalars (pn_ms_rows_prep_kernel)
+    const int r = it >> 5, c4 = it & 31;
+    *reinterpret_cast<float4*>(Us + r * MR_LD + 4 * c4) = mr_ld4(gu + ((size_t)b * MR_R + r) * MR_D + 4 * c4);
+  }
+  if (tid < MR_R) {
+    const float4 sv = mr_ld4(scal + ((size_t)b * MR_R + tid) * 4);
+    sc[tid] = sv.x;
+    sa[tid] = sv.y;
+    sr[tid] = sv.z;
   }
   __syncthreads();
 
@@ -254,8 +285,10 @@ __global__ __launch_bounds__(256) void pn_ms_rows_scatter_kernel(const float* __
   }
 }
 
+static size_t mr_part_bytes(int B, int N) { return pn_align_up((size_t)B * pn_cdiv(N, MR_CB) * MR_R * MR_D * sizeof(float), 256); }
+static size_t mr_gu_bytes(int B) { return pn_align_up((size_t)B * MR_R * MR_D * sizeof(float), 256); }
 extern "C" size_t pn_meanshift_rows_bwd_workspace(int B, int N) {
-  return (size_t)B * pn_cdiv(N, MR_CB) * MR_R * MR_D * sizeof(float);
+  return mr_part_bytes(B, N) + mr_gu_bytes(B) + pn_align_up((size_t)B * MR_R * 4 * sizeof(float), 256);
 }
 
 // One step of the row-restricted backward.  gy, y, q (B,R,D), rsum, unorm (B,R): the R rows of the
@@ -273,18 +306,21 @@ extern "C" int pn_meanshift_rows_bwd_f32(const float* gy, const float* y, const 
     pn_set_error("pn_meanshift_rows_bwd_f32: workspace too small");
     return PN_ERR_WORKSPACE;
   }
-  const size_t lds_bytes = (size_t)(3 * MR_R * MR_LD + 3 * MR_R * MR_LG + 3 * MR_R) * sizeof(float);
+  const size_t lds_valu = (size_t)(3 * MR_R * MR_LD + 3 * MR_R * MR_LG + 3 * MR_R) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pn_ms_rows_bwd_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_valu));
     attr_set = true;
   }
   float* part = static_cast<float*>(workspace);
+  float* gu = reinterpret_cast<float*>(static_cast<char*>(workspace) + mr_part_bytes(B, N));
+  float* scal = reinterpret_cast<float*>(static_cast<char*>(workspace) + mr_part_bytes(B, N) + mr_gu_bytes(B));
   {
     PN_PROF("meanshift_rows_bwd", stream);
-    hipLaunchKernelGGL(pn_ms_rows_bwd_kernel, dim3(nblk, B), dim3(256), lds_bytes, stream, gy, y, q, rsum, unorm, x,
-                       bsq, N, R, nblk, gx, part);
+    hipLaunchKernelGGL(pn_ms_rows_prep_kernel, dim3(MR_R / 4, B), dim3(256), 0, stream, gy, y, rsum, unorm, bsq, R, gu, scal);
+    hipLaunchKernelGGL(pn_ms_rows_bwd_kernel, dim3(nblk, B), dim3(256), lds_valu, stream, (const float*)gu,
+                       (const float*)scal, q, x, bsq, N, R, nblk, gx, part);
   }
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms_rows_reduce_kernel, dim3(pn_cdiv(R * (MR_D / 4), 256), B), dim3(256), 0, stream, part, R, nblk,

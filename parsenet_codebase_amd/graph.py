@@ -31,11 +31,15 @@ def frozen_cache(layer):
 
 def invalidate_frozen_caches(module=None):
     """Forget the folded constants of ``module`` and its sub-modules (all layers if None)."""
+    from . import encoders            # (the split images of frozen weights, encoders._weight_image)
     if module is None:
         _FROZEN.clear()
+        encoders._W_IMAGES.clear()
         return
     for m in module.modules():
         _FROZEN.pop(m, None)
+    for prm in module.parameters():
+        encoders._W_IMAGES.pop(id(prm), None)
 
 
 # --------------------------------------------------------------------------------------

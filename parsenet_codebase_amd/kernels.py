@@ -432,7 +432,8 @@ def meanshift_x3_plan_visited(plans, B, N):
     it with something it waits for anyway)."""
     T = (N + 63) // 64 * 2
     n = B * T * T
-    return torch.stack([p[:n].float().mean() for p in plans]).mean()
+    # (one reduction per plan: the flags are 0 / 1 bytes, their fp32 sum is exact in any order)
+    return torch.stack([p[:n].sum(dtype=torch.float32) for p in plans]).mean() / float(n)
 
 
 def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None, out=None):

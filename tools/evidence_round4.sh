@@ -6,6 +6,8 @@
 #  * rocprofv3 of `bench.py --profile-only` (ONLY the launches the roofline is quoted on): kernel statistics,
 #    SQ counters, FETCH_SIZE and WRITE_SIZE in passes of their own; tools/roofline_check.py;
 #  * kernel statistics of cfg4 / cfg2 / cfg3, step breakdown of cfg5, the named kernels (kbench).
+# EVIDENCE_SHORT=1: tests, determinism, bench lines and the default profile-only passes only (a late change that
+# touches one kernel: the other passes of the previous full run stay valid).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -29,6 +31,7 @@ cd /tmp
 PARSENET_MS_SPARSE=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s5 -o b -- python3 $R/bench.py --profile-only > $O/po_stats.json 2> $O/po_stats.err
 cp $(find $O/s5 -name "b_kernel_trace.csv" | head -1) $O/s5_trace.csv 2>/dev/null
 PARSENET_MS_SPARSE=1 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_SQ_rows -o p -- python3 $R/bench.py --profile-only > $O/po_sq_rows.json 2> $O/po_sq_rows.err
+if [ -z "$EVIDENCE_SHORT" ]; then
 # (b) PARSENET_MS_ROWS_BWD=0: the dense backward passes (what a caller with a dense gradient runs) — all three
 #     matrix-core kernels: statistics, SQ counters, FETCH_SIZE and WRITE_SIZE in passes of their own; planned, then dense launches
 export PARSENET_MS_ROWS_BWD=0
@@ -47,20 +50,25 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s4 -o b -
 for W in cfg2 cfg3; do
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s_$W -o b -- python3 $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 > $O/prof_$W.log 2>&1
 done
+fi
 cd $R
 K=$(find $O/s5 -name "b_kernel_stats.csv" | head -1); C=$(find $O/pmc_SQ_rows -name "p_counter_collection.csv" | head -1)
 python tools/roofline_check.py $O/po_stats.json $K $C $O/roofline_check.txt > /dev/null
+if [ -z "$EVIDENCE_SHORT" ]; then
 Kb=$(find $O/s5b -name "b_kernel_stats.csv" | head -1); Cb=$(find $O/pmc_SQ -name "p_counter_collection.csv" | head -1)
 python tools/roofline_check.py $O/po_stats_bwd.json $Kb $Cb $O/roofline_check_bwd.txt > /dev/null
 Kd=$(find $O/s5d -name "b_kernel_stats.csv" | head -1); Cd=$(find $O/pmc_SQ_dense -name "p_counter_collection.csv" | head -1)
 python tools/roofline_check.py $O/po_stats_dense.json $Kd $Cd $O/roofline_check_dense.txt > /dev/null
+fi
 python tools/step_breakdown.py $O/s5_trace.csv > $O/breakdown.txt 2>&1
 python tools/step_timeline.py $O/s5_trace.csv 1 1 > $O/timeline.txt 2>&1
 rm -f $O/s5_trace.csv
 find $O -name "*kernel_trace.csv" -delete
+if [ -z "$EVIDENCE_SHORT" ]; then
 timeout 300 python tools/kbench.py edge chamfer gemm knnwide > $O/kbench.log 2>&1
 timeout 600 python tools/torch_sites.py > $O/torch_sites.txt 2>&1
 timeout 600 python tools/host_cprofile.py > $O/host_cprofile.txt 2>&1
+fi
 tail -2 $O/smoke.log; cat $O/host.txt; grep -i "passed\|failed\|^rc " $O/pytest.log | cut -c1-300; tail -n 1 $O/det_cfg*.txt
 for f in bench_cfg5 bench_cfg5_b bench_cfg5_c bench_cfg4 bench_cfg2 bench_cfg3; do cut -c1-260 $O/$f.json; done
 cat $O/roofline_check.txt $O/roofline_check_bwd.txt $O/roofline_check_dense.txt; cat $O/breakdown.txt
