@@ -43,6 +43,17 @@ PRIM_NAME = {K.PRIM_PLANE: "plane", K.PRIM_SPHERE: "sphere", K.PRIM_CYLINDER: "c
 CMAX = 64          # padded list of cluster centres (the guard retries above 49 anyway)
 # mean-shift backward through the centre rows only (mean_shift._CentreRows; 0: dense passes over all rows)
 ROWS_BWD = os.environ.get("PARSENET_MS_ROWS_BWD", "1") != "0"
+# the open and the closed SplineNet of a fitting stage on two streams (0: one after the other)
+SPLINE_STREAMS = os.environ.get("PARSENET_SPLINE_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
 
 
 # -------------------------------------------------------------------------------------------
@@ -720,15 +731,32 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
             pts_std, std, mean, R = standardize_segments(P2, w2.detach())      # sync 2
             affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
         nu, nv = _fitter_bases(fitter, dev)
+
+        def spline_group(lo, hi, net, wrap):
+            with record_function("fit:splinenet"):
+                ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
+            return _BSplineEval.apply(ctrl.reshape(hi - lo, 20, 20, 3), nu, nv, affine[lo:hi], wrap)
+        groups = [g for g in ((0, n_open, fitter.open_control_decoder, False),
+                              (n_open, S_s, fitter.closed_control_decoder, True)) if g[1] > g[0]]
+        # The two SplineNets work on a handful of segments each: most of their kernels fill a fraction of the 256
+        # CUs.  With both kinds of segments present the closed net runs on a side stream next to the open one
+        # (same kernels, same inputs, same results; autograd runs each node's backward on its forward stream).
+        two_streams = SPLINE_STREAMS and len(groups) == 2 and dev.type == "cuda"
+        if two_streams:
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(main)                     # pts_std, w2, affine, the bases: produced on main
+            with torch.cuda.stream(side):
+                rec_side = spline_group(*groups[1])
+            rec_main = spline_group(*groups[0])
+            main.wait_stream(side)
+            rec_side.record_stream(main)               # allocated on the side stream, consumed on main
+            rec_list = [rec_main, rec_side]
+        else:
+            rec_list = [spline_group(*g) for g in groups]
         pieces = []
-        for lo, hi, net, wrap in ((0, n_open, fitter.open_control_decoder, False),
-                                  (n_open, S_s, fitter.closed_control_decoder, True)):
-            if hi > lo:
-                with record_function("fit:splinenet"):
-                    ctrl = net(pts_std[lo:hi].permute(0, 2, 1).contiguous(), w2[lo:hi])
-                rec = _BSplineEval.apply(ctrl.reshape(hi - lo, 20, 20, 3), nu, nv, affine[lo:hi], wrap)
-                pieces.append(rec.reshape(-1, 3))
-                recs += [rec[k:k + 1] for k in range(hi - lo)]
+        for (lo, hi, _, _), rec in zip(groups, rec_list):
+            pieces.append(rec.reshape(-1, 3))
+            recs += [rec[k:k + 1] for k in range(hi - lo)]
         pred = torch.cat(pieces, 0)
         gt_cloud = points.reshape(B * N, 3)[T["gt_flat"][int(gt_off[S_p]):].long()]
         with record_function("fit:chamfer"):
