@@ -1070,9 +1070,15 @@ extern "C" int pn_dot_kth_unit_h2_f32(const float* q, int Nq, const void* img_c,
   return PN_OK;
 }
 
+#include "knn_smallk.h"
+
 // ---- kNN graph entry points ---------------------------------------------------------------
 extern "C" size_t pn_knn_workspace(int B, int C, int N, int k) {
   size_t best = 0;
+  {
+    const KskPlan sk = ksk_plan(0, B, C, N, k);
+    if (sk.ok) best = sk.total;
+  }
   for (int mode = 0; mode < 2; ++mode) {
     if (mode == 1 && C != 6) continue;
     KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
@@ -1092,6 +1098,11 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
   PN_CHECK_ARG(mode == 0 || C == 6, "pn_knn_pn: points+normals metric needs C=6, got %d", C);
   PN_CHECK_ARG(workspace && workspace_bytes >= pn_knn_workspace(B, C, N, k),
                "pn_knn: workspace too small");
+  {
+    // small k (the SplineNets' graphs): one distance pass, the k best of a lane in registers (knn_smallk.h)
+    const KskPlan sk = ksk_plan(mode, B, C, N, k);
+    if (sk.ok) return ksk_run(sk, x, B, C, N, k, idx, 0, (char*)workspace, stream);
+  }
   const KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
   if (!p.fast)
     return pn_knn_v1_launch(mode, x, B, C, N, k, idx, workspace, workspace_bytes, stream, nullptr);

@@ -148,3 +148,36 @@ def test_kth_dot_in_bf16x3_arithmetic(gpu, C, N, K):
     val, f1 = got
     assert int(f0.sum()) == 0 and int(f1.sum()) == 0
     assert float((val - exact).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,N,k", [(1, 3, 5000, 10), (2, 64, 5000, 10), (1, 128, 2600, 10), (1, 256, 2111, 10),
+                                     (3, 3, 32, 10), (2, 7, 33, 5), (1, 64, 700, 16), (2, 20, 1500, 11), (4, 6, 97, 1),
+                                     (1, 3, 20000, 10)])
+def test_small_k_one_pass_kernel_bit_exact(gpu, B, C, N, k):
+    """k <= 16 (the SplineNets' graphs, src/model.py:9-22): one distance pass with the k best of a lane in
+    registers (csrc/knn_smallk.h) — sliced candidate ranges merged by the second kernel, a single slice written
+    directly, tails of the last tile, KK = 10 and 16, every channel width — against the C oracle."""
+    from oracle import cbind
+    rng = np.random.RandomState(17 * C + N + k)
+    x = (rng.uniform(-1, 1, (B, C, N)) * rng.uniform(0.2, 3.0, (B, C, 1))).astype(np.float32)
+    got = _gpu_knn(x, k, gpu)
+    want = cbind.knn(x, k, 0)
+    assert got.shape == (B, N, k)
+    assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
+
+
+def test_small_k_ties_and_the_two_pass_engine_agree(gpu, monkeypatch):
+    """Masses of equal values (coincident points, a lattice) order by the smaller index in every lane, between
+    the two lanes of a query and between slices; and the graph equals the two-pass engine's (PN_KNN_SMALLK=0)."""
+    from oracle import cbind
+    rng = np.random.RandomState(23)
+    lat = (rng.randint(-8, 9, (2, 3, 3000)) / 16.0).astype(np.float32)        # many exact ties and duplicates
+    coin = np.zeros((1, 64, 2100), np.float32)
+    coin[0, :, 1000:] = 0.5
+    for x, k in ((lat, 10), (coin, 10), (lat[:, :, :257], 16)):
+        got = _gpu_knn(x, k, gpu)
+        assert np.array_equal(got, cbind.knn(x, k, 0))
+        monkeypatch.setenv("PN_KNN_SMALLK", "0")
+        old = _gpu_knn(x, k, gpu)
+        monkeypatch.delenv("PN_KNN_SMALLK")
+        assert np.array_equal(got, old)

@@ -89,6 +89,34 @@ def bench_knnwide():
               % (B, C, N, k, out["2"][0], out["0"][0], same))
 
 
+def bench_smallk():
+    """The SplineNets' graphs (k = 10) inside a cfg5 step (segments of 5 000 sub-sampled points) and a cfg2 / cfg3
+    step (32 x 700): the one-pass small-k kernel (PN_KNN_SMALLK=1, default) against the two-pass engine (0)."""
+    import os
+    from parsenet_codebase_amd import _lib
+    dev = torch.device("cuda:0")
+    for (B, C, N, k) in [(6, 3, 5000, 10), (6, 64, 5000, 10), (6, 128, 5000, 10), (6, 256, 5000, 10), (3, 256, 5000, 10),
+                         (12, 64, 5000, 10), (32, 3, 700, 10), (32, 64, 700, 10), (32, 128, 700, 10), (32, 256, 700, 10)]:
+        x = torch.randn(B, C, N, device=dev) * (0.5 + torch.rand(B, C, 1, device=dev))
+        out = {}
+        for lvl in ("1", "0"):
+            os.environ["PN_KNN_SMALLK"] = lvl
+            ms = timeit(lambda: kernels.knn(x, k, "feature"))
+            out[lvl] = (ms, kernels.knn(x, k, "feature"))
+            _lib.prof_enable(True)
+            _lib.prof_reset()
+            for _ in range(5):
+                kernels.knn(x, k, "feature")
+            torch.cuda.synchronize()
+            print("    PN_KNN_SMALLK=%s: " % lvl + "  ".join("%s %.3f" % (kn, t / calls) for kn, (t, calls) in sorted(_lib.prof_results().items())))
+            _lib.prof_enable(False)
+        os.environ.pop("PN_KNN_SMALLK")
+        same = bool((out["1"][1] == out["0"][1]).all())
+        gf = B * N * N * (2 * C + 3) / 1e9
+        print("knn B=%d C=%d N=%d k=%d: one pass %.3f ms (%.1f TFLOP/s), two-pass engine %.3f ms, same graph: %s"
+              % (B, C, N, k, out["1"][0], gf / out["1"][0], out["0"][0], same))
+
+
 def bench_knn64():
     """cfg4's 64-channel layer and the bandwidth selection of cfg5, with the per-kernel timers."""
     from parsenet_codebase_amd import _lib
