@@ -74,7 +74,8 @@ class StubStep:
 
     def __init__(self, device, rank, pretrain):
         from parsenet_codebase_amd import workloads
-        from parsenet_codebase_amd.dp import FlatGradBucket
+        from parsenet_codebase_amd.dp import FitStatusError, FlatGradBucket
+        self._fit_status_error = FitStatusError
         torch.manual_seed(100 + rank)            # ranks start from DIFFERENT weights: the broadcast must fix that
         self.model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1)).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
@@ -112,7 +113,7 @@ class StubStep:
 
         def finish():
             if self.calls == self.fail_at:
-                raise RuntimeError("injected: degenerate segment on this rank")
+                raise self._fit_status_error("injected: degenerate segment on this rank")
         _, _, took = self.bucket.finish_or_skip(finish, self.opt)
         self.skipped_steps += 0 if took else 1
         return loss
@@ -513,8 +514,13 @@ def main():
         if hasattr(step, "cursor"):
             step.cursor = snap["cursor"]
 
-    def timed_run():
-        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+    per_rank = {}
+
+    def timed_run(tag="default"):
+        """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks.  Every rank also
+        notes when ITS OWN K steps were done (synchronize, before the closing barrier): the spread over the
+        ranks — data-dependent segment counts, mean-shift retries — goes into the line as
+        ``per_rank_ms`` (per step, min / max over the ranks)."""
         np.random.seed(1000 + rank)
         for _ in range(args.warmup):
             step.step()
@@ -522,12 +528,23 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step.step()
+        sync()
+        own = time.perf_counter() - t0
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+            lo = torch.tensor([own], dtype=torch.float64, device=device)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            own_lo, own_hi = float(lo.item()), float(hi.item())
+        else:
+            own_lo = own_hi = own
+        per_rank[tag] = {"min": round(1e3 * own_lo / max(args.steps, 1), 3),
+                         "max": round(1e3 * own_hi / max(args.steps, 1), 3)}
         return el
 
     # every run (default launches, dense launches, profiled steps) starts from the pre-trained state.
@@ -573,7 +590,7 @@ def main():
         if ms_mode is not None:
             _ms.SPARSE = False
         try:
-            elapsed_dense = timed_run()
+            elapsed_dense = timed_run("dense")
         finally:
             if ms_mode is not None:
                 _ms.SPARSE = ms_mode
@@ -627,10 +644,17 @@ def main():
     if stub:
         for _ in range(nprof):
             step.step()
+    # The CPU baseline: rank 0, outside every timed region (with several ranks the others wait at the barrier
+    # below: a bounded sample, <= 45 s).  The stub workload reports a token entry so that the multi-rank control
+    # flow of this leg is covered on gloo ranks too.
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub and not args.profile_only:
-        cpu = cpu_baseline(args.workload, start["model"] if args.workload == "cfg5" else None,
-                           "the GPU side's pre-trained state_dict" if args.workload == "cfg5" else "random-init weights")
+    if rank == 0 and not args.no_cpu_baseline and not args.profile_only:
+        if stub:
+            cpu = {"value": None, "unit": "shapes/s", "cores": 1, "kind": "port", "sample": "stub workload: none"}
+        else:
+            cpu = cpu_baseline(args.workload, start["model"] if args.workload == "cfg5" else None,
+                               "the GPU side's pre-trained state_dict" if args.workload == "cfg5"
+                               else "random-init weights")
     if world > 1:
         dist.barrier()
 
@@ -649,6 +673,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": None if elapsed is None else 1e3 * elapsed / args.steps,
+            # each rank's own time for its K steps (synchronize, before the closing barrier), per step
+            "per_rank_ms": per_rank.get("default"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

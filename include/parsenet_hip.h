@@ -58,6 +58,14 @@ int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx, void* w
                size_t workspace_bytes, void* stream);
 int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* The same graph with int32 indices — the form the library's own edge-conv kernels consume
+ * (pn_edgeconv_reduce_fwd_i32, pn_edgeconv_bwd_i32: half the index bytes of the torch dtype the
+ * reference's topk returns, src/model.py:19).  metric 0: feature space (pn_knn_f32), 1: points +
+ * normals (pn_knn_pn_f32, C = 6).  k <= 16 (the SplineNets' graphs, src/model.py:9-22 with k = 10)
+ * takes ONE distance pass with the k best candidates of a lane in registers (csrc/knn_smallk.h);
+ * same workspace query. */
+int pn_knn_graph_i32(const float* x, int B, int C, int N, int k, int metric, int32_t* idx,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- dot-product selection between two point sets ------------------------------------
  * Replaces src/mean_shift.py:125-137 (compute_bandwidth: 2 - 2 X X^T, topk(K, largest=False),
@@ -324,6 +332,10 @@ int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float*
                                int N, int k, int Cout, int groups, int per_sample, float* yext,
                                uint8_t* argk, float* s1, double* stats, void* workspace,
                                size_t workspace_bytes, void* stream);
+int pn_edgeconv_reduce_fwd_i32(const float* PQ, const int32_t* idx, const float* gamma, int B,
+                               int N, int k, int Cout, int groups, int per_sample, float* yext,
+                               uint8_t* argk, float* s1, double* stats, void* workspace,
+                               size_t workspace_bytes, void* stream);
 int pn_moments_f32(const double* stats, int n, double count, float eps, float* mean, float* rstd,
                    void* stream);
 int pn_edgeconv_finalize_fwd_f32(const float* yext, const float* mean, const float* rstd,
@@ -336,6 +348,11 @@ int pn_edgeconv_bwd_prep_f32(const float* gout, const float* yext, const float* 
                              float* yhat, void* stream);
 size_t pn_edgeconv_bwd_workspace(int B, int N, int k);
 int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t, const float* s1,
+                        const uint8_t* argk, const float* mean, const float* rstd,
+                        const float* c1c2, int B, int N, int k, int Cout, int groups,
+                        int per_sample, int dense, float* dPQ, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int pn_edgeconv_bwd_i32(const float* PQ, const int32_t* idx, const float* t, const float* s1,
                         const uint8_t* argk, const float* mean, const float* rstd,
                         const float* c1c2, int B, int N, int k, int Cout, int groups,
                         int per_sample, int dense, float* dPQ, void* workspace,

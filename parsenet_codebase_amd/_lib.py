@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 14  # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 15  # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -34,12 +34,16 @@ SIGNATURES = {
     "pn_knn_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pn_knn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_knn_pn_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pn_knn_graph_i32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pn_edge_feature_fwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_edge_feature_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
     "pn_edgeconv_reduce_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pn_edgeconv_reduce_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
+    "pn_edgeconv_reduce_fwd_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                            c_void_p]),
     "pn_moments_f32": (c_int, [c_void_p, c_int, c_double, c_float, c_void_p, c_void_p, c_void_p]),
@@ -49,6 +53,9 @@ SIGNATURES = {
                                          c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "pn_edgeconv_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_edgeconv_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "pn_edgeconv_bwd_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
     "pn_dot_select_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -246,10 +253,18 @@ class _PinnedRing:
     the slot after the event, possibly much later (the fit status of a step is read after the
     backward pass has been queued) — such a slot is taken with ``hold=True`` and stays out of the
     rotation until the reader calls ``release`` (round-3 advisor finding: 32 further takes handed
-    the slot to an upload whose host-side copy overwrote unread results)."""
+    the slot to an upload whose host-side copy overwrote unread results).  Readers release in a
+    ``finally``; a slot whose reader never came back at all (a stage generator abandoned by a dropped
+    step, ``finish()`` never called after a rank-local failure) is reclaimed — with a warning — once
+    ABANDONED_AFTER further takes have gone by: a live reader holds a slot for a fraction of a step, a
+    few dozen takes at most (round-4 advisor finding: leaked slots silently turned every transfer into a
+    fresh page-locked allocation, the multi-millisecond stall the ring exists to avoid)."""
+
+    ABANDONED_AFTER = 256
 
     def __init__(self, slots=32, nbytes=1 << 20):
         self.nbytes, self.nslots, self.slots, self.next = nbytes, slots, None, 0
+        self.takes, self.warned_full, self.warned_lost = 0, False, False
 
     def take(self, nbytes, hold=False):
         """(uint8 pinned view of ``nbytes``, slot) or (None, None) when the request exceeds a slot or
@@ -262,16 +277,29 @@ class _PinnedRing:
             whole = torch.empty(self.nslots * self.nbytes, dtype=torch.uint8).pin_memory()
             self.slots = [{"buf": whole[i * self.nbytes:(i + 1) * self.nbytes], "event": torch.cuda.Event(),
                            "armed": False, "held": False} for i in range(self.nslots)]
+        self.takes += 1
         for _ in range(self.nslots):
             i = self.next
             self.next = (i + 1) % self.nslots
             slot = self.slots[i]
             if slot["held"]:
-                continue
+                if self.takes - slot.get("held_at", self.takes) <= self.ABANDONED_AFTER:
+                    continue
+                if not self.warned_lost:
+                    import warnings
+                    warnings.warn("parsenet_codebase_amd: a pinned download slot was never released by its reader "
+                                  "(abandoned step?); reclaiming it")
+                    self.warned_lost = True
             if slot["armed"]:
                 slot["event"].synchronize()
             slot["held"] = bool(hold)
+            slot["held_at"] = self.takes
             return slot["buf"][:max(nbytes, 1)], slot
+        if not self.warned_full:
+            import warnings
+            warnings.warn("parsenet_codebase_amd: every pinned staging slot is held by a host reader; falling back "
+                          "to a fresh page-locked allocation per transfer")
+            self.warned_full = True
         return None, None
 
     @staticmethod

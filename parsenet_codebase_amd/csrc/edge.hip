@@ -165,7 +165,8 @@ extern "C" int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int 
 // ------------------------------------------------------------------------------------
 // (2) fused edge convolution: gather-reduce over rows of P
 // ------------------------------------------------------------------------------------
-#define EC_PPW 16  // points per wave
+#define EC_PPW_MAX 16  // points per wave (chosen per launch: ec_points_per_wave)
+#define EC_PPW_MIN 2
 #define EC_WAVES 4
 
 struct float4x {
@@ -184,16 +185,28 @@ __device__ static inline void st4(float* p, const float4x& a) {
 // part: double [B][gridDim.x][COUT/Cg][2], one partial (sum y, sum y^2) per workgroup and group,
 // combined in index order by pn_stats_reduce_kernel (no atomics: the moments, and with them every
 // activation of the layer, are bit-reproducible run to run).
-template <int COUT>
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own 4 MiB L2.
+// The gather kernels therefore take their (item, block) from a VIRTUAL id: XCD x works through the x-th
+// contiguous eighth of the item-major block sequence, so that the rows it gathers belong to one item (or two
+// at a boundary) — 2.6 MB of P rows at N = 10 000, Cout = 64 — instead of to all items of the batch at once.
+__device__ static inline int pn_xcd_virtual(int w, int total) {
+  const int per = (total + 7) >> 3;
+  return (w & 7) * per + (w >> 3);
+}
+static inline int pn_xcd_grid(int total) { return 8 * ((total + 7) >> 3); }
+
+template <int COUT, typename IT>
 __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
-    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ gamma,
-    int N, int k, int Cg, int per_sample, float* __restrict__ yext, uint8_t* __restrict__ argk,
-    float* __restrict__ s1out, double* __restrict__ part) {
+    const float* __restrict__ PQ, const IT* __restrict__ idx, const float* __restrict__ gamma,
+    int N, int k, int Cg, int per_sample, int nblk, int B, int ppw, float* __restrict__ yext,
+    uint8_t* __restrict__ argk, float* __restrict__ s1out, double* __restrict__ part) {
   constexpr int NCH = COUT <= 256 ? 1 : COUT / 256;  // float4 chunks per lane
   constexpr int LPR = COUT <= 256 ? COUT / 4 : 64;   // lanes per row
   constexpr int RPI = 64 / LPR;                      // rows per wave step
   __shared__ double s_part[EC_WAVES][2][COUT];
-  const int b = blockIdx.y;
+  const int vid = pn_xcd_virtual(blockIdx.x, nblk * B);
+  if (vid >= nblk * B) return;
+  const int b = vid / nblk, blk = vid - b * nblk;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int rg = lane / LPR, cl = lane - rg * LPR;
   const float* __restrict__ PQb = PQ + (size_t)b * N * 2 * COUT;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) d1[h][u] = d2[h][u] = 0.0;
 
-  const int p0 = (blockIdx.x * EC_WAVES + wave) * EC_PPW;
+  const int p0 = (blk * EC_WAVES + wave) * ppw;
   // The neighbour list of a point lives in registers (lane l holds entries l and l + 64; k <= 128)
   // and is fetched ONE POINT AHEAD: the row gathers then depend on a lane shuffle instead of on a
   // load of the index that has just been issued (the profile showed 80 % of the wave cycles waiting
@@ -216,17 +229,17 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
   const bool regs = k <= 128;
   int nlo = 0, nhi = 0;
   if (regs && p0 < N) {
-    const int64_t* __restrict__ ib0 = idx + ((size_t)b * N + p0) * k;
+    const IT* __restrict__ ib0 = idx + ((size_t)b * N + p0) * k;
     nlo = lane < k ? (int)ib0[lane] : 0;
     nhi = lane + 64 < k ? (int)ib0[lane + 64] : 0;
   }
-  for (int pi = 0; pi < EC_PPW; ++pi) {
+  for (int pi = 0; pi < ppw; ++pi) {
     const int i = p0 + pi;
     if (i >= N) break;  // wave-uniform
-    const int64_t* __restrict__ ib = idx + ((size_t)b * N + i) * k;
+    const IT* __restrict__ ib = idx + ((size_t)b * N + i) * k;
     const int jlo = nlo, jhi = nhi;
-    if (regs && pi + 1 < EC_PPW && i + 1 < N) {
-      const int64_t* __restrict__ ibn = ib + k;
+    if (regs && pi + 1 < ppw && i + 1 < N) {
+      const IT* __restrict__ ibn = ib + k;
       nlo = lane < k ? (int)ibn[lane] : 0;
       nhi = lane + 64 < k ? (int)ibn[lane + 64] : 0;
     }
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
     double acc = 0.0;
     for (int w = 0; w < EC_WAVES; ++w)
       for (int c = g * Cg; c < (g + 1) * Cg; ++c) acc += s_part[w][which][c];
-    part[(((size_t)b * gridDim.x + blockIdx.x) * G + g) * 2 + which] = acc;
+    part[(((size_t)b * nblk + blk) * G + g) * 2 + which] = acc;
   }
 }
 
@@ -341,8 +354,9 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
 // time; used for unusual widths only.  The per-pair sums go through LDS so that the group partial
 // of the workgroup is formed in a fixed order.
 #define EC_GEN_PTS 16
+template <typename IT>
 __global__ __launch_bounds__(256) void pn_edgeconv_reduce_generic_kernel(
-    const float* __restrict__ PQ, const int64_t* __restrict__ idx, const float* __restrict__ gamma,
+    const float* __restrict__ PQ, const IT* __restrict__ idx, const float* __restrict__ gamma,
     int N, int k, int Cout, int Cg, float* __restrict__ yext, uint8_t* __restrict__ argk,
     float* __restrict__ s1out, double* __restrict__ part) {
   extern __shared__ float ec_gen_sh[];  // [2][EC_GEN_PTS * Cout]
@@ -355,13 +369,13 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_generic_kernel(
     const int pl = pc / Cout, c = pc - pl * Cout, i = p0 + pl;
     float s1 = 0.f, s2 = 0.f;
     if (i < N) {
-      const int64_t* ib = idx + ((size_t)b * N + i) * k;
+      const IT* ib = idx + ((size_t)b * N + i) * k;
       const float q = PQb[(size_t)i * 2 * Cout + Cout + c];
       const float sg = gamma[c] >= 0.f ? 1.f : -1.f;
       float best = -__builtin_inff();
       int arg = 0;
       for (int kk = 0; kk < k; ++kk) {
-        const float y = PQb[(size_t)ib[kk] * 2 * Cout + c] + q;
+        const float y = PQb[(size_t)(int)ib[kk] * 2 * Cout + c] + q;
         const float ys = y * sg;
         if (ys > best) {
           best = ys;
@@ -408,31 +422,40 @@ __global__ __launch_bounds__(64) void pn_stats_reduce_kernel(const double* __res
 
 extern "C" size_t pn_edgeconv_reduce_workspace(int B, int N, int Cout, int groups) {
   (void)Cout;
-  return pn_align_up((size_t)B * pn_cdiv(N, EC_GEN_PTS) * groups * 2 * sizeof(double), 256);
+  return pn_align_up((size_t)B * pn_cdiv(N, EC_WAVES * EC_PPW_MIN) * groups * 2 * sizeof(double), 256);
 }
 
-extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma,
-                                          int B, int N, int k, int Cout, int groups,
-                                          int per_sample, float* yext, uint8_t* argk, float* s1,
-                                          double* stats, void* workspace, size_t workspace_bytes,
-                                          void* stream_) {
+// Points per wave of the gather-reduce: the kernel is bound by the latency of its row gathers (two in flight per
+// wave), so the chip wants all the waves it can hold — eight per SIMD — before a wave gets a second point;
+// 16 points per wave (the round-3 value) left 2.5 waves per SIMD at B = 4, N = 10 000.
+static int ec_points_per_wave(int B, int N) {
+  int ppw = (int)(((long long)B * N) / 8192);
+  int p = EC_PPW_MIN;
+  while (p * 2 <= ppw && p < EC_PPW_MAX) p *= 2;
+  return p;
+}
+
+template <typename IT>
+static int edgeconv_reduce_fwd(const float* PQ, const IT* idx, const float* gamma, int B, int N, int k, int Cout,
+                               int groups, int per_sample, float* yext, uint8_t* argk, float* s1, double* stats,
+                               void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(PQ && idx && gamma && yext && argk && s1 && stats && workspace,
-               "pn_edgeconv_reduce_fwd_f32: null pointer");
+               "pn_edgeconv_reduce_fwd: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0 && k > 0 && k <= 255 && Cout > 0,
-               "pn_edgeconv_reduce_fwd_f32: bad sizes (B=%d N=%d k=%d Cout=%d)", B, N, k, Cout);
-  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_reduce_fwd_f32: groups=%d", groups);
+               "pn_edgeconv_reduce_fwd: bad sizes (B=%d N=%d k=%d Cout=%d)", B, N, k, Cout);
+  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_reduce_fwd: groups=%d", groups);
   PN_CHECK_ARG(workspace_bytes >= pn_edgeconv_reduce_workspace(B, N, Cout, groups),
-               "pn_edgeconv_reduce_fwd_f32: workspace too small");
+               "pn_edgeconv_reduce_fwd: workspace too small");
   const int Cg = Cout / groups;
   double* part = (double*)workspace;
-  int nblk;
+  const int ppw = ec_points_per_wave(B, N);
+  int nblk = pn_cdiv(N, EC_WAVES * ppw);
   PN_PROF("edgeconv_reduce_fwd", stream);
-  dim3 grid(pn_cdiv(N, EC_WAVES * EC_PPW), B);
-#define EC_GO(CO)                                                                              \
-  hipLaunchKernelGGL(pn_edgeconv_reduce_kernel<CO>, grid, dim3(256), 0, stream, PQ, idx, gamma, \
-                     N, k, Cg, per_sample, yext, argk, s1, part)
-  nblk = (int)grid.x;
+  dim3 grid(pn_xcd_grid(nblk * B));
+#define EC_GO(CO)                                                                                       \
+  hipLaunchKernelGGL((pn_edgeconv_reduce_kernel<CO, IT>), grid, dim3(256), 0, stream, PQ, idx, gamma, N, k, Cg, \
+                     per_sample, nblk, B, ppw, yext, argk, s1, part)
   if (Cout == 64)
     EC_GO(64);
   else if (Cout == 128)
@@ -444,15 +467,15 @@ extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, c
   else {
     const size_t lds = (size_t)2 * EC_GEN_PTS * Cout * sizeof(float);
     if (lds > 160 * 1024) {
-      pn_set_error("pn_edgeconv_reduce_fwd_f32: Cout=%d is neither 64/128/256/512 nor <= 1280", Cout);
+      pn_set_error("pn_edgeconv_reduce_fwd: Cout=%d is neither 64/128/256/512 nor <= 1280", Cout);
       return PN_ERR_UNSUPPORTED;
     }
     dim3 g2(pn_cdiv(N, EC_GEN_PTS), B);
     nblk = (int)g2.x;
     if (lds > 64 * 1024)
-      PN_CHECK_HIP(hipFuncSetAttribute((const void*)pn_edgeconv_reduce_generic_kernel,
+      PN_CHECK_HIP(hipFuncSetAttribute((const void*)pn_edgeconv_reduce_generic_kernel<IT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pn_edgeconv_reduce_generic_kernel, g2, dim3(256), lds, stream, PQ, idx, gamma,
+    hipLaunchKernelGGL(pn_edgeconv_reduce_generic_kernel<IT>, g2, dim3(256), lds, stream, PQ, idx, gamma,
                        N, k, Cout, Cg, yext, argk, s1, part);
   }
 #undef EC_GO
@@ -460,6 +483,24 @@ extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, c
                      (const double*)part, B, nblk, groups, per_sample, stats);
   PN_CHECK_LAUNCH();
   return PN_OK;
+}
+
+extern "C" int pn_edgeconv_reduce_fwd_f32(const float* PQ, const int64_t* idx, const float* gamma,
+                                          int B, int N, int k, int Cout, int groups,
+                                          int per_sample, float* yext, uint8_t* argk, float* s1,
+                                          double* stats, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
+  return edgeconv_reduce_fwd<int64_t>(PQ, idx, gamma, B, N, k, Cout, groups, per_sample, yext, argk, s1, stats,
+                                      workspace, workspace_bytes, stream_);
+}
+// the same on the library's int32 graph (pn_knn_graph_i32)
+extern "C" int pn_edgeconv_reduce_fwd_i32(const float* PQ, const int32_t* idx, const float* gamma,
+                                          int B, int N, int k, int Cout, int groups,
+                                          int per_sample, float* yext, uint8_t* argk, float* s1,
+                                          double* stats, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
+  return edgeconv_reduce_fwd<int32_t>(PQ, idx, gamma, B, N, k, Cout, groups, per_sample, yext, argk, s1, stats,
+                                      workspace, workspace_bytes, stream_);
 }
 
 // mean / rstd of every group from the fp64 moments (count = elements per group)
@@ -605,7 +646,8 @@ static inline int pn_rev_groups(int N) {
   return g > REV_G_MIN ? g : REV_G_MIN;
 }
 
-__global__ __launch_bounds__(256) void pn_rev_count_lds_kernel(const int64_t* __restrict__ idx, int N, int k,
+template <typename IT>
+__global__ __launch_bounds__(256) void pn_rev_count_lds_kernel(const IT* __restrict__ idx, int N, int k,
                                                                int G, int* __restrict__ part) {
   extern __shared__ int rev_hist[];
   const int b = blockIdx.y, g = blockIdx.x;
@@ -616,7 +658,7 @@ __global__ __launch_bounds__(256) void pn_rev_count_lds_kernel(const int64_t* __
   const long long per = (long long)N * k;
   const long long chunk = (per + G - 1) / G;
   const long long e0 = g * chunk, e1 = e0 + chunk < per ? e0 + chunk : per;
-  const int64_t* __restrict__ ib = idx + (size_t)b * per;
+  const IT* __restrict__ ib = idx + (size_t)b * per;
   for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
     const int j = (int)ib[e] - w0;
     if ((unsigned)j < (unsigned)wn) atomicAdd(&rev_hist[j], 1);
@@ -670,7 +712,8 @@ __global__ __launch_bounds__(1024) void pn_rev_scan_kernel(const int* __restrict
   if (t == 1023) ob[N] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void pn_rev_fill_lds_kernel(const int64_t* __restrict__ idx, int N, int k,
+template <typename IT>
+__global__ __launch_bounds__(256) void pn_rev_fill_lds_kernel(const IT* __restrict__ idx, int N, int k,
                                                               int G, const int* __restrict__ part,
                                                               const int* __restrict__ off,
                                                               uint32_t* __restrict__ rev) {
@@ -685,7 +728,7 @@ __global__ __launch_bounds__(256) void pn_rev_fill_lds_kernel(const int64_t* __r
   const long long per = (long long)N * k;
   const long long chunk = (per + G - 1) / G;
   const long long e0 = g * chunk, e1 = e0 + chunk < per ? e0 + chunk : per;
-  const int64_t* __restrict__ ib = idx + (size_t)b * per;
+  const IT* __restrict__ ib = idx + (size_t)b * per;
   uint32_t* __restrict__ rb = rev + (size_t)b * per;
   for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
     const int j = (int)ib[e] - w0;
@@ -751,7 +794,8 @@ extern "C" size_t pn_edgeconv_bwd_workspace(int B, int N, int k) {
 }
 
 // builds the sorted CSR of the transposed graph in ``workspace``; off (B,N+1), rev (B,N*k)
-static int pn_build_rev_csr(const int64_t* idx, int B, int N, int k, void* workspace, size_t workspace_bytes,
+template <typename IT>
+static int pn_build_rev_csr(const IT* idx, int B, int N, int k, void* workspace, size_t workspace_bytes,
                             hipStream_t stream, const int** off_out, const uint32_t** rev_out) {
   PN_CHECK_ARG(N < (1 << 24) && k <= 255, "reverse graph: N=%d (max 2^24 - 1), k=%d (max 255)", N, k);
   PN_CHECK_ARG(workspace && workspace_bytes >= pn_edgeconv_bwd_workspace(B, N, k),
@@ -767,10 +811,10 @@ static int pn_build_rev_csr(const int64_t* idx, int B, int N, int k, void* works
   int* part = (int*)w;
   const int nwin = pn_cdiv(N, REV_LDS_MAXN);
   const size_t lds = (size_t)(N < REV_LDS_MAXN ? N : REV_LDS_MAXN) * sizeof(int);
-  hipLaunchKernelGGL(pn_rev_count_lds_kernel, dim3(G, B, nwin), dim3(256), lds, stream, idx, N, k, G, part);
+  hipLaunchKernelGGL(pn_rev_count_lds_kernel<IT>, dim3(G, B, nwin), dim3(256), lds, stream, idx, N, k, G, part);
   hipLaunchKernelGGL(pn_rev_binprefix_kernel, dim3(pn_cdiv(N, 256), B), dim3(256), 0, stream, part, N, G, deg);
   hipLaunchKernelGGL(pn_rev_scan_kernel, dim3(B), dim3(1024), 0, stream, (const int*)deg, N, off);
-  hipLaunchKernelGGL(pn_rev_fill_lds_kernel, dim3(G, B, nwin), dim3(256), lds, stream, idx, N, k, G,
+  hipLaunchKernelGGL(pn_rev_fill_lds_kernel<IT>, dim3(G, B, nwin), dim3(256), lds, stream, idx, N, k, G,
                      (const int*)part, (const int*)off, rev);
   hipLaunchKernelGGL(pn_rev_sort_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, (const int*)off,
                      (const int*)part, N, k, G, rev);
@@ -789,13 +833,15 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_gather_kernel(
     const float* __restrict__ PQ, const int* __restrict__ off, const uint32_t* __restrict__ rev,
     const float* __restrict__ t, const uint8_t* __restrict__ argk, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ c1c2, int N, int k, int Cg, int per_sample,
-    int dense, float* __restrict__ dPQ) {
+    int dense, int nblk, int B, float* __restrict__ dPQ) {
   constexpr int NCH = COUT <= 256 ? 1 : COUT / 256;
   constexpr int LPR = COUT <= 256 ? COUT / 4 : 64;
   constexpr int RPI = 64 / LPR;
-  const int b = blockIdx.y;
+  const int vid = pn_xcd_virtual(blockIdx.x, nblk * B);     // (one item per XCD at a time, see above)
+  if (vid >= nblk * B) return;
+  const int b = vid / nblk, blk = vid - b * nblk;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + wave;
+  const int j = blk * 4 + wave;
   if (j >= N) return;
   const int rg = lane / LPR, cl = lane - rg * LPR;
   const int G = COUT / Cg;
@@ -927,28 +973,29 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_point_kernel(
   dPQ[((size_t)b * N + i) * 2 * Cout + Cout + c] = r * (t[o] - fk * c1 - c2 * r * (s1[o] - fk * mu));
 }
 
-extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t,
-                                   const float* s1, const uint8_t* argk, const float* mean,
-                                   const float* rstd, const float* c1c2, int B, int N, int k,
-                                   int Cout, int groups, int per_sample, int dense, float* dPQ,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+template <typename IT>
+static int edgeconv_bwd(const float* PQ, const IT* idx, const float* t, const float* s1, const uint8_t* argk,
+                        const float* mean, const float* rstd, const float* c1c2, int B, int N, int k, int Cout,
+                        int groups, int per_sample, int dense, float* dPQ, void* workspace, size_t workspace_bytes,
+                        void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(PQ && idx && t && s1 && argk && mean && rstd && c1c2 && dPQ,
-               "pn_edgeconv_bwd_f32: null pointer");
-  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_bwd_f32: groups=%d", groups);
+               "pn_edgeconv_bwd: null pointer");
+  PN_CHECK_ARG(groups > 0 && Cout % groups == 0, "pn_edgeconv_bwd: groups=%d", groups);
   const int Cg = Cout / groups;
   const int* off = nullptr;
   const uint32_t* rev = nullptr;
   {
     PN_PROF("edgeconv_bwd_csr", stream);
-    const int rc = pn_build_rev_csr(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
+    const int rc = pn_build_rev_csr<IT>(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
     if (rc != PN_OK) return rc;
   }
   PN_PROF("edgeconv_bwd", stream);
-  dim3 grid(pn_cdiv(N, 4), B);
+  const int nblk = pn_cdiv(N, 4);
+  dim3 grid(pn_xcd_grid(nblk * B));
 #define EC_BG(CO)                                                                               \
   hipLaunchKernelGGL(pn_edgeconv_bwd_gather_kernel<CO>, grid, dim3(256), 0, stream, PQ, off, rev, \
-                     t, argk, mean, rstd, c1c2, N, k, Cg, per_sample, dense, dPQ)
+                     t, argk, mean, rstd, c1c2, N, k, Cg, per_sample, dense, nblk, B, dPQ)
   dim3 g2(pn_cdiv((long long)N * Cout, 256), B);
   if (Cout == 64)
     EC_BG(64);
@@ -966,6 +1013,24 @@ extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const fl
                      Cg, per_sample, dPQ);
   PN_CHECK_LAUNCH();
   return PN_OK;
+}
+
+extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const float* t,
+                                   const float* s1, const uint8_t* argk, const float* mean,
+                                   const float* rstd, const float* c1c2, int B, int N, int k,
+                                   int Cout, int groups, int per_sample, int dense, float* dPQ,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  return edgeconv_bwd<int64_t>(PQ, idx, t, s1, argk, mean, rstd, c1c2, B, N, k, Cout, groups, per_sample, dense,
+                               dPQ, workspace, workspace_bytes, stream_);
+}
+// the same on the library's int32 graph (pn_knn_graph_i32)
+extern "C" int pn_edgeconv_bwd_i32(const float* PQ, const int32_t* idx, const float* t,
+                                   const float* s1, const uint8_t* argk, const float* mean,
+                                   const float* rstd, const float* c1c2, int B, int N, int k,
+                                   int Cout, int groups, int per_sample, int dense, float* dPQ,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+  return edgeconv_bwd<int32_t>(PQ, idx, t, s1, argk, mean, rstd, c1c2, B, N, k, Cout, groups, per_sample, dense,
+                               dPQ, workspace, workspace_bytes, stream_);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1034,7 +1099,7 @@ extern "C" int pn_edge_feature_bwd_f32(const float* gfeat, const int64_t* idx, i
   const int* off = nullptr;
   const uint32_t* rev = nullptr;
   PN_PROF("edge_feature_bwd", stream);
-  const int rc = pn_build_rev_csr(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
+  const int rc = pn_build_rev_csr<int64_t>(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
   if (rc != PN_OK) return rc;
   dim3 grid(pn_cdiv(N, 4), B);
 #define EF_BWD(CW_) \

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void pn_knn_scan_kernel(const float* __restric
                                                           int N, int k, int S, int slice_len,
                                                           u64* __restrict__ lists,
                                                           int* __restrict__ counts,
-                                                          int64_t* __restrict__ out,
+                                                          KnnIdxOut out,
                                                           const int* __restrict__ gate) {
   // grid: (ceil(N/256), S, B).  Wave = 64 queries x one slice of the candidates.
   // S == 1: the sorted result goes straight to `out`; S > 1: every (query, slice) list is
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void pn_knn_scan_kernel(const float* __restric
     u64 k0 = lane < m ? lp[lane] : 0ull;
     u64 k1 = lane + 64 < m ? lp[lane + 64] : 0ull;
     knn_wave_sort128(k0, k1);
-    int64_t* o = out + ((size_t)b * N + qbase + L) * k;
-    if (lane < k) o[lane] = knn_key_index(k0);
-    if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
+    const size_t o = ((size_t)b * N + qbase + L) * k;
+    if (lane < k) out.put(o + lane, knn_key_index(k0));
+    if (lane + 64 < k) out.put(o + lane + 64, knn_key_index(k1));
   }
 }
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void pn_knn_scan_kernel(const float* __restric
 __global__ __launch_bounds__(256) void pn_knn_merge_kernel(const u64* __restrict__ lists,
                                                            const int* __restrict__ counts, int N,
                                                            int k, int S, long long nq_total,
-                                                           int64_t* __restrict__ out) {
+                                                           KnnIdxOut out) {
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
   __shared__ u64 s_keys[4][KNN_CAP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(256) void pn_knn_merge_kernel(const u64* __restrict
   u64 k0 = lane < m ? keys[lane] : 0ull;
   u64 k1 = lane + 64 < m ? keys[lane + 64] : 0ull;
   knn_wave_sort128(k0, k1);
-  int64_t* o = out + (size_t)qi * k;
-  if (lane < k) o[lane] = knn_key_index(k0);
-  if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
+  const size_t o = (size_t)qi * k;
+  if (lane < k) out.put(o + lane, knn_key_index(k0));
+  if (lane + 64 < k) out.put(o + lane + 64, knn_key_index(k1));
 }
 
 static void knn_plan(int B, int N, int k, bool single, int* S_out, int* slice_len_out) {
@@ -246,10 +246,10 @@ size_t pn_knn_v1_workspace(int B, int C, int N, int k, bool gated) {
          pn_align_up((size_t)B * Np * S * KNN_CAP * sizeof(u64), 256);
 }
 
-int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
+int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, KnnIdxOut idx,
                      void* workspace, size_t workspace_bytes, hipStream_t stream,
                      const int* gate, const int* gate_any) {
-  PN_CHECK_ARG(x && idx, "pn_knn: null pointer");
+  PN_CHECK_ARG(x && idx.p, "pn_knn: null pointer");
   PN_CHECK_ARG(B > 0 && C > 0 && N > 0, "pn_knn: empty input (B=%d C=%d N=%d)", B, C, N);
   PN_CHECK_ARG(k >= 1 && k <= KNN_MAXK, "pn_knn: k=%d unsupported (1..%d)", k, KNN_MAXK);
   PN_CHECK_ARG(k <= N, "pn_knn: k=%d exceeds the number of points N=%d", k, N);

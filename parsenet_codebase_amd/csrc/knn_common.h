@@ -11,6 +11,20 @@
 
 typedef unsigned long long u64;
 
+// Where a graph's indices go: int64 at the API (torch's index dtype; src/model.py:19 returns topk's indices),
+// int32 inside the library (the edge-conv kernels read half the bytes).  p == null: no index output.
+struct KnnIdxOut {
+  void* p;
+  int is32;
+  __host__ __device__ explicit operator bool() const { return p != nullptr; }
+  __device__ inline void put(size_t pos, int64_t v) const {
+    if (is32)
+      static_cast<int*>(p)[pos] = (int)v;
+    else
+      static_cast<int64_t*>(p)[pos] = v;
+  }
+};
+
 // larger key = better neighbour: larger value first, then smaller index.  -0.0 is folded
 // into +0.0 so that key order agrees with the float comparison the oracle uses.
 __device__ static inline u64 knn_key(float v, int j) {

@@ -43,7 +43,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 size_t pn_knn_v1_workspace(int B, int C, int N, int k, bool gated);
-int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
+int pn_knn_v1_launch(int mode, const float* x, int B, int C, int N, int k, KnnIdxOut idx,
                      void* workspace, size_t workspace_bytes, hipStream_t stream,
                      const int* gate, const int* gate_any = nullptr);
 
@@ -349,14 +349,14 @@ __global__ __launch_bounds__(256) void pn_knn_mfma_kernel(
 
 // arg-max epilogue: one thread per query, maximum of its 2 S partial keys
 __global__ void pn_knn_argmax_final_kernel(const u64* __restrict__ lists, int Nq, int Nqp, int S,
-                                           KnnPerm perm_q, int64_t* __restrict__ out_idx) {
+                                           KnnPerm perm_q, KnnIdxOut out_idx) {
   const int b = blockIdx.y;
   const int qp = blockIdx.x * blockDim.x + threadIdx.x;
   if (qp >= Nq) return;
   const u64* l = lists + ((size_t)b * Nqp + qp) * S * 2;
   u64 best = 0;
   for (int i = 0; i < 2 * S; ++i) best = l[i] > best ? l[i] : best;
-  out_idx[(size_t)b * Nq + knn_perm(perm_q, qp)] = knn_key_index(best);
+  out_idx.put((size_t)b * Nq + knn_perm(perm_q, qp), knn_key_index(best));
 }
 
 // K2: one wave per query; the T = Ncp/16 tile maxima of the query are contiguous and live in
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void pn_knn_tau_kernel(const float* __restrict
 //   out_val != null: the value of the k-th best (k <= KNN_CAP), row perm_q(q).
 __global__ __launch_bounds__(256) void pn_knn_final_kernel(
     const u64* __restrict__ lists, const int* __restrict__ counts, int Nq, int Nqp, int k, int S,
-    int subcap, KnnPerm perm_q, KnnPerm perm_c, int64_t* __restrict__ out_idx,
+    int subcap, KnnPerm perm_q, KnnPerm perm_c, KnnIdxOut out_idx,
     float* __restrict__ out_val, int* __restrict__ flags, int* __restrict__ anyflag) {
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
   __shared__ u64 s_keys[4][KNN_CAP];
@@ -497,9 +497,9 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
   u64 k0 = lane < m ? keys[lane] : 0ull;
   u64 k1 = lane + 64 < m ? keys[lane + 64] : 0ull;
   knn_wave_sort128(k0, k1);
-  int64_t* o = out_idx + ((size_t)b * Nq + qo) * k;
-  if (lane < k) o[lane] = knn_key_index(k0);
-  if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
+  const size_t o = ((size_t)b * Nq + qo) * k;
+  if (lane < k) out_idx.put(o + lane, knn_key_index(k0));
+  if (lane + 64 < k) out_idx.put(o + lane + 64, knn_key_index(k1));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -652,7 +652,7 @@ static void knn_mfma_launch_pass(int kind, dim3 grid, hipStream_t stream, const 
 // statistics that need fp32-grade, not chain-exact, dot products (pn_dot_kth_x3_f32).
 static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, const float* q,
                       int q_pm, int Nq, const float* c, int c_pm, int Nc, int B, int C, int k,
-                      int64_t* out_idx, float* out_val, int* flags_out, char* base,
+                      KnnIdxOut out_idx, float* out_val, int* flags_out, char* base,
                       hipStream_t stream, bool approx_value = false) {
   float* xc = (float*)(base + w.xc);
   float* xxc = (float*)(base + w.xxc);
@@ -666,7 +666,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   u64* lists = (u64*)(base + w.lists);
   // k = 1 without the value (nearest-centre membership): one pass, no threshold, no lists, and
   // no candidate permutation (it only serves the tile-maxima threshold)
-  const bool argmax = mode == 2 && k == 1 && out_val == nullptr && out_idx != nullptr && !self;
+  const bool argmax = mode == 2 && k == 1 && out_val == nullptr && out_idx.p != nullptr && !self;
   const KnnPerm perm_c = knn_make_perm(Nc, argmax);
   const KnnPerm perm_q = self ? perm_c : knn_make_perm(Nq, true);
 
@@ -678,12 +678,12 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   }
   PN_CHECK_LAUNCH();
   const bool x3p1 = !argmax && (approx_value ? knn_x3_pass1(p, 0, true) : knn_x3_pass1(p, mode));
-  if (approx_value && !(x3p1 && mode == 2 && out_val && !out_idx)) {
+  if (approx_value && !(x3p1 && mode == 2 && out_val && !out_idx.p)) {
     pn_set_error("select_run: the bf16 x 3 value selection needs C <= 128 and Nc >= 2048");
     return PN_ERR_UNSUPPORTED;
   }
   // collecting pass + approximate final: kNN graph of one set, indices only
-  const bool x3p2 = x3p1 && knn_x3_level() >= 2 && self && mode == 0 && out_idx && !out_val;
+  const bool x3p2 = x3p1 && knn_x3_level() >= 2 && self && mode == 0 && out_idx.p && !out_val;
   u32x4* img = (u32x4*)(base + w.img);
   unsigned* xxmax = (unsigned*)(base + w.xxmax);
   float* xpm = x3p2 ? (float*)(base + w.xpm) : nullptr;
@@ -892,7 +892,7 @@ extern "C" int pn_dot_kth_x3_f32(const float* q, int Nq, const float* c, int Nc,
   }
   const KnnWs w = knn_mfma_ws(p, B, C, Nq, k, false, false);
   PN_CHECK_ARG(workspace && workspace_bytes >= w.total, "pn_dot_kth_x3_f32: workspace too small");
-  return select_run(p, w, 2, false, q, 1, Nq, c, 1, Nc, B, C, k, nullptr, out_val, flags, (char*)workspace,
+  return select_run(p, w, 2, false, q, 1, Nq, c, 1, Nc, B, C, k, KnnIdxOut{nullptr, 0}, out_val, flags, (char*)workspace,
                     (hipStream_t)stream, true);
 }
 
@@ -1064,7 +1064,7 @@ extern "C" int pn_dot_kth_unit_h2_f32(const float* q, int Nq, const void* img_c,
   {
     PN_PROF("knn_final", stream);
     hipLaunchKernelGGL(pn_knn_final_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
-                       p.Nqp, k, S, subcap, ident_q, ident_c, (int64_t*)nullptr, out_val, flags, (int*)nullptr);
+                       p.Nqp, k, S, subcap, ident_q, ident_c, KnnIdxOut{nullptr, 0}, out_val, flags, (int*)nullptr);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -1089,9 +1089,9 @@ extern "C" size_t pn_knn_workspace(int B, int C, int N, int k) {
   return best;
 }
 
-static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, int64_t* idx,
+static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, KnnIdxOut idx,
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  PN_CHECK_ARG(x && idx, "pn_knn: null pointer");
+  PN_CHECK_ARG(x && idx.p, "pn_knn: null pointer");
   PN_CHECK_ARG(B > 0 && C > 0 && N > 0, "pn_knn: empty input (B=%d C=%d N=%d)", B, C, N);
   PN_CHECK_ARG(k >= 1 && k <= KNN_MAXK, "pn_knn: k=%d unsupported (1..%d)", k, KNN_MAXK);
   PN_CHECK_ARG(k <= N, "pn_knn: k=%d exceeds the number of points N=%d", k, N);
@@ -1101,7 +1101,7 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
   {
     // small k (the SplineNets' graphs): one distance pass, the k best of a lane in registers (knn_smallk.h)
     const KskPlan sk = ksk_plan(mode, B, C, N, k);
-    if (sk.ok) return ksk_run(sk, x, B, C, N, k, idx, 0, (char*)workspace, stream);
+    if (sk.ok) return ksk_run(sk, x, B, C, N, k, idx.p, idx.is32, (char*)workspace, stream);
   }
   const KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
   if (!p.fast)
@@ -1121,12 +1121,20 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, in
 
 extern "C" int pn_knn_f32(const float* x, int B, int C, int N, int k, int64_t* idx,
                           void* workspace, size_t workspace_bytes, void* stream) {
-  return knn_dispatch(0, x, B, C, N, k, idx, workspace, workspace_bytes, (hipStream_t)stream);
+  return knn_dispatch(0, x, B, C, N, k, KnnIdxOut{idx, 0}, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* workspace,
                              size_t workspace_bytes, void* stream) {
-  return knn_dispatch(1, x6, B, 6, N, k, idx, workspace, workspace_bytes, (hipStream_t)stream);
+  return knn_dispatch(1, x6, B, 6, N, k, KnnIdxOut{idx, 0}, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// The graph as the library's own kernels take it (pn_edgeconv_reduce_fwd_i32, pn_edgeconv_bwd_i32): int32
+// indices, same values as pn_knn_f32 / pn_knn_pn_f32 (metric 0: feature space, 1: points + normals, C = 6).
+extern "C" int pn_knn_graph_i32(const float* x, int B, int C, int N, int k, int metric, int32_t* idx,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  PN_CHECK_ARG(metric == 0 || metric == 1, "pn_knn_graph_i32: metric %d", metric);
+  return knn_dispatch(metric, x, B, C, N, k, KnnIdxOut{idx, 1}, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- dot-product selection between two point-major sets ------------------------------------
@@ -1157,6 +1165,6 @@ extern "C" int pn_dot_select_f32(const float* q, int Nq, const float* c, int Nc,
   }
   const KnnWs w = knn_mfma_ws(p, B, C, Nq, k, false, false);
   PN_CHECK_ARG(workspace && workspace_bytes >= w.total, "pn_dot_select_f32: workspace too small");
-  return select_run(p, w, 2, false, q, 1, Nq, c, 1, Nc, B, C, k, out_idx, out_val, flags,
+  return select_run(p, w, 2, false, q, 1, Nq, c, 1, Nc, B, C, k, KnnIdxOut{out_idx, 0}, out_val, flags,
                     (char*)workspace, (hipStream_t)stream);
 }

@@ -371,7 +371,7 @@ template <int CP>
 __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
     const u64* __restrict__ lists, const int* __restrict__ counts, int Nq, int Nqp, int k, int S, int subcap,
     KnnPerm perm_q, KnnPerm perm_c, const float* __restrict__ xpm, const float* __restrict__ xxo,
-    const unsigned* __restrict__ xxmax, int N, float A, int64_t* __restrict__ out_idx, int* __restrict__ flags,
+    const unsigned* __restrict__ xxmax, int N, float A, KnnIdxOut out_idx, int* __restrict__ flags,
     int* __restrict__ anyflag) {
   __shared__ __attribute__((aligned(16))) uint32_t s_hist[4][256];
   __shared__ u64 s_keys[4][KNN_CAP];
@@ -438,9 +438,9 @@ __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
     u64 e0 = lane < k ? keys[lane] : 0ull;
     u64 e1 = lane + 64 < k ? keys[lane + 64] : 0ull;
     knn_wave_sort128(e0, e1);
-    int64_t* oo = out_idx + ((size_t)b * Nq + qo) * k;
-    if (lane < k) oo[lane] = knn_key_index(e0);
-    if (lane + 64 < k) oo[lane + 64] = knn_key_index(e1);
+    const size_t oo = ((size_t)b * Nq + qo) * k;
+    if (lane < k) out_idx.put(oo + lane, knn_key_index(e0));
+    if (lane + 64 < k) out_idx.put(oo + lane + 64, knn_key_index(e1));
     return;
   }
   u64 k0 = lane < m ? keys[lane] : 0ull;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
     }
     knn_wave_sort128(k0, k1);
   }
-  int64_t* o = out_idx + ((size_t)b * Nq + qo) * k;
-  if (lane < k) o[lane] = knn_key_index(k0);
-  if (lane + 64 < k) o[lane + 64] = knn_key_index(k1);
+  const size_t o = ((size_t)b * Nq + qo) * k;
+  if (lane < k) out_idx.put(o + lane, knn_key_index(k0));
+  if (lane + 64 < k) out_idx.put(o + lane + 64, knn_key_index(k1));
 }

@@ -285,7 +285,7 @@ __attribute__((amdgpu_waves_per_eu(PASS == 1 ? 1 : 2, PASS == 1 ? 1 : 2))) void 
   for (bool first_seg = true;; first_seg = false) {   // list fragments (exactly one without a flat plan)
   int b = blockIdx.z, rblk = blockIdx.y, slice = blockIdx.x;
   // block-sparse plan (pn_meanshift_x3_plan_f32): the streamed tiles this workgroup's resident
-  // block interacts with at all (everything else is below 1e-9 of the smallest row sum)
+  // block interacts with at all (everything else is below rel_eps of the smallest row sum)
   const int* __restrict__ lst = nullptr;
   int t_begin, t_end;
   if (flat) {
@@ -797,16 +797,9 @@ extern "C" int pn_meanshift_x3_exec_tiles(unsigned long long* out3) {
   return PN_OK;
 }
 
-#include "meanshift_rows2.h"
-
-// PN_MS_ROWS2=1: the row pass with the tile split between the two waves of a SIMD
-// (meanshift_rows2.h) — built and measured in round 4, SLOWER than the one-wave kernel
-// (profiles/r04_rows2_ab.txt: 1.96 against 1.47 ms per launch of 4 shapes; a first version that
-// duplicated the elementwise stage 1.59), hence not the default (0).  Same results to fp32 rounding.
-static int x3_rows2() {   // read at every call (tests switch it within one process)
-  const char* e = getenv("PN_MS_ROWS2");
-  return e ? atoi(e) : 0;
-}
+// (A row pass with the tile split between the two waves of a SIMD was built and measured in round 4 —
+// 1.96 against 1.47 ms per launch of 4 shapes, profiles/r04_rows2_ab.txt — and is not part of the
+// library any more; its source is in the history: csrc/meanshift_rows2.h at commit 99c3e53.)
 
 extern "C" size_t pn_meanshift_x3_image_bytes(int B, int N) {
   const int Np = (int)pn_align_up(N, 64);
@@ -827,8 +820,8 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 
 // ---- block-sparse plan ------------------------------------------------------------------
 // K_ij = exp((q_i . x_j - 1) / b^2) decays fast on a clustered embedding: most (row block, tile)
-// pairs contribute less than 1e-9 of the SMALLEST row sum of the block and can be skipped without
-// touching the fp32 result.  The test is rigorous, from bounding caps on the unit sphere (two per
+// pairs contribute less than rel_eps (1e-6 forward-only, 1e-9 under a dense backward: mean_shift.py) of the
+// SMALLEST row sum of the block and can be skipped without touching the fp32 result.  The test is rigorous, from bounding caps on the unit sphere (two per
 // tile, see pn_ms3_tileinfo_kernel; centre c = normalised mean of the cap's rows, angular radius
 // rho = max angle to it; below "tile" reads "cap", and a tile pair is kept when any of its 2 x 2 cap
 // pairs is):
@@ -859,8 +852,11 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 #define X3_DOT_ERR 1.6e-5f
 // Backward passes reuse the forward plan of their iteration.  The terms they drop are the same
 // kernel values times (q.x - 1) / b^2 factors, so the dropped share of a gradient row is bounded by
-// rel_eps / b^2, not rel_eps: 1e-7 at b = 0.1 (fp32 rounding), 1e-4 at the 0.003 floor of the
-// bandwidth clamp (src/mean_shift.py:34) — a bandwidth at which a row sees only itself.
+// rel_eps / b^2, not rel_eps.  The callers that run these dense backward passes therefore plan with
+// rel_eps = 1e-9 (mean_shift.PLAN_REL_EPS_DENSE_BWD): 1e-7 at b = 0.1 (fp32 rounding), 1e-4 at the 0.003
+// floor of the bandwidth clamp (src/mean_shift.py:34) — a bandwidth at which a row sees only itself.  The
+// forward-only plans of the training path (1e-6) are never seen by a backward pass: that path's gradient
+// runs through the centre rows alone, dense and exact (meanshift_rows.hip).
 
 // Two bounding caps per 32-row tile of z (B,N,D); lane = channels (lane, lane + 64).
 // A tile of the locality order often straddles two regions of the sphere (the end of one cell and
@@ -1377,7 +1373,7 @@ extern "C" int pn_meanshift_chain_order_f32(const float* sim, int B, int P, int*
 }
 
 // plan of one iteration from the tile caps of the iterate (Q) and of the data (X); rel_eps: the
-// skipped mass relative to the smallest row sum (1e-9)
+// skipped mass relative to the smallest row sum (the caller's choice: 1e-6 / 1e-9, mean_shift.py)
 extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX,
                                         const float* rhoX, const float* cntX, const float* bsq, int B, int N,
                                         float rel_eps, void* plan, void* stream_) {
@@ -1805,11 +1801,6 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
     const int* offs_x = pv.offs + (size_t)B * (pv.nb0 + pv.nb1) + 2;
     {
       PN_PROF("meanshift_bwd_rows", stream);
-      if (x3_rows2())
-        hipLaunchKernelGGL(pn_ms3_rows2_kernel, dim3(pv.G), dim3(64 * R2_WAVES), 0, stream, q, (const float*)gu,
-                           (const u32x4*)img_x, (const float*)cs, (const float*)alpha, bsq, N, ntiles, 0, opart_q,
-                           pv.pairs, pv.lists, offs_q, pv.nblk, pv.nb0, pv.nb1, B * pv.nb1, pv.cmin, pv.smax);
-      else
       X3_LAUNCH_PP(1, dim3(pv.G), dim3(64 * X3_WAVES(1)), stream, q, (const float*)gu,
                          (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N, ntiles, 0,
                          opart_q, nullptr, pv.pairs, pv.counts, pv.lists, offs_q, pv.nblk, pv.nb0, pv.nb1,
@@ -1844,11 +1835,6 @@ extern "C" int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y
   {
     PN_PROF("meanshift_bwd_rows", stream);
     dim3 grid(S, pn_cdiv(N, 32 * X3_WAVES(1)), B);
-    if (x3_rows2())
-      hipLaunchKernelGGL(pn_ms3_rows2_kernel, grid, dim3(64 * R2_WAVES), 0, stream, q, (const float*)gu,
-                         (const u32x4*)img_x, (const float*)cs, (const float*)alpha, bsq, N, ntiles, tps, opart_q,
-                         nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0);
-    else
     X3_LAUNCH_PP(1, grid, dim3(64 * X3_WAVES(1)), stream, q, (const float*)gu,
                        (const u32x4*)img_x, nullptr, (const float*)cs, (const float*)alpha, bsq, N,
                        ntiles, tps, opart_q, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0);

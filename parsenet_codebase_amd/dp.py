@@ -87,6 +87,13 @@ def shard_range(num_items, rank, world):
     return lo, lo + per + (1 if rank < extra else 0)
 
 
+class FitStatusError(RuntimeError):
+    """The fit status of a step says "drop it": a degenerate segment (no full-rank ridge system in ``lstsq``,
+    a non-finite design matrix or residual).  The reference's loop catches the exception such a segment raises
+    and skips the batch (train_parsenet_e2e.py:243-257); ``FlatGradBucket.finish_or_skip`` treats THIS class —
+    and nothing else — as a skipped step."""
+
+
 class FlatGradBucket:
     """All parameter gradients live in one contiguous fp32 buffer (``p.grad`` are views), so
     the data-parallel reduction is a single collective on a pre-flattened bucket.  Parameters
@@ -133,14 +140,23 @@ class FlatGradBucket:
         """Tail of a data-parallel step whose status arrives late (ParsenetE2EStep: the fit status of
         the batched fitting stage rides in a deferred download; train_parsenet_e2e.py:243-257 drops
         the batch on such an exception).  Runs ``finish()``; if it raised on ANY rank, nobody reduces
-        and nobody moves the weights (returns (None, exception or None, False)); otherwise ONE
-        gradient all-reduce and the optimizer step (returns (finish's result, None, True))."""
+        and nobody moves the weights; otherwise ONE gradient all-reduce and the optimizer step
+        (returns (finish's result, None, True)).
+
+        Only a ``FitStatusError`` is a skipped step (returns (None, the error or None, False)).  Anything
+        else — out of memory, a HIP launch error, a programming error — still goes through the status
+        agreement first, so that no rank is left waiting in a collective, and is then RE-RAISED on the rank
+        it happened on: it must not be recorded as a degenerate segment and silently drop every step that
+        follows (the other ranks return a skipped step for this one and see the failure as the collective
+        error / process exit it then is)."""
         err, out = None, None
         try:
             out = finish()
-        except Exception as e:          # the status of the step: agreed upon below, re-raised by the caller
+        except Exception as e:          # agreed upon below; a FitStatusError is the step's status
             err = e
         if self.any_rank_failed(err is not None):
+            if err is not None and not isinstance(err, FitStatusError):
+                raise err
             return None, err, False
         self.all_reduce_mean()
         optimizer.step()

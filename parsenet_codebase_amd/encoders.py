@@ -263,7 +263,8 @@ class DGCNNControlPoints(nn.Module):
         feats = []
         for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3),
                          (self.conv4, self.bn4)):
-            idx = graph.knn(x, self.k)
+            with graph.library_graphs():
+                idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
         cat = torch.cat(feats, dim=1)
@@ -321,13 +322,14 @@ class DGCNNEncoderGn(nn.Module):
     def forward(self, x):
         require_cuda(x)
         k = self.k
-        if self.mode == 5:
-            idx = graph.knn_points_normals(x, k, k)
-        else:
-            idx = graph.knn_dilated(x, k, k)
-        x1 = graph.edge_conv_norm_max(x, idx, self.conv1[0].weight, self.bn1, slope=0.2)
-        x2 = graph.edge_conv_norm_max(x1, graph.knn_dilated(x1, k, k), self.conv2[0].weight, self.bn2, 0.2)
-        x3 = graph.edge_conv_norm_max(x2, graph.knn_dilated(x2, k, k), self.conv3[0].weight, self.bn3, 0.2)
+        with graph.library_graphs():          # the graphs stay inside the library: int32
+            if self.mode == 5:
+                idx = graph.knn_points_normals(x, k, k)
+            else:
+                idx = graph.knn_dilated(x, k, k)
+            x1 = graph.edge_conv_norm_max(x, idx, self.conv1[0].weight, self.bn1, slope=0.2)
+            x2 = graph.edge_conv_norm_max(x1, graph.knn_dilated(x1, k, k), self.conv2[0].weight, self.bn2, 0.2)
+            x3 = graph.edge_conv_norm_max(x2, graph.knn_dilated(x2, k, k), self.conv3[0].weight, self.bn3, 0.2)
         x_features = torch.cat((x1, x2, x3), dim=1)
         # GroupNorm + ReLU + max over the points in one pass (norm and ReLU are monotone per channel)
         x4 = group_norm_relu_max(conv1x1(x_features, self.mlp1), self.bnmlp1)

@@ -166,7 +166,8 @@ def weights_normalize(weights, bw):
     dev = weights.device
     bwt = bw if torch.is_tensor(bw) else torch.tensor(float(bw), device=dev)
     ncl = torch.full((1,), C, dtype=torch.int64, device=dev)
-    return weights_normalize_batch(weights.unsqueeze(0), bwt.reshape(1).to(weights.dtype), ncl)[0]
+    # (a 0-dim bandwidth on another device — the reference's CPU scalar next to CUDA weights — follows the weights)
+    return weights_normalize_batch(weights.unsqueeze(0), bwt.to(device=dev, dtype=weights.dtype).reshape(1), ncl)[0]
 
 
 def to_one_hot(target, maxx=50, device_id=0):

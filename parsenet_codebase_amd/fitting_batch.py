@@ -33,6 +33,7 @@ from torch.profiler import record_function
 from . import kernels as K
 from . import mean_shift as MSM
 from ._lib import _PinnedRing, h2d, pinned_like, wait_event
+from .dp import FitStatusError
 
 EPS = float(np.finfo(np.float32).eps)
 SPLINE_TYPES = (0, 2, 6, 7, 9, 8)
@@ -356,14 +357,16 @@ def standardize_segments(P2, w):
         Pc = P2 - mean.unsqueeze(1)
         cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
         cov_h, slot = pinned_like(cov.shape, cov.dtype, hold=True)   # host step of the reference: download ...
-        cov_h.copy_(cov, non_blocking=True)
-        if slot is not None:
-            _PinnedRing.arm(slot)
-            wait_event(slot["event"])
-        else:
-            torch.cuda.current_stream(cov.device).synchronize()
-        rot = host_minor_axis_rotations(cov_h)                     # ... batched geev ...
-        _PinnedRing.release(slot)
+        try:
+            cov_h.copy_(cov, non_blocking=True)
+            if slot is not None:
+                _PinnedRing.arm(slot)
+                wait_event(slot["event"])
+            else:
+                torch.cuda.current_stream(cov.device).synchronize()
+            rot = host_minor_axis_rotations(cov_h)                 # ... batched geev ...
+        finally:
+            _PinnedRing.release(slot)
         R = h2d(rot, P2.device)                                    # ... upload
         Pr = torch.bmm(Pc, R.transpose(1, 2))
         wp = Pr * w.unsqueeze(2)
@@ -593,10 +596,11 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         def collect(pend):
             """Wait for a started download and copy it out of its ring slot (the slot goes back into
             the rotation: the uploads of the host stage below — or of another group — may take it)."""
-            wait_event(pend[1])
-            out = pend[0].numpy().copy()
-            _PinnedRing.release(pend[2])
-            return out
+            try:
+                wait_event(pend[1])
+                return pend[0].numpy().copy()
+            finally:
+                _PinnedRing.release(pend[2])
 
         def download(st):
             return collect(start_download(st))
@@ -801,9 +805,11 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         per-shape records.  With ``defer_metrics`` the caller runs this after it has queued the
         backward pass, so the device never waits for the host between the two."""
         if tail_event is not None:
-            wait_event(tail_event)
-            host = tail_host.numpy().copy()
-            _PinnedRing.release(tail_slot)
+            try:
+                wait_event(tail_event)
+                host = tail_host.numpy().copy()
+            finally:
+                _PinnedRing.release(tail_slot)
         else:
             host = tail_dev.cpu().numpy()                                                      # sync 3
         d_h = host[:S_all]
@@ -811,11 +817,11 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
         ptype_h = host[S_all + S_p:].astype(np.int64).reshape(B, Cp)
         if not np.isfinite(d_h).all():
             bad = int(np.nonzero(~np.isfinite(d_h))[0][0])
-            raise RuntimeError("fitting: non-finite residual distance in segment %d of shape %d"
-                               % (all_segs[bad][1]["key"], all_segs[bad][0]))
+            raise FitStatusError("fitting: non-finite residual distance in segment %d of shape %d"
+                                 % (all_segs[bad][1]["key"], all_segs[bad][0]))
         if (st_h & 5).any():
             bad = int(np.nonzero(st_h & 5)[0][0])
-            raise RuntimeError("fitting: %s in segment %d of shape %d" % (
+            raise FitStatusError("fitting: %s in segment %d of shape %d" % (
                 "non-finite design matrix / no full-rank ridge system (lstsq)" if st_h[bad] & 1 else
                 "NaN residual distance", prim_segs[bad][1]["key"], prim_segs[bad][0]))
         out = []

@@ -4,6 +4,8 @@ Public names mirror the reference (src/model.py:9-53, src/PointNet.py:9-140); ev
 numerically heavy is a HIP kernel reached through ``kernels`` (C ABI).  Only tiny
 per-channel reductions and the point-level GEMM are left to torch (rocBLAS).
 """
+import contextlib
+import threading
 import weakref
 
 import numpy as np
@@ -51,30 +53,49 @@ def _as_bcn(x):
     return x.detach()
 
 
+# The public functions return the reference's int64 indices (torch.topk's dtype).  Between the layers of the
+# encoders the graph never leaves the library: inside ``library_graphs()`` the same functions return the same
+# indices as int32, the form the edge-conv kernels read with half the bytes (gather and transposed-graph build).
+_LOCAL = threading.local()
+
+
+@contextlib.contextmanager
+def library_graphs():
+    prev = getattr(_LOCAL, "int32", False)
+    _LOCAL.int32 = True
+    try:
+        yield
+    finally:
+        _LOCAL.int32 = prev
+
+
+def _int32():
+    return getattr(_LOCAL, "int32", False)
+
+
+def _dilate(idx, k1, k2):
+    if k1 != k2:
+        cols = torch.as_tensor(np.arange(0, k2, k2 // k1), device=idx.device)
+        idx = idx.index_select(2, cols).contiguous()
+    return idx
+
+
 def knn(x, k):
     """src/model.py:9-22.  x (B,C,N) -> idx (B,N,k) int64, nearest first, self included."""
     with torch.no_grad():
-        return K.knn(_as_bcn(x), int(k), "feature")
+        return K.knn(_as_bcn(x), int(k), "feature", int32=_int32())
 
 
 def knn_dilated(x, k1, k2):
     """src/PointNet.py:9-26: top-k2, keeping columns arange(0, k2, k2 // k1)."""
     with torch.no_grad():
-        idx = K.knn(_as_bcn(x), int(k2), "feature")
-        if k1 != k2:
-            cols = torch.as_tensor(np.arange(0, k2, k2 // k1), device=idx.device)
-            idx = idx.index_select(2, cols).contiguous()
-        return idx
+        return _dilate(K.knn(_as_bcn(x), int(k2), "feature", int32=_int32()), k1, k2)
 
 
 def knn_points_normals(x, k1, k2):
     """src/PointNet.py:29-69: rows 0:3 xyz, 3:6 unit normals; metric |dp|^2 (1 + (2 - 2 ni.nj))."""
     with torch.no_grad():
-        idx = K.knn(_as_bcn(x), int(k2), "points_normals")
-        if k1 != k2:
-            cols = torch.as_tensor(np.arange(0, k2, k2 // k1), device=idx.device)
-            idx = idx.index_select(2, cols).contiguous()
-        return idx
+        return _dilate(K.knn(_as_bcn(x), int(k2), "points_normals", int32=_int32()), k1, k2)
 
 
 # --------------------------------------------------------------------------------------

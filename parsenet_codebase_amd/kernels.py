@@ -49,32 +49,37 @@ def chamfer_nn(a, b, side_a=True, side_b=True):
     return minA, argA, minB, argB
 
 
-def knn(x, k, metric="feature"):
+def knn(x, k, metric="feature", int32=False):
     """k nearest neighbours in feature space, self included, best first.
 
     x: (B, C, N) fp32 channel-first (the layout the reference's encoders use).
     metric: "feature" (src/model.py:9-22, src/PointNet.py:9-26) or "points_normals"
-    (src/PointNet.py:29-69, C must be 6).  Returns idx (B, N, k) int64.
+    (src/PointNet.py:29-69, C must be 6).  Returns idx (B, N, k) int64 — the dtype of the reference's
+    ``topk`` indices — or, with ``int32``, the same values as int32: the form the library's edge-conv
+    kernels take (half the index bytes), which the encoders use between their own layers.
     """
     require_cuda(x)
     x = _f32c(x, "x")
     if x.dim() != 3:
         raise ValueError("knn expects (B,C,N), got %s" % (tuple(x.shape),))
+    if metric not in ("feature", "points_normals"):
+        raise ValueError("unknown metric %r" % (metric,))
     B, C, N = x.shape
+    if metric == "points_normals" and C != 6:
+        raise ValueError("points_normals metric needs 6 channels, got %d" % C)
     lib = _lib.load()
     dev = x.device
-    idx = torch.empty((B, N, k), dtype=torch.int64, device=dev)
+    idx = torch.empty((B, N, k), dtype=torch.int32 if int32 else torch.int64, device=dev)
     wsz = lib.pn_knn_workspace(B, C, N, k)
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
     with _lib.on_device(dev):
-        if metric == "feature":
+        if int32:
+            rc = lib.pn_knn_graph_i32(ptr(x), B, C, N, k, int(metric == "points_normals"), ptr(idx), ptr(ws), wsz,
+                                      current_stream(dev))
+        elif metric == "feature":
             rc = lib.pn_knn_f32(ptr(x), B, C, N, k, ptr(idx), ptr(ws), wsz, current_stream(dev))
-        elif metric == "points_normals":
-            if C != 6:
-                raise ValueError("points_normals metric needs 6 channels, got %d" % C)
-            rc = lib.pn_knn_pn_f32(ptr(x), B, N, k, ptr(idx), ptr(ws), wsz, current_stream(dev))
         else:
-            raise ValueError("unknown metric %r" % (metric,))
+            rc = lib.pn_knn_pn_f32(ptr(x), B, N, k, ptr(idx), ptr(ws), wsz, current_stream(dev))
     check(rc, "pn_knn")
     return idx
 
@@ -82,6 +87,13 @@ def knn(x, k, metric="feature"):
 def _i64c(t, name):
     if t.dtype != torch.int64:
         raise TypeError("%s must be int64, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _graph_c(t, name):
+    """A kNN graph: int64 (the API dtype) or int32 (the library's own, kernels.knn(..., int32=True))."""
+    if t.dtype not in (torch.int64, torch.int32):
+        raise TypeError("%s must be int64 or int32, got %s" % (name, t.dtype))
     return t.contiguous()
 
 
@@ -135,7 +147,7 @@ def edgeconv_reduce_fwd(PQ, idx, gamma, groups, per_sample):
     and the fp64 group moments stats ((B or 1), groups, 2) of y = P[j] + Q[i] over all edges."""
     require_cuda(PQ, idx, gamma)
     PQ = _f32c(PQ, "PQ")
-    idx = _i64c(idx, "idx")
+    idx = _graph_c(idx, "idx")
     gamma = _f32c(gamma, "gamma")
     B, N, C2 = PQ.shape
     Cout = C2 // 2
@@ -148,11 +160,11 @@ def edgeconv_reduce_fwd(PQ, idx, gamma, groups, per_sample):
     lib = _lib.load()
     wsz = lib.pn_edgeconv_reduce_workspace(B, N, Cout, groups)
     ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    fn = lib.pn_edgeconv_reduce_fwd_i32 if idx.dtype == torch.int32 else lib.pn_edgeconv_reduce_fwd_f32
     with _lib.on_device(dev):
-        rc = lib.pn_edgeconv_reduce_fwd_f32(ptr(PQ), ptr(idx), ptr(gamma), B, N, k, Cout, groups,
-                                            int(per_sample), ptr(yext), ptr(argk), ptr(s1),
-                                            ptr(stats), ptr(ws), wsz, current_stream(dev))
-    check(rc, "pn_edgeconv_reduce_fwd_f32")
+        rc = fn(ptr(PQ), ptr(idx), ptr(gamma), B, N, k, Cout, groups, int(per_sample), ptr(yext), ptr(argk),
+                ptr(s1), ptr(stats), ptr(ws), wsz, current_stream(dev))
+    check(rc, "pn_edgeconv_reduce_fwd")
     return yext, argk, s1, stats
 
 
@@ -210,12 +222,13 @@ def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, den
     lib = _lib.load()
     wsz = lib.pn_edgeconv_bwd_workspace(B, N, k)
     ws = torch.empty(wsz, dtype=torch.uint8, device=PQ.device)
+    idx = _graph_c(idx, "idx")
+    fn = lib.pn_edgeconv_bwd_i32 if idx.dtype == torch.int32 else lib.pn_edgeconv_bwd_f32
     with _lib.on_device(PQ.device):
-        rc = lib.pn_edgeconv_bwd_f32(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk), ptr(mean),
-                                     ptr(rstd), ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout, groups,
-                                     int(per_sample), int(dense), ptr(dPQ), ptr(ws), wsz,
-                                     current_stream(PQ.device))
-    check(rc, "pn_edgeconv_bwd_f32")
+        rc = fn(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk), ptr(mean), ptr(rstd),
+                ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout, groups, int(per_sample), int(dense), ptr(dPQ), ptr(ws), wsz,
+                current_stream(PQ.device))
+    check(rc, "pn_edgeconv_bwd")
     return dPQ
 
 
@@ -377,7 +390,9 @@ def meanshift_chain_order(sim):
 
 def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
     """Block-sparse plan of one iteration (which tile pairs can contribute more than ``rel_eps`` of
-    the smallest row sum): an opaque byte tensor for meanshift_x3_iter_fwd / _bwd."""
+    the smallest row sum): an opaque byte tensor for meanshift_x3_iter_fwd / _bwd.  The product passes
+    mean_shift.PLAN_REL_EPS (1e-6) for the forward-only training path and PLAN_REL_EPS_DENSE_BWD (1e-9)
+    where a dense backward reuses the plan; the default here is the tighter one."""
     cq, rq = q_info[0], q_info[1]
     cx, rx = x_info[0], x_info[1]
     nx = x_info[2] if len(x_info) > 2 else None      # rows of the data caps (None: conservative bounds)

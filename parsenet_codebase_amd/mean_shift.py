@@ -51,6 +51,13 @@ AUTO_STAT = None            # device scalar of the most recent planned call in a
 # pairs at 1e-9 / 1e-6 / 1e-5 (with the round-2/3 criterion; with the mass / row-sum criterion of
 # round 4, csrc/meanshift_x3.h: 0.51 at 1e-6).  PARSENET_MS_REL_EPS overrides (1e-9: rounds 2-3).
 PLAN_REL_EPS = float(os.environ.get("PARSENET_MS_REL_EPS", "1e-6"))
+# Plans that a DENSE backward reuses (the autograd path of mean_shift_iterations: the public API,
+# guard_mean_shift's fallback, PARSENET_MS_ROWS_BWD=0): the backward drops the same pairs, and the share
+# of a gradient row it drops is bounded by rel_eps / b^2, not rel_eps (csrc/meanshift_x3.h) — 1e-4 at
+# b = 0.1 with the forward's 1e-6.  Those plans keep the round-2/3 bound of 1e-9 (1e-7 at b = 0.1); the
+# training path's forward-only state (mean_shift_iterations_state) has an exact, dense row backward
+# (csrc/meanshift_rows.hip) and plans with PLAN_REL_EPS.
+PLAN_REL_EPS_DENSE_BWD = float(os.environ.get("PARSENET_MS_REL_EPS_BWD", str(min(PLAN_REL_EPS, 1e-9))))
 SPARSE_MIN_N = 2048
 SPARSE_MAX_N = 32768        # the plan's threshold search holds one row of <= 2048 cap bounds in registers
 LAST_PLAN_STATS = None      # diagnostics of the most recent call (only filled when PARSENET_MS_STATS=1)
@@ -132,8 +139,9 @@ _SPLIT = {"fp16x2": (K.meanshift_h2_split, K.meanshift_h2_iter_fwd, K.meanshift_
           "bf16x3": (K.meanshift_x3_split, K.meanshift_x3_iter_fwd, K.meanshift_x3_iter_bwd)}
 
 
-def _run_iterations(X, bsq, iterations, stacked=False):
-    """The forward pass of the iterations (no autograd).  Returns a dict: the operands in the order the
+def _run_iterations(X, bsq, iterations, stacked=False, rel_eps=None):
+    """The forward pass of the iterations (no autograd; ``rel_eps``: the bound of the plans, default
+    PLAN_REL_EPS).  Returns a dict: the operands in the order the
     kernels ran on (``x``: the data, locality-ordered when the launches are planned; ``perm`` / ``inv``),
     the iterates / row sums / norms of every step and the plans.  ``stacked``: the iterates, row sums and
     norms of all steps live in ONE buffer each (``iterates_all`` (T+1,B,N,D), ``rsums_all`` / ``norms_all``
@@ -171,7 +179,7 @@ def _run_iterations(X, bsq, iterations, stacked=False):
         if sparse:
             # (the first iterate IS the data: its caps are x_info)
             plan = K.meanshift_x3_plan(x_info if it == 0 else K.meanshift_x3_tileinfo(q), x_info, bsq, N,
-                                       PLAN_REL_EPS)
+                                       PLAN_REL_EPS if rel_eps is None else rel_eps)
             plans.append(plan)
             q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan, out=out)
         elif x3 is not None and ARITH == "bf16x3":
@@ -207,7 +215,7 @@ class _MeanShiftIterations(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, bsq, iterations):
         D = X.shape[2]
-        st = _run_iterations(X, bsq, iterations)
+        st = _run_iterations(X, bsq, iterations, rel_eps=PLAN_REL_EPS_DENSE_BWD)   # (its backward reuses the plans)
         sparse, q = st["sparse"], st["q"]
         ctx.iterations = iterations
         ctx.x3 = st["x3"]

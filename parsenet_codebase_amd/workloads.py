@@ -270,7 +270,17 @@ class ParsenetE2EStep(ParsenetSegStep):
                 loss_b = [0.0] * self.batch
             res_total = sum(loss_b[b] for b in range(self.batch))     # the association of the per-shape sum
             loss = loss + res_total / self.batch
-            loss.backward()
+            try:
+                loss.backward()
+            except Exception as e:
+                # a backward pass that raises on ONE rank: that rank joins the status agreement like the
+                # others (who would wait in it for good) and the error propagates from there
+                if not self.bucket._multi():
+                    raise
+                bwd_error = e
+
+                def finish():                                      # noqa: F811
+                    raise bwd_error
             # The fit status (lstsq failure, non-finite residual) rides in the deferred download: it
             # is read BEFORE the optimizer step, so a degenerate segment leaves the weights
             # untouched, like the reference's skipped batch (train_parsenet_e2e.py:243-257).  The

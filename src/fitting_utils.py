@@ -11,3 +11,4 @@ from parsenet_codebase_amd.fitting import (EPS, CustomSVD, LeastSquares, best_la
                                            up_sample_points_in_range, up_sample_points_torch,
                                            up_sample_points_torch_in_range,
                                            up_sample_points_torch_memory_efficient, weights_normalize)
+from parsenet_codebase_amd.metrics import matching_iou, relaxed_iou  # noqa: F401,E402  (src/fitting_utils.py:18-19)

@@ -217,10 +217,30 @@ def test_bench_step_is_dropped_on_every_rank_when_one_rank_raises():
     assert rec["n_gpus"] == 2 and rec["skipped_steps"] == 1 and rec["value"] > 0
 
 
+def test_bench_control_flow_on_four_gloo_ranks():
+    """bench.py --workload stub with FOUR ranks (the driver's N = 4 leg; 8 CPU ranks do not fit this
+    container's test budget): pre-training on rank 0 + broadcast, timed loop, dense re-run, profiled steps,
+    MAX over ranks, the CPU-baseline leg on rank 0 with the others at the barrier, one line with the
+    per-rank spread."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "stub",
+                        "--steps", "5", "--warmup", "2", "--pretrain", "3"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 4 and rec["world_size_observed"] == 4 and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp4"
+    assert rec["cpu_baseline"] is not None and rec["cpu_baseline"]["kind"] == "port"
+    pr = rec["per_rank_ms"]
+    assert 0 < pr["min"] <= pr["max"] <= rec["ms_per_step"] * 1.001
+
+
 def _status_worker(rank, w, port, out):
     import torch
     import torch.distributed as dist
-    from parsenet_codebase_amd.dp import FlatGradBucket
+    from parsenet_codebase_amd.dp import FitStatusError, FlatGradBucket
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=w)
     torch.manual_seed(0)
@@ -236,21 +256,31 @@ def _status_worker(rank, w, port, out):
 
         def finish():
             if fail:
-                raise RuntimeError("degenerate segment")
+                raise fail
             return "metrics"
         return bucket.finish_or_skip(finish, opt)
-    res, err, took = one(rank == 1)                      # rank 1 raises: BOTH drop the step
+    res, err, took = one(FitStatusError("degenerate segment") if rank == 1 else None)   # rank 1 raises: BOTH drop the step
     ok = (not took) and res is None and torch.equal(net.weight.detach(), w0) and ((err is not None) == (rank == 1))
-    res, err, took = one(False)                          # next step: mean over ranks, one optimizer move
+    res, err, took = one(None)                           # next step: mean over ranks, one optimizer move
     ok = ok and took and res == "metrics" and err is None
     ok = ok and torch.allclose(net.weight.detach(), w0 - 0.5 * torch.full((1, 3), 1.5))
+    # anything that is NOT a fit status (out of memory, a launch error, a bug) goes through the agreement — the
+    # other rank is not left in the gradient all-reduce — and is then re-raised on the rank it happened on
+    w1 = net.weight.detach().clone()
+    try:
+        res, err, took = one(MemoryError("out of memory") if rank == 1 else None)
+        ok = ok and rank == 0 and not took and err is None
+    except MemoryError:
+        ok = ok and rank == 1
+    ok = ok and torch.equal(net.weight.detach(), w1)
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
 
 def test_step_status_is_agreed_upon_before_the_gradient_all_reduce():
     """dp.FlatGradBucket.finish_or_skip on two gloo ranks (workloads.ParsenetE2EStep.step's tail): a
-    status check that raises on ONE rank drops the step on both, the next step reduces and moves."""
+    fit status that raises on ONE rank drops the step on both, the next step reduces and moves; an error of
+    any other kind also keeps the ranks in step, but propagates on the rank it happened on."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_status_worker, args=(2, _free_port(), out), nprocs=2, join=True)
@@ -281,6 +311,11 @@ def test_pinned_ring_never_hands_out_a_slot_a_host_reader_still_holds():
     for t in taken:
         _lib._PinnedRing.release(t)
     assert ring.take(8)[1] is not None
+    # a slot whose reader never comes back (an abandoned step) is reclaimed after ABANDONED_AFTER further takes
+    _, lost = ring.take(8, hold=True)
+    with pytest.warns(UserWarning):
+        seen = [ring.take(8)[1] for _ in range(ring.ABANDONED_AFTER + 8)]
+    assert any(s is lost for s in seen[-8:]) and all(s is not lost for s in seen[:ring.ABANDONED_AFTER - 4])
 
 
 def test_wait_event_spins_for_a_bounded_time_then_blocks(monkeypatch):
@@ -637,3 +672,26 @@ def test_host_thread_cap_and_usable_cpus(monkeypatch):
             assert n <= max(1, int(float(q) / float(p)))
     except OSError:
         pass
+
+
+def test_segmentation_metric_helpers():
+    """metrics.* (src/segment_utils.py helpers): host numpy, checked on hand-made label sets."""
+    from parsenet_codebase_amd import metrics as M
+    gt = np.array([0, 0, 1, 1, 2, 2, 2, 5])
+    pred = np.array([0, 1, 1, 1, 2, 2, 0, 5])
+    # classes 0..5: IoUs 1/3, 2/3, 2/3, 1 (empty), 1 (empty), 1
+    assert abs(M.mean_IOU_one_sample(pred, gt, 6) - (1 / 3 + 2 / 3 + 2 / 3 + 3) / 6) < 1e-6
+    a, b = np.array([0, 6, 7, 8, 1]), np.array([9, 9, 9, 2, 1])
+    assert abs(M.iou_segmentation(a.copy(), b.copy()) - 1.0) < 1e-6 and a[0] == 0      # arguments untouched
+    perm = np.array([2, 0, 1, 3, 4, 5])
+    assert abs(M.SIOU(gt, perm[gt]) - 1.0) < 1e-6                                      # a relabelling is perfect
+    assert 0.3 < M.SIOU(gt, pred) < 1.0
+    p = np.eye(3)[[0, 1, 2, 2]]
+    w = np.array([[1.0, 0], [1, 0], [0, 1], [0, 1]])
+    assert list(M.primitive_type_segment(p, w)) == [0, 2]
+    assert list(M.primitive_type_segment_torch(torch.from_numpy(p), torch.from_numpy(w)).numpy()) == [0, 2]
+    emb = np.eye(4)[:3]
+    cen = np.eye(4)[:2]
+    pm = M.cluster_prob_mutual(emb, cen, 0.5)
+    assert pm.shape == (2, 3) and np.allclose(pm.sum(0), 1.0)
+    assert M.cluster_prob(emb, cen, 0.5).shape == (2, 3)

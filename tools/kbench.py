@@ -163,6 +163,7 @@ def bench_chamfer():
 def bench_edge():
     """The API form of get_graph_feature (src/PointNet.py:72-103): cat(x_j - x_i, x_i) materialised,
     and the fused gather-reduce the networks use instead.  Algorithmic bytes per SURVEY 8(d)."""
+    from parsenet_codebase_amd import _lib
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     for (B, N, k, C) in [(4, 10000, 80, 64), (4, 10000, 80, 6), (32, 700, 10, 64)]:
@@ -176,17 +177,34 @@ def bench_edge():
         ms = timeit(lambda: kernels.edge_feature_bwd(g, idx))
         nb = 4.0 * B * N * C + 8.0 * B * N * k + 4.0 * B * N * k * 2 * C
         print("edge_feature_bwd B=%d N=%d k=%d C=%d: %.3f ms  -> %.0f GB/s" % (B, N, k, C, ms, nb / ms / 1e6))
-    # real kNN graph (spatially coherent neighbours) for the fused kernel
-    B, N, k, Cout = 4, 10000, 80, 64
-    x = torch.randn(B, 64, N, device=dev)
-    idx = kernels.knn(x, k, "feature")
-    PQ = torch.randn(B, N, 2 * Cout, device=dev)
-    gamma = torch.ones(Cout, device=dev)
-    ms = timeit(lambda: kernels.edgeconv_reduce_fwd(PQ, idx, gamma, 2, True))
-    gathered = 4.0 * B * N * k * Cout
-    hbm = 4.0 * B * N * 2 * Cout + 8.0 * B * N * k + 9.0 * B * N * Cout
-    print("edgeconv_reduce_fwd B=%d N=%d k=%d Cout=%d: %.3f ms  gathered rows %.0f GB/s (L2), HBM-algorithmic %.0f GB/s"
-          % (B, N, k, Cout, ms, gathered / ms / 1e6, hbm / ms / 1e6))
+    # real kNN graph (neighbours of a random cloud in feature space) for the fused kernel: the int64 graph of the
+    # API and the library's own int32 graph (what the encoders pass between their layers), forward and backward
+    for (B, N, k, Cin, Cout) in [(4, 10000, 80, 64, 64), (4, 10000, 80, 64, 128), (6, 5000, 10, 64, 64)]:
+        x = torch.randn(B, Cin, N, device=dev)
+        PQ = torch.randn(B, N, 2 * Cout, device=dev)
+        gamma = torch.ones(Cout, device=dev)
+        for int32 in (False, True):
+            idx = kernels.knn(x, k, "feature", int32=int32)
+            ib = 4.0 if int32 else 8.0
+            ms = timeit(lambda: kernels.edgeconv_reduce_fwd(PQ, idx, gamma, 2, True))
+            gathered = 4.0 * B * N * k * Cout
+            hbm = 4.0 * B * N * 2 * Cout + ib * B * N * k + 9.0 * B * N * Cout
+            print("edgeconv_reduce_fwd B=%d N=%d k=%d Cout=%d %s graph: %.3f ms  gathered rows %.0f GB/s (L2), "
+                  "HBM-algorithmic %.0f GB/s" % (B, N, k, Cout, "int32" if int32 else "int64", ms, gathered / ms / 1e6,
+                                                 hbm / ms / 1e6))
+            yext, argk, s1, stats = kernels.edgeconv_reduce_fwd(PQ, idx, gamma, 2, True)
+            mean, rstd = kernels.moments(stats, (Cout // 2) * N * k, 1e-5)
+            t = torch.randn(B, N, Cout, device=dev)
+            c1c2 = torch.randn(B, 2, 2, device=dev) * 1e-3
+            _lib.prof_enable(True)
+            _lib.prof_reset()
+            for _ in range(5):
+                kernels.edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, 2, True, True)
+            torch.cuda.synchronize()
+            pr = {kn: tt / calls for kn, (tt, calls) in _lib.prof_results().items()}
+            _lib.prof_enable(False)
+            print("edgeconv_bwd        B=%d N=%d k=%d Cout=%d %s graph: transposed graph %.3f ms, gather %.3f ms"
+                  % (B, N, k, Cout, "int32" if int32 else "int64", pr.get("edgeconv_bwd_csr", 0), pr.get("edgeconv_bwd", 0)))
 
 
 def bench_meanshift():
