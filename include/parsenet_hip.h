@@ -67,6 +67,19 @@ int pn_knn_pn_f32(const float* x6, int B, int N, int k, int64_t* idx, void* work
 int pn_knn_graph_i32(const float* x, int B, int C, int N, int k, int metric, int32_t* idx,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- neighbours of 3-D points from coordinate differences (evaluation-mode fitting) ----------
+ * Replaces the broadcast difference + topk of src/fitting_utils.py:150-164, 202-237
+ * (up_sample_points_torch(_in_range): k = 5) and the KD-tree search behind open3d's
+ * remove_statistical_outlier (src/fitting_utils.py:704-710: k = 20, float64) for a RAGGED batch of
+ * segments: pts (total,3) fp32, off (S+1) int32 row offsets, max_n >= the largest segment.
+ * d = ((dx^2 + dy^2) + dz^2), each operation rounded once (f64 = 1: in float64 on the fp32 points).
+ * idx (total,k) int32 indices LOCAL to the segment, nearest first, the point itself first, equal
+ * distances -> smaller index; a segment with fewer than k points is padded with the point itself.
+ * dist (total,k) float / double (per f64) or NULL: the Euclidean distances of those neighbours.
+ * Limits: k <= 64; segments up to 10 240 points (float64: 5 120). */
+int pn_knn3_ragged(const float* pts, const int* off, int S, int max_n, int k, int f64, int32_t* idx,
+                   void* dist, void* stream);
+
 /* ---- dot-product selection between two point sets ------------------------------------
  * Replaces src/mean_shift.py:125-137 (compute_bandwidth: 2 - 2 X X^T, topk(K, largest=False),
  * the K-th smallest distance per row) and :146-149 (nms: argmin over centres of 2 - 2 C X^T).

@@ -287,8 +287,14 @@ def _knn_points_by_differences(points, k):
     The kNN kernels use the reference's GEMM form |x|^2 + |y|^2 - 2 x.y (src/model.py:9-22), whose
     rounding (~1e-7 absolute) reorders neighbours once spacings reach 1e-3 — which up-sampled
     segments do; the reference's up-sampling and open3d's KD-tree work on differences, so these
-    two evaluation-only helpers do too (row blocks of 2048 on the GPU, n <= ~10^4)."""
+    two evaluation-only helpers do too: csrc/knn3.hip (one wave per query, the k-th value by bisection;
+    float64 points -> float64 distances), the broadcast + topk only beyond the kernel's segment size."""
     require_cuda(points)
+    n = points.shape[0]
+    f64 = points.dtype == torch.float64
+    if 0 < n <= (5120 if f64 else 10240) and k <= 64:
+        off = h2d(np.asarray([0, n], np.int32), points.device)
+        return K.knn3_ragged(points.float(), off, n, k, f64=f64).long()
     out = []
     for s0 in range(0, points.shape[0], 2048):
         d = ((points[s0:s0 + 2048].unsqueeze(1) - points.unsqueeze(0)) ** 2).sum(2)
@@ -942,6 +948,10 @@ class Evaluation:
         ``evaluation.batched = False`` for the segment-by-segment path.  With B > 1 every shape
         is fitted and only the last result returned (what the reference's loop leaves behind):
         use ``fitting_losses`` to get them all — a warning says so once."""
+        if self.batched and eval and prefetched is None and not debug:
+            # evaluation mode, stage by stage over all shapes and segments (fitting_eval.py)
+            return self.fitting_losses_eval(embedding, points, normals, labels, primitives, primitives_log_prob,
+                                            quantile=quantile, iterations=iterations, lamb=lamb)[-1]
         if self.batched and not eval and prefetched is None and not debug:
             if embedding.shape[0] > 1 and not getattr(self, "_warned_last_only", False):
                 import warnings
@@ -993,6 +1003,18 @@ class Evaluation:
         require_cuda(embedding, points, normals)
         return fitting_losses_train(self, embedding, points, normals, labels, primitives, primitives_log_prob,
                                     quantile, iterations, lamb, defer_metrics)
+
+    def fitting_losses_eval(self, embedding, points, normals, labels, primitives, primitives_log_prob,
+                            quantile=0.125, iterations=5, lamb=1.0, if_optimize=False):
+        """Evaluation-mode ``fitting_loss`` (src/residual_utils.py:210-331: hard memberships, the modal
+        predicted type, outlier removal and re-sampling of spline segments, sqrt residuals; ``if_optimize``:
+        the LS refit of src/primitive_forward.py:153-296) of EVERY shape of the batch, stage by stage over
+        all shapes and segments (fitting_eval.py).  A list of ([Loss, geometric mean, spline mean, s_iou,
+        p_iou], [parameters, cluster ids, weights])."""
+        from .fitting_eval import fitting_losses_eval
+        require_cuda(embedding, points, normals)
+        return fitting_losses_eval(self, embedding, points, normals, labels, primitives, primitives_log_prob,
+                                   quantile, iterations, lamb, if_optimize)
 
     def fitting_losses_pipelined(self, embedding, points, normals, labels, primitives, primitives_log_prob,
                                  quantile=0.125, iterations=5, lamb=1.0, chunks=2):

@@ -84,6 +84,31 @@ def knn(x, k, metric="feature", int32=False):
     return idx
 
 
+def knn3_ragged(pts, off, max_n, k, f64=False, want_dist=False):
+    """Neighbours of 3-D points by coordinate differences inside the segments of a ragged batch
+    (csrc/knn3.hip; src/fitting_utils.py:150-164, 704-710).  pts (total,3) fp32, off (S+1) int32 device
+    offsets, max_n >= the largest segment (a host integer).  Returns idx (total,k) int32 LOCAL to the
+    segment — nearest first, the point itself first — and, with ``want_dist``, their distances
+    (float64 when ``f64``)."""
+    require_cuda(pts, off)
+    pts = _f32c(pts, "pts")
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("knn3_ragged expects (total,3) points, got %s" % (tuple(pts.shape),))
+    if off.dtype != torch.int32:
+        raise TypeError("off must be int32")
+    S = off.numel() - 1
+    total = pts.shape[0]
+    idx = torch.empty((total, k), dtype=torch.int32, device=pts.device)
+    dist = torch.empty((total, k), dtype=torch.float64 if f64 else torch.float32, device=pts.device) if want_dist else None
+    if total == 0 or S <= 0:
+        return (idx, dist) if want_dist else idx
+    with _lib.on_device(pts.device):
+        rc = _lib.load().pn_knn3_ragged(ptr(pts), ptr(off.contiguous()), S, int(max_n), int(k), int(bool(f64)), ptr(idx),
+                                        ptr(dist), current_stream(pts.device))
+    check(rc, "pn_knn3_ragged")
+    return (idx, dist) if want_dist else idx
+
+
 def _i64c(t, name):
     if t.dtype != torch.int64:
         raise TypeError("%s must be int64, got %s" % (name, t.dtype))

@@ -1,0 +1,159 @@
+"""GPU: the evaluation-mode fitting stage (src/residual_utils.py:210-331,
+src/fitting_utils.py:150-237, 704-710, src/primitive_forward.py:153-296, 925-1047) — the difference-form
+neighbour kernel against brute force in the same arithmetic, and the stage-wise path (fitting_eval.py)
+against the per-segment functions of fitting.py on the same clusters and the same numpy generator."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _brute(points, k, dtype):
+    """((dx^2 + dy^2) + dz^2) in ``dtype``, k smallest, ties -> smaller index (numpy on the host)."""
+    p = points.astype(dtype)
+    d = p[:, None, :] - p[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    order = np.lexsort((np.broadcast_to(np.arange(p.shape[0]), d2.shape), d2), axis=1)
+    idx = order[:, :k]
+    return idx, np.take_along_axis(d2, idx, 1)
+
+
+@pytest.mark.parametrize("f64", [False, True])
+@pytest.mark.parametrize("k", [5, 20])
+def test_difference_form_neighbours_of_a_ragged_batch(gpu, k, f64):
+    """csrc/knn3.hip: segments of different sizes in one launch (64 points ... several thousand: every
+    register-block instance), spacings down to 1e-4 (where the GEMM form of the kNN engine reorders
+    neighbours), exact duplicates (ties -> smaller index): indices equal brute force in the same
+    arithmetic, the point itself first, distances to 1 ulp of the square root."""
+    from parsenet_codebase_amd import kernels as K
+    rng = np.random.RandomState(3 + k)
+    sizes = [64, 700, 1025, 2600, 5100] + ([9000] if not f64 else [])
+    segs = []
+    for n in sizes:
+        p = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+        p[n // 2:] = p[:n - n // 2] + rng.normal(0, 1e-4, (n - n // 2, 3)).astype(np.float32)   # tight pairs
+        p[5] = p[3]                                                                            # an exact duplicate
+        segs.append(p)
+    flat = torch.from_numpy(np.concatenate(segs)).to(gpu)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(gpu)
+    idx, dist = K.knn3_ragged(flat, off, max(sizes), k, f64=f64, want_dist=True)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    o = 0
+    for n, p in zip(sizes, segs):
+        want, d2 = _brute(p, k, np.float64 if f64 else np.float32)
+        got = idx[o:o + n]
+        if f64:
+            # (the k survivors are exact; their ORDER comes from the fp32 image of the distance: compare as sets
+            # plus the distances)
+            assert np.array_equal(np.sort(got, 1), np.sort(want, 1)), n
+        else:
+            assert np.array_equal(got, want), (n, int((got != want).any(1).sum()))
+        first = got[:, 0]                       # the point itself — or, for an exact duplicate, its smaller-index twin
+        assert (p[first] == p).all() and (first <= np.arange(n)).all()
+        np.testing.assert_allclose(np.sort(dist[o:o + n], 1), np.sqrt(np.sort(d2, 1).astype(np.float64)),
+                                   rtol=2e-7 if not f64 else 1e-14, atol=0)
+        o += n
+
+
+def test_a_segment_shorter_than_k_is_padded_with_the_point_itself(gpu):
+    from parsenet_codebase_amd import kernels as K
+    p = torch.rand(7, 3, device=gpu)
+    off = torch.tensor([0, 3, 7], dtype=torch.int32, device=gpu)
+    idx = K.knn3_ragged(p, off, 4, 5).cpu().numpy()
+    assert sorted(idx[0, :3]) == [0, 1, 2] and (idx[0, 3:] == 0).all()
+    assert sorted(idx[6, :4]) == [0, 1, 2, 3] and idx[6, 4] == 3
+
+
+def _setup(gpu, ids, N=3000):
+    from parsenet_codebase_amd import synthetic
+    from src.model import DGCNNControlPoints
+    from src.residual_utils import Evaluation
+    from tests.golden.common import deterministic_init
+    pts, nrm, lab, prim = synthetic.make_batch_ids(ids, N, min_segments=4, max_segments=6)
+    open_net = deterministic_init(DGCNNControlPoints(20, num_points=10, mode=0))
+    closed_net = deterministic_init(DGCNNControlPoints(20, num_points=10, mode=1), salt=1)
+    ev = Evaluation(closed_path=closed_net, open_path=open_net)
+    g = torch.Generator().manual_seed(5)
+    code = torch.nn.functional.normalize(torch.randn(64, 128, generator=g), dim=1)
+    emb = torch.nn.functional.normalize(code[torch.from_numpy(lab)] + 0.02 * torch.randn(len(ids), N, 128, generator=g),
+                                        dim=2).to(gpu)
+    logp = torch.log_softmax(8.0 * torch.nn.functional.one_hot(torch.from_numpy(prim), 10).float().permute(0, 2, 1), 1)
+    return ev, emb, torch.from_numpy(pts).to(gpu), torch.from_numpy(nrm).to(gpu), lab, prim, logp.to(gpu)
+
+
+def _kinds(params):
+    return sorted(v[0] for v in params.values() if v is not None)
+
+
+@pytest.mark.parametrize("ids", [(3, 11), (21,)])
+def test_stage_wise_evaluation_equals_the_per_segment_path(gpu, ids):
+    """fitting_loss(eval=True) through fitting_eval.fitting_losses_eval (all shapes and segments per stage)
+    and through the per-segment functions (Evaluation.batched = False), same embedding, same numpy seed: the
+    same clusters, kinds, reconstructions and losses — hard memberships, the members' moments, outlier
+    removal, up-sampling, re-sampling draws and sqrt residuals included."""
+    torch.cuda.set_device(gpu)
+    ev, emb, pts, nrm, lab, prim, logp = _setup(gpu, ids)
+    kw = dict(quantile=0.025, iterations=10, lamb=0.1)
+    np.random.seed(7)
+    got = ev.fitting_losses_eval(emb, pts, nrm, lab, prim, logp, **kw)
+    ev.batched = False
+    np.random.seed(7)
+    want = [ev.fitting_loss(emb[b:b + 1], pts[b:b + 1], nrm[b:b + 1], lab[b:b + 1], prim[b:b + 1], logp[b:b + 1],
+                            eval=True, **kw) for b in range(len(ids))]
+    kinds_seen = set()
+    for b in range(len(ids)):
+        (lg, pg), (lw, pw) = got[b], want[b]
+        assert np.array_equal(pg[1], pw[1])                                      # cluster ids
+        assert _kinds(pg[0]) == _kinds(pw[0]) and set(pg[0]) == set(pw[0])
+        kinds_seen |= set(_kinds(pg[0]))
+        for key, v in pw[0].items():
+            if v is None:
+                assert pg[0][key] is None
+                continue
+            # analytic parameters: the same kernels on the same members (another chunking of the fp64 sums);
+            # spline samples: the SplineNet runs on a batch of segments instead of one (rocBLAS picks other
+            # kernels for other batch sizes: 1e-7 per product, 3e-5 after eight layers — the reference itself moves
+            # by more under a 1-ulp change of its input, tests/golden/reference_noise_e2e.txt)
+            tol = 2e-4 if "spline" in v[0] else 2e-5
+            for a, c in zip(pg[0][key][1:], v[1:]):
+                a, c = torch.as_tensor(a).float().reshape(-1), torch.as_tensor(c).float().reshape(-1)
+                assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max())), (key, v[0])
+        assert abs(lg[0].item() - lw[0].item()) <= 2e-4 * abs(lw[0].item())
+        for t in (1, 2):
+            assert (lg[t] is None) == (lw[t] is None)
+            if lw[t] is not None:
+                assert abs(lg[t] - lw[t]) <= (1e-5 if t == 1 else 2e-4) * abs(lw[t])
+        assert lg[3] == lw[3] and lg[4] == lw[4]
+        assert torch.equal(pg[2], pw[2])
+    if len(ids) > 1:
+        assert any("spline" in k for k in kinds_seen) and any("spline" not in k for k in kinds_seen)
+
+
+def test_stage_wise_refit_equals_the_per_segment_refit(gpu):
+    """if_optimize=True: the LS refit of every spline segment (src/primitive_forward.py:153-296) inside the
+    stage-wise path against residual_eval_mode(if_optimize=True) segment by segment, numpy's generator
+    consumed in the same order (shuffle of the shape's mean-shift call, then per segment the re-sampling
+    draw and the refit's three draws)."""
+    torch.cuda.set_device(gpu)
+    from parsenet_codebase_amd.fitting_eval import cluster_shapes
+    ev, emb, pts, nrm, lab, prim, logp = _setup(gpu, (21,))          # an open and a closed spline segment
+    np.random.seed(11)
+    got = ev.fitting_losses_eval(emb, pts, nrm, lab, prim, logp, quantile=0.025, iterations=10, lamb=0.1,
+                                 if_optimize=True)[0]
+    clusters, calls = cluster_shapes(ev, torch.nn.functional.normalize(emb, dim=2), 0.025, 10)
+    center, bw, ids = clusters[0]
+    np.random.seed(11)
+    for _ in range(calls[0]):
+        np.random.shuffle(np.arange(emb.shape[1]))
+    weights = center @ emb[0].T
+    prim_pred = torch.max(logp, 1)[1].cpu().numpy()
+    with torch.no_grad():
+        loss, params, _ = ev.residual_eval_mode(pts[0], nrm[0], lab[0], torch.from_numpy(ids).to(gpu), prim[0],
+                                                prim_pred[0], weights, bw, lamb=0.1, if_optimize=True)
+    assert _kinds(got[1][0]) == _kinds(params) and any("spline" in k for k in _kinds(params))
+    for key, v in params.items():
+        if v is not None and "spline" in v[0]:
+            a, c = got[1][0][key][1].reshape(-1), v[1].reshape(-1)
+            assert float((a - c).abs().max()) <= 1e-4 * max(1.0, float(c.abs().max())), key
+    assert abs(got[0][0].item() - loss[0].item()) <= 1e-4 * abs(loss[0].item())

@@ -207,6 +207,57 @@ def bench_edge():
                   % (B, N, k, Cout, "int32" if int32 else "int64", pr.get("edgeconv_bwd_csr", 0), pr.get("edgeconv_bwd", 0)))
 
 
+def bench_eval():
+    """Evaluation-mode fitting: Evaluation.fitting_loss(eval=True) of 4 shapes x 10 000 points —
+    the stage-wise path over all shapes and segments (fitting_eval.py) against the per-segment functions, on
+    embeddings with cluster structure (a noisy code of the ground-truth segments, like workloads.warm_paths) and
+    the ground-truth types as predicted types; frozen random-init SplineNets; with and without the LS refit."""
+    import time
+    import numpy as np
+    from parsenet_codebase_amd import synthetic
+    from parsenet_codebase_amd.encoders import DGCNNControlPoints
+    from parsenet_codebase_amd.fitting import Evaluation
+    from parsenet_codebase_amd import dp
+    dp.limit_host_threads()         # like bench.py / the trainers: the host computes nothing, one intra-op thread
+    dev = torch.device("cuda:0")
+    B, N = 4, 10000
+    pts, nrm, lab, prim = synthetic.make_batch(2000, B, N)
+    torch.manual_seed(0)
+    ev = Evaluation(closed_path=DGCNNControlPoints(20, num_points=10, mode=1).eval().to(dev),
+                    open_path=DGCNNControlPoints(20, num_points=10, mode=0).eval().to(dev))
+    g = torch.Generator().manual_seed(5)
+    code = torch.nn.functional.normalize(torch.randn(64, 128, generator=g), dim=1)
+    emb = torch.nn.functional.normalize(code[torch.from_numpy(lab)] + 0.02 * torch.randn(B, N, 128, generator=g), dim=2).to(dev)
+    logp = torch.log_softmax(8.0 * torch.nn.functional.one_hot(torch.from_numpy(prim), 10).float().permute(0, 2, 1), 1).to(dev)
+    P, Nr = torch.from_numpy(pts).to(dev), torch.from_numpy(nrm).to(dev)
+    kw = dict(quantile=0.025, iterations=10, lamb=0.1)
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    for opt in (False, True):
+        np.random.seed(1)
+        t_b = wall(lambda: ev.fitting_losses_eval(emb, P, Nr, lab, prim, logp, if_optimize=opt, **kw), 3)
+        out = ev.fitting_losses_eval(emb, P, Nr, lab, prim, logp, if_optimize=opt, **kw)
+        nseg = sum(sum(1 for v in o[1][0].values() if v is not None) for o in out)
+        nspl = sum(sum(1 for v in o[1][0].values() if v is not None and "spline" in v[0]) for o in out)
+        line = "eval-mode fitting B=4 x 10000 points, %d fitted segments (%d splines), if_optimize=%s: stage-wise %.1f ms " \
+               "per batch = %.1f shapes/s" % (nseg, nspl, opt, 1e3 * t_b, B / t_b)
+        if not opt:
+            ev.batched = False
+            np.random.seed(1)
+            t_s = wall(lambda: [ev.fitting_loss(emb[b:b + 1], P[b:b + 1], Nr[b:b + 1], lab[b:b + 1], prim[b:b + 1],
+                                                logp[b:b + 1], eval=True, **kw) for b in range(B)], 2)
+            ev.batched = True
+            line += "; per-segment path %.1f ms = %.1f shapes/s" % (1e3 * t_s, B / t_s)
+        print(line)
+
+
 def bench_meanshift():
     import numpy as np
     from parsenet_codebase_amd.mean_shift import MeanShift
