@@ -73,6 +73,24 @@ def _int32():
     return getattr(_LOCAL, "int32", False)
 
 
+# TEST HOOK (None in production): a callable (x (B,C,N), k, metric) -> (B,N,k) indices or None.  Parity tests that
+# compare whole networks against the CPU oracle pin BOTH sides to one graph per layer: the oracle's and the
+# product's features of a layer differ by fp32 rounding, and a feature-space kNN graph has near-ties that such a
+# difference flips (one flipped neighbour moves a SplineNet output by percents) — with the hook the product takes
+# the graph the oracle used, so that everything BEHIND the graphs is compared at the arithmetic's own accuracy.
+# The graph kernels themselves are pinned bit for bit elsewhere (tests/test_knn_gpu.py, test_fullsize_gpu.py).
+GRAPH_HOOK = None
+
+
+def _graph(x, k, metric):
+    x = _as_bcn(x)
+    if GRAPH_HOOK is not None:
+        idx = GRAPH_HOOK(x, int(k), metric)
+        if idx is not None:
+            return idx.to(device=x.device, dtype=torch.int32 if _int32() else torch.int64).contiguous()
+    return K.knn(x, int(k), metric, int32=_int32())
+
+
 def _dilate(idx, k1, k2):
     if k1 != k2:
         cols = torch.as_tensor(np.arange(0, k2, k2 // k1), device=idx.device)
@@ -83,19 +101,19 @@ def _dilate(idx, k1, k2):
 def knn(x, k):
     """src/model.py:9-22.  x (B,C,N) -> idx (B,N,k) int64, nearest first, self included."""
     with torch.no_grad():
-        return K.knn(_as_bcn(x), int(k), "feature", int32=_int32())
+        return _graph(x, k, "feature")
 
 
 def knn_dilated(x, k1, k2):
     """src/PointNet.py:9-26: top-k2, keeping columns arange(0, k2, k2 // k1)."""
     with torch.no_grad():
-        return _dilate(K.knn(_as_bcn(x), int(k2), "feature", int32=_int32()), k1, k2)
+        return _dilate(_graph(x, k2, "feature"), k1, k2)
 
 
 def knn_points_normals(x, k1, k2):
     """src/PointNet.py:29-69: rows 0:3 xyz, 3:6 unit normals; metric |dp|^2 (1 + (2 - 2 ni.nj))."""
     with torch.no_grad():
-        return _dilate(K.knn(_as_bcn(x), int(k2), "points_normals", int32=_int32()), k1, k2)
+        return _dilate(_graph(x, k2, "points_normals"), k1, k2)
 
 
 # --------------------------------------------------------------------------------------
