@@ -215,6 +215,9 @@ int pn_meanshift_rows_bwd_f32(const float* gy, const float* y, const float* q, c
 int pn_meanshift_rows_scatter_add_f32(const float* g, const int64_t* rows, int B, int N, int D, int R, float* gx,
                                       void* stream);
 size_t pn_meanshift_x3_plan_bytes(int B, int N);
+/* the part of a plan its consumers read (the rest is scratch of the plan call: plans of T iterations may be placed
+ * core_bytes apart in one buffer of T * core + (plan_bytes - core) bytes) */
+size_t pn_meanshift_x3_plan_core_bytes(int B, int N);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
                                  void* stream);
 int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,

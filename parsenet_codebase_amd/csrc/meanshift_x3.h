@@ -1303,6 +1303,18 @@ extern "C" size_t pn_meanshift_x3_plan_bytes(int B, int N) {
   x3_plan_layout(B, N, &nt, &a, &b_, &c, &oc, &ol, &tot);
   return tot;
 }
+// The leading part of a plan that its consumers (iterations, nearest, statistics) read: pairs, counts,
+// offsets, lists.  The rest — two (2 ntiles)^2 fp32 tables and the sweep buffers — is scratch of the plan
+// call itself, dead once it returns: a caller that keeps the plans of T iterations places them
+// pn_meanshift_x3_plan_core_bytes apart in ONE buffer of T * core + (plan_bytes - core) bytes, so that the
+// scratch of plan t overlaps the not-yet-written plans t + 1 ... and ONE scratch region is kept, not T
+// (round-4 advisor finding: ~12.6 MB of dead scratch per saved plan at B = 4, N = 10 000).
+extern "C" size_t pn_meanshift_x3_plan_core_bytes(int B, int N) {
+  int nt, a, b_, c;
+  size_t oc, ol, tot;
+  x3_plan_layout(B, N, &nt, &a, &b_, &c, &oc, &ol, &tot);
+  return tot - x3_plan_scratch(B, nt);
+}
 
 // cen (B,ntiles,2,D), rho (B,ntiles,2) with ntiles = align_up(N,64)/32
 extern "C" int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,

@@ -108,14 +108,48 @@ class FlatGradBucket:
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
         self.collective = True      # False: steps that only one rank runs (workloads.train_on_rank0_then_broadcast)
         self._side = None           # host-side (gloo) group for the step-status flag, created on first use
+        self.views = []
         o = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[o:o + n].view_as(p)
+            self.views.append(self.flat[o:o + n].view_as(p))
+            p.grad = self.views[-1]
             o += n
+        self._written = set()        # parameters whose slot holds a gradient of the previous gather()
 
     def zero(self):
+        """Zero the bucket and (re-)attach the views: backward passes then ACCUMULATE into it (several
+        micro-batches per optimizer step: trainer.accumulate_or_skip)."""
         self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def begin(self):
+        """Start of a step with ONE backward pass: detach the parameters from the bucket.  autograd then hands
+        every gradient over as a tensor of its own instead of adding it into a zeroed view — an in-place add per
+        parameter, ~75 small launches per cfg5 step (profiles/r04_cfg5_torch_sites.txt: workloads.py step) —
+        and ``gather()`` moves them into the bucket with one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """After the backward pass of a ``begin()`` step: all gradients into the flat bucket (one multi-tensor
+        copy), ``p.grad`` are its views again.  A parameter that received no gradient keeps a zero slot."""
+        dst, src, now = [], [], set()
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.detach())
+                now.add(i)
+        for i in self._written - now:            # had a gradient last time, none now: its slot must not keep the old one
+            self.views[i].zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self._written = now
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self.flat
 
     def _multi(self):
         return self.collective and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

@@ -413,17 +413,33 @@ def meanshift_chain_order(sim):
     return rank.long()
 
 
-def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9):
+def meanshift_x3_plan_bytes(B, N):
+    return int(_lib.load().pn_meanshift_x3_plan_bytes(B, N))
+
+
+def meanshift_x3_plan_buffer(B, N, iterations, device):
+    """One buffer for the plans of ``iterations`` launches: plan t lives at t * core bytes, the scratch of the plan
+    call (dead once it returns) of plan t overlaps the plans still to be written, ONE scratch region at the end.
+    Returns (buffer, [views of plan_bytes each], core bytes)."""
+    lib = _lib.load()
+    full, core = int(lib.pn_meanshift_x3_plan_bytes(B, N)), int(lib.pn_meanshift_x3_plan_core_bytes(B, N))
+    buf = torch.empty(iterations * core + (full - core), dtype=torch.uint8, device=device)
+    return buf, [buf[t * core:t * core + full] for t in range(iterations)], core
+
+
+def meanshift_x3_plan(q_info, x_info, bsq, N, rel_eps=1e-9, out=None):
     """Block-sparse plan of one iteration (which tile pairs can contribute more than ``rel_eps`` of
     the smallest row sum): an opaque byte tensor for meanshift_x3_iter_fwd / _bwd.  The product passes
     mean_shift.PLAN_REL_EPS (1e-6) for the forward-only training path and PLAN_REL_EPS_DENSE_BWD (1e-9)
-    where a dense backward reuses the plan; the default here is the tighter one."""
+    where a dense backward reuses the plan; the default here is the tighter one.  ``out``: a contiguous uint8
+    tensor of meanshift_x3_plan_bytes(B, N) to write into (a row of the buffer that holds all plans of a call)."""
     cq, rq = q_info[0], q_info[1]
     cx, rx = x_info[0], x_info[1]
     nx = x_info[2] if len(x_info) > 2 else None      # rows of the data caps (None: conservative bounds)
     B = cq.shape[0]
     lib = _lib.load()
-    plan = torch.empty(lib.pn_meanshift_x3_plan_bytes(B, N), dtype=torch.uint8, device=cq.device)
+    plan = out if out is not None else torch.empty(lib.pn_meanshift_x3_plan_bytes(B, N), dtype=torch.uint8,
+                                                   device=cq.device)
     with _lib.on_device(cq.device):
         rc = lib.pn_meanshift_x3_plan_f32(ptr(cq), ptr(rq), ptr(cx), ptr(rx), ptr(nx), ptr(bsq), B, N, float(rel_eps),
                                           ptr(plan), current_stream(cq.device))
@@ -472,7 +488,11 @@ def meanshift_x3_plan_visited(plans, B, N):
     it with something it waits for anyway)."""
     T = (N + 63) // 64 * 2
     n = B * T * T
-    # (one reduction per plan: the flags are 0 / 1 bytes, their fp32 sum is exact in any order)
+    if isinstance(plans, tuple):
+        # all plans of the call in one buffer (meanshift_x3_plan_buffer), ``core`` bytes apart: ONE reduction (the
+        # flags are 0 / 1 bytes, the fp32 sum of <= 2^24 of them is exact in any order)
+        buf, count, core = plans
+        return buf.as_strided((count, n), (core, 1)).sum(dtype=torch.float32) / float(n * count)
     return torch.stack([p[:n].sum(dtype=torch.float32) for p in plans]).mean() / float(n)
 
 

@@ -173,13 +173,16 @@ def _run_iterations(X, bsq, iterations, stacked=False, rel_eps=None):
         x = it_all[0]
     iterates, rsums, norms, plans = [x], [], [], []
     x_info = K.meanshift_x3_tileinfo(x) if sparse else None
+    # (the plans of all iterations in one buffer: the auto mode's statistic is then one reduction, not one per plan)
+    plans_buf, plan_slots, plan_core = K.meanshift_x3_plan_buffer(B, N, iterations, x.device) \
+        if sparse and iterations > 0 else (None, None, 0)
     q = x
     for it in range(iterations):
         out = (it_all[it + 1], rs_all[it], nr_all[it]) if direct else None
         if sparse:
             # (the first iterate IS the data: its caps are x_info)
             plan = K.meanshift_x3_plan(x_info if it == 0 else K.meanshift_x3_tileinfo(q), x_info, bsq, N,
-                                       PLAN_REL_EPS if rel_eps is None else rel_eps)
+                                       PLAN_REL_EPS if rel_eps is None else rel_eps, out=plan_slots[it])
             plans.append(plan)
             q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan, out=out)
         elif x3 is not None and ARITH == "bf16x3":
@@ -198,7 +201,7 @@ def _run_iterations(X, bsq, iterations, stacked=False, rel_eps=None):
     if sparse and os.environ.get("PARSENET_MS_STATS") == "1":
         LAST_PLAN_STATS = [K.meanshift_x3_plan_stats(p, B, N) for p in plans]
     if sparse and SPARSE == "auto" and plans:
-        AUTO_STAT = K.meanshift_x3_plan_visited(plans, B, N)
+        AUTO_STAT = K.meanshift_x3_plan_visited((plans_buf, len(plans), plan_core), B, N)
     if stacked and not direct:
         it_all = torch.stack(iterates)
         rs_all = torch.stack(rsums) if rsums else torch.empty((0, B, N), device=x.device)

@@ -101,10 +101,11 @@ class ParsenetSegStep:
 
     def seg_step(self):
         self.next_batch()
-        self.bucket.zero()
+        self.bucket.begin()          # one backward pass: gradients are handed over, then gathered (dp.FlatGradBucket)
         embedding, log_prob, embed_loss = self.model(self.x, self.labels, True)
         loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
         loss.backward()
+        self.bucket.gather()
         self.bucket.all_reduce_mean()
         self.opt.step()
         return loss
@@ -247,7 +248,7 @@ class ParsenetE2EStep(ParsenetSegStep):
         if not self._warmed:
             self.warm_paths()
         self.next_batch()
-        self.bucket.zero()
+        self.bucket.begin()
         embedding, log_prob, embed_loss = self.model(self.x, self.labels, True)
         loss = torch.mean(embed_loss) + primitive_loss(log_prob, self.prim)
         emb = embedding.permute(0, 2, 1)
@@ -288,6 +289,7 @@ class ParsenetE2EStep(ParsenetSegStep):
             # pass while the host waits for it.  With several ranks the status is agreed upon first
             # (dp.FlatGradBucket.finish_or_skip): either every rank reduces and steps or none does —
             # a rank that raised alone would leave the others in the gradient all-reduce for good.
+            self.bucket.gather()
             self.last_metrics, err, took = self.bucket.finish_or_skip(finish, self.opt)
             self.last_res = res_total
             if not took:
@@ -324,6 +326,7 @@ class ParsenetE2EStep(ParsenetSegStep):
             res_total = res_total + res[0]
         loss = loss + res_total / self.batch
         loss.backward()
+        self.bucket.gather()
         self.bucket.all_reduce_mean()
         self.opt.step()
         self.last_res = res_total
@@ -392,10 +395,11 @@ class SplineNetStep:
         return loss, cd, l_reg, lap
 
     def step(self):
-        self.bucket.zero()
+        self.bucket.begin()
         output = self.model(self.points)
         loss, cd, l_reg, lap = self.losses(output)
         loss.backward()
+        self.bucket.gather()
         self.bucket.all_reduce_mean()
         self.opt.step()
         self.last = (cd, l_reg, lap)
