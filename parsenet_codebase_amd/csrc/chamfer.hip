@@ -13,6 +13,10 @@
 //     through the scalar cache) and enter the VALU instructions as SGPR operands: no LDS tile, no
 //     staging pass, no barrier — the one-query-per-lane LDS version issued three ds_read_b32
 //     per 11 VALU instructions and was bound by the LDS port;
+//     (round 5: the same eight operations for two queries of a lane on v_pk_add_f32 / v_pk_mul_f32 — 4.5 instead
+//     of 8.5 issue slots per pair, bit-identical results — measured NO faster: 0.065 against 0.061 ms at 10k x 10k
+//     with two queries per lane, 0.071 with four (tools/jobs/r5m.sh); the waves wait for the scalar loads of the
+//     next group (SQ_WAIT_ANY 42 %), not for issue slots; not kept)
 //   * selection per GROUP of 8 candidates: v_min3 chain + one compare/select pair per group
 //     instead of per candidate (8.9 instead of 11 VALU instructions per pair); the arg-min is
 //     the first candidate of the winning group that reproduces the minimum, resolved once per
