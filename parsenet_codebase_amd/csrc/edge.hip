@@ -168,6 +168,7 @@ extern "C" int pn_edge_feature_fwd_f32(const float* xt, const int64_t* idx, int 
 #define EC_PPW_MAX 16  // points per wave (chosen per launch: ec_points_per_wave)
 #define EC_PPW_MIN 2
 #define EC_WAVES 4
+#define EC_INFL 2      // row gathers in flight per lane (4: measured slower, 0.107 against 0.094 ms at cfg4 — occupancy)
 
 struct float4x {
   float v[4];
@@ -256,36 +257,34 @@ __global__ __launch_bounds__(256) void pn_edgeconv_reduce_kernel(
         arg[h][u] = 0;
       }
     }
-    // two steps of the neighbour loop per trip, both row gathers issued before either is used
-    for (int kk0 = 0; kk0 < k; kk0 += 2 * RPI) {
-      const int kka = kk0 + rg, kkb = kka + RPI;
-      // (the shuffles are executed by every lane: the source lane must be active)
-      const int sa = kka < 64 ? __shfl(jlo, kka & 63, 64) : __shfl(jhi, (kka - 64) & 63, 64);
-      const int sb = kkb < 64 ? __shfl(jlo, kkb & 63, 64) : __shfl(jhi, (kkb - 64) & 63, 64);
-      const bool oa = kka < k, ob = kkb < k;
-      const int ja = oa ? (regs ? sa : (int)ib[kka]) : i;      // inactive: a row that exists
-      const int jb = ob ? (regs ? sb : (int)ib[kkb]) : i;
-      float4x va[NCH], vb[NCH];
+    // EC_INFL steps of the neighbour loop per trip, all row gathers issued before any is used (the kernel waits
+    // for gathers, not for issue slots: round 3 went from one to two in flight; four measured slower, see EC_INFL)
+    for (int kk0 = 0; kk0 < k; kk0 += EC_INFL * RPI) {
+      int kkv[EC_INFL];
+      bool onv[EC_INFL];
+      float4x vv[EC_INFL][NCH];
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) {
-        va[h] = ld4(PQb + (size_t)ja * 2 * COUT + (cl + h * 64) * 4);
-        vb[h] = ld4(PQb + (size_t)jb * 2 * COUT + (cl + h * 64) * 4);
+      for (int f = 0; f < EC_INFL; ++f) {
+        kkv[f] = kk0 + rg + f * RPI;
+        // (the shuffles are executed by every lane: the source lane must be active)
+        const int sj = kkv[f] < 64 ? __shfl(jlo, kkv[f] & 63, 64) : __shfl(jhi, (kkv[f] - 64) & 63, 64);
+        onv[f] = kkv[f] < k;
+        const int jf = onv[f] ? (regs ? sj : (int)ib[kkv[f]]) : i;      // inactive: a row that exists
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) vv[f][h] = ld4(PQb + (size_t)jf * 2 * COUT + (cl + h * 64) * 4);
       }
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const bool on = half ? ob : oa;
-        const int kk = half ? kkb : kka;
-        if (on) {
+      for (int f = 0; f < EC_INFL; ++f) {
+        if (onv[f]) {
 #pragma unroll
           for (int h = 0; h < NCH; ++h) {
-            const float4x v = half ? vb[h] : va[h];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const float y = v.v[u] + q[h].v[u];
+              const float y = vv[f][h].v[u] + q[h].v[u];
               const float ys = y * sgn[h][u];
               if (ys > best[h].v[u]) {
                 best[h].v[u] = ys;
-                arg[h][u] = kk;
+                arg[h][u] = kkv[f];
               }
               s1[h].v[u] += y;
               s2[h].v[u] = __builtin_fmaf(y, y, s2[h].v[u]);
