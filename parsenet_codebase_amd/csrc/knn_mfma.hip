@@ -88,7 +88,20 @@ __global__ void pn_knn_prep_kernel(const float* __restrict__ x, int C, int N, in
   if (jp < N) {
     const int j = knn_perm(perm, jp);
     const int cnorm = mode == 1 ? 3 : C;
-    for (int c = 0; c < C; ++c) {
+    // (eight channels at a time: independent loads ahead of the norm's fma chain)
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = point_major ? xb[(size_t)j * C + c + e] : xb[(size_t)(c + e) * N + j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int cd = (mode == 1 && c + e >= 3) ? c + e + 1 : c + e;
+        xpb[(size_t)cd * Np + jp] = v[e];
+        if (c + e < cnorm) acc = __builtin_fmaf(v[e], v[e], acc);
+      }
+    }
+    for (; c < C; ++c) {
       const float v = point_major ? xb[(size_t)j * C + c] : xb[(size_t)c * N + j];
       const int cd = (mode == 1 && c >= 3) ? c + 1 : c;
       xpb[(size_t)cd * Np + jp] = v;
