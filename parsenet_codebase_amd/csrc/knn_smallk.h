@@ -124,6 +124,24 @@ __global__ void pn_knn_smallk_prep_kernel(const float* __restrict__ x, int C, in
 // above the representable thr only if it IS above it); the buffer keeps the accumulator and the flush forms
 // v = fl(2 acc' - |q|^2), the reference's value, for what it inserts (strict >: what the bound let through
 // without being above the threshold is dropped there).
+#ifdef KSK_TIMERS
+// -DKSK_TIMERS (tools/jobs only): shader cycles of wave 0 of every workgroup by phase, summed over the launch
+__device__ unsigned long long ksk_timers[8];
+#define KT_NOW() ((long long)__builtin_readcyclecounter())
+#define KT_ADD(I, T0) kt[I] += KT_NOW() - (T0)
+extern "C" int pn_knn_smallk_timers(unsigned long long* host8, int reset) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ksk_timers), sizeof(ksk_timers)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ksk_timers), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define KT_NOW() 0ll
+#define KT_ADD(I, T0) (void)(T0)
+#endif
+
 template <int KSX, int KK>
 __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restrict__ xp, int N, int Np,
                                                             int stages_per_slice, int k, u64* __restrict__ lists,
@@ -152,6 +170,10 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
   const int S = gridDim.x, slice = blockIdx.x;
   const int s_begin = slice * stages_per_slice;
   const int s_end = min(nstages, s_begin + stages_per_slice);
+#ifdef KSK_TIMERS
+  long long kt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  const long long kt_start = KT_NOW();
 
   // resident query operand; the query meets the candidates' norm row with 1 (k = 1 of the last step)
   float bq[KSX];
@@ -231,8 +253,12 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
   int jp = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) accp[r] = -__builtin_inff();    // (nothing passes before the first tile)
+  KT_ADD(1, kt_start);
   for (int st = s_begin; st < s_end; ++st) {
+    const long long kt_a = KT_NOW();
     if (st + 1 < s_end) KS_STAGE(st + 1, cur ^ 1);
+    KT_ADD(2, kt_a);
+    const long long kt_b = KT_NOW();
     if (wave_on) {
 #pragma unroll
       for (int tt = 0; tt < TPS; ++tt) {
@@ -286,11 +312,17 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
       }
       if (TPS == 1 && __ballot(wp > bbase + (CAP - 16) * 64) != 0ull && lane == 0) flag[st % 3] = 1;
     }
+    KT_ADD(3, kt_b);
+    const long long kt_c = KT_NOW();
     if (TPS == 1 && tid == 0) flag[(st + 1) % 3] = 0;
     __syncthreads();
+    KT_ADD(4, kt_c);
+    const long long kt_d = KT_NOW();
     if (TPS == 1 && flag[st % 3] != 0 && wave_on) KS_FLUSH();
+    KT_ADD(5, kt_d);
     cur ^= 1;
   }
+  const long long kt_e = KT_NOW();
 #undef KS_STAGE
   if (!wave_on) return;
   // the last tile's rows
@@ -312,6 +344,14 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < KK; ++i) ksk_insert_key<KK>(L, pv[i], pj[i]);
   }
+#ifdef KSK_TIMERS
+  KT_ADD(6, kt_e);
+  KT_ADD(0, kt_start);
+  if (tid == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&ksk_timers[i], (unsigned long long)kt[i]);
+    atomicAdd(&ksk_timers[7], 1ull);
+  }
+#endif
   if (h != 0 || q >= N) return;
   if (S == 1) {
     if (out32) {

@@ -1,5 +1,6 @@
 """Per-step GPU time of the LAST steps of a rocprofv3 kernel trace of bench.py, grouped by stage
-(kernel-name patterns), and the GPU idle time inside a step.  python tools/step_breakdown.py trace.csv [steps]"""
+(kernel-name patterns), and the GPU idle time inside a step.  python tools/step_breakdown.py trace.csv [steps] [detail]
+("detail": under every group its kernels by name — launches and ms per step, grid size of the heaviest launch)"""
 import csv
 import sys
 import collections
@@ -28,8 +29,10 @@ groups = collections.OrderedDict([
     ("GEMM (rocBLAS / hipBLASLt)", ("Cijk", "gemm", "rocblas")),
     ("elementwise / reductions / sort (torch)", ("",)),
 ])
+detail = len(sys.argv) > 3 and sys.argv[3] == "detail"
 tot = collections.Counter()
 cnt = collections.Counter()
+per = collections.defaultdict(lambda: [0, 0, 0, ""])      # (group, name) -> ns, launches, longest, its grid
 busy = 0
 span = 0
 for a, b in zip(ends[:-1], ends[1:]):
@@ -42,9 +45,19 @@ for a, b in zip(ends[:-1], ends[1:]):
             if any(p in r["Kernel_Name"] for p in pats):
                 tot[g] += d
                 cnt[g] += 1
+                e = per[(g, r["Kernel_Name"][:110])]
+                e[0] += d
+                e[1] += 1
+                if d > e[2]:
+                    e[2] = d
+                    e[3] = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
                 break
 n = len(ends) - 1
 print("steps analysed: %d; wall per step (first to last kernel) %.2f ms; kernel time %.2f ms; launches per step %.0f"
       % (n, span / n / 1e6, busy / n / 1e6, sum(cnt.values()) / n))
 for g in groups:
     print("  %-42s %7.2f ms  %6.0f launches" % (g, tot[g] / n / 1e6, cnt[g] / n))
+    if detail:
+        mine = sorted(((k[1], v) for k, v in per.items() if k[0] == g), key=lambda t: -t[1][0])
+        for name, (ns, c, longest, grid) in mine[:14]:
+            print("      %7.3f ms %6.1f x  longest %7.1f us (grid %s)  %s" % (ns / n / 1e6, c / n, longest / 1e3, grid, name))
