@@ -226,6 +226,13 @@ int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* 
 int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img_x, const float* bsq, int B, int N,
                                       int D, float* opart, float* rpart, float* y, float* rsum,
                                       float* unorm, const void* plan, void* stream);
+/* the same, and the bounding caps of the result's tiles (what pn_meanshift_x3_tileinfo_f32 of y returns:
+ * the q caps of the NEXT iteration's plan) out of the launch that combines the partial results; cen / rho
+ * NULL: exactly pn_meanshift_x3_iter_fwd_plan_f32.  src/mean_shift.py:58-64, one iteration. */
+int pn_meanshift_x3_iter_fwd_info_f32(const float* q, const void* img_x, const float* bsq, int B, int N,
+                                      int D, float* opart, float* rpart, float* y, float* rsum,
+                                      float* unorm, const void* plan, float* cen, float* rho, float* cnt,
+                                      void* stream);
 int pn_meanshift_x3_iter_bwd_plan_f32(const float* gy, const float* y, const float* q, const float* x,
                                       const void* img_x, const float* rsum, const float* unorm,
                                       const float* bsq, int B, int N, int D, float* gu, float* cs,

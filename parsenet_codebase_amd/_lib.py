@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 16  # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 17  # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -88,6 +88,8 @@ SIGNATURES = {
     "pn_meanshift_x3_plan_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p, c_void_p]),
     "pn_meanshift_x3_iter_fwd_plan_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int] + [c_void_p] * 5 +
                                           [c_void_p, c_void_p]),
+    "pn_meanshift_x3_iter_fwd_info_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int] + [c_void_p] * 5 +
+                                          [c_void_p] * 5),
     "pn_meanshift_x3_iter_bwd_plan_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 8 +
                                           [c_void_p, c_void_p]),
     "pn_dot_kth_x3_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -411,10 +411,20 @@ __global__ __launch_bounds__(64) void pn_stats_reduce_kernel(const double* __res
   const int which = out & 1, g = (out >> 1) % G, s = (out >> 1) / G;
   const int b0 = per_sample ? s : 0, nb = per_sample ? 1 : B;
   double acc = 0.0;
-  for (int e = threadIdx.x; e < nb * nblk; e += 64) {
-    const int bb = b0 + e / nblk, blk = e - (e / nblk) * nblk;
-    acc += part[(((size_t)bb * nblk + blk) * G + g) * 2 + which];
+  // (item bb, block blk) = entry b0 * nblk + e of the (items x blocks) sequence: one stride for all entries;
+  // eight loads in flight, added in the same order as one at a time
+  const double* __restrict__ pp = part + ((size_t)b0 * nblk * G + g) * 2 + which;
+  const size_t stride = (size_t)G * 2;
+  const int total = nb * nblk;
+  int e = threadIdx.x;
+  for (; e + 7 * 64 < total; e += 8 * 64) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = pp[(size_t)(e + 64 * u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
   }
+  for (; e < total; e += 64) acc += pp[(size_t)e * stride];
   acc = pn_wave_sum_d(acc);
   if (threadIdx.x == 0) stats[out] = acc;
 }

@@ -865,38 +865,53 @@ __global__ __launch_bounds__(256) void pn_wmax_fwd_kernel(const float* __restric
 }
 
 // gw[s][n] = sum over the channels whose arg-max is n of g[s][c] * val[s][c], channels in order.
-// One wave per segment walks the channels 64 at a time; lanes that hit the same point are resolved
-// inside the wave (the lowest lane of a group adds the group's terms in lane = channel order), so
-// the accumulation order is exactly the serial one, without a serial loop of C additions.
+// One wave per segment walks the channels 64 at a time.  Every lane ORs its bit into a 64-bit mask of its
+// point (LDS); the lowest lane of a mask adds the terms of the mask's lanes in lane = channel order to the
+// point's accumulator — the groups of a chunk side by side, each in the serial order.  (Round 3 resolved the
+// groups one after the other through ballots: up to 64 rounds per chunk, 115 us for 1 024 channels.)
 __global__ __launch_bounds__(64) void pn_wmax_bwd_kernel(const float* __restrict__ g, const int* __restrict__ idx,
                                                          const float* __restrict__ val, int C, int N,
                                                          float* __restrict__ gw) {
-  extern __shared__ float acc[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long wm_mask[];   // [N] masks, [N] sums, [64] terms
+  float* acc = reinterpret_cast<float*>(wm_mask + N);
+  float* term = acc + N;
   const int s = blockIdx.x, lane = threadIdx.x;
-  for (int n = lane; n < N; n += 64) acc[n] = 0.f;
+  for (int n = lane; n < N; n += 64) {
+    acc[n] = 0.f;
+    wm_mask[n] = 0ull;
+  }
+  int i_n = -1;
+  float v_n = 0.f;
+  if (lane < C) {
+    i_n = idx[(size_t)s * C + lane];
+    v_n = g[(size_t)s * C + lane] * val[(size_t)s * C + lane];
+  }
   __syncthreads();
   for (int base = 0; base < C; base += 64) {
-    const int c = base + lane;
-    int i = -1;
-    float v = 0.f;
-    if (c < C) {
-      i = idx[(size_t)s * C + c];
-      v = g[(size_t)s * C + c] * val[(size_t)s * C + c];
-      if (i < 0 || i >= N) i = -1;
+    int i = i_n;
+    const float v = v_n;
+    if (i < 0 || i >= N) i = -1;
+    const int cn = base + 64 + lane;          // the next chunk's loads under this chunk's work
+    i_n = -1;
+    v_n = 0.f;
+    if (cn < C) {
+      i_n = idx[(size_t)s * C + cn];
+      v_n = g[(size_t)s * C + cn] * val[(size_t)s * C + cn];
     }
-    unsigned long long todo = __ballot(i >= 0);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int li = __shfl(i, leader, 64);
-      unsigned long long same = __ballot(i == li);
-      todo &= ~same;
-      float sum = acc[li];                 // (one address for the whole wave: a broadcast read)
-      while (same) {                       // ascending lanes = ascending channels: the serial order
-        const int l = __ffsll((long long)same) - 1;
-        sum += __shfl(v, l, 64);
-        same &= same - 1;
+    term[lane] = v;
+    if (i >= 0) atomicOr(&wm_mask[i], 1ull << lane);
+    __syncthreads();
+    unsigned long long m = i >= 0 ? wm_mask[i] : 0ull;
+    const bool first = i >= 0 && (m & ((1ull << lane) - 1ull)) == 0ull;
+    __syncthreads();                          // every lane has its mask: the first lanes may clear them
+    if (first) {
+      wm_mask[i] = 0ull;
+      float sum = acc[i];
+      while (m) {                             // ascending lanes = ascending channels: the serial order
+        sum += term[__ffsll((long long)m) - 1];
+        m &= m - 1ull;
       }
-      if (lane == leader) acc[li] = sum;
+      acc[i] = sum;
     }
     __syncthreads();
   }
@@ -918,12 +933,19 @@ extern "C" int pn_weighted_max_fwd_f32(const float* x, const float* scale, const
 extern "C" int pn_weighted_max_bwd_f32(const float* g, const int* idx, const float* val, int S, int C, int N,
                                        float* gw, void* stream) {
   PN_CHECK_ARG(g && idx && val && gw && S > 0 && C > 0 && N > 0, "pn_weighted_max_bwd_f32: bad arguments");
-  if ((size_t)N * sizeof(float) > 64 * 1024) {
-    pn_set_error("pn_weighted_max_bwd_f32: N=%d exceeds the LDS accumulator (16384 points)", N);
+  const size_t smem = pn_align_up((size_t)N * 12 + 64 * sizeof(float), 16);
+  if (smem > 160 * 1024 - 256) {
+    pn_set_error("pn_weighted_max_bwd_f32: N=%d exceeds the LDS accumulator (13 600 points)", N);
     return PN_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(pn_wmax_bwd_kernel, dim3(S), dim3(64), (size_t)N * sizeof(float), (hipStream_t)stream, g, idx, val,
-                     C, N, gw);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PN_CHECK_HIP(hipFuncSetAttribute((const void*)pn_wmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 256));
+    attr_set = true;
+  }
+  PN_PROF("weighted_max_bwd", (hipStream_t)stream);
+  hipLaunchKernelGGL(pn_wmax_bwd_kernel, dim3(S), dim3(64), smem, (hipStream_t)stream, g, idx, val, C, N, gw);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -344,9 +344,9 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < KK; ++i) ksk_insert_key<KK>(L, pv[i], pj[i]);
   }
-#ifdef KSK_TIMERS
   KT_ADD(6, kt_e);
   KT_ADD(0, kt_start);
+#ifdef KSK_TIMERS
   if (tid == 0) {
     for (int i = 0; i < 7; ++i) atomicAdd(&ksk_timers[i], (unsigned long long)kt[i]);
     atomicAdd(&ksk_timers[7], 1ull);

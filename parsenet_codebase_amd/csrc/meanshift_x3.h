@@ -850,6 +850,9 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 // ARGUMENT, on the side that keeps the bound: a radius is acos(dot - err) >= the true angle, an
 // upper bound of a centre angle acos(dot - err), a lower bound acos(dot + err) (0 when >= 1).
 #define X3_DOT_ERR 1.6e-5f
+// rounding of the cosines of (centre angle +- radii) formed from the dot product, the sines and cosines of the
+// radii and one square root (pn_ms3_pairs_kernel): a dozen operations on values <= 1
+#define X3_TRIG_ERR 2e-6f
 // Backward passes reuse the forward plan of their iteration.  The terms they drop are the same
 // kernel values times (q.x - 1) / b^2 factors, so the dropped share of a gradient row is bounded by
 // rel_eps / b^2, not rel_eps.  The callers that run these dense backward passes therefore plan with
@@ -869,36 +872,17 @@ extern "C" int pn_meanshift_x3_split_f32(const float* x, int B, int N, int D, vo
 // row pass 0.40 -> 0.28 of all.)
 // (four waves per tile, eight rows each: the dot products of a round are wave-wide sums, and one
 // wave per tile left the SIMDs with a single wave of serial reductions: 53 us per call)
-__global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __restrict__ z, int N, int ntiles,
-                                                              float* __restrict__ cen, float* __restrict__ rho,
-                                                              float* __restrict__ cnt_out) {
+// The caps of ONE tile from its rows in registers: this wave's rows 8 wave .. 8 wave + 7, channels (lane,
+// lane + 64), rows >= cnt zero; `rows`: the tile's rows again, MS_D floats apart, for the two seed rows (global
+// memory, or LDS when the caller produced the rows itself).  All 256 threads of the workgroup call it.
+__device__ static inline void x3_tile_caps(const float (&z0)[8], const float (&z1)[8], int cnt,
+                                           const float* __restrict__ rows, float* __restrict__ co,
+                                           float* __restrict__ ro, float* __restrict__ no) {
   __shared__ float part[4][2][MS_D];
   __shared__ float sd[3][32];
   __shared__ float smin[4][2];
-  const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const float* zb = z + (size_t)b * N * MS_D;
-  const int j0 = t * 32, cnt = min(32, N - j0);
-  float* co = cen + ((size_t)b * ntiles + t) * 2 * MS_D;
-  float* ro = rho + ((size_t)b * ntiles + t) * 2;
-  float* no = cnt_out ? cnt_out + ((size_t)b * ntiles + t) * 2 : nullptr;   // rows of the two caps
-  if (cnt <= 0) {   // padding tile: interacts with everything (its image rows are zero)
-    if (tid < 2 * MS_D) co[tid] = 0.f;
-    if (tid == 0) {
-      ro[0] = 3.2f;
-      ro[1] = -1.f;
-      if (no) no[0] = no[1] = 0.f;
-    }
-    return;
-  }
-  // this wave's rows 8 wave .. 8 wave + 7, channels (lane, lane + 64)
-  float z0[8], z1[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int j = 8 * wave + i;
-    z0[i] = j < cnt ? zb[(size_t)(j0 + j) * MS_D + lane] : 0.f;
-    z1[i] = j < cnt ? zb[(size_t)(j0 + j) * MS_D + lane + 64] : 0.f;
-  }
   // dot products of the rows with a vector (v0, v1) -> sd[slot][0..31]
 #define X3_TI_DOTS(SLOT, V0, V1)                                                    \
   {                                                                                 \
@@ -928,7 +912,7 @@ __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __res
       best = sd[0][j];
       ia = j;
     }
-  const float a0 = zb[(size_t)(j0 + ia) * MS_D + lane], a1 = zb[(size_t)(j0 + ia) * MS_D + lane + 64];
+  const float a0 = rows[(size_t)ia * MS_D + lane], a1 = rows[(size_t)ia * MS_D + lane + 64];
   X3_TI_DOTS(1, a0, a1);
   best = 3.4e38f;
   for (int j = 0; j < cnt; ++j)
@@ -936,7 +920,7 @@ __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __res
       best = sd[1][j];
       ib = j;
     }
-  const float b0 = zb[(size_t)(j0 + ib) * MS_D + lane], b1 = zb[(size_t)(j0 + ib) * MS_D + lane + 64];
+  const float b0 = rows[(size_t)ib * MS_D + lane], b1 = rows[(size_t)ib * MS_D + lane + 64];
   X3_TI_DOTS(2, b0, b1);
   unsigned second = 0;   // bit j: row j goes with s2 (larger dot product)
   for (int j = 0; j < cnt; ++j) second |= sd[2][j] > sd[1][j] ? 1u << j : 0u;
@@ -1003,24 +987,57 @@ __global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __res
 #undef X3_TI_DOTS
 }
 
-// pairs[b][tQ][tX] in two sweeps of single-wave workgroups, one per (32 q caps) x (32 x caps) block:
-// the 32 x 32 dot products of the cap centres on the fp32 matrix cores (64 v_mfma_f32_32x32x2_f32;
+// a padding tile (no rows): interacts with everything (its image rows are zero)
+__device__ static inline void x3_tile_caps_empty(float* __restrict__ co, float* __restrict__ ro,
+                                                 float* __restrict__ no) {
+  const int tid = threadIdx.x;
+  if (tid < 2 * MS_D) co[tid] = 0.f;
+  if (tid == 0) {
+    ro[0] = 3.2f;
+    ro[1] = -1.f;
+    if (no) no[0] = no[1] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void pn_ms3_tileinfo_kernel(const float* __restrict__ z, int N, int ntiles,
+                                                              float* __restrict__ cen, float* __restrict__ rho,
+                                                              float* __restrict__ cnt_out) {
+  const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const float* zb = z + (size_t)b * N * MS_D;
+  const int j0 = t * 32, cnt = min(32, N - j0);
+  float* co = cen + ((size_t)b * ntiles + t) * 2 * MS_D;
+  float* ro = rho + ((size_t)b * ntiles + t) * 2;
+  float* no = cnt_out ? cnt_out + ((size_t)b * ntiles + t) * 2 : nullptr;   // rows of the two caps
+  if (cnt <= 0) {
+    x3_tile_caps_empty(co, ro, no);
+    return;
+  }
+  float z0[8], z1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = 8 * wave + i;
+    z0[i] = j < cnt ? zb[(size_t)(j0 + j) * MS_D + lane] : 0.f;
+    z1[i] = j < cnt ? zb[(size_t)(j0 + j) * MS_D + lane + 64] : 0.f;
+  }
+  x3_tile_caps(z0, z1, cnt, zb + (size_t)j0 * MS_D, co, ro, no);
+}
+
+// Bounds of the dot products of every cap pair, single-wave workgroups, one per (32 q caps) x (32 x caps)
+// block: the 32 x 32 dot products of the cap centres on the fp32 matrix cores (64 v_mfma_f32_32x32x2_f32;
 // the angles need 1e-3, bf16 would not do).  Lane (col, h) feeds k-step m with channel 64 h + m of
 // row col (the order of the k-steps is free), i.e. reads one contiguous half row.
-//   SWEEP 0: pm[b][q cap][x block] = max over the block's x caps of cos(th + rho_q + rho_x)
-//   SWEEP 1: L_q = max over the x blocks of pm, predicate of every cap pair, OR over the 2 x 2 cap
-//            pairs of a tile pair -> pairs.
-// Recomputing the dot products in the second sweep is cheaper than a (2T)^2 table of angles.
-template <int SWEEP>
+//   utab[b][q cap][x cap]  = U,  the upper bound  cos(max(th - rho_q - rho_x, 0))  of the pair's dot products
+//   lotab[b][q cap][x cap] = Lo, the lower bound  cos(min(th + rho_q + rho_x, pi)) of ALL of them
+//   pm[b][q cap][x block]  = max of Lo over the block's x caps (L_q = its maximum over the blocks)
+// (-2: a cap without rows).  pn_ms3_thr_kernel turns a cap's rows of the tables into its drop threshold and
+// the predicate of its pairs.
 __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restrict__ cenQ,
                                                           const float* __restrict__ rhoQ,
                                                           const float* __restrict__ cenX,
-                                                          const float* __restrict__ rhoX,
-                                                          const float* __restrict__ bsq, int ntiles,
-                                                          float logterm, float* __restrict__ pm,
-                                                          unsigned char* __restrict__ pairs,
-                                                          float* __restrict__ utab, float* __restrict__ lotab,
-                                                          const float* __restrict__ thr) {
+                                                          const float* __restrict__ rhoX, int ntiles,
+                                                          float* __restrict__ pm, float* __restrict__ utab,
+                                                          float* __restrict__ lotab) {
   const int b = blockIdx.z, qb = blockIdx.y, xb = blockIdx.x, lane = threadIdx.x;
   const int col = lane & 31, h = lane >> 5;
   const int ncap = 2 * ntiles, nxb = gridDim.x;
@@ -1045,51 +1062,43 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
   }
   // D[i = q cap][j = x cap]: lane holds column j = col, rows i = (r & 3) + 8 (r >> 2) + 4 h
   const float rx = ux < ncap ? rhoX[(size_t)b * ncap + uxc] : -1.f;
-  const float cutoff = bsq[b] * logterm;
-  // lane col keeps radius and L of q cap qb * 32 + col; the rows of a lane fetch them by shuffle
+  // lane col keeps the radius of q cap qb * 32 + col; the rows of a lane fetch it by shuffle
   const int qmine = qb * 32 + col;
   const float rq_mine = qmine < ncap ? rhoQ[(size_t)b * ncap + qmine] : -1.f;
-  // sweep 1: the drop threshold t of the q cap (pn_ms3_thr_kernel)
-  const float L_mine = SWEEP == 1 && qmine < ncap ? thr[(size_t)b * ncap + qmine] : 2.f;
-  (void)cutoff;
+  // cos(th +- (rq + rx)) from the dot product d = cos(th) itself:
+  //   cos(th + r) = d cos r - sqrt(1 - d^2) sin r,   cos(th - r) = d cos r + sqrt(1 - d^2) sin r,
+  //   cos r = cos rq cos rx - sin rq sin rx,  sin r = sin rq cos rx + cos rq sin rx
+  // — two sine / cosine pairs per LANE instead of two arc cosines and two cosines per cap pair (what the sweep
+  // spent its 35 us on).  A dozen roundings of values <= 1: the bounds move outwards by X3_TRIG_ERR; the radii
+  // already carry X3_PLAN_SLACK.
+  float cq_mine, sq_mine, cx, sx;
+  sincosf(fmaxf(rq_mine, 0.f), &sq_mine, &cq_mine);
+  sincosf(fmaxf(rx, 0.f), &sx, &cx);
 #pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    bool on = false;
+  for (int r = 0; r < 16; ++r) {
+    const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float rq = __shfl(rq_mine, qi - qb * 32, 64);
+    const float cq = __shfl(cq_mine, qi - qb * 32, 64), sq = __shfl(sq_mine, qi - qb * 32, 64);
+    const float rr = rq + rx;                                  // < pi: both cosines below are monotone in th
+    const float cr = cq * cx - sq * sx, sr = sq * cx + cq * sx;
+    const bool both = rq >= 0.f && rx >= 0.f;
+    // the centre angle from above: d - err (for Lo), from below: d + err (for U)
+    const float d_lo = fmaxf(acc[r] - X3_DOT_ERR, -1.f), d_hi = fminf(acc[r] + X3_DOT_ERR, 1.f);
+    // Lo = cos(min(th_hi + r, pi)): th_hi + r >= pi  <=>  d_lo <= cos(pi - r) = -cos r
+    const float lo_cos = (rr >= 3.14159f || d_lo <= -cr)
+                             ? -1.f
+                             : fmaxf(d_lo * cr - sqrtf(fmaxf(1.f - d_lo * d_lo, 0.f)) * sr - X3_TRIG_ERR, -1.f);
+    // U = cos(max(th_lo - r, 0)): th_lo <= r  <=>  d_hi >= cos r
+    const float up_cos = (rr >= 3.14159f || d_hi >= cr)
+                             ? 1.f
+                             : fminf(d_hi * cr + sqrtf(fmaxf(1.f - d_hi * d_hi, 0.f)) * sr + X3_TRIG_ERR, 1.f);
+    float m = rx >= 0.f ? lo_cos : -2.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int qi = qb * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2) + 4 * h;   // r even: qi, qi + 1 = one tile
-      const float rq = __shfl(rq_mine, qi - qb * 32, 64);
-      // upper bound of the centre angle for L (sweep 0), lower bound for U (sweep 1)
-      const float th = acosf(fminf(fmaxf(acc[r + k] + (SWEEP == 0 ? -X3_DOT_ERR : X3_DOT_ERR), -1.f), 1.f));
-      if (SWEEP == 0) {
-        const float hi = th + rq + rx;
-        float m = rx >= 0.f ? (hi >= 3.14159f ? -1.f : cosf(hi)) : -2.f;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if (col == 0 && qi < ncap) pm[((size_t)b * ncap + qi) * nxb + xb] = m;
-        // the upper bound U of the pair's dot products (from the LOWER bound of the centre angle, like
-        // sweep 1 recomputes it) for the threshold search; -2: a cap without rows (no mass)
-        const float th_lo = acosf(fminf(fmaxf(acc[r + k] + X3_DOT_ERR, -1.f), 1.f));
-        const float lo = th_lo - rq - rx;
-        if (qi < ncap && ux < ncap) {
-          const bool both = rq >= 0.f && rx >= 0.f;
-          utab[((size_t)b * ncap + qi) * ncap + ux] = both ? (lo <= 0.f ? 1.f : cosf(lo)) : -2.f;
-          // ... and the lower bound Lo of ALL of them (what `m` maximises): the row-sum bound R
-          lotab[((size_t)b * ncap + qi) * ncap + ux] = both ? (hi >= 3.14159f ? -1.f : cosf(hi)) : -2.f;
-        }
-      } else {
-        const float t = __shfl(L_mine, qi - qb * 32, 64);
-        const float lo = th - rq - rx;
-        const float U = lo <= 0.f ? 1.f : cosf(lo);
-        on |= rq >= 0.f && rx >= 0.f && U >= t;
-      }
-    }
-    if (SWEEP == 1) {
-      // the x caps 2v, 2v + 1 of a tile are neighbouring lanes
-      const bool other = __shfl_xor((int)on, 1, 64) != 0;
-      const int tq = (qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) >> 1;
-      if ((col & 1) == 0 && ux < ncap && tq < ntiles)
-        pairs[((size_t)b * ntiles + tq) * ntiles + (ux >> 1)] = (on || other) ? 1 : 0;
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (col == 0 && qi < ncap) pm[((size_t)b * ncap + qi) * nxb + xb] = m;
+    if (qi < ncap && ux < ncap) {
+      utab[((size_t)b * ncap + qi) * ncap + ux] = both ? up_cos : -2.f;
+      lotab[((size_t)b * ncap + qi) * ncap + ux] = both ? lo_cos : -2.f;
     }
   }
 }
@@ -1098,57 +1107,89 @@ __global__ __launch_bounds__(64) void pn_ms3_pairs_kernel(const float* __restric
 //   sum_{x caps with U < t} n_x exp((U - L) / b^2) <= 0.9 rel_eps R,   R = sum_x n_x exp((Lo - L) / b^2)
 // (0.9: the fp32 summation of <= 2 ntiles positive terms on either side), by bisection over the cap's
 // rows of the U and Lo tables; L = the cap's lower bound of the best dot product (sweep 0), n_x the
-// rows of data cap x.  Caps with U >= t are kept.
+// rows of data cap x.  Caps with U >= t are kept — and since the cap's row of U values is in the wave's
+// registers, the wave forms the predicate of its cap pairs itself: one workgroup per q TILE, its two waves the
+// tile's two caps; pairs[tQ][tX] = OR over the 2 x 2 cap pairs.  (Round 4 recomputed the dot products of all
+// cap pairs in a second sweep of pn_ms3_pairs_kernel for this: 20 us per plan.)
 template <int MAXV>   // 64 MAXV >= the number of caps (the cap's rows of bounds live in registers)
-__global__ __launch_bounds__(64) void pn_ms3_thr_kernel(const float* __restrict__ utab, const float* __restrict__ lotab,
-                                                        const float* __restrict__ pm, const float* __restrict__ rhoQ,
-                                                        const float* __restrict__ cntX, const float* __restrict__ bsq,
-                                                        int ncap, int nxb, float rel_eps, float* __restrict__ thr) {
-  const int b = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(128) void pn_ms3_thr_kernel(const float* __restrict__ utab, const float* __restrict__ lotab,
+                                                         const float* __restrict__ pm, const float* __restrict__ rhoQ,
+                                                         const float* __restrict__ cntX, const float* __restrict__ bsq,
+                                                         int ncap, int nxb, float rel_eps, float* __restrict__ thr,
+                                                         unsigned char* __restrict__ pairs) {
+  __shared__ unsigned char s_on[MAXV][64];
+  const int b = blockIdx.y, tq = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int a = 2 * tq + wave, ntiles = ncap >> 1;
   const size_t row = (size_t)b * ncap + a;
-  if (rhoQ[row] < 0.f) {          // a cap without rows: its pairs are never set
-    if (lane == 0) thr[row] = 2.f;
-    return;
-  }
-  float L = -2.f;
-  for (int e = lane; e < nxb; e += 64) L = fmaxf(L, pm[row * nxb + e]);
-  L = pn_wave_max(L);
-  if (rel_eps < 0.f) {
-    // EXACT pruning (pn_meanshift_x3_nearest_f32: the arg-max of a dot product): every row of the cap has
-    // a candidate with dot >= L, so a candidate cap whose upper bound lies below L cannot hold a row's
-    // maximum — minus the rounding of the fp32 chains the two values are compared in (each within
-    // X3_DOT_ERR of the real dot product of unit rows)
-    if (lane == 0) thr[row] = L - 4.f * X3_DOT_ERR;
-    return;
-  }
-  const float ib = 1.0f / bsq[b];
-  float u[MAXV], m[MAXV];
   const int nv = (ncap + 63) / 64;
-  float R = 0.f;
+  float u[MAXV];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
     const int i = lane + 64 * v;
-    const bool in = v < nv && i < ncap;
-    const float uu = in ? utab[row * ncap + i] : -2.f;
-    const float ll = in ? lotab[row * ncap + i] : -2.f;
-    const float n = in ? (cntX ? cntX[(size_t)b * ncap + i] : 32.f) : 0.f;
-    u[v] = uu;
-    m[v] = uu > -1.5f ? n * __expf(fminf((uu - L) * ib, 80.f)) : 0.f;
-    // without counts every non-empty cap is known to hold one row
-    R += ll > -1.5f ? (cntX ? n : 1.f) * __expf(fminf((ll - L) * ib, 0.f)) : 0.f;
+    u[v] = (v < nv && i < ncap) ? utab[row * ncap + i] : -2.f;
   }
-  R = fmaxf(pn_wave_sum(R), 1.f);
-  float lo = -1.5f, hi = L;       // f(lo) = 0 <= budget; the cap attaining L has mass >= its share of R > budget
-  const float budget = 0.9f * rel_eps * R;
-  for (int it = 0; it < 32; ++it) {
-    const float t = 0.5f * (lo + hi);
-    float f = 0.f;
+  float t = 2.f;                  // a cap without rows: its pairs are never set
+  if (rhoQ[row] >= 0.f) {
+    float L = -2.f;
+    for (int e = lane; e < nxb; e += 64) L = fmaxf(L, pm[row * nxb + e]);
+    L = pn_wave_max(L);
+    if (rel_eps < 0.f) {
+      // EXACT pruning (pn_meanshift_x3_nearest_f32: the arg-max of a dot product): every row of the cap has
+      // a candidate with dot >= L, so a candidate cap whose upper bound lies below L cannot hold a row's
+      // maximum — minus the rounding of the fp32 chains the two values are compared in (each within
+      // X3_DOT_ERR of the real dot product of unit rows)
+      t = L - 4.f * X3_DOT_ERR;
+    } else {
+      const float ib = 1.0f / bsq[b];
+      float m[MAXV];
+      float R = 0.f;
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) f += u[v] < t ? m[v] : 0.f;
-    f = pn_wave_sum(f);
-    if (f <= budget) lo = t; else hi = t;
+      for (int v = 0; v < MAXV; ++v) {
+        const int i = lane + 64 * v;
+        const bool in = v < nv && i < ncap;
+        const float uu = u[v];
+        const float ll = in ? lotab[row * ncap + i] : -2.f;
+        const float n = in ? (cntX ? cntX[(size_t)b * ncap + i] : 32.f) : 0.f;
+        m[v] = uu > -1.5f ? n * __expf(fminf((uu - L) * ib, 80.f)) : 0.f;
+        // without counts every non-empty cap is known to hold one row
+        R += ll > -1.5f ? (cntX ? n : 1.f) * __expf(fminf((ll - L) * ib, 0.f)) : 0.f;
+      }
+      R = fmaxf(pn_wave_sum(R), 1.f);
+      float lo = -1.5f, hi = L;   // f(lo) = 0 <= budget; the cap attaining L has mass >= its share of R > budget
+      const float budget = 0.9f * rel_eps * R;
+      // (18 halvings of an interval of at most 2.5: `lo`, the side that is always within the budget, ends within
+      // 1e-5 of the largest admissible threshold)
+      for (int it = 0; it < 18; ++it) {
+        const float tm = 0.5f * (lo + hi);
+        float f = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) f += u[v] < tm ? m[v] : 0.f;
+        f = pn_wave_sum(f);
+        if (f <= budget) lo = tm; else hi = tm;
+      }
+      t = lo;
+    }
   }
-  if (lane == 0) thr[row] = lo;
+  if (lane == 0) thr[row] = t;
+  // the predicate of the cap's pairs (a cap without rows carries U = -2), OR over the x caps 2j, 2j + 1 of a
+  // tile (neighbouring lanes), then over the tile's two q caps (the two waves)
+  bool on[MAXV];
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const bool o = u[v] >= t;
+    const bool other = __shfl_xor((int)o, 1, 64) != 0;     // (every lane takes part: not behind the ||)
+    on[v] = o || other;
+    if (wave == 1) s_on[v][lane] = on[v] ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0 && (lane & 1) == 0 && tq < ntiles) {
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int ux = lane + 64 * v;
+      if (v < nv && ux < ncap)
+        pairs[((size_t)b * ntiles + tq) * ntiles + (ux >> 1)] = (on[v] || s_on[v][lane] != 0) ? 1 : 0;
+    }
+  }
 }
 
 // compact lists; one wave per resident block: [0,nb0) pass 0, [nb0,nb0+nb1) pass 1, then pass 2
@@ -1245,6 +1286,61 @@ __global__ __launch_bounds__(256) void pn_ms3_combine_fwd_kernel(
     rsum[(size_t)b * N + i] = r;
     unorm[(size_t)b * N + i] = nn;
   }
+}
+
+// pn_ms3_combine_fwd_kernel and pn_ms3_tileinfo_kernel of its result in one launch: one workgroup per tile of
+// 32 rows, wave w combines rows 8 w .. 8 w + 7 (the same arithmetic per row: y, rsum, unorm are bit-identical),
+// keeps them in registers and in LDS, and the workgroup forms the tile's caps from there — the plan of the next
+// iteration needs them, and a kernel of its own read the 20 MB iterate back for it (20 + 22 us per iteration).
+__global__ __launch_bounds__(256) void pn_ms3_combine_fwd_info_kernel(
+    const float* __restrict__ opart, const float* __restrict__ rpart, const float* __restrict__ q, int N, int S,
+    const int* __restrict__ offs, int nbp, int nbB, int G, int cmin, float* __restrict__ y,
+    float* __restrict__ rsum, float* __restrict__ unorm, int ntiles, float* __restrict__ cen,
+    float* __restrict__ rho, float* __restrict__ cnt_out) {
+  __shared__ float rows[32][MS_D];
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j0 = t * 32, cnt = min(32, N - j0);
+  float* co = cen + ((size_t)b * ntiles + t) * 2 * MS_D;
+  float* ro = rho + ((size_t)b * ntiles + t) * 2;
+  float* no = cnt_out ? cnt_out + ((size_t)b * ntiles + t) * 2 : nullptr;
+  if (cnt <= 0) {
+    x3_tile_caps_empty(co, ro, no);
+    return;
+  }
+  const int ns = x3_flat_slices(offs, b * nbp + j0 / (32 * X3_WAVES(0)), nbB, G, cmin);
+  float z0[8], z1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = 8 * wave + u, i = j0 + j;
+    z0[u] = z1[u] = 0.f;
+    if (j < cnt) {
+      float o0 = 0.f, o1 = 0.f, r = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float* op = opart + (((size_t)b * S + s) * N + i) * MS_D;
+        o0 += op[lane];
+        o1 += op[lane + 64];
+        r += rpart[((size_t)b * S + s) * N + i];
+      }
+      const float D = 1.0f / r;
+      const size_t base = ((size_t)b * N + i) * MS_D;
+      const float q0 = q[base + lane], q1 = q[base + lane + 64];
+      const float n0 = q0 + (o0 * D - q0), n1 = q1 + (o1 * D - q1);
+      const float nn = sqrtf(pn_wave_sum(n0 * n0 + n1 * n1));
+      z0[u] = n0 / nn;
+      z1[u] = n1 / nn;
+      y[base + lane] = z0[u];
+      y[base + lane + 64] = z1[u];
+      if (lane == 0) {
+        rsum[(size_t)b * N + i] = r;
+        unorm[(size_t)b * N + i] = nn;
+      }
+    }
+    rows[j][lane] = z0[u];
+    rows[j][lane + 64] = z1[u];
+  }
+  __syncthreads();
+  x3_tile_caps(z0, z1, cnt, &rows[0][0], co, ro, no);
 }
 
 __global__ __launch_bounds__(256) void pn_ms3_combine_bwd_kernel(
@@ -1398,7 +1494,6 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   unsigned char* pairs = (unsigned char*)plan;
   int* counts = (int*)((char*)plan + oc);
   int* lists = (int*)((char*)plan + ol);
-  const float logterm = rel_eps > 0.f ? logf((float)N / rel_eps) : 0.f;   // (rel_eps < 0: exact pruning, see pn_ms3_thr_kernel)
   PN_CHECK_ARG(2 * nt <= 2048, "pn_meanshift_x3_plan_f32: N=%d (the threshold search holds <= 2048 caps: N <= 32768)", N);
   // (the scratch of the sweeps sits behind the lists)
   char* scratch = (char*)plan + tot - x3_plan_scratch(B, nt);
@@ -1407,13 +1502,13 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   float* utab = (float*)(scratch + x3_plan_scratch_pm(B, nt) + pn_align_up((size_t)B * 2 * nt * sizeof(float), 256));
   float* lotab = utab + pn_align_up((size_t)B * 2 * nt * 2 * nt * sizeof(float), 256) / sizeof(float);
   const dim3 pgrid(pn_cdiv(2 * nt, 32), pn_cdiv(2 * nt, 32), B);
-  hipLaunchKernelGGL(pn_ms3_pairs_kernel<0>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
-                     pairs, utab, lotab, (const float*)thr);
+  hipLaunchKernelGGL(pn_ms3_pairs_kernel, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, nt, pm, utab, lotab);
+  PN_CHECK_LAUNCH();
   // cntX (rows of every data cap, pn_meanshift_x3_tileinfo_f32) may be NULL: one row per non-empty cap in the
   // row-sum bound, 32 in the dropped mass — still rigorous, keeps more pairs
 #define X3_THR(MV)                                                                                              \
-  hipLaunchKernelGGL(pn_ms3_thr_kernel<MV>, dim3(2 * nt, B), dim3(64), 0, stream, (const float*)utab,           \
-                     (const float*)lotab, (const float*)pm, rhoQ, cntX, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr)
+  hipLaunchKernelGGL(pn_ms3_thr_kernel<MV>, dim3(nt, B), dim3(128), 0, stream, (const float*)utab,              \
+                     (const float*)lotab, (const float*)pm, rhoQ, cntX, bsq, 2 * nt, (int)pgrid.x, rel_eps, thr, pairs)
   if (2 * nt <= 512)
     X3_THR(8);
   else if (2 * nt <= 768)       // N <= 12 288: the benchmark's 626 caps
@@ -1423,8 +1518,6 @@ extern "C" int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, co
   else
     X3_THR(32);
 #undef X3_THR
-  hipLaunchKernelGGL(pn_ms3_pairs_kernel<1>, pgrid, dim3(64), 0, stream, cenQ, rhoQ, cenX, rhoX, bsq, nt, logterm, pm,
-                     pairs, utab, lotab, (const float*)thr);
   PN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pn_ms3_lists_kernel, dim3(nb0 + nb1 + nb2, B), dim3(64), 0, stream, pairs, nt, nb0, nb1, nb2,
                      counts, lists);
@@ -1726,10 +1819,26 @@ extern "C" int pn_meanshift_x3_iter_fwd_f32(const float* q, const void* img_x, c
 }
 
 // The same with a block-sparse plan (pn_meanshift_x3_plan_f32 of THIS q against x; NULL = dense).
+extern "C" int pn_meanshift_x3_iter_fwd_info_f32(const float* q, const void* img_x, const float* bsq, int B,
+                                                 int N, int D, float* opart, float* rpart, float* y,
+                                                 float* rsum, float* unorm, const void* plan, float* cen,
+                                                 float* rho, float* cnt, void* stream_);
 extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img_x, const float* bsq, int B,
                                                  int N, int D, float* opart, float* rpart, float* y,
                                                  float* rsum, float* unorm, const void* plan, void* stream_) {
+  return pn_meanshift_x3_iter_fwd_info_f32(q, img_x, bsq, B, N, D, opart, rpart, y, rsum, unorm, plan, nullptr,
+                                           nullptr, nullptr, stream_);
+}
+
+// ... and, when cen / rho are given, the bounding caps of the result's tiles (pn_meanshift_x3_tileinfo_f32 of y:
+// cen (B,ntiles,2,D), rho (B,ntiles,2), cnt (B,ntiles,2) or NULL) — what the plan of the NEXT iteration takes as
+// its q caps; with a plan they come out of the launch that combines the partial results.
+extern "C" int pn_meanshift_x3_iter_fwd_info_f32(const float* q, const void* img_x, const float* bsq, int B,
+                                                 int N, int D, float* opart, float* rpart, float* y,
+                                                 float* rsum, float* unorm, const void* plan, float* cen,
+                                                 float* rho, float* cnt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG((cen == nullptr) == (rho == nullptr), "pn_meanshift_x3_iter_fwd_info_f32: cen and rho go together");
   PN_CHECK_ARG(q && img_x && bsq && opart && rpart && y && rsum && unorm,
                "pn_meanshift_x3_iter_fwd_f32: null pointer");
   PN_CHECK_ARG(D == MS_D, "pn_meanshift: embedding size %d unsupported (built for %d)", D, MS_D);
@@ -1744,8 +1853,12 @@ extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img
                          pv.offs, pv.nblk, 0, pv.nb0, B * pv.nb0, pv.cmin, pv.smax);
     }
     PN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pn_ms3_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart, rpart, q, N,
-                       pv.smax, pv.offs, pv.nb0, B * pv.nb0, pv.G, pv.cmin, y, rsum, unorm);
+    if (cen)
+      hipLaunchKernelGGL(pn_ms3_combine_fwd_info_kernel, dim3(ntiles, B), dim3(256), 0, stream, opart, rpart, q, N,
+                         pv.smax, pv.offs, pv.nb0, B * pv.nb0, pv.G, pv.cmin, y, rsum, unorm, ntiles, cen, rho, cnt);
+    else
+      hipLaunchKernelGGL(pn_ms3_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart, rpart, q, N,
+                         pv.smax, pv.offs, pv.nb0, B * pv.nb0, pv.G, pv.cmin, y, rsum, unorm);
     PN_CHECK_LAUNCH();
     return PN_OK;
   }
@@ -1766,6 +1879,10 @@ extern "C" int pn_meanshift_x3_iter_fwd_plan_f32(const float* q, const void* img
   hipLaunchKernelGGL(pn_ms_combine_fwd_kernel, dim3(pn_cdiv(N, 4), B), dim3(256), 0, stream, opart,
                      rpart, q, N, S, y, rsum, unorm);
   PN_CHECK_LAUNCH();
+  if (cen) {
+    hipLaunchKernelGGL(pn_ms3_tileinfo_kernel, dim3(ntiles, B), dim3(256), 0, stream, y, N, ntiles, cen, rho, cnt);
+    PN_CHECK_LAUNCH();
+  }
   return PN_OK;
 }
 

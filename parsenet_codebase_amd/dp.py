@@ -7,6 +7,8 @@ import os
 import torch
 import torch.distributed as dist
 
+BUCKET_GATHER = os.environ.get("PARSENET_BUCKET_GATHER", "1") != "0"
+
 
 def usable_cpus():
     """CPUs this process may actually use: the smaller of the visible cores and the cgroup's CFS quota.
@@ -128,13 +130,19 @@ class FlatGradBucket:
         """Start of a step with ONE backward pass: detach the parameters from the bucket.  autograd then hands
         every gradient over as a tensor of its own instead of adding it into a zeroed view — an in-place add per
         parameter, ~75 small launches per cfg5 step (profiles/r04_cfg5_torch_sites.txt: workloads.py step) —
-        and ``gather()`` moves them into the bucket with one multi-tensor copy."""
+        and ``gather()`` moves them into the bucket with one multi-tensor copy.
+        (PARSENET_BUCKET_GATHER=0, developer A/B: the old form — zero the bucket, autograd adds into the views.)"""
+        if not BUCKET_GATHER:
+            self.zero()
+            return
         for p in self.params:
             p.grad = None
 
     def gather(self):
         """After the backward pass of a ``begin()`` step: all gradients into the flat bucket (one multi-tensor
         copy), ``p.grad`` are its views again.  A parameter that received no gradient keeps a zero slot."""
+        if not BUCKET_GATHER:
+            return self.flat
         dst, src, now = [], [], set()
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             g = p.grad

@@ -496,9 +496,10 @@ def meanshift_x3_plan_visited(plans, B, N):
     return torch.stack([p[:n].sum(dtype=torch.float32) for p in plans]).mean() / float(n)
 
 
-def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None, out=None):
+def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None, out=None, want_info=False):
     """``out`` = (y (B,N,D), rsum (B,N), unorm (B,N)) contiguous fp32 tensors to write into (slices of
-    the buffers that keep all iterates of a call together), or None: allocated here."""
+    the buffers that keep all iterates of a call together), or None: allocated here.  ``want_info``: also
+    return meanshift_x3_tileinfo(y) — the caps come out of the launch that combines the partial results."""
     B, N, D = q.shape
     if out is not None:
         y, rsum, unorm = out
@@ -509,12 +510,20 @@ def meanshift_x3_iter_fwd(q, x_image, bsq, ws, plan=None, out=None):
         y = torch.empty_like(q)
         rsum = torch.empty((B, N), dtype=torch.float32, device=q.device)
         unorm = torch.empty((B, N), dtype=torch.float32, device=q.device)
+    info = None
+    if want_info:
+        T = (N + 63) // 64 * 2
+        info = (torch.empty((B, T, 2, D), dtype=torch.float32, device=q.device),
+                torch.empty((B, T, 2), dtype=torch.float32, device=q.device),
+                torch.empty((B, T, 2), dtype=torch.float32, device=q.device))
     with _lib.on_device(q.device):
-        rc = _lib.load().pn_meanshift_x3_iter_fwd_plan_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
+        rc = _lib.load().pn_meanshift_x3_iter_fwd_info_f32(ptr(q), ptr(x_image), ptr(bsq), B, N, D, ptr(ws.opart),
                                                            ptr(ws.rpart), ptr(y), ptr(rsum), ptr(unorm),
-                                                           ptr(plan), current_stream(q.device))
-    check(rc, "pn_meanshift_x3_iter_fwd_plan_f32")
-    return y, rsum, unorm
+                                                           ptr(plan), ptr(info[0]) if info else None,
+                                                           ptr(info[1]) if info else None,
+                                                           ptr(info[2]) if info else None, current_stream(q.device))
+    check(rc, "pn_meanshift_x3_iter_fwd_info_f32")
+    return (y, rsum, unorm, info) if want_info else (y, rsum, unorm)
 
 
 def meanshift_x3_iter_bwd(gy, y, q, x, x_image, rsum, unorm, bsq, ws, gx, plan=None):

@@ -177,14 +177,16 @@ def _run_iterations(X, bsq, iterations, stacked=False, rel_eps=None):
     plans_buf, plan_slots, plan_core = K.meanshift_x3_plan_buffer(B, N, iterations, x.device) \
         if sparse and iterations > 0 else (None, None, 0)
     q = x
+    q_info = x_info          # (the first iterate IS the data: its caps are x_info)
     for it in range(iterations):
         out = (it_all[it + 1], rs_all[it], nr_all[it]) if direct else None
         if sparse:
-            # (the first iterate IS the data: its caps are x_info)
-            plan = K.meanshift_x3_plan(x_info if it == 0 else K.meanshift_x3_tileinfo(q), x_info, bsq, N,
-                                       PLAN_REL_EPS if rel_eps is None else rel_eps, out=plan_slots[it])
+            plan = K.meanshift_x3_plan(q_info, x_info, bsq, N, PLAN_REL_EPS if rel_eps is None else rel_eps,
+                                       out=plan_slots[it])
             plans.append(plan)
-            q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan, out=out)
+            # (the caps of the new iterate — the next plan's, and the nearest-point search's at the end — come
+            # out of the launch that combines the partial results)
+            q, r, n, q_info = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, plan, out=out, want_info=True)
         elif x3 is not None and ARITH == "bf16x3":
             q, r, n = K.meanshift_x3_iter_fwd(q, x3, bsq, ws, None, out=out)
         elif x3 is not None:
@@ -197,7 +199,7 @@ def _run_iterations(X, bsq, iterations, stacked=False, rel_eps=None):
     global LAST_PLAN_STATS, AUTO_STAT, LAST_NEAREST
     LAST_NEAREST = None
     if sparse and WANT_NEAREST and iterations > 0:
-        LAST_NEAREST = K.meanshift_x3_nearest(x, q, x_info, K.meanshift_x3_tileinfo(q), perm)
+        LAST_NEAREST = K.meanshift_x3_nearest(x, q, x_info, q_info, perm)
     if sparse and os.environ.get("PARSENET_MS_STATS") == "1":
         LAST_PLAN_STATS = [K.meanshift_x3_plan_stats(p, B, N) for p in plans]
     if sparse and SPARSE == "auto" and plans:

@@ -199,3 +199,27 @@ def test_frozen_splinenet_head_weighted_max(gpu):
     net.bn5.weight.requires_grad = False
     assert _rel(res[0][0], res[1][0]) < 5e-6
     assert _rel(res[0][1], res[1][1]) < 5e-5
+
+
+def test_weighted_max_backward_adds_shared_points_in_channel_order(gpu):
+    """pn_weighted_max_bwd_f32: gw[s][n] = the terms g * val of the channels whose arg-max is n, added one
+    after the other in channel order (what a serial loop does) — bit for bit, with most channels of a chunk
+    of 64 naming one of a few points (the in-wave resolution), others a point of their own (the direct
+    path), and a channel count that is not a multiple of 64."""
+    from parsenet_codebase_amd import kernels as K
+    rng = np.random.RandomState(2)
+    S, C, N = 3, 1024 + 37, 700
+    idx = rng.randint(0, N, (S, C)).astype(np.int32)
+    hot = rng.rand(S, C) < 0.45
+    idx[hot] = rng.choice([5, 6, 311, 699], int(hot.sum())).astype(np.int32)
+    idx[1, 64:128] = 17                                  # a whole chunk on one point
+    idx[2, 200:264] = np.arange(64)                      # a chunk without any shared point
+    g = rng.standard_normal((S, C)).astype(np.float32)
+    val = rng.standard_normal((S, C)).astype(np.float32)
+    want = np.zeros((S, N), np.float32)
+    for s in range(S):
+        for c in range(C):
+            want[s, idx[s, c]] = np.float32(want[s, idx[s, c]] + np.float32(g[s, c] * val[s, c]))
+    got = K.weighted_max_bwd(torch.from_numpy(g).to(gpu), torch.from_numpy(idx).to(gpu),
+                             torch.from_numpy(val).to(gpu), N).cpu().numpy()
+    assert np.array_equal(got, want)

@@ -576,3 +576,29 @@ def test_centre_rows_backward_against_the_fp64_reference(gpu, monkeypatch):
     (c * w.to(gpu)).sum().backward()
     assert _rel(c, torch.stack(outs)) < 1e-5
     assert _rel(xg.grad, xr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("N", [4100, 10000])
+def test_caps_of_the_new_iterate_come_out_of_the_combining_launch(gpu, N):
+    """pn_meanshift_x3_iter_fwd_info_f32: iterate, row sums and norms equal the plain planned launch bit for bit,
+    and the caps it returns equal pn_meanshift_x3_tileinfo_f32 of that iterate bit for bit (N = 4 100: the last
+    tile holds 4 rows and a padding tile follows)."""
+    from parsenet_codebase_amd import kernels as K
+    torch.cuda.set_device(gpu)
+    B = 2
+    X = torch.stack([_clustered(N, 7, 3 + b)[0] for b in range(B)]).to(gpu)
+    bsq = torch.tensor([0.09 ** 2, 0.13 ** 2], device=gpu)
+    x3 = K.meanshift_x3_split(X)
+    ws = K.MeanShiftWorkspace(B, N, 128, X.device)
+    info = K.meanshift_x3_tileinfo(X)
+    plan = K.meanshift_x3_plan(info, info, bsq, N, 1e-6)
+    y0, r0, n0 = K.meanshift_x3_iter_fwd(X, x3, bsq, ws, plan)
+    y1, r1, n1, got = K.meanshift_x3_iter_fwd(X, x3, bsq, ws, plan, want_info=True)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1) and torch.equal(n0, n1)
+    want = K.meanshift_x3_tileinfo(y0)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # dense launch (no plan): the caps come from the tile-info kernel behind it
+    y2, _, _, got2 = K.meanshift_x3_iter_fwd(X, x3, bsq, ws, None, want_info=True)
+    for a, b in zip(got2, K.meanshift_x3_tileinfo(y2)):
+        assert torch.equal(a, b)

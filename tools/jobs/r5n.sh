@@ -15,3 +15,7 @@ cd $GRAFT_REPO_ROOT
 T=$(find $O/tr -name "b_kernel_trace.csv" | head -1)
 python tools/step_breakdown.py $T 5 detail > $O/breakdown_detail.txt 2>&1
 rm -rf $O/tr
+# cfg2 / cfg3 / cfg4: gradients gathered into the bucket (default) against added into its views, alternating
+for i in 1 2 3; do for G in 1 0; do for W in cfg2 cfg3; do
+  PARSENET_BUCKET_GATHER=$G timeout 300 python bench.py --workload $W --no-cpu-baseline --profile-steps 0 --steps 40 --warmup 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$W gather=$G', round(d['value'],1), round(d['ms_per_step'],3))" | tee -a $O/bucket_ab.txt
+done; done; done
