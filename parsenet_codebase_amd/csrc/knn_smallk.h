@@ -28,12 +28,19 @@
 // how many entries the flushes process in all does not depend on the trigger (measured on a
 // host model: 170 +- 10 entries per 157 tiles for triggers of 4 ... 16), so the capacity is chosen for the
 // LDS budget: 8 bytes per entry, one more slot per lane as the target of candidates that do not pass.
-template <int KSX>
+template <int KSX, int KK, int NW_>
 struct KskCfg {
   // tiles per stage: the narrow instances (3 ... 7 channels) form a tile in ~300 cycles, far less than the
   // latency of the DMA that stages the next one — they stage four tiles at a time
   static constexpr int TPS = KSX <= 4 ? 4 : 1;
-  static constexpr int CAP = KSX == 65 ? 22 : 24;   // 65 k-steps: 33.3 + 46 KiB, two workgroups per CU
+  // waves per workgroup (32 queries each).  The 256-channel instance holds its 129 query operands in registers
+  // and its two tile buffers are 66 KiB: four waves = ONE wave per SIMD, and a single chain of dependent
+  // v_mfma_f32_32x32x2_f32 issues every ~82 cycles instead of every 64 (phase timers, tools/probes/ksk_timers.py:
+  // 10 500 cycles per tile of 129 k-steps).  Eight waves share the tiles — two per SIMD, 256 registers each —
+  // when the segments are long enough to fill the chip with 256-query workgroups (ksk_plan).
+  static constexpr int NW = NW_;
+  // 65 k-steps: 33.3 + 46 KiB, two workgroups per CU;  129 k-steps, eight waves: 64.5 + 84 KiB, one
+  static constexpr int CAP = NW == 8 ? 20 : (KSX == 65 ? 22 : 24);
 };
 
 template <int KK>
@@ -67,6 +74,22 @@ __device__ static inline void ksk_insert_key(KskList<KK>& L, float v, int j) {
     L.v[i] = ci ? iv : L.v[i];
     L.j[i] = ci ? ij : L.j[i];
   }
+}
+
+// The KK-th best value of a QUERY = of the union of the sorted lists of its two lanes (l, l + 32):
+//   max( b[KK-1], a[KK-1], max_{i = 1 .. KK-1} min(a[i-1], b[KK-1-i]) )     (a, b descending)
+// — the threshold both lanes may use: KK candidates of the query are already at least this good and precede
+// everything still to come in index order, so a later candidate has to BEAT it.  A lane's own KK-th value
+// is the query's ~2 KK-th: with it the lanes buffered about twice as many candidates in the steady state.
+template <int KK>
+__device__ static inline float ksk_union_kth(const KskList<KK>& L) {
+  float b[KK];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) b[i] = __shfl_xor(L.v[i], 32, 64);
+  float kth = __builtin_fmaxf(L.v[KK - 1], b[KK - 1]);
+#pragma unroll
+  for (int i = 1; i < KK; ++i) kth = __builtin_fmaxf(kth, __builtin_fminf(L.v[i - 1], b[KK - 1 - i]));
+  return kth;
 }
 
 // K0 of this path: xp (B, 2 KSX, Np), channel-first in ORIGINAL order: rows 0 .. C-1 the channels, zero rows,
@@ -142,15 +165,15 @@ extern "C" int pn_knn_smallk_timers(unsigned long long* host8, int reset) {
 #define KT_ADD(I, T0) (void)(T0)
 #endif
 
-template <int KSX, int KK>
-__global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restrict__ xp, int N, int Np,
+template <int KSX, int KK, int NW>
+__global__ __launch_bounds__(64 * NW) void pn_knn_smallk_kernel(const float* __restrict__ xp, int N, int Np,
                                                             int stages_per_slice, int k, u64* __restrict__ lists,
                                                             void* __restrict__ out, int out32) {
   constexpr int CPX = 2 * KSX;
-  constexpr int TPS = KskCfg<KSX>::TPS;
+  constexpr int TPS = KskCfg<KSX, KK, NW>::TPS;
   constexpr int TILE = CPX * 32;            // floats of one tile: [CPX rows][32 candidates]
   constexpr int STAGE = TILE * TPS;
-  constexpr int CAP = KskCfg<KSX>::CAP;
+  constexpr int CAP = KskCfg<KSX, KK, NW>::CAP;
   constexpr int SLOTS = CAP + 1;
   // dynamic LDS: [2][STAGE] floats of candidate tiles, then per wave [SLOTS][64] accumulators and
   // [SLOTS][64] indices (the two stores of an entry are SLOTS * 256 bytes apart: one ds_write2st64_b32)
@@ -161,9 +184,9 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, h = lane >> 5;
-  const int q = (blockIdx.y * 4 + wave) * 32 + col;
+  const int q = (blockIdx.y * NW + wave) * 32 + col;
   const int qcl = q < Np ? q : Np - 1;
-  const bool wave_on = (blockIdx.y * 4 + wave) * 32 < N;
+  const bool wave_on = (blockIdx.y * NW + wave) * 32 < N;
   const float* __restrict__ xb = xp + (size_t)b * CPX * Np;
   const int ntiles = (N + 31) / 32;
   const int nstages = (ntiles + TPS - 1) / TPS;
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
   // flush together: a wave that has to flush says so in flag[tile mod 3]; behind the barrier of the tile all
   // four waves flush.  (A flush of one wave holds the other three at the next barrier, so four flushes at four
   // different tiles cost the workgroup four times what one common flush costs.)
-  ksk_lds_int* const flag = (ksk_lds_int*)(buf + 4 * (2 * SLOTS * 64));
+  ksk_lds_int* const flag = (ksk_lds_int*)(buf + NW * (2 * SLOTS * 64));
   if (tid < 3) flag[tid] = 0;   // (three flags: the one cleared during tile t was last read behind barrier t - 2)
 
   typedef const __attribute__((address_space(1))) void* ks_gptr;
@@ -209,7 +232,7 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
     _Pragma("unroll") for (int tt = 0; tt < TPS; ++tt) {                                                    \
       const int j0s = min(((ST) * TPS + tt) * 32, Np - 32);                                                 \
       _Pragma("unroll") for (int c = 0; c < NCHUNK; ++c) {                                                  \
-        if (((c + tt * NCHUNK) & 3) == wave) {                                                              \
+        if (((c + tt * NCHUNK) & (NW - 1)) == wave) {                                                              \
           const int row = c * 8 + (lane >> 3);                                                              \
           if (row < CPX)                                                                                    \
             __builtin_amdgcn_global_load_lds((ks_gptr)(xb + (size_t)row * Np + j0s + ((lane & 7) << 2)),    \
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
       fj_ = nj_;                                                                  \
     }                                                                             \
     wp = bbase;                                                                   \
-    const float s_ = L.v[KK - 1] + xxq;                                           \
+    const float s_ = ksk_union_kth<KK>(L) + xxq;                                  \
     a_lo = __builtin_fmaf(-__builtin_fabsf(s_), 0x1p-22f, 0.5f * s_);             \
   }
   // one row of the previous tile: threshold test on the accumulator, branch-free append
@@ -273,29 +296,41 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
         constexpr int NG = 16 <= KSX ? 16 : 1;
         constexpr int REST = KSX - PER * NG;     // the norm step (and nothing else) of the wide instances
         static_assert(REST <= PER, "the norm step rides in the operand registers of a group");
-        float a_cur[PER], a_nxt[PER];
+        // (two waves per SIMD, 256 registers each: no second operand group — the other wave's MFMAs cover the
+        // reads)
+        constexpr bool AHEAD = NW == 4;
+        float a_cur[PER], a_nxt[AHEAD ? PER : 1];
 #pragma unroll
-        for (int p = 0; p < PER; ++p) {
-          a_cur[p] = lx[(2 * p + h) * 32 + col];
-          a_nxt[p] = 0.f;
-        }
+        for (int p = 0; p < (AHEAD ? PER : 1); ++p) a_nxt[p] = 0.f;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) a_cur[p] = lx[(2 * p + h) * 32 + col];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          if (g + 1 < NG) {
+          if (AHEAD) {
+            if (g + 1 < NG) {
 #pragma unroll
-            for (int p = 0; p < PER; ++p) a_nxt[p] = lx[(2 * ((g + 1) * PER + p) + h) * 32 + col];
-          } else {
+              for (int p = 0; p < PER; ++p) a_nxt[AHEAD ? p : 0] = lx[(2 * ((g + 1) * PER + p) + h) * 32 + col];
+            } else {
 #pragma unroll
-            for (int p = 0; p < REST; ++p) a_nxt[p] = lx[(2 * (NG * PER + p) + h) * 32 + col];
+              for (int p = 0; p < REST; ++p) a_nxt[AHEAD ? p : 0] = lx[(2 * (NG * PER + p) + h) * 32 + col];
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int p = 0; p < PER; ++p)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[p], bq[g * PER + p], acc, 0, 0, 0);
-          if (KSX >= 16) KS_ROW(g);
+          if (KSX >= 16 && AHEAD) KS_ROW(g);
           __builtin_amdgcn_sched_barrier(0);
+          if (AHEAD) {
 #pragma unroll
-          for (int p = 0; p < PER; ++p) a_cur[p] = a_nxt[p];
+            for (int p = 0; p < PER; ++p) a_cur[p] = a_nxt[AHEAD ? p : 0];
+          } else if (g + 1 < NG) {
+#pragma unroll
+            for (int p = 0; p < PER; ++p) a_cur[p] = lx[(2 * ((g + 1) * PER + p) + h) * 32 + col];
+          } else {
+#pragma unroll
+            for (int p = 0; p < REST; ++p) a_cur[p] = lx[(2 * (NG * PER + p) + h) * 32 + col];
+          }
         }
 #pragma unroll
         for (int p = 0; p < REST; ++p)
@@ -306,6 +341,14 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_kernel(const float* __restr
         }
         accp = acc;
         jp = (st * TPS + tt) * 32 + 4 * h;
+        if (!AHEAD) {
+          // two waves per SIMD: the rows of THIS tile right behind its MFMAs (the other wave's chain runs
+          // meanwhile) — no second set of accumulators
+#pragma unroll
+          for (int r = 0; r < 16; ++r) KS_ROW(r);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accp[r] = -__builtin_inff();
+        }
         if (TPS > 1) {
           if (__ballot(wp > bbase + (CAP - 16) * 64) != 0ull) KS_FLUSH();
         }
@@ -410,18 +453,24 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_merge_kernel(const u64* __r
   }
 }
 
-template <int KSX>
+template <int KSX, int KK, int NW>
 static size_t ksk_smem_bytes_t() {
-  return (size_t)2 * (2 * KSX * 32) * KskCfg<KSX>::TPS * 4 + (size_t)4 * 2 * (KskCfg<KSX>::CAP + 1) * 64 * 4 + 16;
+  typedef KskCfg<KSX, KK, NW> Cfg;
+  return (size_t)2 * (2 * KSX * 32) * Cfg::TPS * 4 + (size_t)NW * 2 * (Cfg::CAP + 1) * 64 * 4 + 16;
 }
-static size_t ksk_smem_bytes(int ksx) {
-  return ksx == 2 ? ksk_smem_bytes_t<2>() : ksx == 4 ? ksk_smem_bytes_t<4>() : ksx == 33 ? ksk_smem_bytes_t<33>()
-         : ksx == 65 ? ksk_smem_bytes_t<65>() : ksk_smem_bytes_t<129>();
+template <int KK>
+static size_t ksk_smem_bytes_k(int ksx, int nw) {
+  return ksx == 2 ? ksk_smem_bytes_t<2, KK, 4>() : ksx == 4 ? ksk_smem_bytes_t<4, KK, 4>()
+         : ksx == 33 ? ksk_smem_bytes_t<33, KK, 4>() : ksx == 65 ? ksk_smem_bytes_t<65, KK, 4>()
+         : (nw == 8 ? ksk_smem_bytes_t<129, KK, 8>() : ksk_smem_bytes_t<129, KK, 4>());
+}
+static size_t ksk_smem_bytes(int ksx, int kk, int nw) {
+  return kk == 10 ? ksk_smem_bytes_k<10>(ksx, nw) : ksk_smem_bytes_k<16>(ksx, nw);
 }
 
 struct KskPlan {
   bool ok;
-  int ksx, Np, S, stages_per_slice, KK;
+  int ksx, Np, S, stages_per_slice, KK, nw;
   size_t xp, lists, total;
 };
 
@@ -441,11 +490,14 @@ static KskPlan ksk_plan(int mode, int B, int C, int N, int k) {
   p.KK = k <= 10 ? 10 : 16;
   const int tps = p.ksx <= 4 ? 4 : 1;
   const int nstages = pn_cdiv(pn_cdiv(N, 32), tps);
-  const long long wgs = (long long)B * pn_cdiv(N, 128);
+  // waves per workgroup: eight for the 256-channel instance on segments of >= 2 048 points (B = 32 patches of
+  // 700 points measured 0.26 against 0.23 ms with eight: 96 workgroups of 256 queries do not fill the chip)
+  p.nw = (p.ksx == 129 && p.KK == 10 && N >= 2048) ? 8 : 4;
+  const long long wgs = (long long)B * pn_cdiv(N, 32 * p.nw);
   // Slices of the candidate range: whole rounds over the CU slots (two workgroups per CU while the LDS allows,
   // one for the 256-channel instance), against the cold start every slice pays — its first ~50 candidates per
   // lane all pass: ~11 600 cycles of insertions, in units of a stage's duration.
-  const long long slots = 256 * (ksk_smem_bytes(p.ksx) <= 80 * 1024 ? 2 : 1);
+  const long long slots = 256 * (ksk_smem_bytes(p.ksx, p.KK, p.nw) <= 80 * 1024 ? 2 : 1);
   const double stage_cycles = (64.0 * p.ksx + 200.0 < 500.0 ? 500.0 : 64.0 * p.ksx + 200.0) * tps;
   const double cold = 11600.0 / stage_cycles;
   int S = 1;
@@ -484,36 +536,38 @@ static int ksk_run(const KskPlan& p, const float* x, int B, int C, int N, int k,
                        2 * p.ksx, p.Np, xp);
   }
   PN_CHECK_LAUNCH();
-  dim3 grid(p.S, pn_cdiv(N, 128), B);
+  dim3 grid(p.S, pn_cdiv(N, 32 * p.nw), B);
   {
     PN_PROF(p.ksx <= 4 ? "knn_smallk_c4" : (p.ksx == 33 ? "knn_smallk_c64" : "knn_smallk_wide"), stream);
-#define KSK_GO(KS, KK_)                                                                                         \
+#define KSK_GO(KS, KK_, NW_)                                                                                    \
   {                                                                                                             \
-    const size_t smem = ksk_smem_bytes_t<KS>();                                                                 \
+    const size_t smem = ksk_smem_bytes_t<KS, KK_, NW_>();                                                       \
     static bool attr_set = false;   /* (idempotent: a race sets it twice) */                                    \
     if (!attr_set) {                                                                                            \
-      PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pn_knn_smallk_kernel<KS, KK_>),            \
+      PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pn_knn_smallk_kernel<KS, KK_, NW_>),       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                 \
       attr_set = true;                                                                                          \
     }                                                                                                           \
-    hipLaunchKernelGGL((pn_knn_smallk_kernel<KS, KK_>), grid, dim3(256), smem, stream, (const float*)xp, N,     \
-                       p.Np, p.stages_per_slice, k, lists, out, out32);                                         \
+    hipLaunchKernelGGL((pn_knn_smallk_kernel<KS, KK_, NW_>), grid, dim3(64 * NW_), smem, stream,                \
+                       (const float*)xp, N, p.Np, p.stages_per_slice, k, lists, out, out32);                    \
   }
-#define KSK_GO_K(KS)      \
+#define KSK_GO_K(KS, NW_) \
   if (p.KK == 10)         \
-    KSK_GO(KS, 10)        \
+    KSK_GO(KS, 10, NW_)   \
   else                    \
-    KSK_GO(KS, 16)
+    KSK_GO(KS, 16, NW_)
     if (p.ksx == 2) {
-      KSK_GO_K(2);
+      KSK_GO_K(2, 4);
     } else if (p.ksx == 4) {
-      KSK_GO_K(4);
+      KSK_GO_K(4, 4);
     } else if (p.ksx == 33) {
-      KSK_GO_K(33);
+      KSK_GO_K(33, 4);
     } else if (p.ksx == 65) {
-      KSK_GO_K(65);
+      KSK_GO_K(65, 4);
+    } else if (p.nw == 8) {
+      KSK_GO(129, 10, 8);
     } else {
-      KSK_GO_K(129);
+      KSK_GO_K(129, 4);
     }
 #undef KSK_GO_K
 #undef KSK_GO
