@@ -218,6 +218,14 @@ size_t pn_meanshift_x3_plan_bytes(int B, int N);
 /* the part of a plan its consumers read (the rest is scratch of the plan call: plans of T iterations may be placed
  * core_bytes apart in one buffer of T * core + (plan_bytes - core) bytes) */
 size_t pn_meanshift_x3_plan_core_bytes(int B, int N);
+/* Spherical k-means steps of the locality order the block-sparse iterations run on (no counterpart in the
+ * reference: mean-shift, src/mean_shift.py:45-79, is permutation-equivariant and the order is free).
+ * x (B,N,128) unit rows, cen / old (B,K,128); lab (B,N) int32 = arg-max over the centres of the dot product
+ * (ties -> the smaller centre); new centre = normalised sum of the cell's points in index order, the old
+ * centre when the cell is empty.  Deterministic. */
+int pn_kmeans_assign_f32(const float* x, const float* cen, int B, int N, int D, int K, int* lab, void* stream);
+int pn_kmeans_centres_f32(const float* x, const int* lab, const float* old, int B, int N, int D, int K,
+                          float* cen, void* stream);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
                                  void* stream);
 int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,

@@ -21,7 +21,7 @@ c_size_t = ctypes.c_size_t
 c_double = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/parsenet_hip.h one to one
-ABI_VERSION = 17  # pn_abi_version() of the library these signatures describe
+ABI_VERSION = 18  # pn_abi_version() of the library these signatures describe
 
 SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
@@ -83,6 +83,8 @@ SIGNATURES = {
     "pn_meanshift_rows_scatter_add_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_plan_bytes": (c_size_t, [c_int, c_int]),
     "pn_meanshift_x3_plan_core_bytes": (c_size_t, [c_int, c_int]),
+    "pn_kmeans_assign_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_kmeans_centres_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_chain_order_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_tileinfo_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pn_meanshift_x3_plan_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p, c_void_p]),

@@ -15,4 +15,4 @@ extern "C" const char* pn_last_error(void) { return g_err; }
 
 // 2: edge-conv backward takes a workspace, mean-shift backward reduces its partial sums itself,
 //    bf16 x 3 mean-shift entry points
-extern "C" int pn_abi_version(void) { return 17; }
+extern "C" int pn_abi_version(void) { return 18; }

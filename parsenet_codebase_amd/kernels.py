@@ -400,6 +400,34 @@ def meanshift_x3_tileinfo(z):
     return cen, rho, cnt
 
 
+def kmeans_assign(x, cen):
+    """x (B,N,128), cen (B,K,128) -> (B,N) int32: the centre with the largest dot product (ties -> smaller index)."""
+    require_cuda(x, cen)
+    x, cen = _f32c(x, "x"), _f32c(cen, "cen")
+    B, N, D = x.shape
+    lab = torch.empty((B, N), dtype=torch.int32, device=x.device)
+    with _lib.on_device(x.device):
+        rc = _lib.load().pn_kmeans_assign_f32(ptr(x), ptr(cen), B, N, D, cen.shape[1], ptr(lab), current_stream(x.device))
+    check(rc, "pn_kmeans_assign_f32")
+    return lab
+
+
+def kmeans_centres(x, lab, old):
+    """Normalised sums of the points of every cell (lab (B,N) int32 from kmeans_assign); an empty cell keeps
+    ``old`` (B,K,128)."""
+    require_cuda(x, lab, old)
+    x, old = _f32c(x, "x"), _f32c(old, "old")
+    if lab.dtype != torch.int32 or not lab.is_contiguous():
+        raise ValueError("kmeans_centres: lab must be a contiguous int32 tensor")
+    B, N, D = x.shape
+    cen = torch.empty_like(old)
+    with _lib.on_device(x.device):
+        rc = _lib.load().pn_kmeans_centres_f32(ptr(x), ptr(lab), ptr(old), B, N, D, old.shape[1], ptr(cen),
+                                               current_stream(x.device))
+    check(rc, "pn_kmeans_centres_f32")
+    return cen
+
+
 def meanshift_chain_order(sim):
     """sim (B,128,128) similarities of cell centres -> (B,128) int64 position of every cell in the
     greedy nearest-neighbour chain that starts at cell 0."""

@@ -91,6 +91,7 @@ def auto_report(B, N, share):
         st["left"], st["hist"] = AUTO_DENSE_STEPS, []
 
 
+KMEANS_KERNELS = os.environ.get("PARSENET_MS_KMEANS_KERNELS", "1") != "0"   # (0: the tensor-library form, A/B)
 FINE_CELLS = int(os.environ.get("PARSENET_MS_FINE", "384"))    # second-level cells of the locality order (0: off)
 
 
@@ -107,10 +108,16 @@ def locality_order(x, lloyd=2):
     B, N, D = x.shape
     P = 128
 
+    fused = D == 128 and KMEANS_KERNELS      # csrc/kmeans.hip: two launches per Lloyd step instead of a dozen
+
     def assign(pts, cen):
+        if fused:
+            return K.kmeans_assign(pts, cen)                     # int32 (converted once, below)
         return torch.bmm(pts, cen.transpose(1, 2)).argmax(2)
 
     def centres(pts, lab, K_, old):
+        if fused:
+            return K.kmeans_centres(pts, lab, old)
         # one-hot GEMM instead of index_add_: atomics would make the order — and with it the
         # summation order of every later launch — vary from run to run
         hot = torch.nn.functional.one_hot(lab, K_).to(pts.dtype)             # (B,n,K)
@@ -119,7 +126,7 @@ def locality_order(x, lloyd=2):
         return torch.where(nrm > 1e-6, acc / nrm.clamp_min(1e-6), old)      # empty cell: keep its seed
 
     def kmeans(K_):
-        cen = x[:, torch.linspace(0, N - 1, K_, device=x.device).long()]
+        cen = x[:, torch.linspace(0, N - 1, K_, device=x.device).long()].contiguous()
         lab = assign(x, cen)
         for _ in range(lloyd):
             cen = centres(x, lab, K_, cen)
@@ -128,9 +135,10 @@ def locality_order(x, lloyd=2):
     cen, coarse = kmeans(P)
     rank = K.meanshift_chain_order(torch.bmm(cen, cen.transpose(1, 2)))       # (B,P)
     if FINE_CELLS <= P or N < 8 * FINE_CELLS:
-        return torch.argsort(torch.gather(rank, 1, coarse), dim=1, stable=True)
+        return torch.argsort(torch.gather(rank, 1, coarse.long()), dim=1, stable=True)
     cen2, fine = kmeans(FINE_CELLS)
-    home = assign(cen2, cen)                                                   # (B,FINE): coarse cell of a fine centre
+    fine = fine.long()
+    home = assign(cen2, cen).long()                                            # (B,FINE): coarse cell of a fine centre
     key = torch.gather(rank, 1, torch.gather(home, 1, fine)).long() * FINE_CELLS + fine
     return torch.argsort(key, dim=1, stable=True)
 

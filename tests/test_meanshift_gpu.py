@@ -602,3 +602,36 @@ def test_caps_of_the_new_iterate_come_out_of_the_combining_launch(gpu, N):
     y2, _, _, got2 = K.meanshift_x3_iter_fwd(X, x3, bsq, ws, None, want_info=True)
     for a, b in zip(got2, K.meanshift_x3_tileinfo(y2)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,K_", [(10000, 128), (4100, 384), (384, 128)])
+def test_kmeans_kernels_of_the_locality_order(gpu, N, K_):
+    """csrc/kmeans.hip against the tensor expressions they replace: the assignment is the arg-max of the dot
+    products (compared where the two best centres of a point are not within rounding of each other, ties to
+    the smaller index on exactly duplicated centres), the centres are the normalised sums of their cells
+    (an empty cell keeps its old centre); two calls give the same bits."""
+    from parsenet_codebase_amd import kernels as K
+    torch.cuda.set_device(gpu)
+    B = 2
+    x = torch.stack([_clustered(N, 9, 20 + b)[0] for b in range(B)]).to(gpu)
+    cen = x[:, torch.linspace(0, N - 1, K_).long()].contiguous()
+    cen[:, 7] = cen[:, 3]                                        # a duplicated centre: never chosen over its twin
+    lab = K.kmeans_assign(x, cen)
+    assert lab.dtype == torch.int32 and torch.equal(lab, K.kmeans_assign(x, cen))
+    dots = torch.bmm(x.double(), cen.double().transpose(1, 2))
+    top2 = dots.topk(2, dim=2)
+    clear = (top2.values[..., 0] - top2.values[..., 1]) > 1e-5
+    assert float(clear.float().mean()) > 0.9
+    assert torch.equal(lab.long()[clear], top2.indices[..., 0][clear])
+    assert int((lab == 7).sum()) == 0
+    picked = torch.gather(dots, 2, lab.long().unsqueeze(2)).squeeze(2)
+    assert float((top2.values[..., 0] - picked).max()) < 1e-5    # elsewhere: a centre within rounding of the best
+    new = K.kmeans_centres(x, lab, cen)
+    assert torch.equal(new, K.kmeans_centres(x, lab, cen))
+    hot = torch.nn.functional.one_hot(lab.long(), K_).double()
+    acc = torch.bmm(hot.transpose(1, 2), x.double())
+    nrm = acc.norm(dim=2, keepdim=True)
+    want = torch.where(nrm > 1e-6, acc / nrm.clamp_min(1e-6), cen.double())
+    assert float((new.double() - want).abs().max()) < 2e-6
+    empty = (hot.sum(1) == 0)
+    assert bool(empty.any()) and torch.equal(new[empty], cen[empty])      # (the duplicated centre's cell, at least)
