@@ -428,9 +428,13 @@ __global__ __launch_bounds__(256) void pn_knn_smallk_merge_kernel(const u64* __r
 #pragma unroll
   for (int i = 0; i < KK; ++i) best[i] = l[i];
   for (int s = 1; s < S; ++s) {
+    // (the slice's keys first, all loads in flight, then the insertions)
+    u64 in_[KK];
+#pragma unroll
+    for (int e = 0; e < KK; ++e) in_[e] = l[s * KK + e];
 #pragma unroll
     for (int e = 0; e < KK; ++e) {
-      const u64 key = l[s * KK + e];
+      const u64 key = in_[e];
 #pragma unroll
       for (int i = KK - 1; i >= 0; --i) {
         const bool ci = key > best[i];
