@@ -347,6 +347,9 @@ def standardize_segments(P2, w):
     with torch.no_grad():
         hi = w > 0.8
         cnt = hi.sum(1, keepdim=True)
+        # (the top-half fallback is computed unconditionally: deciding on the host whether any segment needs it —
+        # the counts could ride with the covariances — was built in round 5 and costs a second round trip in
+        # EVERY cfg5 step: some spline segment of a batch always has fewer than 400 memberships above 0.8)
         kf = n // 4 if n >= 7500 else n // 2
         top = torch.topk(w, kf, dim=1)[1]
         fb = torch.zeros_like(hi).scatter_(1, top, torch.ones_like(top, dtype=torch.bool))

@@ -364,3 +364,28 @@ def test_sixteen_groups_do_not_recycle_a_download_slot_before_it_is_read(gpu):
     assert float(relerr.max()) <= 2e-5
     for a, b in zip(out[16][2] + out[16][3], out[1][2] + out[1][3]):                    # metrics from the deferred download
         assert (a is None and b is None) or abs(a - b) <= 2e-5 * max(abs(b), 1e-12)
+
+
+def test_standardisation_with_and_without_the_top_half_fallback(gpu):
+    """standardize_segments against the oracle's standardize_point_torch (src/fitting_utils.py:512-553) segment
+    by segment: one segment with thousands of memberships above 0.8 (the common case: the selection is decided
+    without the fallback's sort), one with fewer than 400 (the top half of the memberships is taken instead —
+    the second round trip of the batched form)."""
+    from oracle import ref_fitting as RF
+    from parsenet_codebase_amd.fitting_batch import standardize_segments
+    torch.cuda.set_device(gpu)
+    g = torch.Generator().manual_seed(8)
+    n = 5000
+    P = torch.randn(2, n, 3, generator=g) * torch.tensor([1.0, 0.6, 0.25])
+    w = torch.rand(2, n, generator=g)
+    w[0, :3000] = 0.8 + 0.2 * torch.rand(3000, generator=g)          # 3 000 confident points
+    w[1] = 0.79 * w[1]
+    w[1, :150] = 0.9                                                   # 150: below the 400 of the rule
+    w = w + EPS
+    for segs in ([0], [0, 1]):
+        pts, std, mean, R = standardize_segments(P[segs].to(gpu), w[segs].to(gpu))
+        for i, s in enumerate(segs):
+            p0, s0, m0, R0 = RF.standardize_point_torch(P[s], w[s].reshape(n, 1))
+            assert float((R[i].cpu() - R0).abs().max()) < 1e-5
+            assert float((mean[i].cpu() - m0).abs().max()) < 1e-5 and float((std[i].cpu() - s0.reshape(3)).abs().max()) < 1e-5
+            assert float((pts[i].cpu() - p0).abs().max()) < 1e-4 * float(p0.abs().max())

@@ -22,6 +22,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 sites = collections.Counter()
 counts = collections.Counter()
+ops = collections.Counter()          # (site, operator) -> us
+opn = collections.Counter()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for ev in prof.events():
     if not ev.kernels:
@@ -47,7 +49,12 @@ for ev in prof.events():
         site = "(no frame) " + " < ".join(names[:3])
     sites[site] += t
     counts[site] += n
+    ops[(site, ev.name)] += t
+    opn[(site, ev.name)] += n
 tot = sum(sites.values())
 print("torch-side kernels of one step: %.2f ms in %d launches" % (tot / 1e3, sum(counts.values())))
 for s, t in sites.most_common(45):
     print("%8.3f ms %5d  %s" % (t / 1e3, counts[s], s[:150]))
+print("\nby (site, operator):")
+for (site, name), t in ops.most_common(60):
+    print("%8.3f ms %5d  %-34s %s" % (t / 1e3, opn[(site, name)], name[:34], site[:110]))
