@@ -134,7 +134,7 @@ __global__ void pn_knn_smallk_prep_kernel(const float* __restrict__ x, int C, in
   xpb[(size_t)(CPX - 1) * Np + j] = acc;
 }
 
-// grid (slices, blocks of 128 queries, B); 4 waves, each 32 queries; candidate tiles staged once per
+// grid (slices, blocks of 32 NW queries, B); NW = 4 (or 8: KskCfg) waves, each 32 queries; candidate tiles staged once per
 // workgroup with the LDS DMA like pn_knn_mfma_kernel.  S == 1: out (B, N, k) indices (int64, or int32 when
 // out32); otherwise lists (B, Np, S, KK) keys.
 //
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NW) void pn_knn_smallk_kernel(const float* __r
   ksk_lds_float* const dump = bbase + CAP * 64;
   ksk_lds_float* wp = bbase;
   // flush together: a wave that has to flush says so in flag[tile mod 3]; behind the barrier of the tile all
-  // four waves flush.  (A flush of one wave holds the other three at the next barrier, so four flushes at four
+  // waves flush.  (A flush of one wave holds the others at the next barrier, so four flushes at four
   // different tiles cost the workgroup four times what one common flush costs.)
   ksk_lds_int* const flag = (ksk_lds_int*)(buf + NW * (2 * SLOTS * 64));
   if (tid < 3) flag[tid] = 0;   // (three flags: the one cleared during tile t was last read behind barrier t - 2)

@@ -152,11 +152,12 @@ def test_kth_dot_in_bf16x3_arithmetic(gpu, C, N, K):
 
 @pytest.mark.parametrize("B,C,N,k", [(1, 3, 5000, 10), (2, 64, 5000, 10), (1, 128, 2600, 10), (1, 256, 2111, 10),
                                      (3, 3, 32, 10), (2, 7, 33, 5), (1, 64, 700, 16), (2, 20, 1500, 11), (4, 6, 97, 1),
-                                     (1, 3, 20000, 10)])
+                                     (1, 3, 20000, 10), (2, 200, 1500, 10), (3, 256, 5000, 8)])
 def test_small_k_one_pass_kernel_bit_exact(gpu, B, C, N, k):
     """k <= 16 (the SplineNets' graphs, src/model.py:9-22): one distance pass with the k best of a lane in
     registers (csrc/knn_smallk.h) — sliced candidate ranges merged by the second kernel, a single slice written
-    directly, tails of the last tile, KK = 10 and 16, every channel width — against the C oracle."""
+    directly, tails of the last tile, KK = 10 and 16, every channel width, the 256-channel instance with four
+    (N < 2 048) and with eight waves per workgroup — against the C oracle."""
     from oracle import cbind
     rng = np.random.RandomState(17 * C + N + k)
     x = (rng.uniform(-1, 1, (B, C, N)) * rng.uniform(0.2, 3.0, (B, C, 1))).astype(np.float32)
@@ -174,7 +175,10 @@ def test_small_k_ties_and_the_two_pass_engine_agree(gpu, monkeypatch):
     lat = (rng.randint(-8, 9, (2, 3, 3000)) / 16.0).astype(np.float32)        # many exact ties and duplicates
     coin = np.zeros((1, 64, 2100), np.float32)
     coin[0, :, 1000:] = 0.5
-    for x, k in ((lat, 10), (coin, 10), (lat[:, :, :257], 16)):
+    wide = np.zeros((1, 250, 2100), np.float32)                               # (the eight-wave instance)
+    wide[0, :, 700:] = 0.25
+    wide[0, :7, 1400:] = -0.5
+    for x, k in ((lat, 10), (coin, 10), (lat[:, :, :257], 16), (wide, 10)):
         got = _gpu_knn(x, k, gpu)
         assert np.array_equal(got, cbind.knn(x, k, 0))
         monkeypatch.setenv("PN_KNN_SMALLK", "0")
