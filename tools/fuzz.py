@@ -45,6 +45,25 @@ while time.time() - t0 < budget:
     assert np.array_equal(got, cbind.knn(x, k, 0)), ("knn_x3", os.environ["PN_KNN_X3"], B, C, N, k)
     os.environ.pop("PN_KNN_X3")
     n["knn_x3"] = n.get("knn_x3", 0) + 1
+    # small k (k <= 16): the one-pass kernel of csrc/knn_smallk.h on every instance (2 / 4 / 33 / 65 / 129 k-steps,
+    # four and eight waves, sliced and unsliced candidate ranges), clumped rows, duplicates, lattices of ties
+    C = int(rng.choice([1, 2, 3, 5, 7, 8, 40, 64, 65, 128, 129, 200, 256]))
+    N = int(rng.randint(32, 3200 if C > 128 else 6000))
+    B, k = int(rng.randint(1, 4)), int(rng.randint(1, 17))
+    x = (rng.randn(B, C, N) * rng.choice([0.1, 1.0, 5.0])).astype(np.float32)
+    mode = rng.rand()
+    if mode < 0.3:
+        cen = (rng.randn(B, C, 7) * 3).astype(np.float32)
+        lab = rng.randint(0, 7, (B, N))
+        x = np.take_along_axis(cen, lab[:, None, :].repeat(C, 1), 2) + x * np.float32(rng.choice([0.0, 1e-5, 1e-3, 0.1]))
+    elif mode < 0.5:
+        x = (rng.randint(-4, 5, (B, C, N)) / 8.0).astype(np.float32)
+    if rng.rand() < 0.3:
+        x[:, :, rng.randint(0, N, N // 4)] = x[:, :, :1]
+    x = np.ascontiguousarray(x.astype(np.float32))
+    got = K.knn(torch.from_numpy(x).to(dev), k, "feature", int32=bool(rng.rand() < 0.5)).cpu().numpy()
+    assert np.array_equal(got, cbind.knn(x, k, 0)), ("knn_smallk", B, C, N, k)
+    n["knn_smallk"] = n.get("knn_smallk", 0) + 1
     # points + normals metric
     N = int(rng.randint(60, 1200))
     k = int(rng.randint(1, min(N, 81)))
