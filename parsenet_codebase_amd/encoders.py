@@ -20,13 +20,20 @@ from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
-# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers: OPT-IN
-# (PARSENET_GEMM_X3=1).  As accurate as the rocBLAS fp32 product (tests/test_gemm_gpu.py), 1.2-1.6 x faster per
-# product, but worth +2 % on a cfg3 step and nothing on a cfg5 step so far (profiles/r04_gemm_x3_ab.txt), and a
-# change of the products' rounding trains ANOTHER network over hundreds of steps: the whole-step parity bars
-# (tests/test_parity_fullsize_bwd_gpu.py) and the benchmark's pre-trained state are pinned to the rocBLAS
-# arithmetic.  Below GEMM_X3_MIN_FLOP / GEMM_X3_MIN_ROWS the split images do not pay.
-GEMM_X3 = os.environ.get("PARSENET_GEMM_X3", "0") == "1"
+# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers.  As accurate as the
+# rocBLAS fp32 product (tests/test_gemm_gpu.py), 1.2-2.6 x faster per product.  PARSENET_GEMM_X3:
+#   "frozen" (default, round 5): products with a FROZEN weight only (requires_grad False: the SplineNets inside an
+#            end-to-end step, whose 1152 -> 1024 layer on S x 5 000 points is the step's largest product and runs at
+#            55-90 TFLOP/s in rocBLAS depending on S — 1.06 ms at S = 6, tools/probes/slow_gemm_probe.py); their weight
+#            images are cached, nothing that is trained changes its rounding;
+#   "1"      every product above the thresholds below — also the trained layers: +2 % on a cfg3 step, inside the noise
+#            on cfg5, and a change of the products' rounding trains ANOTHER network over hundreds of steps: the
+#            whole-step parity bars (tests/test_parity_fullsize_bwd_gpu.py) and the benchmark's pre-trained state are
+#            pinned to the rocBLAS arithmetic of the trained layers;
+#   "0"      rocBLAS everywhere.
+# Below GEMM_X3_MIN_FLOP / GEMM_X3_MIN_ROWS the split images do not pay.
+GEMM_X3_MODE = os.environ.get("PARSENET_GEMM_X3", "frozen")
+GEMM_X3 = GEMM_X3_MODE in ("1", "frozen")
 GEMM_X3_MIN_FLOP = float(os.environ.get("PARSENET_GEMM_X3_MIN_GFLOP", "2")) * 1e9
 GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "512"))
 _W_IMAGES = {}          # id(frozen parameter) -> {view: ((version, data_ptr), image)}; entries die with the parameter
@@ -90,6 +97,8 @@ def _gemm_x3_rows_pay(M):
 
 
 def _gemm_x3_pays(w, x):
+    if GEMM_X3_MODE == "frozen" and (w._base if w._base is not None else w).requires_grad:
+        return False
     return (GEMM_X3 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and
             _gemm_x3_rows_pay(w.shape[0]) and w.shape[1] >= 64 and
             2.0 * w.shape[0] * w.shape[1] * x.shape[0] * x.shape[2] >= GEMM_X3_MIN_FLOP)

@@ -52,6 +52,7 @@ def test_conv1x1_forward_and_backward_on_both_paths(gpu, monkeypatch):
     res = {}
     for on in (True, False):
         monkeypatch.setattr(E, "GEMM_X3", on)
+        monkeypatch.setattr(E, "GEMM_X3_MODE", "1" if on else "0")
         conv.zero_grad()
         xi = x.clone().requires_grad_(True)
         y = E.conv1x1(xi, conv)
@@ -61,6 +62,7 @@ def test_conv1x1_forward_and_backward_on_both_paths(gpu, monkeypatch):
     for a, b in zip(res[True], res[False]):
         assert float((a - b).abs().max() / b.abs().max()) < 2e-6
     monkeypatch.setattr(E, "GEMM_X3", True)
+    monkeypatch.setattr(E, "GEMM_X3_MODE", "1")
     with torch.no_grad():
         conv.weight.mul_(2.0)
         y2 = E.conv1x1(x, conv) - conv.bias.view(1, -1, 1)
@@ -91,3 +93,24 @@ def test_frozen_weight_images_follow_the_parameter_not_its_address(gpu, monkeypa
         del conv, y, y2
         gc.collect()
     assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+
+
+def test_default_mode_takes_frozen_weights_only(gpu):
+    """PARSENET_GEMM_X3 unset ("frozen"): a layer whose weight is trained keeps the rocBLAS product (its rounding is
+    what the pre-trained states and the whole-step parity bars are pinned to), a frozen one — the SplineNets inside
+    an end-to-end step — runs on the matrix cores, with the gradient with respect to its input."""
+    from parsenet_codebase_amd import encoders as E
+    assert E.GEMM_X3_MODE == "frozen" and E.GEMM_X3
+    torch.manual_seed(5)
+    conv = torch.nn.Conv1d(1152, 1024, 1).to(gpu)
+    x = torch.randn(2, 1152, 5000, device=gpu, requires_grad=True)
+    y = E.conv1x1(x, conv)
+    assert not y.grad_fn.name().startswith("_WeightGemmX3")
+    conv.requires_grad_(False)
+    yf = E.conv1x1(x, conv)
+    assert yf.grad_fn.name().startswith("_WeightGemmX3")
+    assert float((yf - y).abs().max() / y.abs().max()) < 1e-5       # (1 152 terms per output, two roundings)
+    gy = torch.randn_like(y)
+    g0, = torch.autograd.grad(y, x, gy, retain_graph=True)
+    g1, = torch.autograd.grad(yf, x, gy)
+    assert float((g1 - g0).abs().max() / g0.abs().max()) < 1e-5

@@ -43,7 +43,12 @@ def bench_gemm():
                                 (4, 1024, 256, 10000, "cfg5 mlp1"), (4, 512, 256, 10000, "cfg5 conv1 (local part)"),
                                 (4, 256, 512, 10000, "cfg5 conv2"), (4, 256, 256, 10000, "cfg5 seg_prob1"),
                                 (4, 128, 256, 10000, "cfg5 seg_prob2"), (10, 1024, 512, 2500, "cfg5 open SplineNet conv5"),
-                                (10, 1024, 1152, 2500, "cfg5 closed SplineNet conv5"), (32, 1024, 256, 700, "cfg3 layer 4 half")]:
+                                (10, 1024, 1152, 2500, "cfg5 closed SplineNet conv5"), (32, 1024, 256, 700, "cfg3 layer 4 half"),
+                                (6, 1024, 1152, 5000, "cfg5 SplineNet conv5, 6 segments"),
+                                (3, 1024, 1152, 5000, "cfg5 SplineNet conv5, 3 segments"),
+                                (4, 1024, 1152, 5000, "cfg5 SplineNet conv5, 4 segments"),
+                                (1, 1024, 1152, 5000, "cfg5 SplineNet conv5, 1 segment"),
+                                (5, 1024, 512, 5000, "cfg5 SplineNet layer, 5 segments")]:
         w = torch.randn(M, Kd, device=dev)
         x = torch.randn(B, Kd, N, device=dev)
         img = kernels.gemm_x3_weight_image(w)
