@@ -124,7 +124,7 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     launch configuration (profiles/: FETCH_SIZE and WRITE_SIZE in KB, separate passes; FETCH
     doubled for 16-byte-per-lane reads as the guide's gfx950 correction prescribes).  None if
     the file is not there — bench.py never profiles counters itself (rocprofv3 does, in passes of
-    their own: tools/evidence_round4.sh).  The round-3 / round-4 files were collected inside
+    their own: tools/evidence_round5.sh).  The round-3 / round-4 files were collected inside
     ``bench.py --workload cfg5`` (batched launches of 4 shapes; round 4: ``--profile-only``, i.e. only
     the launches the roofline is quoted on): one for planned launches (256 workgroups), one for dense
     ones; the round-1 files are per shape."""
@@ -135,10 +135,15 @@ def pmc_traffic(kernel_name, arith, shapes_per_launch=1, planned=False):
     scale = float(shapes_per_launch)
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     if arith == "bf16x3" and shapes_per_launch == 4:
-        cand = (["r04_meanshift_x3_planned_cfg5_pmc.csv", "r03_meanshift_x3_planned_cfg5_pmc.csv",
-                 "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
-                ["r04_meanshift_x3_dense_cfg5_pmc.csv", "r03_meanshift_x3_dense_cfg5_pmc.csv",
-                 "r02_meanshift_x3_batch4_pmc.csv"])
+        # (round 5: the planned file of the DEFAULT process — forward-only plans at a bound of 1e-6, the launches the
+        # line times — comes first; the older planned files hold the launches of a process with the dense backward
+        # passes, whose plans at 1e-9 keep more pairs)
+        fwd_only = os.environ.get("PARSENET_MS_ROWS_BWD", "1") != "0"
+        cand = ((["r05_meanshift_x3_planned_fwd_only_cfg5_pmc.csv"] if fwd_only else []) +
+                ["r05_meanshift_x3_planned_cfg5_pmc.csv", "r04_meanshift_x3_planned_cfg5_pmc.csv",
+                 "r03_meanshift_x3_planned_cfg5_pmc.csv", "r02_meanshift_x3_sparse_cfg5_pmc.csv"] if planned else
+                ["r05_meanshift_x3_dense_cfg5_pmc.csv", "r04_meanshift_x3_dense_cfg5_pmc.csv",
+                 "r03_meanshift_x3_dense_cfg5_pmc.csv", "r02_meanshift_x3_batch4_pmc.csv"])
         cand = [c for c in cand if os.path.exists(os.path.join(prof, c)) and
                 "FETCH_SIZE" in open(os.path.join(prof, c)).read()] or cand
         files["bf16x3"] = (next((c for c in cand if os.path.exists(os.path.join(prof, c))), cand[-1]),

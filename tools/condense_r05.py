@@ -87,6 +87,7 @@ for j in ("bench_cfg5", "bench_cfg5_b", "bench_cfg5_c", "bench_cfg4", "bench_cfg
                    "po_stats_bwd": "bench_cfg5_profile_only_dense_backward_under_rocprofv3",
                    "po_stats_dense": "bench_cfg5_profile_only_dense_under_rocprofv3"}.get(j, j)
             open(os.path.join(P, "r05_" + out + ".json"), "w").write(lines[-1] + "\n")
+pmc(["pmc_FETCH_SIZE_rows", "pmc_WRITE_SIZE_rows", "pmc_SQ_rows"], os.path.join(P, "r05_meanshift_x3_planned_fwd_only_cfg5_pmc.csv"), ("pn_ms3_kernel",))
 pmc(["pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_SQ"], os.path.join(P, "r05_meanshift_x3_planned_cfg5_pmc.csv"), ("pn_ms3_kernel",))
 pmc(["pmc_FETCH_SIZE_dense", "pmc_WRITE_SIZE_dense", "pmc_SQ_dense"], os.path.join(P, "r05_meanshift_x3_dense_cfg5_pmc.csv"), ("pn_ms3_kernel",))
 copy("roofline_check.txt", "r05_roofline_check.txt")

@@ -31,6 +31,11 @@ cd /tmp
 PARSENET_MS_SPARSE=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s5 -o b -- python3 $R/bench.py --profile-only > $O/po_stats.json 2> $O/po_stats.err
 cp $(find $O/s5 -name "b_kernel_trace.csv" | head -1) $O/s5_trace.csv 2>/dev/null
 PARSENET_MS_SPARSE=1 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_SQ_rows -o p -- python3 $R/bench.py --profile-only > $O/po_sq_rows.json 2> $O/po_sq_rows.err
+# (HBM traffic of exactly those launches — the forward-only plans at 1e-6 — in passes of their own: what `roofline.traffic`
+#  of the default line quotes)
+for C in FETCH_SIZE WRITE_SIZE; do
+PARSENET_MS_SPARSE=1 timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${C}_rows -o p -- python3 $R/bench.py --profile-only > /dev/null 2> $O/po_${C}_rows.err
+done
 if [ -z "$EVIDENCE_SHORT" ]; then
 # (b) PARSENET_MS_ROWS_BWD=0: the dense backward passes (what a caller with a dense gradient runs) — all three
 #     matrix-core kernels: statistics, SQ counters, FETCH_SIZE and WRITE_SIZE in passes of their own; planned, then dense launches

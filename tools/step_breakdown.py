@@ -26,7 +26,7 @@ groups = collections.OrderedDict([
     ("edge conv / group norm (HIP)", ("pn_edge", "pn_ecb", "pn_gn", "pn_transpose", "pn_moments", "pn_rev_")),
     ("fused glue: triplet / memberships / affine (HIP)", ("pn_triplet", "pn_member", "pn_affine")),
     ("batched fits (HIP)", ("pn_wmom", "pn_primfit", "pn_cone", "pn_prim_residual", "pn_bspline", "pn_chamfer")),
-    ("GEMM (rocBLAS / hipBLASLt)", ("Cijk", "gemm", "rocblas")),
+    ("GEMM (rocBLAS / hipBLASLt; pn_gemm_x3: bf16 x 3)", ("Cijk", "gemm", "rocblas", "pn_gx", "gx_")),
     ("elementwise / reductions / sort (torch)", ("",)),
 ])
 detail = len(sys.argv) > 3 and sys.argv[3] == "detail"
