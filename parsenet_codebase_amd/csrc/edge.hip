@@ -438,6 +438,10 @@ extern "C" size_t pn_edgeconv_reduce_workspace(int B, int N, int Cout, int group
 // wave), so the chip wants all the waves it can hold — eight per SIMD — before a wave gets a second point;
 // 16 points per wave (the round-3 value) left 2.5 waves per SIMD at B = 4, N = 10 000.
 static int ec_points_per_wave(int B, int N) {
+  if (const char* e = getenv("PN_EC_PPW")) {       // developer override (a power of two in [EC_PPW_MIN, EC_PPW_MAX])
+    const int v = atoi(e);
+    if (v >= EC_PPW_MIN && v <= EC_PPW_MAX && (v & (v - 1)) == 0) return v;
+  }
   int ppw = (int)(((long long)B * N) / 8192);
   int p = EC_PPW_MIN;
   while (p * 2 <= ppw && p < EC_PPW_MAX) p *= 2;
