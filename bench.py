@@ -431,7 +431,9 @@ def launch_ranks(gpus):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    # the CPUs this job may USE (cgroup quota: 16 of 256 visible on this pool), not the visible ones
+    from parsenet_codebase_amd.dp import usable_cpus
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // gpus)))
     rc = subprocess.call(cmd, env=env)
     if rc != 0:
         print("bench.py: a rank failed (torch.distributed.run exit status %d)" % rc, file=sys.stderr)
@@ -495,6 +497,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
     if stub:
         device = torch.device("cpu")
+    multi = dp.multi_rank()     # several ranks, or PARSENET_FORCE_COLLECTIVE=1 (the RCCL path on one GPU)
     import copy
     import numpy as np
 
@@ -505,7 +508,7 @@ def main():
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         sync()
 
@@ -537,7 +540,7 @@ def main():
         own = time.perf_counter() - t0
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -612,7 +615,7 @@ def main():
     census = None
     if ms_mode is not None:
         tally = torch.tensor([calls_timed["planned"], calls_timed["dense"]], dtype=torch.float64, device=device)
-        if world > 1:     # ONE decision for all ranks: the steps below contain collectives
+        if multi:     # ONE decision for all ranks: the steps below contain collectives
             dist.all_reduce(tally)
         mostly_planned = bool(tally[0] > tally[1])
         _ms.SPARSE = mostly_planned
@@ -660,7 +663,7 @@ def main():
             cpu = cpu_baseline(args.workload, start["model"] if args.workload == "cfg5" else None,
                                "the GPU side's pre-trained state_dict" if args.workload == "cfg5"
                                else "random-init weights")
-    if world > 1:
+    if multi:
         dist.barrier()
 
     if rank == 0:
@@ -674,7 +677,7 @@ def main():
             "value": None if elapsed is None else shapes / elapsed,
             "unit": "shapes/s",
             "n_gpus": world,
-            "world_size_observed": dist.get_world_size() if world > 1 else 1,
+            "world_size_observed": dist.get_world_size() if multi else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": None if elapsed is None else 1e3 * elapsed / args.steps,
@@ -689,6 +692,8 @@ def main():
             "host": {"threads": args.host_threads or _HOST_THREADS_AT_START, "usable_cpus": dp.usable_cpus(),
                      "visible_cores": os.cpu_count()},
             "config": dict(cfg, parallelism="dp%d" % world, global_batch=step.shapes_per_step() * world,
+                           **({"collective": "forced on one rank (PARSENET_FORCE_COLLECTIVE=1)"}
+                              if dp.collective_forced() and world == 1 else {}),
                            **({"meanshift_products": _ms_arith()} if args.workload == "cfg5" else {})),
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -706,7 +711,7 @@ def main():
             out["value_dense"] = shapes / elapsed_dense
             out["ms_per_step_dense"] = 1e3 * elapsed_dense / args.steps
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -10,6 +10,21 @@ import torch.distributed as dist
 BUCKET_GATHER = os.environ.get("PARSENET_BUCKET_GATHER", "1") != "0"
 
 
+def collective_forced():
+    """PARSENET_FORCE_COLLECTIVE=1: run the data-parallel machinery — process group, rank-0 broadcast, status
+    agreement, gradient all-reduce, barriers — even with ONE rank.  A one-GPU box can then execute the RCCL code
+    path the 8-GPU job takes (tests/test_rccl_world1_gpu.py); the result equals the plain step bit for bit (a sum
+    over one rank, divided by 1)."""
+    return os.environ.get("PARSENET_FORCE_COLLECTIVE", "0") == "1"
+
+
+def multi_rank():
+    """True when the step's collectives must run: a process group with more than one rank, or a forced one."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or collective_forced()
+
+
 def usable_cpus():
     """CPUs this process may actually use: the smaller of the visible cores and the cgroup's CFS quota.
     The boxes of this pool show 256 cores and grant 16 (``cpu.max`` = 1600000 100000)."""
@@ -69,7 +84,7 @@ def init_from_env(backend=None):
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or collective_forced()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if device.type == "cuda" else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -160,7 +175,7 @@ class FlatGradBucket:
         return self.flat
 
     def _multi(self):
-        return self.collective and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return self.collective and multi_rank()
 
     def any_rank_failed(self, failed):
         """True if ``failed`` is set on ANY rank.  A rank whose fitting stage raises must not skip the

@@ -97,7 +97,7 @@ def sync_module_from_rank0(*modules):
     """Every rank must hold ONE set of weights (the reference's DataParallel replicates rank 0's
     module each step, train_parsenet.py:90-91): broadcast all parameters and buffers from rank 0
     as one flat fp32 collective (plus one per other dtype).  No-op on a single rank."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not dp.multi_rank():
         return
     tensors = []
     for m in modules:
@@ -193,7 +193,7 @@ class ReduceLROnPlateau:
 
 def _mean_over_ranks(value, device):
     """Mean of a python float over ranks (nan-aware), so that every rank decides alike."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not dp.multi_rank():
         return float(value)
     ok = 0.0 if np.isnan(value) else 1.0
     t = torch.tensor([0.0 if np.isnan(value) else float(value), ok], dtype=torch.float64, device=device)
@@ -371,7 +371,7 @@ def accumulate_or_skip(bucket, optimizer, num_iter, micro, world=1, device=None,
                 on_exception(str(e))
             mistake = True
             break
-    if world > 1:   # a skipped step must be skipped by every rank (the all-reduce is collective)
+    if world > 1 or dp.multi_rank():   # a skipped step must be skipped by every rank (the all-reduce is collective)
         flag = torch.tensor([1.0 if mistake else 0.0], device=device)
         dist.all_reduce(flag)
         mistake = bool(flag.item() > 0)

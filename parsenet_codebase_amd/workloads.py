@@ -24,7 +24,8 @@ def train_on_rank0_then_broadcast(model, bucket, train):
     broadcast per dtype (trainer.sync_module_from_rank0).  On a single rank: just ``train()``."""
     import torch.distributed as dist
     from .trainer import sync_module_from_rank0
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    from .dp import multi_rank
+    multi = multi_rank()
     if not multi:
         return train()
     if dist.get_rank() == 0:

@@ -201,6 +201,26 @@ def test_bench_whole_control_flow_on_two_gloo_ranks():
     assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 1
 
 
+def test_bench_forced_collective_on_one_gloo_rank():
+    """PARSENET_FORCE_COLLECTIVE=1 with WORLD_SIZE=1: the process group is created, the rank-0 pre-training +
+    broadcast, the status agreement, the gradient all-reduce and the barriers all run on the single rank (the CPU
+    twin of tests/test_rccl_world1_gpu.py, which does the same with RCCL on the GPU box) and the line says so."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PARSENET_FORCE_COLLECTIVE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stub", "--steps", "3",
+                        "--warmup", "1", "--pretrain", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["world_size_observed"] == 1 and rec["value"] > 0
+    assert rec["config"]["collective"].startswith("forced on one rank")
+
+
 def test_bench_step_is_dropped_on_every_rank_when_one_rank_raises():
     """bench.py --workload stub on two gloo ranks with a failure injected into rank 1's status check
     (PN_STUB_FAIL): the step is dropped on BOTH ranks — nobody enters the gradient all-reduce alone —
