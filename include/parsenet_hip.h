@@ -565,7 +565,7 @@ int pn_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, i
 /* out[s][c] = max_n act(x[s][c][n] * scale[c] + shift[c]) * w[s][n]: the frozen SplineNet's
  * conv5 -> bn5 (evaluation mode) -> LeakyReLU, "x *= weights" and the max pool over the points
  * (src/model.py:160-170) in one pass; idx (S,C) int32 first arg-max, val (S,C) the activation there.
- * _bwd: gw (S,N) = d / d w from g (S,C) (no gradient to x: the network is frozen); N <= 16384. */
+ * _bwd: gw (S,N) = d / d w from g (S,C) (no gradient to x: the network is frozen); N <= 13 600 (12 bytes of LDS per point). */
 int pn_weighted_max_fwd_f32(const float* x, const float* scale, const float* shift, const float* w, int S, int C,
                             int N, int act, float slope, float* out, int* idx, float* val, void* stream);
 int pn_weighted_max_bwd_f32(const float* g, const int* idx, const float* val, int S, int C, int N, float* gw,

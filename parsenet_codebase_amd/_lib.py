@@ -264,9 +264,23 @@ class _PinnedRing:
     step, ``finish()`` never called after a rank-local failure) is reclaimed — with a warning — once
     ABANDONED_AFTER further takes have gone by: a live reader holds a slot for a fraction of a step, a
     few dozen takes at most (round-4 advisor finding: leaked slots silently turned every transfer into a
-    fresh page-locked allocation, the multi-millisecond stall the ring exists to avoid)."""
+    fresh page-locked allocation, the multi-millisecond stall the ring exists to avoid).
+
+    Every take hands out a HANDLE carrying the slot's generation number.  A reader that is merely late — not gone
+    — when its slot is reclaimed still has its handle: ``release`` with a stale generation raises instead of clearing
+    the hold of the slot's NEW owner, so the late reader fails loudly on data that may have been overwritten
+    (round-5 advisor finding)."""
 
     ABANDONED_AFTER = 256
+
+    class Handle:
+        __slots__ = ("slot", "gen")
+
+        def __init__(self, slot, gen):
+            self.slot, self.gen = slot, gen
+
+        def __getitem__(self, key):          # handle["event"]: the slot's event
+            return self.slot[key]
 
     def __init__(self, slots=32, nbytes=1 << 20):
         self.nbytes, self.nslots, self.slots, self.next = nbytes, slots, None, 0
@@ -282,7 +296,7 @@ class _PinnedRing:
             # over the first dozens of uploads — i.e. over somebody's timed steps)
             whole = torch.empty(self.nslots * self.nbytes, dtype=torch.uint8).pin_memory()
             self.slots = [{"buf": whole[i * self.nbytes:(i + 1) * self.nbytes], "event": torch.cuda.Event(),
-                           "armed": False, "held": False} for i in range(self.nslots)]
+                           "armed": False, "held": False, "gen": 0} for i in range(self.nslots)]
         self.takes += 1
         for _ in range(self.nslots):
             i = self.next
@@ -300,7 +314,8 @@ class _PinnedRing:
                 slot["event"].synchronize()
             slot["held"] = bool(hold)
             slot["held_at"] = self.takes
-            return slot["buf"][:max(nbytes, 1)], slot
+            slot["gen"] += 1
+            return slot["buf"][:max(nbytes, 1)], _PinnedRing.Handle(slot, slot["gen"])
         if not self.warned_full:
             import warnings
             warnings.warn("parsenet_codebase_amd: every pinned staging slot is held by a host reader; falling back "
@@ -309,16 +324,22 @@ class _PinnedRing:
         return None, None
 
     @staticmethod
-    def release(slot):
-        """The host has read (or copied out) what the download left in the slot."""
-        if slot is not None:
-            slot["held"] = False
+    def release(handle):
+        """The host has read (or copied out) what the download left in the slot.  Raises if the slot was reclaimed
+        and handed to another taker meanwhile (the data this reader just read may have been overwritten)."""
+        if handle is None:
+            return
+        if handle.gen != handle.slot["gen"]:
+            raise RuntimeError("parsenet_codebase_amd: a pinned download slot was reclaimed (%d further transfers) "
+                               "before its reader came back: the downloaded data may have been overwritten"
+                               % _PinnedRing.ABANDONED_AFTER)
+        handle.slot["held"] = False
 
     @staticmethod
-    def arm(slot):
+    def arm(handle):
         """Record the slot's event on the current stream: call right after queuing the copy."""
-        slot["event"].record()
-        slot["armed"] = True
+        handle.slot["event"].record()
+        handle.slot["armed"] = True
 
 
 _RING = _PinnedRing()

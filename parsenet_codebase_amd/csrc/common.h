@@ -63,6 +63,18 @@ struct PnProfScope {
 static inline size_t pn_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int pn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute is PER DEVICE and the library takes tensors on any device of the process: a call site keeps
+// one word of "done" bits (a function-local static), one bit per device.  True the first time the current device
+// passes the site (a race sets the attribute twice: idempotent); always true beyond 32 devices.
+static inline bool pn_first_on_device(unsigned* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return true;
+  const unsigned bit = 1u << dev;
+  if (__atomic_load_n(done, __ATOMIC_RELAXED) & bit) return false;
+  __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+  return true;
+}
+
 // ---- order-preserving float keys ------------------------------------------
 // ord(f) is monotone increasing in f over all non-NaN floats.
 __host__ __device__ static inline uint32_t pn_f2ord(float f) {

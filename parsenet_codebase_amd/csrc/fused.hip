@@ -938,11 +938,10 @@ extern "C" int pn_weighted_max_bwd_f32(const float* g, const int* idx, const flo
     pn_set_error("pn_weighted_max_bwd_f32: N=%d exceeds the LDS accumulator (13 600 points)", N);
     return PN_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned attr_devs = 0;
+  if (pn_first_on_device(&attr_devs)) {
     PN_CHECK_HIP(hipFuncSetAttribute((const void*)pn_wmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024 - 256));
-    attr_set = true;
   }
   PN_PROF("weighted_max_bwd", (hipStream_t)stream);
   hipLaunchKernelGGL(pn_wmax_bwd_kernel, dim3(S), dim3(64), smem, (hipStream_t)stream, g, idx, val, C, N, gw);

@@ -129,11 +129,12 @@ static int knn3_launch(const float* pts, const int* off, int S, int max_n, int k
     KNN3_GO(40);
   else if (max_n <= 64 * 80)
     KNN3_GO(80);
-  else if (sizeof(T) == 4 && max_n <= 64 * 160) {
-    if constexpr (sizeof(T) == 4) KNN3_GO(160);
-  } else {
-    pn_set_error("pn_knn3_ragged: segments of up to %d points (max %d in this precision)", max_n,
-                 sizeof(T) == 4 ? 64 * 160 : 64 * 80);
+  else if (max_n <= 64 * 160)
+    // (float64: 320 registers of values per lane — one wave per SIMD and 38 registers in scratch; a rare size, but a
+    // segment that is most of a 10 000-point shape must not abort the whole batch's evaluation)
+    KNN3_GO(160);
+  else {
+    pn_set_error("pn_knn3_ragged: segments of up to %d points (max %d)", max_n, 64 * 160);
     return PN_ERR_UNSUPPORTED;
   }
 #undef KNN3_GO

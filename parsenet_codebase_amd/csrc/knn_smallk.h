@@ -546,11 +546,10 @@ static int ksk_run(const KskPlan& p, const float* x, int B, int C, int N, int k,
 #define KSK_GO(KS, KK_, NW_)                                                                                    \
   {                                                                                                             \
     const size_t smem = ksk_smem_bytes_t<KS, KK_, NW_>();                                                       \
-    static bool attr_set = false;   /* (idempotent: a race sets it twice) */                                    \
-    if (!attr_set) {                                                                                            \
+    static unsigned attr_devs = 0;  /* per device: pn_first_on_device */                                        \
+    if (pn_first_on_device(&attr_devs)) {                                                                       \
       PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pn_knn_smallk_kernel<KS, KK_, NW_>),       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                 \
-      attr_set = true;                                                                                          \
     }                                                                                                           \
     hipLaunchKernelGGL((pn_knn_smallk_kernel<KS, KK_, NW_>), grid, dim3(64 * NW_), smem, stream,                \
                        (const float*)xp, N, p.Np, p.stages_per_slice, k, lists, out, out32);                    \

@@ -322,11 +322,10 @@ extern "C" int pn_meanshift_rows_bwd_f32(const float* gy, const float* y, const 
     return PN_ERR_WORKSPACE;
   }
   const size_t lds_valu = (size_t)(3 * MR_R * MR_LD + 3 * MR_R * MR_LG + 3 * MR_R) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned attr_devs = 0;
+  if (pn_first_on_device(&attr_devs)) {
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pn_ms_rows_bwd_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_valu));
-    attr_set = true;
   }
   float* part = static_cast<float*>(workspace);
   float* gu = reinterpret_cast<float*>(static_cast<char*>(workspace) + mr_part_bytes(B, N));

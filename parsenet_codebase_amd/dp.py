@@ -140,6 +140,9 @@ class FlatGradBucket:
         self.flat.zero_()
         for p, v in zip(self.params, self.views):
             p.grad = v
+        # autograd now ACCUMULATES into the views: gather() cannot see which slots that fills, so a later
+        # begin() / gather() step must treat every slot as written (a parameter without a gradient then gets zeros)
+        self._written = set(range(len(self.params)))
 
     def begin(self):
         """Start of a step with ONE backward pass: detach the parameters from the bucket.  autograd then hands

@@ -160,6 +160,7 @@ class _AffineAct(torch.autograd.Function):
 
 
 _ACT = {"none": 0, "relu": 1, "leaky": 2}
+_WMAX_BWD_MAX_POINTS = 13600     # pn_weighted_max_bwd_f32 keeps 12 bytes per point in LDS (160 KiB - 256 - 256)
 
 
 def _frozen_affine(conv, bn, x):
@@ -279,7 +280,7 @@ class DGCNNControlPoints(nn.Module):
         cat = torch.cat(feats, dim=1)
         aff = _frozen_affine(self.conv5[0], self.bn5, cat)
         if (aff is not None and isinstance(weights, torch.Tensor) and weights.numel() == batch_size * cat.shape[2]
-                and cat.shape[2] <= 16384 and not (torch.is_grad_enabled() and (
+                and cat.shape[2] <= _WMAX_BWD_MAX_POINTS and not (torch.is_grad_enabled() and (
                     cat.requires_grad or self.conv5[0].weight.requires_grad))):
             # frozen network inside the fitting stage: activation, membership weighting and the max over
             # the points in ONE pass over the 1024-channel features (they are never written out)

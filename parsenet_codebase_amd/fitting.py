@@ -292,7 +292,7 @@ def _knn_points_by_differences(points, k):
     require_cuda(points)
     n = points.shape[0]
     f64 = points.dtype == torch.float64
-    if 0 < n <= (5120 if f64 else 10240) and k <= 64:
+    if 0 < n <= 10240 and k <= 64:
         off = h2d(np.asarray([0, n], np.int32), points.device)
         return K.knn3_ragged(points.float(), off, n, k, f64=f64).long()
     out = []

@@ -150,7 +150,12 @@ def outlier_keep_mask(pts, off_h, off_d):
     k = int(min(20, counts.min()))
     if counts.min() < 20:       # a segment shorter than the neighbourhood: the search returns what there is (n)
         raise ValueError("outlier removal of a segment with fewer than 20 points")
-    _, dist = K.knn3_ragged(pts, off_d, nmax, k, f64=True, want_dist=True)
+    if nmax <= KNN3_MAX_POINTS:
+        _, dist = K.knn3_ragged(pts, off_d, nmax, k, f64=True, want_dist=True)
+    else:
+        # a segment beyond the kernel's size (shapes of more than 10 240 points): float64 differences block-wise
+        # and topk, segment by segment — what fitting._knn_points_by_differences and the reference fall back on
+        dist = torch.cat([_mean_dist_broadcast(pts[off_h[s]:off_h[s + 1]].double(), k) for s in range(S)], 0)
     avg = dist.mean(1)                                                         # (total,) fp64
     dev = pts.device
     seg = torch.repeat_interleave(torch.arange(S, device=dev), h2d(counts.astype(np.int64), dev),
@@ -166,6 +171,20 @@ def outlier_keep_mask(pts, off_h, off_d):
     std = torch.sqrt(dev2.sum(1) / torch.clamp(n_t - 1, min=1))
     std = torch.where(n_t > 1, std, torch.zeros_like(std))
     return valid & (avg < (cloud_mean + 0.5 * std)[seg])
+
+
+KNN3_MAX_POINTS = 10240          # csrc/knn3.hip: 160 values per lane
+
+
+def _mean_dist_broadcast(p, k):
+    """(n,k) float64 distances of every point to its k nearest (itself included), 2 048 queries at a time."""
+    out = []
+    for s0 in range(0, p.shape[0], 2048):
+        q = p[s0:s0 + 2048]
+        dx, dy, dz = (q[:, None, c] - p[None, :, c] for c in range(3))
+        d = (dx * dx + dy * dy) + dz * dz
+        out.append(torch.sqrt(torch.topk(d, k, 1, largest=False)[0]))
+    return torch.cat(out, 0)
 
 
 def upsample_rounds(pts, counts, rounds):
@@ -207,6 +226,8 @@ def upsample_rounds(pts, counts, rounds):
 
 def _rounds_to_reach(n, a_max):
     """up_sample_points(_torch)_in_range: at least one doubling, until n >= a_max."""
+    if n <= 0:
+        raise ValueError("up-sampling of an empty segment")
     r = 1
     while n * (1 << r) < a_max:
         r += 1
@@ -282,6 +303,13 @@ def fitting_losses_eval(ev, embedding, points, normals, labels, primitives, prim
                 tot = csum[ends]
                 kept = torch.cat([tot[:1], tot[1:] - tot[:-1]])
                 kept_h = kept.cpu().numpy().astype(np.int64)                              # download 2
+                if (kept_h < 5).any():
+                    # every mean distance equal (std 0: nothing is below the mean) or coincident points: the
+                    # reference's up-sampling raises in topk on such a cloud (src/fitting_utils.py:155-158) and
+                    # its caller skips the shape — never pad a segment with self-neighbours
+                    j = int(np.flatnonzero(kept_h < 5)[0])
+                    raise RuntimeError("fitting: outlier removal left %d point(s) of spline segment %d of shape %d "
+                                       "(up-sampling needs 5)" % (kept_h[j], spl_segs[j][1]["key"], spl_segs[j][0]))
                 seg_pts = seg_pts[keep]
             # numpy's draws in the reference's order: per shape the shuffle(s) of its mean-shift call(s), then,
             # segment by segment, the re-sampling draw and the draws of the refit (every draw depends on counts

@@ -319,13 +319,13 @@ def test_pinned_ring_never_hands_out_a_slot_a_host_reader_still_holds():
         def record(self):
             pass
     ring = _lib._PinnedRing(slots=4, nbytes=64)
-    ring.slots = [{"buf": torch.zeros(64, dtype=torch.uint8), "event": Ev(), "armed": False, "held": False}
+    ring.slots = [{"buf": torch.zeros(64, dtype=torch.uint8), "event": Ev(), "armed": False, "held": False, "gen": 0}
                   for _ in range(4)]
     _, held = ring.take(8, hold=True)
     seen = [ring.take(8)[1] for _ in range(40)]
-    assert all(s is not held for s in seen) and len({id(s) for s in seen}) == 3
+    assert all(s.slot is not held.slot for s in seen) and len({id(s.slot) for s in seen}) == 3
     _lib._PinnedRing.release(held)
-    assert any(ring.take(8)[1] is held for _ in range(4))
+    assert any(ring.take(8)[1].slot is held.slot for _ in range(4))
     taken = [ring.take(8, hold=True)[1] for _ in range(4)]
     assert all(t is not None for t in taken) and ring.take(8) == (None, None)
     for t in taken:
@@ -335,7 +335,42 @@ def test_pinned_ring_never_hands_out_a_slot_a_host_reader_still_holds():
     _, lost = ring.take(8, hold=True)
     with pytest.warns(UserWarning):
         seen = [ring.take(8)[1] for _ in range(ring.ABANDONED_AFTER + 8)]
-    assert any(s is lost for s in seen[-8:]) and all(s is not lost for s in seen[:ring.ABANDONED_AFTER - 4])
+    assert any(s.slot is lost.slot for s in seen[-8:])
+    assert all(s.slot is not lost.slot for s in seen[:ring.ABANDONED_AFTER - 4])
+
+
+def test_a_late_reader_of_a_reclaimed_pinned_slot_fails_loudly_and_cannot_release_the_new_owner():
+    """Round-5 advisor finding: the reader of a reclaimed slot was merely late.  Its handle carries the slot's
+    generation: releasing it raises, and the hold of the slot's new owner stays in place."""
+    from parsenet_codebase_amd import _lib
+
+    class Ev:
+        def synchronize(self):
+            pass
+
+        def record(self):
+            pass
+    ring = _lib._PinnedRing(slots=2, nbytes=64)
+    ring.slots = [{"buf": torch.zeros(64, dtype=torch.uint8), "event": Ev(), "armed": False, "held": False, "gen": 0}
+                  for _ in range(2)]
+    _, late = ring.take(8, hold=True)
+    with pytest.warns(UserWarning):
+        for _ in range(ring.ABANDONED_AFTER + 2):
+            ring.take(8)
+    # the reclaimed slot goes to a new download
+    owner = None
+    for _ in range(4):
+        _, h = ring.take(8, hold=True)
+        if h.slot is late.slot:
+            owner = h
+            break
+        _lib._PinnedRing.release(h)
+    assert owner is not None
+    with pytest.raises(RuntimeError, match="reclaimed"):
+        _lib._PinnedRing.release(late)
+    assert owner.slot["held"]                        # still the new owner's
+    _lib._PinnedRing.release(owner)
+    assert not owner.slot["held"]
 
 
 def test_wait_event_spins_for_a_bounded_time_then_blocks(monkeypatch):
