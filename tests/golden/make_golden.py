@@ -99,6 +99,9 @@ def lattice_cloud(B, C, N, seed, bits=6):
     return (rng.randint(-(2 ** bits), 2 ** bits, (B, C, N)) / float(2 ** bits)).astype(np.float32)
 
 
+GRAD_FULL, GRAD_SAMPLE = 40000, 16384
+
+
 def tie_free(neg_dist, k):
     top = np.sort(neg_dist, -1)[..., ::-1][..., :k + 1]
     return bool((np.diff(top, axis=-1) < 0).all())
@@ -211,6 +214,32 @@ def main():
                parsenet_grad_seg2=net.mlp_seg_prob2.weight.grad.numpy().copy())
     save("networks", **out)
 
+    # ---- EVERY parameter gradient of the segmentation network (train_parsenet.py:176-183: triplet + NLL) -------
+    # Same network, same input, same numpy stream as above; parameters of up to GRAD_FULL elements are stored whole,
+    # larger ones as GRAD_SAMPLE elements at seeded positions plus the norm of the whole gradient.
+    # (ONE thread: the CPU backward of the neighbour gather adds in thread order — 1e-8 differences between runs
+    # otherwise, and this generator leaves byte-identical files when nothing changed)
+    net.zero_grad()
+    np.random.seed(11)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    emb, logp, eloss = net(x, torch.from_numpy(lab), True)
+    (torch.mean(eloss) + ref_sl.primitive_loss(logp, torch.from_numpy(prim.astype(np.int64)))).backward()
+    torch.set_num_threads(threads)
+    gout = {"prim": prim.astype(np.int32)}
+    for name, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        gfl = p_.grad.numpy().reshape(-1)
+        gout["norm/" + name] = np.float64(np.linalg.norm(gfl.astype(np.float64)))
+        if gfl.size <= GRAD_FULL:
+            gout["full/" + name] = gfl.copy()
+        else:
+            pos = np.random.RandomState(zlib.crc32(name.encode())).choice(gfl.size, GRAD_SAMPLE, replace=False)
+            gout["pos/" + name] = pos.astype(np.int32)
+            gout["sample/" + name] = gfl[pos].copy()
+    save("networks_grads", **gout)
+
     # ---- metrics and the torus distance: reference functions without another pin ----------------
     # evaluate_miou (src/segment_loss.py:127-148) and ComputePrimitiveDistance.distance_from_torus
     # (src/primitives.py:58-87; no caller in the training scripts, kept for API completeness)
@@ -250,6 +279,20 @@ def main():
     save("mean_shift", X=X.numpy(), truth=lab6.numpy().astype(np.int32), bw=np.float32(bw.item()),
          new_X_proj=(new_X.detach() @ proj).numpy(), labels=labels.numpy().astype(np.int32),
          n_centers=np.int32(center.shape[0]), grad_X_proj=(Xr.grad @ proj).numpy())
+
+    # ---- mean-shift iterations at another embedding width and with the Epanechnikov kernel (mean_shift.py:45-79) --
+    g = torch.Generator().manual_seed(31)
+    cen = torch.nn.functional.normalize(torch.randn(5, 64, generator=g), dim=1)
+    X64 = torch.nn.functional.normalize(cen[torch.randint(0, 5, (300,), generator=g)]
+                                        + 0.2 * torch.randn(300, 64, generator=g) / 8.0, dim=1)
+    w64 = torch.randn(300, 64, generator=g)
+    out = {"X": X64.numpy(), "w": w64.numpy(), "b": np.float32(0.5)}
+    for kt in ("gaussian", "epa"):
+        xr = X64.clone().requires_grad_(True)
+        yr, _ = ref_ms.MeanShift().mean_shift_(xr, torch.tensor(0.5), 5, kernel_type=kt)
+        (yr * w64).sum().backward()
+        out["new_X_" + kt], out["grad_" + kt] = yr.detach().numpy(), xr.grad.numpy().copy()
+    save("mean_shift_variants", **out)
 
     # ---- Chamfer + spline losses ----------------------------------------------------------------
     g = torch.Generator().manual_seed(9)
@@ -361,6 +404,32 @@ def main():
     P3 = np.einsum("ni,nj,ijk->nk", bu, bv, ctrl_true) + 1e-3 * rng.randn(400, 3)
     out.update(kron_bu=bu, kron_bv=bv, kron_P=P3, kron_ctrl=ref_approx.fit_bezier_surface_fit_kronecker(P3, bu, bv))
     save("fitting", **out)
+
+    # ---- the LS control-point solve at cfg3's stated size: the 1 600 x 100 system of the refit ----------------
+    # (src/primitive_forward.py:153-296: 1 600 (u, v) parameters = random ones + the boundary parameterisation —
+    # 76 of grid 20 for the open refit at degree 2, 116 of grid 30 for the closed refit at degree 3 — a 10 x 10
+    # control grid, knots of uniform_knot_bspline_(10, 10, degree, degree, 2); approximation.py:338-364)
+    import src.curve_utils as ref_cu
+    draw = ref_cu.DrawSurfs()
+    out = {}
+    for kind, (degree, bgrid) in {"open": (2, 20), "closed": (3, 30)}.items():
+        rng = np.random.RandomState(40 + degree)
+        bpar = draw.boundary_parameterization(bgrid)
+        par = np.concatenate([rng.random_sample((1600 - bpar.shape[0], 2)), bpar], 0)
+        _, _, ku, kv = ref_approx.uniform_knot_bspline_(10, 10, degree, degree, 2)
+        NU, NV = [], []
+        for i in range(par.shape[0]):
+            a, b_ = bs.basis_functions(par[i], 10, 10, ku, kv, degree, degree)
+            NU.append(a)
+            NV.append(b_)
+        NU, NV = np.concatenate(NU, 1).T, np.concatenate(NV, 1).T
+        ctrl_true = rng.rand(10, 10, 3) + np.stack(list(np.meshgrid(np.arange(10.0), np.arange(10.0), indexing="ij"))
+                                                   + [np.zeros((10, 10))], 2)
+        Pm = np.einsum("ni,nj,ijk->nk", NU, NV, ctrl_true) + 5e-3 * rng.randn(1600, 3)
+        out.update({kind + "_par": par, kind + "_NU": NU, kind + "_NV": NV, kind + "_P": Pm,
+                    kind + "_degree": np.int32(degree),
+                    kind + "_ctrl": ref_approx.fit_bezier_surface_fit_kronecker(Pm, NU, NV)})
+    save("kron1600", **out)
 
     # ---- cylinder fit (primitive_forward.py:784-806) + the reference's own ridge noise -------------
     # The circle fit on the points projected along the axis is rank deficient by construction, so

@@ -73,6 +73,90 @@ def test_networks(gpu):
     assert rel(net.mlp_seg_prob2.weight.grad, g["parsenet_grad_seg2"]) < 1e-3
 
 
+def test_every_parameter_gradient_of_the_segmentation_network(gpu):
+    """train_parsenet.py:176-183 (triplet + NLL) on the fixture's 600-point shape: EVERY parameter gradient whose
+    norm exceeds 1e-3 of the largest one within 1e-3 (relative, in the 2-norm) of the reference's — small
+    parameters whole, the large ones on 16 384 seeded positions plus the norm of the whole gradient
+    (tests/golden/make_golden.py: networks_grads.npz).  Round 5 pinned one of them."""
+    from src.PointNet import PrimitivesEmbeddingDGCNGn
+    from src.segment_loss import EmbeddingLoss, primitive_loss
+    from tests.golden.common import deterministic_init
+    g, gg = load("networks"), load("networks_grads")
+    net = deterministic_init(PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True,
+                                                       num_primitives=10,
+                                                       loss_function=EmbeddingLoss(1.0).triplet_loss, mode=5,
+                                                       num_channels=6, nn_nb=80)).to(gpu)
+    np.random.seed(11)
+    emb, logp, eloss = net(torch.from_numpy(g["parsenet_x"]).to(gpu),
+                           torch.from_numpy(g["parsenet_labels"].astype(np.int64)), True)
+    (torch.mean(eloss) + primitive_loss(logp, torch.from_numpy(gg["prim"].astype(np.int64)).to(gpu))).backward()
+    names = [k[5:] for k in gg.files if k.startswith("norm/")]
+    top = max(float(gg["norm/" + n]) for n in names)
+    have = {n for n, p_ in net.named_parameters() if p_.grad is not None}
+    assert set(names) == have                           # the same parameters receive a gradient
+    checked, worst = 0, (0.0, None)
+    for name, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        ref_norm = float(gg["norm/" + name])
+        if ref_norm <= 1e-3 * top:
+            continue
+        got = p_.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
+        if "full/" + name in gg.files:
+            want = gg["full/" + name].astype(np.float64)
+            err = np.linalg.norm(got - want) / np.linalg.norm(want)
+        else:
+            pos = gg["pos/" + name]
+            want = gg["sample/" + name].astype(np.float64)
+            err = max(np.linalg.norm(got[pos] - want) / np.linalg.norm(want),
+                      abs(np.linalg.norm(got) - ref_norm) / ref_norm)
+        worst = max(worst, (err, name))
+        assert err < 1e-3, (name, err)
+        checked += 1
+    assert checked >= 25, checked
+    print("segmentation network: %d parameter gradients within 1e-3 (worst %.2e, %s)" % (checked, *worst))
+
+
+def test_mean_shift_at_width_64_and_with_the_epanechnikov_kernel(gpu):
+    """MeanShift.mean_shift_ outside the configs' 128-wide Gaussian case (src/mean_shift.py:45-79, both kernels)
+    against the REFERENCE's iterates and gradient (tests/golden/mean_shift_variants.npz)."""
+    from src.mean_shift import MeanShift
+    g = load("mean_shift_variants")
+    X, w = torch.from_numpy(g["X"]).to(gpu), torch.from_numpy(g["w"]).to(gpu)
+    for kt in ("gaussian", "epa"):
+        xg = X.clone().requires_grad_(True)
+        yg, _ = MeanShift().mean_shift_(xg, torch.tensor(float(g["b"]), device=gpu), 5, kernel_type=kt)
+        (yg * w).sum().backward()
+        assert rel(yg, g["new_X_" + kt]) < 1e-5 and rel(xg.grad, g["grad_" + kt]) < 5e-5
+
+
+def test_control_point_solve_at_the_1600_row_size_of_the_refit(gpu):
+    """a27 at cfg3's stated size: the 1 600 x 100 system of optimize_open/close_spline_kronecker
+    (src/primitive_forward.py:153-296; approximation.py:338-364) — 1 600 parameters of which 76 / 116 on the
+    boundary, degree 2 (open) and 3 (closed), a 10 x 10 control grid.  The basis rows from the parameters equal
+    the reference's, the solve equals numpy's lstsq at 1e-7 (fp64 Cholesky on the GPU), numpy in and torch in."""
+    from src.approximation import BSpline, fit_bezier_surface_fit_kronecker, uniform_knot_bspline_
+    g = load("kron1600")
+    bs = BSpline()
+    for kind in ("open", "closed"):
+        deg = int(g[kind + "_degree"])
+        par, NU, NV = g[kind + "_par"], g[kind + "_NU"], g[kind + "_NV"]
+        assert par.shape == (1600, 2) and NU.shape == (1600, 10) and NV.shape == (1600, 10)
+        _, _, ku, kv = uniform_knot_bspline_(10, 10, deg, deg, 2)
+        for i in list(range(0, 1600, 97)) + list(range(1590, 1600)):        # random and boundary rows
+            nu, nv = bs.basis_functions(par[i], 10, 10, ku, kv, deg, deg)
+            assert np.allclose(nu.reshape(-1), NU[i], rtol=0, atol=1e-15)
+            assert np.allclose(nv.reshape(-1), NV[i], rtol=0, atol=1e-15)
+        ctrl = fit_bezier_surface_fit_kronecker(g[kind + "_P"], NU, NV)
+        assert ctrl.shape == (10, 10, 3) and rel(ctrl, g[kind + "_ctrl"]) < 1e-7
+        P = torch.from_numpy(g[kind + "_P"]).to(gpu).requires_grad_(True)
+        c2 = fit_bezier_surface_fit_kronecker(P, torch.from_numpy(NU), torch.from_numpy(NV))
+        assert rel(c2, g[kind + "_ctrl"]) < 1e-7
+        c2.sum().backward()
+        # the sum of the control points is linear in P: d/dP = pinv(A)^T 1, the same for the three coordinates
+        assert torch.isfinite(P.grad).all() and float((P.grad[:, 0] - P.grad[:, 1]).abs().max()) < 1e-9
+
+
 def test_cfg1_open_splinenet_single_700_point_patch(gpu):
     """cfg1 of BASELINE.json at its stated size (configs/config_open_splines.yml:22-43,
     train_open_splines.py:152): ONE 700-point patch through the open SplineNet in evaluation mode,

@@ -750,3 +750,83 @@ def test_segmentation_metric_helpers():
     pm = M.cluster_prob_mutual(emb, cen, 0.5)
     assert pm.shape == (2, 3) and np.allclose(pm.sum(0), 1.0)
     assert M.cluster_prob(emb, cen, 0.5).shape == (2, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Hungarian matching: which optimum among EQUAL-cost assignments (src/fitting_utils.py:362-376 uses
+# lapsolver.solve_dense, absent here; scipy's linear_sum_assignment stands in — SURVEY 8c "tie order unpinned")
+# ---------------------------------------------------------------------------------------------------------------
+def _shuffled_solver(rng):
+    """An equally exact assignment solver with ANOTHER tie order: scipy on a row- and column-permuted matrix,
+    mapped back.  Every optimum of a tied cost matrix is reachable this way."""
+    from scipy.optimize import linear_sum_assignment
+
+    def solve(cost):
+        cost = np.asarray(cost)
+        pr, pc = rng.permutation(cost.shape[0]), rng.permutation(cost.shape[1])
+        r, c = linear_sum_assignment(cost[pr][:, pc])
+        rows, cols = pr[r], pc[c]
+        o = np.argsort(rows)
+        return rows[o], cols[o]
+    return solve
+
+
+@pytest.mark.parametrize("n_pred,n_gt", [(5, 9), (9, 5), (7, 7), (1, 6), (12, 3)])
+def test_matching_results_do_not_depend_on_the_tie_order_of_the_assignment_solver(monkeypatch, n_pred, n_gt):
+    """The 50 x 50 relaxed-IoU matrix of a shape is mostly ties: every empty one-hot column / row costs 1.0 against
+    everything, and so does a predicted cluster against a ground-truth segment it does not touch.  Whatever optimum
+    the solver returns, the things the loss is built from are the same: the segments that get fitted with their
+    ground-truth partners and types (training: fitting_batch.build_segment_table; evaluation:
+    fitting_eval.eval_segments), and the segment IoU / type accuracy of the matched pairs."""
+    from parsenet_codebase_amd import fitting, fitting_batch as FB, fitting_eval as FE
+    rng = np.random.RandomState(100 * n_pred + n_gt)
+    N = 6000
+    gt = rng.randint(0, n_gt, N)
+    prim_of_gt = rng.choice([1, 3, 4, 5, 2, 8, 0, 6], n_gt)
+    prim = prim_of_gt[gt]
+    # predicted clusters: a noisy relabelling with another number of clusters (merges / splits / strays)
+    pred = (rng.permutation(50)[:n_gt][gt] % n_pred + (rng.rand(N) < 0.15) * rng.randint(0, n_pred, N)) % n_pred
+    prim_pred = np.where(rng.rand(N) < 0.9, prim, rng.randint(0, 10, N))
+    ref_segs = ref_metrics = ref_eval = None
+    for trial in range(25):
+        solver = fitting.solve_dense if trial == 0 else _shuffled_solver(np.random.RandomState(trial))
+        monkeypatch.setattr(fitting, "solve_dense", solver)
+        segs, match = FB.build_segment_table(gt, prim, pred, N)
+        segs = [(s["row"], s["key"], s["type"], s["kind"], s["gt"].tobytes()) for s in segs]
+        modal_pred = np.asarray([np.bincount(prim_pred[pred == c], minlength=10).argmax() if (pred == c).any() else 0
+                                 for c in range(50)])
+        siou, pacc, _, pairs = FB.siou_matched_segments_fast(match, modal_pred, prim)
+        esegs, _ = FE.eval_segments(gt, pred, prim_pred)
+        esegs = [(s["index"], s["key"], s["type"], s["kind"], s["pred"].tobytes(), s["gt"].tobytes(), float(s["wv"]),
+                  s["fit"]) for s in esegs]
+        metrics = (siou, pacc, sorted(map(tuple, pairs)))
+        if trial == 0:
+            ref_segs, ref_metrics, ref_eval = segs, metrics, esegs
+            assert segs                                  # something IS fitted
+        else:
+            assert segs == ref_segs and esegs == ref_eval
+            assert metrics[0] == ref_metrics[0] and metrics[1] == ref_metrics[1] and metrics[2] == ref_metrics[2]
+
+
+def test_a_genuine_tie_between_occupied_segments_keeps_the_matched_iou(monkeypatch):
+    """The one tie that CAN change the pairing: two predicted clusters that each cover exactly half of two equally
+    large ground-truth segments (equal integer counts — a measure-zero event on real clusterings).  Both pairings are
+    optima; the matched segment IoU (s_iou) is the same under either, the total cost is the optimum of all 2 x 2
+    pairings, and scipy's choice is one of the two — the reference's lapsolver may return the other one, which is why
+    SURVEY 8c calls the tie order unpinned."""
+    from parsenet_codebase_amd import fitting, fitting_batch as FB
+    gt = np.repeat([0, 1, 2], [400, 400, 300])
+    pred = np.concatenate([np.tile([0, 1], 200), np.tile([1, 0], 200), np.full(300, 2)])
+    prim = np.repeat([1, 1, 5], [400, 400, 300])
+    seen = set()
+    sious = set()
+    for trial in range(40):
+        solver = fitting.solve_dense if trial == 0 else _shuffled_solver(np.random.RandomState(trial))
+        monkeypatch.setattr(fitting, "solve_dense", solver)
+        segs, match = FB.build_segment_table(gt, prim, pred, gt.size)
+        rids, cids = match[0], match[1]
+        seen.add((int(cids[0]), int(cids[1]), int(cids[2])))
+        sious.add(FB.siou_matched_segments_fast(match, np.zeros(50, np.int64), prim)[0])
+        assert [s["kind"] for s in segs] == ["prim"] * 3
+    assert seen == {(0, 1, 2), (1, 0, 2)}               # both optima occur, nothing else
+    assert len(sious) == 1                               # the matched IoU does not depend on which

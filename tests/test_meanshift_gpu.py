@@ -635,3 +635,34 @@ def test_kmeans_kernels_of_the_locality_order(gpu, N, K_):
     assert float((new.double() - want).abs().max()) < 2e-6
     empty = (hot.sum(1) == 0)
     assert bool(empty.any()) and torch.equal(new[empty], cen[empty])      # (the duplicated centre's cell, at least)
+
+
+@pytest.mark.parametrize("d,kernel_type", [(64, "gaussian"), (64, "epa"), (128, "epa")])
+def test_other_embedding_widths_and_the_epanechnikov_kernel_against_the_oracle(gpu, d, kernel_type):
+    """src/mean_shift.py:45-79 with an embedding that is not 128 wide and / or the Epanechnikov kernel
+    (:64-68) — no config uses them; the product runs them as materialised N x N tensor expressions
+    (mean_shift.py: the one place it builds such a matrix).  Iterates and the gradient through the
+    iterations against the oracle; whole clustering (bandwidth, partition) at width 64."""
+    from oracle import ref_torch as R
+    from parsenet_codebase_amd.mean_shift import MeanShift
+    N = 1500
+    X, lab = _clustered(N, 6, 21 + d, spread=0.2, d=d)
+    b = torch.tensor(0.5)
+    w = torch.randn(N, d, generator=torch.Generator().manual_seed(4))
+    xr = X.clone().requires_grad_(True)
+    yr, _ = R.MeanShift().mean_shift_(xr, b, 5, kernel_type=kernel_type)
+    (yr * w).sum().backward()
+    xg = X.to(gpu).requires_grad_(True)
+    yg, _ = MeanShift().mean_shift_(xg, b.to(gpu), 5, kernel_type=kernel_type)
+    (yg * w.to(gpu)).sum().backward()
+    assert _rel(yg, yr) < 1e-5
+    assert _rel(xg.grad, xr.grad) < 5e-5
+    if kernel_type == "gaussian":
+        np.random.seed(0)
+        newr, cr, bwr, lr = R.MeanShift().mean_shift(X, 10000, 0.05, 10)
+        np.random.seed(0)
+        newg, cg, bwg, lg = MeanShift().mean_shift(X.to(gpu), 10000, 0.05, 10)
+        assert abs(bwg.item() - bwr.item()) / bwr.item() < 1e-5
+        assert _rel(newg, newr) < 1e-4 and cg.shape == cr.shape
+        assert np.array_equal(_canonical(lg.cpu().numpy()), _canonical(lr.numpy()))
+        assert np.array_equal(_canonical(lr.numpy()), _canonical(lab.numpy()))
