@@ -197,6 +197,14 @@ size_t pn_gemm_x3_points_image_bytes(int B, int C, int N);
 int pn_gemm_x3_weight_image_f32(const float* w, int M, int K, int transposed, void* img, void* stream);
 int pn_gemm_x3_f32(const void* img_a, const float* x, const float* bias, int B, int M, int K, int N, float* out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The weight gradient of such a layer (what autograd's conv1d backward forms over the B N points:
+ * src/model.py:157-176, src/PointNet.py:196-284 under loss.backward()): gw (M,K) = sum_b gy[b] (M,N) x[b]^T (N,K)
+ * in the same arithmetic, split over the points with a FIXED-ORDER sum of the partial results (bit-reproducible,
+ * no atomics); gb (M) or NULL: the bias gradient sum_b sum_n gy[b][m][n].  gy (B,M,N), x (B,K,N) channel-first;
+ * workspace: pn_gemm_x3_wgrad_workspace(B, M, K, N) bytes. */
+size_t pn_gemm_x3_wgrad_workspace(int B, int M, int K, int N);
+int pn_gemm_x3_wgrad_f32(const float* gy, const float* x, int B, int M, int K, int N, float* gw, float* gb,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* Mean-shift backward restricted to R <= 64 rows per batch item (csrc/meanshift_rows.hip).  A step of
  * src/mean_shift.py:45-79 maps row i of the iterate to a function of that row and of the data alone, and
  * the training path reads the final iterate only at the cluster centres (src/mean_shift.py:36-43): the

@@ -25,11 +25,27 @@
 //     with a 64-bit packed (distance, index) atomicMin; a single split writes its result directly;
 //   * ragged batches: item i owns rows [off[i], off[i+1]) of a concatenated cloud (the spline
 //     segments of a step have different numbers of ground-truth points).
-#include "common.h"
+//
+// Round 6 — the large searches run a PRE-FILTER on the bf16 matrix cores and decide exactly (pn_chamfer_mfma_kernel):
+//   D(q, c) = |q|^2 + |c|^2 - 2 q.c; a 32 candidates x 32 queries tile of  t(q, c) = |c|^2 - 2 q.c - e(q, c)  is ONE
+//   v_mfma_f32_32x32x16_bf16: both points split into two bf16 pieces (16 of the 24 bits), the four piece products
+//   of the three coordinates in 12 of the 16 contraction slots, |c|^2 (lowered by 2^-18, three pieces) in three,
+//   and the error budget e = 2^-13 |q| |c| (both factors rounded up) in the last one.  t is a CERTIFIED lower
+//   bound of D - |q|^2 (dropped piece products <= 2^-14 |q||c|, fp32 accumulation of 16 terms <= 2^-19 |q||c| +
+//   2^-20 |c|^2), so a candidate with  t > best - |q|^2 (+ 2^-20 slack for the roundings of the exact chain)
+//   cannot be the minimum nor tie with it.  Everything else — a handful of candidates per query: the record lows of
+//   its scan and the near ties — is evaluated with the reference's chain ((dx^2 + dy^2) + dz^2, each operation rounded
+//   once) and decided on (distance, index): minima and arg-mins are bit-identical to the scalar kernel's and the
+//   oracle's.  A lane holds 16 candidates of its query per tile: eight v_min3 and a compare per 16 pairs instead
+//   of 8.9 instructions per pair.  The waves of a workgroup scan interleaved candidate tiles for the SAME 32 queries
+//   and share their running minima through LDS, so the thresholds tighten as fast as in one long scan.
+#include "split_common.h"
 #include <stdlib.h>
 
 #define CH_THREADS 128
 #define CH_GROUP 8
+
+typedef float ch_f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ static inline float ch_dist(float qx, float qy, float qz, float cx, float cy, float cz) {
   const float dx = __fsub_rn(qx, cx);
@@ -143,6 +159,142 @@ __global__ void pn_chamfer_unpack_kernel(const unsigned long long* __restrict__ 
   if (arg) arg[i] = (int64_t)(uint32_t)(k & 0xffffffffu);
 }
 
+// ---- matrix-core pre-filter -------------------------------------------------------------------------------------
+// images of the points, one 64-byte record per point: [candidate row 16 bf16][query row 16 bf16], contraction slots
+//   candidate: chx chy chz cmx cmy cmz chx chy | chz cmx cmy cmz n0 n1 n2 cn
+//   query:     -2 (qhx qhy qhz qhx qhy qhz qmx qmy | qmz qmx qmy qmz)  1 1 1  -eq
+// n0 + n1 + n2 = |c|^2 (1 - 2^-18), cn >= |c|, eq >= 2^-13 |q|.
+__device__ static inline float ch_bf16_rn(float x) {
+  bf16x2 p = __builtin_convertvector(f32x2{x, 0.f}, bf16x2);
+  return (float)p[0];
+}
+__device__ static inline uint32_t ch_pack(float a, float b) {   // two bf16-representable floats
+  return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void pn_chamfer_image_kernel(const float* __restrict__ a, long long na,
+                                                               const float* __restrict__ b, long long nb,
+                                                               u32x4* __restrict__ img) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= na + nb) return;
+  const float* p = i < na ? a + 3 * i : b + 3 * (i - na);
+  const float x = p[0], y = p[1], z = p[2];
+  const float hx = ch_bf16_rn(x), hy = ch_bf16_rn(y), hz = ch_bf16_rn(z);
+  const float mx = ch_bf16_rn(x - hx), my = ch_bf16_rn(y - hy), mz = ch_bf16_rn(z - hz);
+  const float nn = (x * x + y * y) + z * z;
+  const float nl = nn * (1.0f - 0x1p-18f);
+  const float n0 = ch_bf16_rn(nl), n1 = ch_bf16_rn(nl - n0), n2 = ch_bf16_rn((nl - n0) - n1);
+  const float nrm = sqrtf(nn);
+  const float cn = ch_bf16_rn(nrm * (1.0f + 0x1p-6f));                 // >= |c|  (bf16 rounds by <= 2^-8)
+  const float eq = ch_bf16_rn(nrm * (0x1p-13f * (1.0f + 0x1p-6f)));    // >= 2^-13 |q|
+  u32x4 c0, c1, q0, q1;
+  c0[0] = ch_pack(hx, hy), c0[1] = ch_pack(hz, mx), c0[2] = ch_pack(my, mz), c0[3] = ch_pack(hx, hy);
+  c1[0] = ch_pack(hz, mx), c1[1] = ch_pack(my, mz), c1[2] = ch_pack(n0, n1), c1[3] = ch_pack(n2, cn);
+  const float ax = -2.f * hx, ay = -2.f * hy, az = -2.f * hz, bx = -2.f * mx, by = -2.f * my, bz = -2.f * mz;
+  q0[0] = ch_pack(ax, ay), q0[1] = ch_pack(az, ax), q0[2] = ch_pack(ay, az), q0[3] = ch_pack(bx, by);
+  q1[0] = ch_pack(bz, bx), q1[1] = ch_pack(by, bz), q1[2] = ch_pack(1.f, 1.f), q1[3] = ch_pack(1.f, -eq);
+  u32x4* o = img + 4 * i;
+  o[0] = c0, o[1] = c1, o[2] = q0, o[3] = q1;
+}
+
+struct ChSide {
+  const float* q;       // query coordinates (rows of 3)
+  const float* c;       // candidate coordinates
+  const u32x4* qimg;    // image records of the queries' cloud / the candidates' cloud
+  const u32x4* cimg;
+  const int* qoff;      // ragged: item offsets (B + 1) into the rows, else null
+  const int* coff;
+  int Nq, Nc;           // uniform item sizes (grid sizing when ragged: the largest item)
+  float* mind;
+  int64_t* arg;
+};
+
+// grid (ceil(max Nq / 32), B, sides); NW waves: wave w scans the candidate tiles w, w + NW, ... for the 32 queries
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void pn_chamfer_mfma_kernel(ChSide s0, ChSide s1) {
+  __shared__ unsigned s_best[32];
+  __shared__ unsigned long long s_key[32];
+  const ChSide& S = blockIdx.z == 0 ? s0 : s1;
+  const int b = blockIdx.y;
+  const int q0 = S.qoff ? S.qoff[b] : b * S.Nq;
+  const int Nq = S.qoff ? S.qoff[b + 1] - q0 : S.Nq;
+  const int c0 = S.coff ? S.coff[b] : b * S.Nc;
+  const int Nc = S.coff ? S.coff[b + 1] - c0 : S.Nc;
+  const int qbase = blockIdx.x * 32;
+  if (qbase >= Nq) return;                     // block-uniform
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  if (tid < 32) {
+    s_best[tid] = 0x7f800000u;                 // +inf
+    s_key[tid] = ~0ull;
+  }
+  const int i = qbase + col;
+  const int iq = i < Nq ? i : Nq - 1;
+  const float* qp = S.q + 3 * (size_t)(q0 + iq);
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float nq = (qx * qx + qy * qy) + qz * qz;
+  const bf16x8 bq = x3_as_bf16(S.qimg[4 * (size_t)(q0 + iq) + 2 + h]);
+  const float* cb = S.c + 3 * (size_t)c0;
+  const u32x4* __restrict__ ci = S.cimg + 4 * (size_t)c0;
+  unsigned long long key = ~0ull;              // (bits of the exact minimum << 32) | candidate index
+  float bestf = __builtin_inff();
+  const int ntiles = (Nc + 31) >> 5;
+  __syncthreads();
+  int t = wave;
+  u32x4 a_next = {0u, 0u, 0u, 0u};
+  if (t < ntiles) a_next = ci[4 * (size_t)min(32 * t + col, Nc - 1) + h];
+  for (; t < ntiles; t += NW) {
+    const bf16x8 a = x3_as_bf16(a_next);
+    if (t + NW < ntiles) a_next = ci[4 * (size_t)min(32 * (t + NW) + col, Nc - 1) + h];
+    ch_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
+    // the smallest of the lane's 16 bounds (rows past the end of the cloud repeat its last point: harmless)
+    float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, acc[r]), acc[r + 1]);
+    m = fminf(m, acc[15]);
+    const float bcur = fminf(bestf, __uint_as_float(s_best[col]));
+    const float thr = (bcur - nq) + 0x1p-20f * (bcur + nq);       // inf while nothing is known: everything passes
+    if (__ballot(!(m > thr))) {
+      bool improved = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!(acc[r] > thr)) {
+          const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (j < Nc) {
+            const float* cp = cb + 3 * (size_t)j;
+            const float d = ch_dist(qx, qy, qz, cp[0], cp[1], cp[2]);
+            if (d < __builtin_inff()) {          // (NaN / inf distances never win: the scalar kernel's rule)
+              const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+              if (k < key) {
+                key = k;
+                bestf = d;
+                improved = true;
+              }
+            }
+          }
+        }
+      }
+      if (improved) atomicMin(&s_best[col], __float_as_uint(bestf));   // d >= 0: the bit pattern orders like the value
+    }
+  }
+  // smallest (distance, index) over the two half waves, then over the waves
+  {
+    const unsigned lo = __shfl_xor((unsigned)key, 32, 64), hi = __shfl_xor((unsigned)(key >> 32), 32, 64);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    if (other < key) key = other;
+  }
+  if (h == 0 && key != ~0ull) atomicMin(&s_key[col], key);
+  __syncthreads();
+  if (tid < 32 && qbase + tid < Nq) {
+    const unsigned long long k = s_key[tid];
+    const size_t o = (size_t)q0 + qbase + tid;
+    if (S.mind) S.mind[o] = __uint_as_float((uint32_t)(k >> 32));
+    if (S.arg) S.arg[o] = (int64_t)(uint32_t)(k & 0xffffffffu);
+  }
+}
+
 // one direction: queries q (rows qoff / uniform Nq) against candidates c
 static int chamfer_one_side(const float* q, const int* qoff, int Nq, long long total_q, const float* c,
                             const int* coff, int Nc, int B, unsigned long long* packed, float* mind,
@@ -189,8 +341,55 @@ static int chamfer_one_side(const float* q, const int* qoff, int Nq, long long t
   return PN_OK;
 }
 
+// The matrix-core path pays from ~1e6 pairs on (an image launch first); PN_CHAMFER_MFMA=0 / 1 forces the scalar /
+// the matrix-core kernel (tests and A/B runs).
+static bool chamfer_use_mfma(long long items, int Nq, int Nc) {
+  if (const char* e = getenv("PN_CHAMFER_MFMA")) return atoi(e) != 0;
+  return Nq >= 64 && Nc >= 64 && items * (long long)Nq * Nc >= 1000000ll;
+}
+
+static size_t chamfer_image_bytes(long long total) { return pn_align_up((size_t)total * 64, 256); }
+
+// both clouds' images in one launch, then ONE launch for the requested sides (blockIdx.z)
+static int chamfer_mfma(const float* a, const int* offA, int Na, long long totalA, const float* b, const int* offB, int Nb,
+                        long long totalB, int B, float* minA, int64_t* argA, float* minB, int64_t* argB, void* img_,
+                        hipStream_t stream) {
+  u32x4* img = (u32x4*)img_;
+  {
+    PN_PROF("chamfer_image", stream);
+    hipLaunchKernelGGL(pn_chamfer_image_kernel, dim3(pn_cdiv(totalA + totalB, 256)), dim3(256), 0, stream, a, totalA, b,
+                       totalB, img);
+  }
+  PN_CHECK_LAUNCH();
+  const u32x4* imgA = img;
+  const u32x4* imgB = img + 4 * (size_t)totalA;
+  ChSide sa = {a, b, imgA, imgB, offA, offB, Na, Nb, minA, argA};
+  ChSide sb = {b, a, imgB, imgA, offB, offA, Nb, Na, minB, argB};
+  const bool wantA = minA || argA, wantB = minB || argB;
+  ChSide s0 = wantA ? sa : sb, s1 = sb;
+  const int sides = (wantA ? 1 : 0) + (wantB ? 1 : 0);
+  const int nq_max = sides == 2 ? (Na > Nb ? Na : Nb) : s0.Nq;
+  const int nc_min = sides == 2 ? (Na < Nb ? Na : Nb) : s0.Nc;
+  const int ntiles = pn_cdiv(nc_min, 32);
+  dim3 grid(pn_cdiv(nq_max, 32), B, sides);
+  {
+    PN_PROF("chamfer_nn", stream);
+    if (ntiles >= 64)
+      hipLaunchKernelGGL(pn_chamfer_mfma_kernel<8>, grid, dim3(512), 0, stream, s0, s1);
+    else if (ntiles >= 16)
+      hipLaunchKernelGGL(pn_chamfer_mfma_kernel<4>, grid, dim3(256), 0, stream, s0, s1);
+    else if (ntiles >= 4)
+      hipLaunchKernelGGL(pn_chamfer_mfma_kernel<2>, grid, dim3(128), 0, stream, s0, s1);
+    else
+      hipLaunchKernelGGL(pn_chamfer_mfma_kernel<1>, grid, dim3(64), 0, stream, s0, s1);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 extern "C" size_t pn_chamfer_nn_workspace(int B, int Na, int Nb) {
-  return pn_align_up((size_t)B * Na * 8, 256) + pn_align_up((size_t)B * Nb * 8, 256);
+  return pn_align_up((size_t)B * Na * 8, 256) + pn_align_up((size_t)B * Nb * 8, 256) +
+         chamfer_image_bytes((long long)B * Na + (long long)B * Nb);
 }
 
 extern "C" int pn_chamfer_nn_f32(const float* a, const float* b, int B, int Na, int Nb,
@@ -205,6 +404,9 @@ extern "C" int pn_chamfer_nn_f32(const float* a, const float* b, int B, int Na, 
   unsigned long long* pa = (unsigned long long*)workspace;
   unsigned long long* pb =
       (unsigned long long*)((char*)workspace + pn_align_up((size_t)B * Na * 8, 256));
+  if (chamfer_use_mfma(B, Na, Nb))
+    return chamfer_mfma(a, nullptr, Na, (long long)B * Na, b, nullptr, Nb, (long long)B * Nb, B, minA, argA, minB, argB,
+                        (char*)pb + pn_align_up((size_t)B * Nb * 8, 256), stream);
   int rc = PN_OK;
   if (minA || argA) {
     rc = chamfer_one_side(a, nullptr, Na, (long long)B * Na, b, nullptr, Nb, B, pa, minA, argA, stream);
@@ -222,7 +424,8 @@ extern "C" int pn_chamfer_nn_f32(const float* a, const float* b, int B, int Na, 
 // row counts of the concatenated clouds.  Outputs are concatenated like the inputs; indices are
 // local to the item.  Items must be non-empty.
 extern "C" size_t pn_chamfer_nn_ragged_workspace(int totalA, int totalB) {
-  return pn_align_up((size_t)totalA * 8, 256) + pn_align_up((size_t)totalB * 8, 256);
+  return pn_align_up((size_t)totalA * 8, 256) + pn_align_up((size_t)totalB * 8, 256) +
+         chamfer_image_bytes((long long)totalA + totalB);
 }
 
 extern "C" int pn_chamfer_nn_ragged_f32(const float* a, const int* offA, int totalA, int maxA, const float* b,
@@ -236,6 +439,10 @@ extern "C" int pn_chamfer_nn_ragged_f32(const float* a, const int* offA, int tot
                "pn_chamfer_nn_ragged_f32: workspace too small");
   unsigned long long* pa = (unsigned long long*)workspace;
   unsigned long long* pb = (unsigned long long*)((char*)workspace + pn_align_up((size_t)totalA * 8, 256));
+  // (the items' sizes are on the device: decide on the mean item)
+  if (chamfer_use_mfma(B, pn_cdiv(totalA, B), pn_cdiv(totalB, B)))
+    return chamfer_mfma(a, offA, maxA, totalA, b, offB, maxB, totalB, B, minA, argA, minB, argB,
+                        (char*)pb + pn_align_up((size_t)totalB * 8, 256), stream);
   int rc = PN_OK;
   if (minA || argA) {
     rc = chamfer_one_side(a, offA, maxA, totalA, b, offB, maxB, B, pa, minA, argA, stream);

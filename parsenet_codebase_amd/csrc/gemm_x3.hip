@@ -27,16 +27,27 @@ typedef float gx_f32x16 __attribute__((ext_vector_type(16)));
 #define GX_PIECE 64             // u32x4 per piece of a unit
 
 // rows image of a row-major matrix src (R, K): unit (row tile, k block); rows >= R and k >= K are zero
+// (blockIdx.y: one matrix of a batch of them — the weight gradient images gy[b] (M, N) and x[b] (K, N) with the
+// POINTS as contraction index; image b follows image b - 1)
 __global__ __launch_bounds__(256) void pn_gx_img_rows_kernel(const float* __restrict__ src, int R, int K, int nkb,
                                                              u32x4* __restrict__ img) {
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int rt = unit / nkb, kb = unit - rt * nkb;
   const int lane = threadIdx.x & 63, r = lane & 31, c = lane >> 5;
   if (rt * 32 >= R) return;
+  src += (size_t)blockIdx.y * R * K;
+  img += (size_t)blockIdx.y * ((R + 31) / 32) * nkb * GX_UNIT;
   const int row = rt * 32 + r, k0 = kb * 16 + 8 * c;
   float v[8];
+  if (row < R && k0 + 8 <= K && (K & 3) == 0) {
+    // (a lane's 8 contraction indices are contiguous in memory: two 16-byte loads)
+    const float4 a = *reinterpret_cast<const float4*>(src + (size_t)row * K + k0);
+    const float4 b = *reinterpret_cast<const float4*>(src + (size_t)row * K + k0 + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? src[(size_t)row * K + k0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] = (row < R && k0 + e < K) ? src[(size_t)row * K + k0 + e] : 0.f;
+  }
   u32x4 vh, vm, vl;
   X3_SPLIT_TO(v[0], v[1], vh, vm, vl, 0);
   X3_SPLIT_TO(v[2], v[3], vh, vm, vl, 1);
@@ -77,15 +88,24 @@ __global__ __launch_bounds__(256) void pn_gx_img_cf_kernel(const float* __restri
 // out[b][m][n] = sum_k A[m][k] X[b][n][k] (+ bias[m]); imgA: rows image with mt tiles, imgX: point image with
 // B * nt tiles (tile t of batch item b at b * nt + t), nkb blocks of 16 contraction indices in both.
 // grid (ceil(mt / 4), ceil(B nt / 4)): consecutive workgroups share the activation tiles (L2).
+// blockIdx.z = zb * zs + s (the weight gradient; the forward product has ONE z): operand pair zb — imgA and imgX
+// advance by a_z / x_z units per pair — and slice s of the contraction, k blocks [s kb_per, (s + 1) kb_per); the
+// block's result goes to out + z * out_z (partial sums, added up in z order by pn_gx_reduce_kernel).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void pn_gemm_x3_kernel(
     const u32x4* __restrict__ imgA, const u32x4* __restrict__ imgX, int M, int N, int mt, int nt, int ntot, int nkb,
-    const float* __restrict__ bias, float* __restrict__ out) {
+    const float* __restrict__ bias, float* __restrict__ out, int zs, int kb_per, size_t a_z, size_t x_z,
+    size_t out_z) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][8 * GX_UNIT];      // per stage: 4 A units, 4 X units
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int at0 = blockIdx.x * 4, xt0 = blockIdx.y * 4;
+  const int zb = blockIdx.z / zs, sl = blockIdx.z - zb * zs;
+  const int kb0 = sl * kb_per, kb1 = min(nkb, kb0 + kb_per);
+  imgA += zb * a_z * GX_UNIT;
+  imgX += zb * x_z * GX_UNIT;
+  out += blockIdx.z * out_z;
   // DMA: a stage is 24 chunks of 1 KiB (8 units x 3); wave w moves chunks 6 w .. 6 w + 5 = units 2 w, 2 w + 1
   const u32x4* src[2];
 #pragma unroll
@@ -111,12 +131,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-  GX_STAGE(0, 0);
+  if (kb0 < kb1) GX_STAGE(kb0, 0);
   int cur = 0;
-  for (int kb = 0; kb < nkb; ++kb) {
+  for (int kb = kb0; kb < kb1; ++kb) {
     __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): this wave's share of stage kb has landed
     __syncthreads();                        // ... everybody's; and everybody is done with the other buffer
-    if (kb + 1 < nkb) GX_STAGE(kb + 1, cur ^ 1);
+    if (kb + 1 < kb1) GX_STAGE(kb + 1, cur ^ 1);
     const u32x4* __restrict__ L = lds[cur];
     bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
@@ -214,7 +234,102 @@ extern "C" int pn_gemm_x3_f32(const void* img_a, const float* x, const float* bi
   {
     PN_PROF("gemm_x3", stream);
     hipLaunchKernelGGL(pn_gemm_x3_kernel, dim3(pn_cdiv(mt, 4), pn_cdiv(B * nt, 4)), dim3(256), 0, stream,
-                       (const u32x4*)img_a, (const u32x4*)workspace, M, N, mt, nt, B * nt, nkb, bias, out);
+                       (const u32x4*)img_a, (const u32x4*)workspace, M, N, mt, nt, B * nt, nkb, bias, out, 1, nkb,
+                       (size_t)0, (size_t)0, (size_t)0);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ---- the weight gradient: gw (M, K) = sum_b gy[b] (M, N) x[b]^T (N, K), contraction over the POINTS -----------
+// (src/model.py:157-176, src/PointNet.py:196-284: what autograd's conv1d backward computes with a rocBLAS product
+// over B N = 40 000 points.)  Rows images of gy[b] and x[b] (the points are contiguous in both: 16-byte loads),
+// the kernel above on (M / 128) x (K / 128) output blocks x B operand pairs x S slices of the points — S so that
+// the launch has ~3 workgroups per CU — and a FIXED-ORDER sum of the B S partial results: bit-reproducible, no
+// atomics.  gb (M) or NULL: the bias gradient sum_b sum_n gy[b][m][n] from the same pass (fixed order as well).
+static inline int gx_wgrad_slices(int B, int M, int K, int nkb) {
+  const int blocks = pn_cdiv(pn_cdiv(M, 32), 4) * pn_cdiv(pn_cdiv(K, 32), 4) * B;
+  int S = pn_cdiv(768, blocks);
+  const int smax = nkb / 16 > 0 ? nkb / 16 : 1;       // at least 16 k blocks (256 points) per slice
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  return S;
+}
+
+// out[i] = sum_z part[z][i] in z order; grid-stride, 4 elements per thread
+__global__ __launch_bounds__(256) void pn_gx_reduce_kernel(const float* __restrict__ part, int Z, size_t n,
+                                                           float* __restrict__ out) {
+  for (size_t i = (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      float4 acc = *reinterpret_cast<const float4*>(part + i);
+      for (int z = 1; z < Z; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * n + i);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out + i) = acc;
+    } else {
+      for (size_t j = i; j < n; ++j) {
+        float acc = part[j];
+        for (int z = 1; z < Z; ++z) acc += part[(size_t)z * n + j];
+        out[j] = acc;
+      }
+    }
+  }
+}
+
+// gb[m] = sum_b sum_n gy[b][m][n]: one wave per output channel, lanes stride the points, batch items in order,
+// a fixed butterfly at the end
+__global__ __launch_bounds__(256) void pn_gx_bias_grad_kernel(const float* __restrict__ gy, int B, int M, int N,
+                                                              float* __restrict__ gb) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* row = gy + ((size_t)b * M + m) * N;
+    for (int n = lane; n < N; n += 64) acc += row[n];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) gb[m] = acc;
+}
+
+extern "C" size_t pn_gemm_x3_wgrad_workspace(int B, int M, int K, int N) {
+  const int nkb = gx_nkb(N);
+  const size_t img = ((size_t)pn_cdiv(M, 32) + pn_cdiv(K, 32)) * B * nkb * GX_UNIT * 16;
+  const size_t part = (size_t)B * gx_wgrad_slices(B, M, K, nkb) * M * K * sizeof(float);
+  return img + part;
+}
+
+extern "C" int pn_gemm_x3_wgrad_f32(const float* gy, const float* x, int B, int M, int K, int N, float* gw, float* gb,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(gy && x && gw, "pn_gemm_x3_wgrad_f32: null pointer");
+  PN_CHECK_ARG(B >= 1 && M >= 1 && K >= 1 && N >= 1, "pn_gemm_x3_wgrad_f32: empty operand");
+  if (workspace_bytes < pn_gemm_x3_wgrad_workspace(B, M, K, N)) {
+    pn_set_error("pn_gemm_x3_wgrad_f32: workspace too small");
+    return PN_ERR_WORKSPACE;
+  }
+  const int nkb = gx_nkb(N), mt = pn_cdiv(M, 32), kt = pn_cdiv(K, 32);
+  const int S = gx_wgrad_slices(B, M, K, nkb), kb_per = pn_cdiv(nkb, S);
+  u32x4* imgG = (u32x4*)workspace;
+  u32x4* imgX = imgG + (size_t)B * mt * nkb * GX_UNIT;
+  float* part = (float*)(imgX + (size_t)B * kt * nkb * GX_UNIT);
+  {
+    PN_PROF("gemm_x3_image", stream);
+    hipLaunchKernelGGL(pn_gx_img_rows_kernel, dim3(pn_cdiv(mt * nkb, 4), B), dim3(256), 0, stream, gy, M, N, nkb, imgG);
+    hipLaunchKernelGGL(pn_gx_img_rows_kernel, dim3(pn_cdiv(kt * nkb, 4), B), dim3(256), 0, stream, x, K, N, nkb, imgX);
+  }
+  PN_CHECK_LAUNCH();
+  {
+    PN_PROF("gemm_x3_wgrad", stream);
+    // "points" of the kernel = the K rows of x[b]: out[z][m][k]
+    hipLaunchKernelGGL(pn_gemm_x3_kernel, dim3(pn_cdiv(mt, 4), pn_cdiv(kt, 4), B * S), dim3(256), 0, stream,
+                       (const u32x4*)imgG, (const u32x4*)imgX, M, K, mt, kt, kt, nkb, (const float*)nullptr, part, S,
+                       kb_per, (size_t)mt * nkb, (size_t)kt * nkb, (size_t)M * K);
+    const size_t n = (size_t)M * K;
+    hipLaunchKernelGGL(pn_gx_reduce_kernel, dim3((unsigned)pn_cdiv((long long)pn_cdiv((long long)n, 4), 256)), dim3(256),
+                       0, stream, (const float*)part, B * S, n, gw);
+    if (gb) hipLaunchKernelGGL(pn_gx_bias_grad_kernel, dim3(pn_cdiv(M, 4)), dim3(256), 0, stream, gy, B, M, N, gb);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;

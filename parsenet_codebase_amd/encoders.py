@@ -20,22 +20,21 @@ from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
-# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers.  As accurate as the
-# rocBLAS fp32 product (tests/test_gemm_gpu.py), 1.2-2.6 x faster per product.  PARSENET_GEMM_X3:
-#   "frozen" (default, round 5): products with a FROZEN weight only (requires_grad False: the SplineNets inside an
-#            end-to-end step, whose 1152 -> 1024 layer on S x 5 000 points is the step's largest product and runs at
-#            55-90 TFLOP/s in rocBLAS depending on S — 1.06 ms at S = 6, tools/probes/slow_gemm_probe.py); their weight
-#            images are cached, nothing that is trained changes its rounding;
-#   "1"      every product above the thresholds below — also the trained layers: +2 % on a cfg3 step, inside the noise
-#            on cfg5, and a change of the products' rounding trains ANOTHER network over hundreds of steps: the
-#            whole-step parity bars (tests/test_parity_fullsize_bwd_gpu.py) and the benchmark's pre-trained state are
-#            pinned to the rocBLAS arithmetic of the trained layers;
+# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the per-point layers.  As accurate as the rocBLAS
+# fp32 product (tests/test_gemm_gpu.py), 1.2-2.6 x faster per product.  PARSENET_GEMM_X3:
+#   "1"      (default, round 6) every product above the thresholds below, trained layers included: forward, the
+#            gradient w.r.t. the activations (image of W^T) AND the weight gradient (pn_gemm_x3_wgrad_f32: split over
+#            the points, fixed-order sum) — no rocBLAS product of a large layer is left in a training step;
+#   "frozen" (round 5) products with a FROZEN weight only (requires_grad False: the SplineNets inside an end-to-end
+#            step; their weight images are cached), the trained layers on rocBLAS;
 #   "0"      rocBLAS everywhere.
+# A change of the products' rounding trains ANOTHER network over hundreds of steps: the whole-step parity tests
+# (tests/test_parity_fullsize_bwd_gpu.py) and the benchmark's pre-trained state are pinned to the default arithmetic.
 # Below GEMM_X3_MIN_FLOP / GEMM_X3_MIN_ROWS the split images do not pay.
-GEMM_X3_MODE = os.environ.get("PARSENET_GEMM_X3", "frozen")
+GEMM_X3_MODE = os.environ.get("PARSENET_GEMM_X3", "1")
 GEMM_X3 = GEMM_X3_MODE in ("1", "frozen")
 GEMM_X3_MIN_FLOP = float(os.environ.get("PARSENET_GEMM_X3_MIN_GFLOP", "2")) * 1e9
-GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "512"))
+GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "128"))
 _W_IMAGES = {}          # id(frozen parameter) -> {view: ((version, data_ptr), image)}; entries die with the parameter
 
 
@@ -62,7 +61,7 @@ def _weight_image(w, transposed):
 
 class _WeightGemmX3(torch.autograd.Function):
     """w (Co,Ci) applied to x (B,Ci,N) (+ bias) on the bf16 matrix cores; the gradient w.r.t. x the same way
-    with the image of w^T, the gradient w.r.t. w as a rocBLAS product over the points."""
+    with the image of w^T, the gradient w.r.t. w (and the bias) by pn_gemm_x3_wgrad_f32."""
 
     @staticmethod
     def forward(ctx, w, x, bias):
@@ -82,9 +81,12 @@ class _WeightGemmX3(torch.autograd.Function):
                 gx = K.gemm_x3(_weight_image(w, True), w.shape[1], gy, None)
             else:
                 gx = torch.bmm(w.t().unsqueeze(0).expand(gy.shape[0], -1, -1), gy)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[0]:
-            gw = torch.bmm(gy, x.transpose(1, 2)).sum(0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # over the B N points: split-K on the matrix cores, fixed-order sum; the bias gradient from the same call
+            res = K.gemm_x3_wgrad(gy, x, want_bias=want_b)
+            gw, gb = res if want_b else (res, None)
+        elif want_b:
             gb = gy.sum((0, 2))
         return gw, gx, gb
 

@@ -615,6 +615,29 @@ def gemm_x3(img_a, M, x, bias=None):
     return out
 
 
+def gemm_x3_wgrad(gy, x, want_bias=False):
+    """Weight gradient of y[b] = W x[b] (+ bias): gw (M,K) = sum_b gy[b] x[b]^T over the points, bf16 x 3 on the
+    matrix cores with a fixed-order split over the points (csrc/gemm_x3.hip).  gy (B,M,N), x (B,K,N) fp32
+    channel-first.  Returns gw, or (gw, gb (M)) with ``want_bias``."""
+    require_cuda(gy, x)
+    gy, x = _f32c(gy, "gy"), _f32c(x, "x")
+    if gy.dim() != 3 or x.dim() != 3 or gy.shape[0] != x.shape[0] or gy.shape[2] != x.shape[2]:
+        raise ValueError("gemm_x3_wgrad expects gy (B,M,N) and x (B,K,N), got %s and %s"
+                         % (tuple(gy.shape), tuple(x.shape)))
+    B, M, N = gy.shape
+    Kd = x.shape[1]
+    lib = _lib.load()
+    gw = torch.empty((M, Kd), dtype=torch.float32, device=x.device)
+    gb = torch.empty((M,), dtype=torch.float32, device=x.device) if want_bias else None
+    wsz = lib.pn_gemm_x3_wgrad_workspace(B, M, Kd, N)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=x.device)
+    with _lib.on_device(x.device):
+        rc = lib.pn_gemm_x3_wgrad_f32(ptr(gy), ptr(x), B, M, Kd, N, ptr(gw), ptr(gb), ptr(ws), wsz,
+                                      current_stream(x.device))
+    check(rc, "pn_gemm_x3_wgrad_f32")
+    return (gw, gb) if want_bias else gw
+
+
 def meanshift_rows_bwd(gy, y, q, rsum, unorm, x, bsq, gx, ws=None):
     """One step of the mean-shift backward restricted to R <= 64 rows per batch item (csrc/meanshift_rows.hip;
     src/mean_shift.py:45-79 maps every row on its own): gy, y, q (B,R,128), rsum, unorm (B,R), x (B,N,128),

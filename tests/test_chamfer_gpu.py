@@ -8,6 +8,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["scalar", "mfma", "auto"], autouse=True)
+def chamfer_path(request, monkeypatch):
+    """Every test of this file on both kernels — PN_CHAMFER_MFMA=0: the scalar kernel, =1: the matrix-core
+    pre-filter with the exact decision (round 6), whatever the size — and on the library's own choice."""
+    if request.param == "auto":
+        monkeypatch.delenv("PN_CHAMFER_MFMA", raising=False)
+    else:
+        monkeypatch.setenv("PN_CHAMFER_MFMA", "1" if request.param == "mfma" else "0")
+    return request.param
+
+
 def _run(a, b, gpu):
     from parsenet_codebase_amd import kernels
     ta = torch.from_numpy(a).to(gpu)
@@ -50,3 +61,45 @@ def test_full_size_properties(gpu):
     assert (minA == 0).all() and (minB == 0).all()
     assert np.array_equal(argB[0], perm)
     assert np.array_equal(perm[argA[0]], np.arange(10000))
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (40.0, 0.0), (1.0, 300.0), (1e-3, 0.0), (1.0, -2.5)])
+def test_prefilter_bound_holds_far_from_the_origin_and_on_clumps(gpu, scale, offset):
+    """The certified bound of the matrix-core pre-filter scales with |q||c|: clouds far from the origin (where the
+    norms dwarf the distances and almost every candidate passes the filter), tiny and large extents, tight clumps
+    and exact duplicates — minima and arg-mins stay bit-identical to the oracle's."""
+    from oracle import cbind
+    rng = np.random.RandomState(17)
+    a = rng.uniform(-0.5, 0.5, (2, 1500, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, (2, 2100, 3)).astype(np.float32)
+    b[:, 1000:1400] = b[:, 600:1000] + rng.normal(0, 1e-5, (2, 400, 3)).astype(np.float32)     # clumps
+    b[:, 1400:1500] = b[:, 100:200]                                                            # exact duplicates
+    a[:, :100] = b[:, 1400:1500]                                                               # distance 0, ties
+    a = (a * scale + offset).astype(np.float32)
+    b = (b * scale + offset).astype(np.float32)
+    minA, argA, minB, argB = _run(a, b, gpu)
+    oA, oiA = cbind.chamfer_nn(a, b)
+    oB, oiB = cbind.chamfer_nn(b, a)
+    assert np.array_equal(argA, oiA) and np.array_equal(argB, oiB)
+    assert np.array_equal(minA.view(np.uint32), oA.view(np.uint32))
+    assert np.array_equal(minB.view(np.uint32), oB.view(np.uint32))
+
+
+def test_non_finite_coordinates_give_the_empty_key_on_both_kernels(gpu):
+    """A query with a NaN / inf coordinate has no finite distance: both kernels leave the "empty" pattern; a
+    non-finite CANDIDATE never wins."""
+    rng = np.random.RandomState(3)
+    a = rng.uniform(-0.5, 0.5, (1, 300, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, (1, 400, 3)).astype(np.float32)
+    a[0, 5, 1] = np.nan
+    a[0, 9, 0] = np.inf
+    b[0, 17, 2] = np.nan
+    minA, argA, minB, argB = _run(a, b, gpu)
+    assert argA[0, 5] == 0xffffffff and argA[0, 9] == 0xffffffff
+    ok = np.ones(300, bool)
+    ok[[5, 9]] = False
+    assert (argA[0, ok] != 17).all() and np.isfinite(minA[0, ok]).all()
+    d = ((a[0, ok, None, :] - b[0, None, :, :]) ** 2)
+    d = (d[..., 0] + d[..., 1]) + d[..., 2]
+    d[:, 17] = np.inf
+    assert np.array_equal(argA[0, ok], d.argmin(1))

@@ -187,7 +187,10 @@ def test_static_nms_equals_the_dynamic_one(gpu):
         assert torch.equal(wide[key], st[key]), key
 
 
-def test_ragged_chamfer_and_bspline_kernels(gpu):
+@pytest.mark.parametrize("chamfer_kernel", ["0", "1"])
+def test_ragged_chamfer_and_bspline_kernels(gpu, chamfer_kernel, monkeypatch):
+    # PN_CHAMFER_MFMA: the scalar kernel / the matrix-core pre-filter with the exact decision (csrc/chamfer.hip)
+    monkeypatch.setenv("PN_CHAMFER_MFMA", chamfer_kernel)
     from parsenet_codebase_amd import kernels as K
     from parsenet_codebase_amd.bspline import evaluate_surface, uniform_knot_bspline
     from parsenet_codebase_amd.fitting_batch import _BSplineEval, _RaggedChamfer

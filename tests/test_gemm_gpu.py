@@ -41,6 +41,30 @@ def test_gemm_x3_is_fp32_grade(gpu, B, M, K, N):
     assert err < max(3 * err_blas, 4 * 2.0 ** -24) and err < 1e-5, (err, err_blas)
 
 
+@pytest.mark.parametrize("B,M,K,N", [(4, 1024, 256, 10000), (4, 256, 512, 10000), (32, 1024, 512, 700), (3, 70, 100, 1000),
+                                     (1, 33, 17, 31), (2, 512, 520, 333), (4, 128, 256, 9999)])
+def test_weight_gradient_is_fp32_grade_and_bit_reproducible(gpu, B, M, K, N):
+    """pn_gemm_x3_wgrad_f32: gw = sum_b gy[b] x[b]^T over the points (split over the points, fixed-order sum of the
+    partial results) and the bias gradient: as close to the float64 result as the rocBLAS product, relative to
+    sum |gy||x|; two calls give the same bits; ragged rows / columns / point counts."""
+    from parsenet_codebase_amd import kernels as Kn
+    g = torch.Generator().manual_seed(M + 3 * K + N)
+    gy = (torch.randn(B, M, N, generator=g) * torch.rand(B, M, 1, generator=g) * 2).to(gpu)
+    x = (torch.randn(B, K, N, generator=g) * (0.1 + torch.rand(B, K, 1, generator=g) * 5)).to(gpu)
+    gw, gb = Kn.gemm_x3_wgrad(gy, x, want_bias=True)
+    want = torch.einsum("bmn,bkn->mk", gy.double(), x.double())
+    scale = torch.einsum("bmn,bkn->mk", gy.abs().double(), x.abs().double()) + 1e-30
+    err = ((gw.double() - want).abs() / scale).max().item()
+    blas = torch.bmm(gy, x.transpose(1, 2)).sum(0)
+    err_blas = ((blas.double() - want).abs() / scale).max().item()
+    assert err < max(3 * err_blas, 4 * 2.0 ** -24) and err < 1e-5, (err, err_blas)
+    wb = gy.double().sum((0, 2))
+    assert float(((gb.double() - wb).abs() / (gy.abs().double().sum((0, 2)) + 1e-30)).max()) < 1e-6
+    gw2, gb2 = Kn.gemm_x3_wgrad(gy, x, want_bias=True)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    assert torch.equal(Kn.gemm_x3_wgrad(gy, x), gw)
+
+
 def test_conv1x1_forward_and_backward_on_both_paths(gpu, monkeypatch):
     """encoders.conv1x1 above the size threshold runs on the matrix-core path; outputs and all three gradients
     agree with the rocBLAS path to fp32 noise; a weight edited in place gets a new image."""

@@ -68,6 +68,32 @@ def bench_gemm():
               pr.get("gemm_x3", 0), gf / pr.get("gemm_x3", 1), 6 * gf / pr.get("gemm_x3", 1) / 2500.0, t_bl, gf / t_bl))
 
 
+def bench_wgrad():
+    """Weight gradients of the trained per-point layers: pn_gemm_x3_wgrad_f32 (two rows images + split-K GEMM +
+    fixed-order reduction + bias gradient) against torch.bmm(gy, x^T).sum(0) + gy.sum((0, 2)) on rocBLAS."""
+    from parsenet_codebase_amd import _lib
+    dev = torch.device("cuda:0")
+    for (B, M, Kd, N, what) in [(4, 1024, 256, 10000, "cfg5 mlp1"), (4, 512, 256, 10000, "cfg5 conv1 (local part)"),
+                                (4, 256, 512, 10000, "cfg5 conv2"), (4, 256, 256, 10000, "cfg5 seg_prob1"),
+                                (4, 128, 256, 10000, "cfg5 seg_prob2"), (32, 1024, 512, 700, "cfg2 conv5"),
+                                (32, 1024, 1152, 700, "cfg3 conv5")]:
+        gy = torch.randn(B, M, N, device=dev)
+        x = torch.randn(B, Kd, N, device=dev)
+        t_x3 = timeit(lambda: kernels.gemm_x3_wgrad(gy, x, want_bias=True))
+        t_bl = timeit(lambda: (torch.bmm(gy, x.transpose(1, 2)).sum(0), gy.sum((0, 2))))
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        for _ in range(5):
+            kernels.gemm_x3_wgrad(gy, x, want_bias=True)
+        torch.cuda.synchronize()
+        pr = {kn: t / calls for kn, (t, calls) in _lib.prof_results().items()}
+        _lib.prof_enable(False)
+        gf = 2.0 * M * Kd * B * N / 1e9
+        print("%-26s M=%d K=%d points=%d: bf16x3 %.3f ms (images %.3f + GEMM, reduction, bias %.3f = %.0f TFLOP/s "
+              "fp32-equivalent), rocBLAS %.3f ms (%.0f TFLOP/s)" % (what, M, Kd, B * N, t_x3, pr.get("gemm_x3_image", 0),
+              pr.get("gemm_x3_wgrad", 0), gf / max(pr.get("gemm_x3_wgrad", 1), 1e-9), t_bl, gf / t_bl))
+
+
 def bench_knnwide():
     """The wide layers of the SplineNets inside a cfg5 step (segments of 2 500 sub-sampled points) and of a
     cfg3 step, bf16 x 3 passes on (PN_KNN_X3 = 2, default) and off (0: the fp32 matrix-core engine)."""
@@ -143,26 +169,39 @@ def bench_knn64():
 
 
 def bench_chamfer():
+    """Both nearest-neighbour kernels of csrc/chamfer.hip (PN_CHAMFER_MFMA=0: scalar, =1: matrix-core pre-filter with
+    the exact decision) at the sizes the configs name; results compared bit for bit."""
+    import os
+    from parsenet_codebase_amd import _lib
     dev = torch.device("cuda:0")
-    for (B, Na, Nb) in [(1, 10000, 10000), (32, 1600, 700), (1, 900, 2000), (8, 900, 1200)]:
+    for (B, Na, Nb) in [(1, 10000, 10000), (32, 1600, 700), (1, 900, 2000), (8, 900, 1200), (16, 930, 1500)]:
         a = torch.rand(B, Na, 3, device=dev)
         b = torch.rand(B, Nb, 3, device=dev)
-        ms = timeit(lambda: kernels.chamfer_nn(a, b))
-        from parsenet_codebase_amd import _lib
-        _lib.prof_reset(); _lib.prof_enable(True)
-        for _ in range(5):
-            kernels.chamfer_nn(a, b)
-        torch.cuda.synchronize()
-        kms, calls = _lib.prof_results()["chamfer_nn"]
-        _lib.prof_enable(False)
-        kms = 2 * kms / calls                      # two launches (one per direction) per call
-        # roof of this kernel: fp32 VALU issue.  8 arithmetic instructions per pair (3 sub, 3 mul,
-        # 2 add, unfused like the reference's elementwise path); 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-        pairs = 2.0 * B * Na * Nb
-        print("chamfer B=%d %dx%d: whole call %.3f ms; the two search kernels %.3f ms = %.2f Tpair/s x 8 arithmetic "
-              "instructions = %.1f %% of the 78.6 Tinstr/s fp32 VALU issue roof; %.1f GB/s of algorithmic HBM bytes" %
-              (B, Na, Nb, ms, kms, pairs / kms / 1e9, 100 * 8.0 * pairs / kms / 1e9 / 78.6,
-               (12.0 * B * (Na + Nb) + 12.0 * B * (Na + Nb)) / kms / 1e6))
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["PN_CHAMFER_MFMA"] = mode
+            ms = timeit(lambda: kernels.chamfer_nn(a, b))
+            res[mode] = kernels.chamfer_nn(a, b)
+            _lib.prof_reset(); _lib.prof_enable(True)
+            for _ in range(5):
+                kernels.chamfer_nn(a, b)
+            torch.cuda.synchronize()
+            pr = _lib.prof_results()
+            _lib.prof_enable(False)
+            kms = sum(pr[k][0] for k in ("chamfer_nn", "chamfer_image") if k in pr) / 5.0     # per call, both directions
+            # roofs: fp32 VALU issue (8 arithmetic instructions per pair, unfused like the reference's elementwise
+            # path; 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tinstr/s) for the pairs of the problem; the
+            # pre-filter executes one 32 x 32 x 16 bf16 MFMA (32 768 FLOP) per 1 024 pairs: 2.5 PFLOP/s dense
+            pairs = 2.0 * B * Na * Nb
+            extra = "" if mode == "0" else "; %.2f of the bf16 MFMA peak on the pre-filter's products" % (
+                pairs / 1024 * 32768 / (kms * 1e-3) / 2.5e15)
+            print("chamfer B=%d %dx%d %s: whole call %.3f ms; kernels %.4f ms = %.2f Tpair/s = %.2f of the 78.6 "
+                  "Tinstr/s VALU issue roof at 8 instructions per pair%s" %
+                  (B, Na, Nb, "matrix-core pre-filter" if mode == "1" else "scalar kernel         ", ms, kms,
+                   pairs / kms / 1e9, 8.0 * pairs / kms / 1e9 / 78.6, extra))
+        os.environ.pop("PN_CHAMFER_MFMA", None)
+        same = all(torch.equal(x, y) for x, y in zip(res["0"], res["1"]))
+        print("    minima and arg-mins of the two kernels bit-identical: %s" % same)
 
 
 def bench_edge():
