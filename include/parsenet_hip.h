@@ -197,6 +197,11 @@ size_t pn_gemm_x3_points_image_bytes(int B, int C, int N);
 int pn_gemm_x3_weight_image_f32(const float* w, int M, int K, int transposed, void* img, void* stream);
 int pn_gemm_x3_f32(const void* img_a, const float* x, const float* bias, int B, int M, int K, int N, float* out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* pn_gemm_x3_cat_f32: the same product with the K input channels spread over nsrc <= 4 tensors xs[s] (B, cs[s], N)
+ * (every cs[s] a multiple of 8, K = sum cs): W applied to the concatenation torch.cat builds in src/model.py:150
+ * without writing it.  xs, cs: HOST arrays of nsrc device pointers / channel counts. */
+int pn_gemm_x3_cat_f32(const void* img_a, const float* const* xs, const int* cs, int nsrc, const float* bias, int B,
+                       int M, int N, float* out, void* workspace, size_t workspace_bytes, void* stream);
 /* The weight gradient of such a layer (what autograd's conv1d backward forms over the B N points:
  * src/model.py:157-176, src/PointNet.py:196-284 under loss.backward()): gw (M,K) = sum_b gy[b] (M,N) x[b]^T (N,K)
  * in the same arithmetic, split over the points with a FIXED-ORDER sum of the partial results (bit-reproducible,
@@ -578,6 +583,12 @@ int pn_weighted_max_fwd_f32(const float* x, const float* scale, const float* shi
                             int N, int act, float slope, float* out, int* idx, float* val, void* stream);
 int pn_weighted_max_bwd_f32(const float* g, const int* idx, const float* val, int S, int C, int N, float* gw,
                             void* stream);
+
+/* Adam (torch.optim.Adam's defaults and update rule: train_parsenet.py:96, train_parsenet_e2e.py:88,
+ * train_open_splines.py:81) on ONE flat fp32 buffer of n parameters: p, the gradients g and both moments m, v are
+ * contiguous arrays of n floats; step = the 1-based count of this update.  One launch for the whole model. */
+int pn_adam_flat_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                     float eps, int step, void* stream);
 
 #ifdef __cplusplus
 }

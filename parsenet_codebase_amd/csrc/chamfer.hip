@@ -240,11 +240,25 @@ __global__ __launch_bounds__(64 * NW) void pn_chamfer_mfma_kernel(ChSide s0, ChS
   const int ntiles = (Nc + 31) >> 5;
   __syncthreads();
   int t = wave;
+  // one tile ahead: the bf16 record of the lane's row AND its fp32 coordinates (lane l and l + 32 hold candidate
+  // 32 t + (l & 31)): the exact evaluations below take their operands from a lane shuffle — a candidate that passes
+  // the filter costs ~30 instructions, not a memory latency (the first version loaded them per hit: 0.7 us each,
+  // serialised by the branches — 0.046 ms at 10k x 10k where the scalar kernel takes 0.061)
   u32x4 a_next = {0u, 0u, 0u, 0u};
-  if (t < ntiles) a_next = ci[4 * (size_t)min(32 * t + col, Nc - 1) + h];
+  float cx_n = 0.f, cy_n = 0.f, cz_n = 0.f;
+  if (t < ntiles) {
+    const int row = min(32 * t + col, Nc - 1);
+    a_next = ci[4 * (size_t)row + h];
+    cx_n = cb[3 * (size_t)row], cy_n = cb[3 * (size_t)row + 1], cz_n = cb[3 * (size_t)row + 2];
+  }
   for (; t < ntiles; t += NW) {
     const bf16x8 a = x3_as_bf16(a_next);
-    if (t + NW < ntiles) a_next = ci[4 * (size_t)min(32 * (t + NW) + col, Nc - 1) + h];
+    const float ccx = cx_n, ccy = cy_n, ccz = cz_n;
+    if (t + NW < ntiles) {
+      const int row = min(32 * (t + NW) + col, Nc - 1);
+      a_next = ci[4 * (size_t)row + h];
+      cx_n = cb[3 * (size_t)row], cy_n = cb[3 * (size_t)row + 1], cz_n = cb[3 * (size_t)row + 2];
+    }
     ch_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -260,11 +274,13 @@ __global__ __launch_bounds__(64 * NW) void pn_chamfer_mfma_kernel(ChSide s0, ChS
       bool improved = false;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (!(acc[r] > thr)) {
-          const int j = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (j < Nc) {
-            const float* cp = cb + 3 * (size_t)j;
-            const float d = ch_dist(qx, qy, qz, cp[0], cp[1], cp[2]);
+        const bool hit = !(acc[r] > thr);
+        if (__ballot(hit)) {                   // wave-uniform: the shuffles below run with every lane active
+          const int rowl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float x = __shfl(ccx, rowl, 64), y = __shfl(ccy, rowl, 64), z = __shfl(ccz, rowl, 64);
+          const int j = 32 * t + rowl;
+          if (hit && j < Nc) {
+            const float d = ch_dist(qx, qy, qz, x, y, z);
             if (d < __builtin_inff()) {          // (NaN / inf distances never win: the scalar kernel's rule)
               const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
               if (k < key) {

@@ -696,6 +696,58 @@ extern "C" int pn_affine_act_bwd_f32(const float* gy, const float* y, const floa
 }
 
 // =============================================================================================
+// Adam on ONE flat parameter buffer (train_parsenet.py:96, train_parsenet_e2e.py:88, train_open_splines.py:81:
+// optim.Adam(model.parameters(), lr) with torch's defaults).  torch's rule, operation by operation:
+//   m <- m + (g - m) (1 - beta1);  v <- beta2 v + (1 - beta2) g g
+//   p <- p - (lr / (1 - beta1^t)) m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+// All parameters of the model, their gradients (dp.FlatGradBucket) and both moments are contiguous: one launch,
+// 16-byte lanes, no per-tensor grouping on the host.
+// =============================================================================================
+__global__ __launch_bounds__(256) void pn_adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long long n,
+                                                           float one_minus_b1, float b2, float one_minus_b2,
+                                                           float step_size, float bc2_sqrt, float eps) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i);
+    float4 V = *reinterpret_cast<float4*>(v + i);
+    const float4 G = *reinterpret_cast<const float4*>(g + i);
+#define PN_ADAM1(PP, GG, MM, VV)                          \
+  {                                                       \
+    MM = MM + (GG - MM) * one_minus_b1;                   \
+    VV = b2 * VV + one_minus_b2 * GG * GG;                \
+    PP = PP - step_size * (MM / (sqrtf(VV) / bc2_sqrt + eps)); \
+  }
+    PN_ADAM1(P.x, G.x, M.x, V.x);
+    PN_ADAM1(P.y, G.y, M.y, V.y);
+    PN_ADAM1(P.z, G.z, M.z, V.z);
+    PN_ADAM1(P.w, G.w, M.w, V.w);
+    *reinterpret_cast<float4*>(p + i) = P;
+    *reinterpret_cast<float4*>(m + i) = M;
+    *reinterpret_cast<float4*>(v + i) = V;
+  } else {
+    for (long long j = i; j < n; ++j) {
+      float P = p[j], M = m[j], V = v[j];
+      const float G = g[j];
+      PN_ADAM1(P, G, M, V);
+      p[j] = P, m[j] = M, v[j] = V;
+    }
+  }
+#undef PN_ADAM1
+}
+
+extern "C" int pn_adam_flat_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                                float beta2, float eps, int step, void* stream) {
+  PN_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "pn_adam_flat_f32: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(pn_adam_flat_kernel, dim3((unsigned)pn_cdiv(pn_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, p,
+                     g, m, v, n, 1.0f - beta1, beta2, 1.0f - beta2, (float)((double)lr / bc1), (float)sqrt(bc2), eps);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// =============================================================================================
 // non-maximum suppression of the shifted points (src/mean_shift.py:139-179), device side
 // =============================================================================================
 // counts[b][membership[b][n]] += 1 (integer atomics: order-independent)

@@ -62,7 +62,15 @@ __global__ __launch_bounds__(256) void pn_gx_img_rows_kernel(const float* __rest
 // image of a channel-first tensor src (B, C, N) with the POINTS as rows and the channels as the
 // contraction index: unit ((b, point tile), k block); points >= N and channels >= C are zero.
 // (A row-major matrix W (M, K) read this way — B = 1, C = M, N = K — gives the rows image of W^T.)
-__global__ __launch_bounds__(256) void pn_gx_img_cf_kernel(const float* __restrict__ src, int C, int N, int ntile, int nkb,
+// The channels may come from up to four tensors (B, C_s, N) laid end to end — the concatenation of the edge-conv
+// layers' outputs that src/model.py:150 builds with torch.cat is never written out: source s holds the channels
+// [cbeg[s], cbeg[s + 1]), every boundary a multiple of 8 (one lane's chunk comes from one source).
+struct GxSources {
+  const float* ptr[4];
+  int cbeg[4];      // first channel of source s (unused sources: INT_MAX)
+  int ccnt[4];      // its channel count (the batch stride is ccnt * N)
+};
+__global__ __launch_bounds__(256) void pn_gx_img_cf_kernel(GxSources S, int C, int N, int ntile, int nkb,
                                                            u32x4* __restrict__ img) {
   const int b = blockIdx.y;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);      // inside the batch item
@@ -70,7 +78,10 @@ __global__ __launch_bounds__(256) void pn_gx_img_cf_kernel(const float* __restri
   const int lane = threadIdx.x & 63, r = lane & 31, c = lane >> 5;
   if (pt >= ntile) return;
   const int n = pt * 32 + r, k0 = kb * 16 + 8 * c;
-  const float* __restrict__ sb = src + (size_t)b * C * N;
+  int si = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t) si += (k0 >= S.cbeg[t]) ? 1 : 0;
+  const float* __restrict__ sb = S.ptr[si] + (size_t)b * S.ccnt[si] * N - (size_t)S.cbeg[si] * N;
   float v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = (n < N && k0 + e < C) ? sb[(size_t)(k0 + e) * N + n] : 0.f;
@@ -186,6 +197,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 static inline int gx_nkb(int K) { return (K + 15) / 16; }
+static inline GxSources gx_one_source(const float* p, int C) {
+  GxSources S;
+  for (int t = 0; t < 4; ++t) {
+    S.ptr[t] = p;
+    S.cbeg[t] = t == 0 ? 0 : 0x7fffffff;
+    S.ccnt[t] = C;
+  }
+  return S;
+}
 
 extern "C" size_t pn_gemm_x3_weight_image_bytes(int M, int K) {
   return (size_t)pn_cdiv(M, 32) * gx_nkb(K) * GX_UNIT * 16;
@@ -205,8 +225,8 @@ extern "C" int pn_gemm_x3_weight_image_f32(const float* w, int M, int K, int tra
                        (u32x4*)img);
   } else {
     const int ntile = pn_cdiv(K, 32), nkb = gx_nkb(M);
-    hipLaunchKernelGGL(pn_gx_img_cf_kernel, dim3(pn_cdiv(ntile * nkb, 4), 1), dim3(256), 0, stream, w, M, K, ntile, nkb,
-                       (u32x4*)img);
+    hipLaunchKernelGGL(pn_gx_img_cf_kernel, dim3(pn_cdiv(ntile * nkb, 4), 1), dim3(256), 0, stream, gx_one_source(w, M), M,
+                       K, ntile, nkb, (u32x4*)img);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -215,9 +235,37 @@ extern "C" int pn_gemm_x3_weight_image_f32(const float* w, int M, int K, int tra
 // out (B, M, N) = A x (+ bias (M), may be NULL).  img_a: pn_gemm_x3_weight_image_f32 of an (M, K) operand
 // (i.e. of W, or of W^T with M and K exchanged); x (B, K, N) channel-first fp32; workspace:
 // pn_gemm_x3_points_image_bytes(B, K, N) bytes for the image of x.
+static int gemm_x3_sources(const void* img_a, GxSources S, const float* bias, int B, int M, int K, int N, float* out,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 extern "C" int pn_gemm_x3_f32(const void* img_a, const float* x, const float* bias, int B, int M, int K, int N, float* out,
                               void* workspace, size_t workspace_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(x, "pn_gemm_x3_f32: null input");
+  return gemm_x3_sources(img_a, gx_one_source(x, K), bias, B, M, K, N, out, workspace, workspace_bytes,
+                         (hipStream_t)stream_);
+}
+
+// the same product with the K input channels spread over nsrc <= 4 tensors xs[s] (B, cs[s], N), every cs[s] a
+// multiple of 8, sum cs = K: W applied to the concatenation without writing it
+extern "C" int pn_gemm_x3_cat_f32(const void* img_a, const float* const* xs, const int* cs, int nsrc, const float* bias,
+                                  int B, int M, int N, float* out, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
+  PN_CHECK_ARG(xs && cs && nsrc >= 1 && nsrc <= 4, "pn_gemm_x3_cat_f32: 1 to 4 sources");
+  GxSources S = gx_one_source(xs[0], cs[0]);
+  int K = 0;
+  for (int t = 0; t < nsrc; ++t) {
+    PN_CHECK_ARG(xs[t] && cs[t] >= 8 && cs[t] % 8 == 0, "pn_gemm_x3_cat_f32: source %d has %d channels (multiples of 8)", t,
+                 cs[t]);
+    S.ptr[t] = xs[t];
+    S.cbeg[t] = K;
+    S.ccnt[t] = cs[t];
+    K += cs[t];
+  }
+  return gemm_x3_sources(img_a, S, bias, B, M, K, N, out, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+static int gemm_x3_sources(const void* img_a, GxSources S, const float* bias, int B, int M, int K, int N, float* out,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream) {
   PN_CHECK_ARG(B >= 1 && M >= 1 && K >= 1 && N >= 1, "pn_gemm_x3_f32: empty operand");
   if (workspace_bytes < pn_gemm_x3_points_image_bytes(B, K, N)) {
     pn_set_error("pn_gemm_x3_f32: workspace too small");
@@ -227,7 +275,7 @@ extern "C" int pn_gemm_x3_f32(const void* img_a, const float* x, const float* bi
   PN_CHECK_ARG((long long)B * nt < (1ll << 30), "pn_gemm_x3_f32: too many point tiles");
   {
     PN_PROF("gemm_x3_image", stream);
-    hipLaunchKernelGGL(pn_gx_img_cf_kernel, dim3(pn_cdiv(nt * nkb, 4), B), dim3(256), 0, stream, x, K, N, nt, nkb,
+    hipLaunchKernelGGL(pn_gx_img_cf_kernel, dim3(pn_cdiv(nt * nkb, 4), B), dim3(256), 0, stream, S, K, N, nt, nkb,
                        (u32x4*)workspace);
   }
   PN_CHECK_LAUNCH();
@@ -277,20 +325,49 @@ __global__ __launch_bounds__(256) void pn_gx_reduce_kernel(const float* __restri
   }
 }
 
-// gb[m] = sum_b sum_n gy[b][m][n]: one wave per output channel, lanes stride the points, batch items in order,
-// a fixed butterfly at the end
+// gb[m] = sum_b sum_n gy[b][m][n]: one 256-thread workgroup per output channel; a thread adds the elements
+// 4 t .. 4 t + 3 (mod 1024) of every batch item's row in order (four independent 16-byte loads in flight), the 256
+// partial sums meet in a fixed LDS tree: the same bits on every run.
+// (Round 6, first version: one WAVE per channel striding the row 64 floats at a time — 625 dependent trips of a
+// memory latency each, 0.3 ms per layer whatever its size; it made the whole weight gradient slower than rocBLAS.)
 __global__ __launch_bounds__(256) void pn_gx_bias_grad_kernel(const float* __restrict__ gy, int B, int M, int N,
                                                               float* __restrict__ gb) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (m >= M) return;
+  __shared__ float red[256];
+  const int m = blockIdx.x, t = threadIdx.x;
   float acc = 0.f;
+  const bool vec = (N & 3) == 0;
   for (int b = 0; b < B; ++b) {
     const float* row = gy + ((size_t)b * M + m) * N;
-    for (int n = lane; n < N; n += 64) acc += row[n];
+    if (vec) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int n = 4 * t;
+      for (; n + 3 * 1024 < N; n += 4 * 1024) {
+        const float4 v0 = *reinterpret_cast<const float4*>(row + n);
+        const float4 v1 = *reinterpret_cast<const float4*>(row + n + 1024);
+        const float4 v2 = *reinterpret_cast<const float4*>(row + n + 2048);
+        const float4 v3 = *reinterpret_cast<const float4*>(row + n + 3072);
+        a0 += (v0.x + v0.y) + (v0.z + v0.w);
+        a1 += (v1.x + v1.y) + (v1.z + v1.w);
+        a2 += (v2.x + v2.y) + (v2.z + v2.w);
+        a3 += (v3.x + v3.y) + (v3.z + v3.w);
+      }
+      for (; n < N; n += 1024) {
+        const float4 v0 = *reinterpret_cast<const float4*>(row + n);
+        a0 += (v0.x + v0.y) + (v0.z + v0.w);
+      }
+      acc += (a0 + a1) + (a2 + a3);
+    } else {
+      for (int n = t; n < N; n += 256) acc += row[n];
+    }
   }
+  red[t] = acc;
+  __syncthreads();
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (lane == 0) gb[m] = acc;
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) gb[m] = red[0];
 }
 
 extern "C" size_t pn_gemm_x3_wgrad_workspace(int B, int M, int K, int N) {
@@ -329,7 +406,7 @@ extern "C" int pn_gemm_x3_wgrad_f32(const float* gy, const float* x, int B, int 
     const size_t n = (size_t)M * K;
     hipLaunchKernelGGL(pn_gx_reduce_kernel, dim3((unsigned)pn_cdiv((long long)pn_cdiv((long long)n, 4), 256)), dim3(256),
                        0, stream, (const float*)part, B * S, n, gw);
-    if (gb) hipLaunchKernelGGL(pn_gx_bias_grad_kernel, dim3(pn_cdiv(M, 4)), dim3(256), 0, stream, gy, B, M, N, gb);
+    if (gb) hipLaunchKernelGGL(pn_gx_bias_grad_kernel, dim3(M), dim3(256), 0, stream, gy, B, M, N, gb);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;

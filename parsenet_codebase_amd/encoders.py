@@ -279,20 +279,33 @@ class DGCNNControlPoints(nn.Module):
                 idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
-        cat = torch.cat(feats, dim=1)
-        aff = _frozen_affine(self.conv5[0], self.bn5, cat)
-        if (aff is not None and isinstance(weights, torch.Tensor) and weights.numel() == batch_size * cat.shape[2]
-                and cat.shape[2] <= _WMAX_BWD_MAX_POINTS and not (torch.is_grad_enabled() and (
-                    cat.requires_grad or self.conv5[0].weight.requires_grad))):
+        w5 = self.conv5[0].weight[:, :, 0]
+        aff = _frozen_affine(self.conv5[0], self.bn5, feats[0])
+        npts = feats[0].shape[2]
+        grad5 = torch.is_grad_enabled() and (any(f.requires_grad for f in feats) or self.conv5[0].weight.requires_grad)
+
+        def conv5_product():
+            # frozen network (the fitting stage's SplineNets): W applied to the four layers' outputs where they lie —
+            # the concatenation of src/model.py:150 (S x 512 / 1152 x 5000 floats, 0.37 ms of copies per cfg5 step)
+            # is never written
+            if not grad5 and _gemm_x3_pays(w5, feats[0]) and all(f.shape[1] % 8 == 0 for f in feats):
+                from . import kernels as K
+                return K.gemm_x3_cat(_weight_image(w5, False), w5.shape[0], feats)
+            return weight_bmm(w5, torch.cat(feats, dim=1))
+        if (aff is not None and isinstance(weights, torch.Tensor) and weights.numel() == batch_size * npts
+                and npts <= _WMAX_BWD_MAX_POINTS and not grad5):
             # frozen network inside the fitting stage: activation, membership weighting and the max over
             # the points in ONE pass over the 1024-channel features (they are never written out)
-            x = _WeightedMax.apply(weight_bmm(self.conv5[0].weight[:, :, 0], cat), aff[0], aff[1],
+            x = _WeightedMax.apply(conv5_product(), aff[0], aff[1],
                                    weights.reshape(batch_size, -1), _ACT["leaky"], 0.2).unsqueeze(2)
             x = conv_bn_act(x, self.conv6, self.bn6, "relu")
             x = conv_bn_act(x, self.conv7, self.bn7, "relu")
             x = self.tanh(conv1x1(x, self.conv8)[:, :, 0])
             return x.view(batch_size, self.controlpoints * self.controlpoints, 3)
-        x = conv_bn_act(cat, self.conv5[0], self.bn5, "leaky", 0.2)
+        if aff is None:
+            x = conv_bn_act(torch.cat(feats, dim=1), self.conv5[0], self.bn5, "leaky", 0.2)
+        else:
+            x = _AffineAct.apply(conv5_product(), aff[0], aff[1], _ACT["leaky"], 0.2)
         if isinstance(weights, torch.Tensor):
             # the reference reshapes to (1,1,-1) (one segment per call); a (B,n) matrix weights
             # every item of a batch of segments with its own memberships

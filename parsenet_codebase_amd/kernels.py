@@ -615,6 +615,34 @@ def gemm_x3(img_a, M, x, bias=None):
     return out
 
 
+def gemm_x3_cat(img_a, M, xs, bias=None):
+    """gemm_x3 applied to the concatenation of xs (a list of 1 to 4 tensors (B,C_s,N), every C_s a multiple of 8)
+    along the channels — without writing the concatenation (src/model.py:150 builds it with torch.cat)."""
+    import ctypes
+    require_cuda(img_a, *xs)
+    xs = [_f32c(t, "x") for t in xs]
+    if not 1 <= len(xs) <= 4 or any(t.dim() != 3 or t.shape[0] != xs[0].shape[0] or t.shape[2] != xs[0].shape[2]
+                                    or t.shape[1] % 8 for t in xs):
+        raise ValueError("gemm_x3_cat expects 1 to 4 tensors (B,C_s,N) with C_s a multiple of 8")
+    B, _, N = xs[0].shape
+    Kd = sum(t.shape[1] for t in xs)
+    lib = _lib.load()
+    if img_a.numel() != lib.pn_gemm_x3_weight_image_bytes(M, Kd):
+        raise ValueError("gemm_x3_cat: the weight image does not belong to a (%d,%d) operand" % (M, Kd))
+    if bias is not None:
+        bias = _f32c(bias, "bias")
+    out = torch.empty((B, M, N), dtype=torch.float32, device=xs[0].device)
+    wsz = lib.pn_gemm_x3_points_image_bytes(B, Kd, N)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=out.device)
+    ptrs = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+    chans = (ctypes.c_int * len(xs))(*[t.shape[1] for t in xs])
+    with _lib.on_device(out.device):
+        rc = lib.pn_gemm_x3_cat_f32(ptr(img_a), ptrs, chans, len(xs), ptr(bias), B, M, N, ptr(out), ptr(ws), wsz,
+                                    current_stream(out.device))
+    check(rc, "pn_gemm_x3_cat_f32")
+    return out
+
+
 def gemm_x3_wgrad(gy, x, want_bias=False):
     """Weight gradient of y[b] = W x[b] (+ bias): gw (M,K) = sum_b gy[b] x[b]^T over the points, bf16 x 3 on the
     matrix cores with a fixed-order split over the points (csrc/gemm_x3.hip).  gy (B,M,N), x (B,K,N) fp32

@@ -1,6 +1,8 @@
 """The BASELINE.json configurations as callable training steps on synthetic data (used by
 bench.py, __graft_entry__.smoke() and the tests).  Everything a step touches is resident on
 the GPU before the timed region starts."""
+import os
+
 import numpy as np
 import torch
 
@@ -10,10 +12,17 @@ from .encoders import PrimitivesEmbeddingDGCNGn
 from .losses import EmbeddingLoss, primitive_loss
 
 
-def _adam(params, lr):
-    """torch.optim.Adam with the multi-tensor FUSED kernel on the GPU: the same update rule in one
-    or two launches instead of a dozen foreach launches per step."""
+FLAT_ADAM = os.environ.get("PARSENET_FLAT_ADAM", "1") != "0"
+
+
+def _adam(params, lr, bucket=None):
+    """Adam with torch's defaults.  With the model's gradient bucket on the GPU: optim.FlatAdam — parameters,
+    gradients and moments in flat buffers, ONE launch per step (round 6).  PARSENET_FLAT_ADAM=0 (developer A/B) or
+    no bucket: torch.optim.Adam with the multi-tensor fused kernel."""
     params = list(params)
+    if FLAT_ADAM and bucket is not None and params and params[0].is_cuda:
+        from .optim import FlatAdam
+        return FlatAdam(bucket, lr=lr)
     return torch.optim.Adam(params, lr=lr, fused=bool(params and params[0].is_cuda))
 
 
@@ -60,7 +69,7 @@ class ParsenetSegStep:
                                                num_primitives=10, loss_function=self.loss.triplet_loss,
                                                mode=5, num_channels=6, nn_nb=nn_nb).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
-        self.opt = _adam(self.model.parameters(), lr)
+        self.opt = _adam(self.model.parameters(), lr, self.bucket)
         self.rng_seed = seed
         self.shape_ids = None if shape_ids is None else list(shape_ids)
         if shape_ids is not None:
@@ -144,7 +153,7 @@ class ParsenetE2EStep(ParsenetSegStep):
         self.pretrain_loss = None
         if self.pretrain_steps:
             self._pretrain(seed, first_shape, pretrain_lr)
-        self.opt = _adam(self.model.parameters(), lr)
+        self.opt = _adam(self.model.parameters(), lr, self.bucket)
         torch.manual_seed(seed + 1)
         open_net = DGCNNControlPoints(20, num_points=10, mode=0)
         closed_net = DGCNNControlPoints(20, num_points=10, mode=1)
@@ -360,7 +369,7 @@ class SplineNetStep:
         self.loss_weight = loss_weight
         self.model = DGCNNControlPoints(20, num_points=10, mode=1 if closed else 0).to(device)
         self.bucket = FlatGradBucket(self.model.parameters())
-        self.opt = _adam(self.model.parameters(), lr)
+        self.opt = _adam(self.model.parameters(), lr, self.bucket)
         nu, nv = uniform_knot_bspline(20, 20, 3, 3, 30 if closed else 40)
         self.nu = torch.from_numpy(nu.astype(np.float32)).to(device)
         self.nv = torch.from_numpy(nv.astype(np.float32)).to(device)

@@ -65,6 +65,24 @@ def test_weight_gradient_is_fp32_grade_and_bit_reproducible(gpu, B, M, K, N):
     assert torch.equal(Kn.gemm_x3_wgrad(gy, x), gw)
 
 
+@pytest.mark.parametrize("chans", [(64, 64, 128, 256), (128, 256, 256, 512), (8,), (16, 24)])
+def test_product_with_the_concatenation_without_writing_it(gpu, chans):
+    """pn_gemm_x3_cat_f32: W applied to channels that lie in up to four tensors (the SplineNets' conv5 on the four
+    edge-conv outputs, src/model.py:150-157) — the same bits as the product with torch.cat of them."""
+    from parsenet_codebase_amd import kernels as Kn
+    g = torch.Generator().manual_seed(sum(chans))
+    B, N, M = 3, 1500, 96
+    xs = [torch.randn(B, c, N, generator=g).to(gpu) for c in chans]
+    w = torch.randn(M, sum(chans), generator=g).to(gpu)
+    bias = torch.randn(M, generator=g).to(gpu)
+    img = Kn.gemm_x3_weight_image(w)
+    want = Kn.gemm_x3(img, M, torch.cat(xs, 1).contiguous(), bias)
+    got = Kn.gemm_x3_cat(img, M, xs, bias)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        Kn.gemm_x3_cat(img, M, [torch.randn(B, 12, N, device=gpu)])          # not a multiple of 8
+
+
 def test_conv1x1_forward_and_backward_on_both_paths(gpu, monkeypatch):
     """encoders.conv1x1 above the size threshold runs on the matrix-core path; outputs and all three gradients
     agree with the rocBLAS path to fp32 noise; a weight edited in place gets a new image."""
@@ -119,22 +137,27 @@ def test_frozen_weight_images_follow_the_parameter_not_its_address(gpu, monkeypa
     assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
 
 
-def test_default_mode_takes_frozen_weights_only(gpu):
-    """PARSENET_GEMM_X3 unset ("frozen"): a layer whose weight is trained keeps the rocBLAS product (its rounding is
-    what the pre-trained states and the whole-step parity bars are pinned to), a frozen one — the SplineNets inside
-    an end-to-end step — runs on the matrix cores, with the gradient with respect to its input."""
+def test_default_mode_takes_trained_and_frozen_weights(gpu, monkeypatch):
+    """PARSENET_GEMM_X3 unset ("1", round 6): a large layer runs on the matrix cores whether its weight is trained or
+    frozen — forward, the gradient with respect to its input and, for a trained weight, the weight and bias gradients
+    (pn_gemm_x3_wgrad_f32).  Mode "frozen" (round 5's default) keeps the trained layers on rocBLAS; results agree to
+    fp32 noise either way."""
     from parsenet_codebase_amd import encoders as E
-    assert E.GEMM_X3_MODE == "frozen" and E.GEMM_X3
+    assert E.GEMM_X3_MODE == "1" and E.GEMM_X3
     torch.manual_seed(5)
     conv = torch.nn.Conv1d(1152, 1024, 1).to(gpu)
     x = torch.randn(2, 1152, 5000, device=gpu, requires_grad=True)
+    gy = torch.randn(2, 1024, 5000, device=gpu)
     y = E.conv1x1(x, conv)
-    assert not y.grad_fn.name().startswith("_WeightGemmX3")
+    assert y.grad_fn.name().startswith("_WeightGemmX3")
+    gx1, gw1, gb1 = torch.autograd.grad(y, (x, conv.weight, conv.bias), gy)
+    monkeypatch.setattr(E, "GEMM_X3_MODE", "frozen")
+    yb = E.conv1x1(x, conv)
+    assert not yb.grad_fn.name().startswith("_WeightGemmX3")
+    gx0, gw0, gb0 = torch.autograd.grad(yb, (x, conv.weight, conv.bias), gy)
+    for a, b in ((y, yb), (gx1, gx0), (gw1, gw0), (gb1, gb0)):
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-5       # (>= 1 024 terms per output, two roundings)
     conv.requires_grad_(False)
     yf = E.conv1x1(x, conv)
-    assert yf.grad_fn.name().startswith("_WeightGemmX3")
-    assert float((yf - y).abs().max() / y.abs().max()) < 1e-5       # (1 152 terms per output, two roundings)
-    gy = torch.randn_like(y)
-    g0, = torch.autograd.grad(y, x, gy, retain_graph=True)
-    g1, = torch.autograd.grad(yf, x, gy)
-    assert float((g1 - g0).abs().max() / g0.abs().max()) < 1e-5
+    assert yf.grad_fn.name().startswith("_WeightGemmX3")               # frozen weights: on the matrix cores in both modes
+    assert torch.equal(yf, y)
