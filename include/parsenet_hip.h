@@ -590,6 +590,12 @@ int pn_weighted_max_bwd_f32(const float* g, const int* idx, const float* val, in
 int pn_adam_flat_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                      float eps, int step, void* stream);
 
+/* Gradient tensors into the flat data-parallel bucket (the buffer the ONE all-reduce of a step works on; the
+ * reference's DataParallel reduces per parameter, train_parsenet.py:90-91): tensor e = ns[e] floats at srcs[e] goes
+ * to flat + offs[e].  srcs / offs / ns are HOST arrays of count entries; 64 tensors per launch. */
+int pn_gather_flat_f32(const float* const* srcs, const long long* offs, const long long* ns, int count, float* flat,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

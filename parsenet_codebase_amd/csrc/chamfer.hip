@@ -44,6 +44,7 @@
 
 #define CH_THREADS 128
 #define CH_GROUP 8
+#define CH_DEPTH 4        // tiles of prefetch in the matrix-core kernel
 
 typedef float ch_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -239,62 +240,71 @@ __global__ __launch_bounds__(64 * NW) void pn_chamfer_mfma_kernel(ChSide s0, ChS
   float bestf = __builtin_inff();
   const int ntiles = (Nc + 31) >> 5;
   __syncthreads();
-  int t = wave;
-  // one tile ahead: the bf16 record of the lane's row AND its fp32 coordinates (lane l and l + 32 hold candidate
+  // CH_DEPTH tiles ahead: the bf16 record of the lane's row AND its fp32 coordinates (lane l and l + 32 hold candidate
   // 32 t + (l & 31)): the exact evaluations below take their operands from a lane shuffle — a candidate that passes
-  // the filter costs ~30 instructions, not a memory latency (the first version loaded them per hit: 0.7 us each,
-  // serialised by the branches — 0.046 ms at 10k x 10k where the scalar kernel takes 0.061)
-  u32x4 a_next = {0u, 0u, 0u, 0u};
-  float cx_n = 0.f, cy_n = 0.f, cz_n = 0.f;
-  if (t < ntiles) {
-    const int row = min(32 * t + col, Nc - 1);
-    a_next = ci[4 * (size_t)row + h];
-    cx_n = cb[3 * (size_t)row], cy_n = cb[3 * (size_t)row + 1], cz_n = cb[3 * (size_t)row + 2];
+  // the filter costs ~30 instructions, not a memory latency.  (First versions: operands loaded per hit — 0.7 us each,
+  // serialised by the branches — and then ONE tile of prefetch: a wave's 39 tiles each waited a full L2 latency,
+  // 0.046 ms at 10k x 10k where the scalar kernel takes 0.061.)
+  u32x4 aq[CH_DEPTH];
+  float cxq[CH_DEPTH], cyq[CH_DEPTH], czq[CH_DEPTH];
+#define CH_LOAD(D_, T_)                                                          \
+  {                                                                              \
+    const int row_ = min(32 * (T_) + col, Nc - 1);                               \
+    aq[D_] = ci[4 * (size_t)row_ + h];                                           \
+    cxq[D_] = cb[3 * (size_t)row_], cyq[D_] = cb[3 * (size_t)row_ + 1], czq[D_] = cb[3 * (size_t)row_ + 2]; \
   }
-  for (; t < ntiles; t += NW) {
-    const bf16x8 a = x3_as_bf16(a_next);
-    const float ccx = cx_n, ccy = cy_n, ccz = cz_n;
-    if (t + NW < ntiles) {
-      const int row = min(32 * (t + NW) + col, Nc - 1);
-      a_next = ci[4 * (size_t)row + h];
-      cx_n = cb[3 * (size_t)row], cy_n = cb[3 * (size_t)row + 1], cz_n = cb[3 * (size_t)row + 2];
-    }
-    ch_f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
-    // the smallest of the lane's 16 bounds (rows past the end of the cloud repeat its last point: harmless)
-    float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+  for (int d = 0; d < CH_DEPTH; ++d) {
+    aq[d] = u32x4{0u, 0u, 0u, 0u};
+    cxq[d] = cyq[d] = czq[d] = 0.f;
+    if (wave + d * NW < ntiles) CH_LOAD(d, wave + d * NW);
+  }
+  for (int t0 = wave; t0 < ntiles; t0 += NW * CH_DEPTH) {
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, acc[r]), acc[r + 1]);
-    m = fminf(m, acc[15]);
-    const float bcur = fminf(bestf, __uint_as_float(s_best[col]));
-    const float thr = (bcur - nq) + 0x1p-20f * (bcur + nq);       // inf while nothing is known: everything passes
-    if (__ballot(!(m > thr))) {
-      bool improved = false;
+    for (int d = 0; d < CH_DEPTH; ++d) {
+      const int t = t0 + d * NW;
+      if (t >= ntiles) break;
+      const bf16x8 a = x3_as_bf16(aq[d]);
+      const float ccx = cxq[d], ccy = cyq[d], ccz = czq[d];
+      if (t + NW * CH_DEPTH < ntiles) CH_LOAD(d, t + NW * CH_DEPTH);
+      ch_f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool hit = !(acc[r] > thr);
-        if (__ballot(hit)) {                   // wave-uniform: the shuffles below run with every lane active
-          const int rowl = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float x = __shfl(ccx, rowl, 64), y = __shfl(ccy, rowl, 64), z = __shfl(ccz, rowl, 64);
-          const int j = 32 * t + rowl;
-          if (hit && j < Nc) {
-            const float d = ch_dist(qx, qy, qz, x, y, z);
-            if (d < __builtin_inff()) {          // (NaN / inf distances never win: the scalar kernel's rule)
-              const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
-              if (k < key) {
-                key = k;
-                bestf = d;
-                improved = true;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc, 0, 0, 0);
+      // the smallest of the lane's 16 bounds (rows past the end of the cloud repeat its last point: harmless)
+      float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) m = fminf(fminf(m, acc[r]), acc[r + 1]);
+      m = fminf(m, acc[15]);
+      const float bcur = fminf(bestf, __uint_as_float(s_best[col]));
+      const float thr = (bcur - nq) + 0x1p-20f * (bcur + nq);       // inf while nothing is known: everything passes
+      if (__ballot(!(m > thr))) {
+        bool improved = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool hit = !(acc[r] > thr);
+          if (__ballot(hit)) {                   // wave-uniform: the shuffles below run with every lane active
+            const int rowl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float x = __shfl(ccx, rowl, 64), y = __shfl(ccy, rowl, 64), z = __shfl(ccz, rowl, 64);
+            const int j = 32 * t + rowl;
+            if (hit && j < Nc) {
+              const float d2 = ch_dist(qx, qy, qz, x, y, z);
+              if (d2 < __builtin_inff()) {        // (NaN / inf distances never win: the scalar kernel's rule)
+                const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+                if (k < key) {
+                  key = k;
+                  bestf = d2;
+                  improved = true;
+                }
               }
             }
           }
         }
+        if (improved) atomicMin(&s_best[col], __float_as_uint(bestf));   // d >= 0: the bit pattern orders like the value
       }
-      if (improved) atomicMin(&s_best[col], __float_as_uint(bestf));   // d >= 0: the bit pattern orders like the value
     }
   }
+#undef CH_LOAD
   // smallest (distance, index) over the two half waves, then over the waves
   {
     const unsigned lo = __shfl_xor((unsigned)key, 32, 64), hi = __shfl_xor((unsigned)(key >> 32), 32, 64);

@@ -748,6 +748,50 @@ extern "C" int pn_adam_flat_f32(float* p, const float* g, float* m, float* v, lo
 }
 
 // =============================================================================================
+// The gradients autograd hands over (one tensor per parameter) into the flat bucket of dp.FlatGradBucket: ONE launch
+// for up to 64 tensors — the pointers travel in the kernel arguments — instead of one device-to-device copy per
+// parameter (torch._foreach_copy_ issues 46 of them for the segmentation network: 134 copy launches per cfg5 step
+// in profiles/r05_cfg5_profile_only_kernel_stats.csv).
+// =============================================================================================
+struct PnGatherTable {
+  const float* src[64];
+  long long off[64];
+  long long n[64];
+};
+
+__global__ __launch_bounds__(256) void pn_gather_flat_kernel(PnGatherTable T, float* __restrict__ flat) {
+  const int e = blockIdx.y;
+  const float* __restrict__ s = T.src[e];
+  float* __restrict__ d = flat + T.off[e];
+  const long long n = T.n[e];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    d[i] = s[i];
+}
+
+// srcs / offs / ns: HOST arrays of ``count`` entries: tensor e = ns[e] floats at srcs[e] -> flat + offs[e]
+extern "C" int pn_gather_flat_f32(const float* const* srcs, const long long* offs, const long long* ns, int count,
+                                  float* flat, void* stream) {
+  PN_CHECK_ARG(srcs && offs && ns && flat && count >= 0, "pn_gather_flat_f32: bad arguments");
+  for (int e0 = 0; e0 < count; e0 += 64) {
+    PnGatherTable T;
+    const int m = count - e0 < 64 ? count - e0 : 64;
+    long long nmax = 0;
+    for (int e = 0; e < m; ++e) {
+      PN_CHECK_ARG(srcs[e0 + e] && ns[e0 + e] >= 0 && offs[e0 + e] >= 0, "pn_gather_flat_f32: bad entry %d", e0 + e);
+      T.src[e] = srcs[e0 + e];
+      T.off[e] = offs[e0 + e];
+      T.n[e] = ns[e0 + e];
+      if (T.n[e] > nmax) nmax = T.n[e];
+    }
+    int bx = pn_cdiv(nmax, 256 * 16);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL(pn_gather_flat_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, T, flat);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// =============================================================================================
 // non-maximum suppression of the shifted points (src/mean_shift.py:139-179), device side
 // =============================================================================================
 // counts[b][membership[b][n]] += 1 (integer atomics: order-independent)

@@ -126,10 +126,12 @@ class FlatGradBucket:
         self.collective = True      # False: steps that only one rank runs (workloads.train_on_rank0_then_broadcast)
         self._side = None           # host-side (gloo) group for the step-status flag, created on first use
         self.views = []
+        self._offsets = []
         o = 0
         for p in self.params:
             n = p.numel()
             self.views.append(self.flat[o:o + n].view_as(p))
+            self._offsets.append(o)
             p.grad = self.views[-1]
             o += n
         self._written = set()        # parameters whose slot holds a gradient of the previous gather()
@@ -165,17 +167,36 @@ class FlatGradBucket:
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             g = p.grad
             if g is not None and g.data_ptr() != v.data_ptr():
-                dst.append(v)
+                dst.append(i)
                 src.append(g.detach())
                 now.add(i)
         for i in self._written - now:            # had a gradient last time, none now: its slot must not keep the old one
             self.views[i].zero_()
         if dst:
-            torch._foreach_copy_(dst, src)
+            self._gather(dst, src)
         self._written = now
         for p, v in zip(self.params, self.views):
             p.grad = v
         return self.flat
+
+    def _gather(self, slots, grads):
+        """``grads[j]`` into slot ``slots[j]`` of the flat buffer.  On the GPU: ONE launch for up to 64 tensors
+        (pn_gather_flat_f32; torch._foreach_copy_ decomposes into a device-to-device copy per parameter on this
+        stack — 46 launches for the segmentation network)."""
+        if self.flat.is_cuda and self.flat.dtype == torch.float32:
+            import ctypes
+            from . import _lib
+            grads = [g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float() for g in grads]
+            n = len(grads)
+            srcs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+            offs = (ctypes.c_longlong * n)(*[self._offsets[i] for i in slots])
+            ns = (ctypes.c_longlong * n)(*[g.numel() for g in grads])
+            with _lib.on_device(self.flat.device):
+                rc = _lib.load().pn_gather_flat_f32(srcs, offs, ns, n, _lib.ptr(self.flat),
+                                                    _lib.current_stream(self.flat.device))
+            _lib.check(rc, "pn_gather_flat_f32")
+            return
+        torch._foreach_copy_([self.views[i] for i in slots], grads)
 
     def _multi(self):
         return self.collective and multi_rank()

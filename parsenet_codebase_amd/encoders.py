@@ -20,21 +20,28 @@ from .norms import group_norm_relu, group_norm_relu_max
 from ._lib import require_cuda
 
 
-# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the per-point layers.  As accurate as the rocBLAS
-# fp32 product (tests/test_gemm_gpu.py), 1.2-2.6 x faster per product.  PARSENET_GEMM_X3:
-#   "1"      (default, round 6) every product above the thresholds below, trained layers included: forward, the
-#            gradient w.r.t. the activations (image of W^T) AND the weight gradient (pn_gemm_x3_wgrad_f32: split over
-#            the points, fixed-order sum) — no rocBLAS product of a large layer is left in a training step;
-#   "frozen" (round 5) products with a FROZEN weight only (requires_grad False: the SplineNets inside an end-to-end
-#            step; their weight images are cached), the trained layers on rocBLAS;
+# fp32-grade GEMMs on the bf16 matrix cores (csrc/gemm_x3.hip) for the large per-point layers.  As accurate as the
+# rocBLAS fp32 product (tests/test_gemm_gpu.py), 1.2-2.6 x faster per forward product.  PARSENET_GEMM_X3:
+#   "frozen" (default) products with a FROZEN weight only (requires_grad False: the SplineNets inside an end-to-end
+#            step, whose 1152 -> 1024 layer on S x 5 000 points is the step's largest product); their weight images are
+#            cached, nothing that is trained changes its rounding;
+#   "1"      every product above the thresholds below — also the trained layers: forward, the gradient w.r.t. the
+#            activations and (round 6) the weight + bias gradient (pn_gemm_x3_wgrad_f32: split over the points, fixed-
+#            order sum).  Measured in round 6 on one box, alternating (tools/jobs/r6c.sh, profiles/r06_gemm_x3_ab.txt):
+#            cfg4 504 against 518 shapes/s, cfg5 inside the spread, cfg3 +1 %, cfg2 +14 %.  The weight gradient is
+#            where it loses: the split images of BOTH operands (gy and x over 40 000 points: 0.03-0.09 ms) are written
+#            for ONE use, and rocBLAS already runs these skinny products at 90-100 TFLOP/s — 0.275 against 0.234 ms
+#            for the 1024 x 256 layer, 0.107 against 0.056 ms for 128 x 256; it wins from ~1M weight elements on
+#            (cfg3's 1024 x 1152 conv5: 0.432 against 0.492 ms).  And a change of the trained products' rounding trains
+#            ANOTHER network over hundreds of steps: the three whole-step parity tests pre-train their own network and
+#            their pinned partitions flip (re-pin search in tools/jobs/r6c.sh: every candidate recipe moves some shape
+#            across a merge) — so the trained layers stay on rocBLAS by default;
 #   "0"      rocBLAS everywhere.
-# A change of the products' rounding trains ANOTHER network over hundreds of steps: the whole-step parity tests
-# (tests/test_parity_fullsize_bwd_gpu.py) and the benchmark's pre-trained state are pinned to the default arithmetic.
 # Below GEMM_X3_MIN_FLOP / GEMM_X3_MIN_ROWS the split images do not pay.
-GEMM_X3_MODE = os.environ.get("PARSENET_GEMM_X3", "1")
+GEMM_X3_MODE = os.environ.get("PARSENET_GEMM_X3", "frozen")
 GEMM_X3 = GEMM_X3_MODE in ("1", "frozen")
 GEMM_X3_MIN_FLOP = float(os.environ.get("PARSENET_GEMM_X3_MIN_GFLOP", "2")) * 1e9
-GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "128"))
+GEMM_X3_MIN_ROWS = int(os.environ.get("PARSENET_GEMM_X3_MIN_ROWS", "512"))
 _W_IMAGES = {}          # id(frozen parameter) -> {view: ((version, data_ptr), image)}; entries die with the parameter
 
 

@@ -25,7 +25,11 @@ class FlatAdam(torch.optim.Optimizer):
             raise RuntimeError("FlatAdam runs on the GPU (no CPU path)")
         if any(p.dtype != torch.float32 for p in params):
             raise TypeError("FlatAdam: fp32 parameters only")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # torch.optim.Adam's param-group keys, at its defaults (the ones that change the rule are refused in step()):
+        # a state_dict of either optimizer loads into the other
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self.bucket = bucket
         dev = params[0].device
         self.flat_p = torch.empty(bucket.numel, dtype=torch.float32, device=dev)
@@ -62,6 +66,8 @@ class FlatAdam(torch.optim.Optimizer):
             raise RuntimeError("FlatAdam: a parameter left the flat buffer (module.to() / a new .data after the "
                                "optimizer was built); build the optimizer last")
         g = self.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise NotImplementedError("FlatAdam: plain Adam only (no weight decay / amsgrad / maximize)")
         self.steps += 1
         with _lib.on_device(self.flat_p.device):
             rc = _lib.load().pn_adam_flat_f32(ptr(self.flat_p), ptr(self.bucket.flat), ptr(self.flat_m),

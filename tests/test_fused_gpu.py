@@ -280,3 +280,38 @@ def test_flat_adam_follows_torch_adam_and_round_trips_its_state(gpu):
     params[0].data = params[0].data.clone()
     with pytest.raises(RuntimeError):
         opt.step()
+
+
+def test_bucket_gather_is_one_launch_and_equals_the_accumulated_bucket(gpu):
+    """dp.FlatGradBucket.begin() / gather() on the GPU (pn_gather_flat_f32: the gradients autograd hands over go
+    into the flat buffer in one launch) against zero() + accumulation into the views: the same bucket, also for
+    more than 64 parameters (two launches), non-contiguous gradients and a parameter without a gradient."""
+    from parsenet_codebase_amd.dp import FlatGradBucket
+    torch.manual_seed(2)
+    shapes = [(64, 6, 1, 1), (64,), (7, 3), (1,), (1024, 256, 1)] + [(5, k + 1) for k in range(70)]
+    params = [torch.nn.Parameter(torch.randn(s, device=gpu)) for s in shapes]
+    bucket = FlatGradBucket(params)
+    x = torch.randn(3, device=gpu)
+
+    def loss():
+        # parameter 3 gets no gradient; parameter 2's gradient arrives as a transposed (non-contiguous) tensor
+        tot = (params[2].t() * torch.arange(3, device=gpu).view(3, 1)).sum() * x.sum()
+        for k, p in enumerate(params):
+            if k not in (2, 3):
+                tot = tot + (p * p).sum() * (k + 1)
+        return tot
+    bucket.zero()
+    loss().backward()
+    want = bucket.flat.clone()
+    bucket.begin()
+    assert all(p.grad is None for p in params)
+    loss().backward()
+    got = bucket.gather()
+    assert torch.equal(got, want)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+    # a second step in which parameter 0 gets no gradient: its slot is cleared, not stale
+    bucket.begin()
+    (params[1] * 2).sum().backward()
+    g2 = bucket.gather()
+    assert float(g2[:params[0].numel()].abs().max()) == 0.0
+    assert torch.equal(bucket.views[1], torch.full_like(params[1], 2.0))
