@@ -401,6 +401,15 @@ int pn_edgeconv_bwd_i32(const float* PQ, const int32_t* idx, const float* t, con
                         const float* c1c2, int B, int N, int k, int Cout, int groups,
                         int per_sample, int dense, float* dPQ, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* The transposed graph is a function of idx alone: pn_edgeconv_csr_build writes it into a workspace of
+ * pn_edgeconv_bwd_workspace(B, N, k) bytes (idx_is_i32: int32 / int64 indices) — e.g. during the forward pass, on a
+ * side stream — and pn_edgeconv_bwd_prebuilt runs the backward on it (same kernels, same result). */
+int pn_edgeconv_csr_build(const void* idx, int idx_is_i32, int B, int N, int k, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int pn_edgeconv_bwd_prebuilt(const float* PQ, const void* idx, int idx_is_i32, const float* t, const float* s1,
+                             const uint8_t* argk, const float* mean, const float* rstd, const float* c1c2, int B, int N,
+                             int k, int Cout, int groups, int per_sample, int dense, float* dPQ, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- Chamfer nearest neighbour ---------------------------------------------------
  * Replaces the (M,N,3) broadcast + torch.min of src/utils.py:286-296 (chamfer_distance),

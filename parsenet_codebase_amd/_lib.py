@@ -53,6 +53,9 @@ SIGNATURES = {
     "pn_edgeconv_bwd_prep_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "pn_edgeconv_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "pn_edgeconv_csr_build": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "pn_edgeconv_bwd_prebuilt": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 7 +
+                                 [c_void_p, c_void_p, c_size_t, c_void_p]),
     "pn_edgeconv_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),

@@ -44,7 +44,7 @@
 
 #define CH_THREADS 128
 #define CH_GROUP 8
-#define CH_DEPTH 4        // tiles of prefetch in the matrix-core kernel
+#define CH_DEPTH 1        // tiles of prefetch in the matrix-core kernel (4 measured slower: 103 registers, 0.068 ms)
 
 typedef float ch_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -367,11 +367,16 @@ static int chamfer_one_side(const float* q, const int* qoff, int Nq, long long t
   return PN_OK;
 }
 
-// The matrix-core path pays from ~1e6 pairs on (an image launch first); PN_CHAMFER_MFMA=0 / 1 forces the scalar /
-// the matrix-core kernel (tests and A/B runs).
+// Measured (tools/kbench.py chamfer, profiles/r06_named_kernels_kbench.txt): 10k x 10k 0.047 against 0.061 ms for the
+// scalar kernel; 32 x 1600 x 700 0.049 against 0.038; ragged items of ~900 x 2000: equal.  A wave's scan has to be
+// long for its threshold to tighten (every candidate that beats the running minimum costs an exact evaluation and
+// the first tiles of a scan all do), so the matrix-core kernel takes the searches with >= 4 096 points on both sides
+// — the 10 000-point coverage distances of test.py:157-168.  PN_CHAMFER_MFMA=0 / 1 forces the scalar / the
+// matrix-core kernel (tests run both on every size).
 static bool chamfer_use_mfma(long long items, int Nq, int Nc) {
+  (void)items;
   if (const char* e = getenv("PN_CHAMFER_MFMA")) return atoi(e) != 0;
-  return Nq >= 64 && Nc >= 64 && items * (long long)Nq * Nc >= 1000000ll;
+  return Nq >= 4096 && Nc >= 4096;
 }
 
 static size_t chamfer_image_bytes(long long total) { return pn_align_up((size_t)total * 64, 256); }

@@ -997,11 +997,20 @@ __global__ __launch_bounds__(256) void pn_edgeconv_bwd_point_kernel(
   dPQ[((size_t)b * N + i) * 2 * Cout + Cout + c] = r * (t[o] - fk * c1 - c2 * r * (s1[o] - fk * mu));
 }
 
+// where pn_build_rev_csr leaves the transposed graph inside a workspace of pn_edgeconv_bwd_workspace(B, N, k) bytes
+static inline void pn_rev_csr_in_workspace(void* workspace, int B, int N, const int** off, const uint32_t** rev) {
+  char* w = (char*)workspace + pn_align_up((size_t)B * N * 4, 256);
+  *off = (const int*)w;
+  *rev = (const uint32_t*)(w + pn_align_up((size_t)B * (N + 1) * 4, 256));
+}
+
+// ``prebuilt``: the workspace already holds the transposed graph of idx (pn_edgeconv_csr_build_*): the graph depends
+// on idx alone, so a caller can build it during the FORWARD pass on a side stream, off the backward's critical path
 template <typename IT>
 static int edgeconv_bwd(const float* PQ, const IT* idx, const float* t, const float* s1, const uint8_t* argk,
                         const float* mean, const float* rstd, const float* c1c2, int B, int N, int k, int Cout,
                         int groups, int per_sample, int dense, float* dPQ, void* workspace, size_t workspace_bytes,
-                        void* stream_) {
+                        void* stream_, int prebuilt = 0) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(PQ && idx && t && s1 && argk && mean && rstd && c1c2 && dPQ,
                "pn_edgeconv_bwd: null pointer");
@@ -1009,7 +1018,11 @@ static int edgeconv_bwd(const float* PQ, const IT* idx, const float* t, const fl
   const int Cg = Cout / groups;
   const int* off = nullptr;
   const uint32_t* rev = nullptr;
-  {
+  if (prebuilt) {
+    PN_CHECK_ARG(workspace && workspace_bytes >= pn_edgeconv_bwd_workspace(B, N, k),
+                 "pn_edgeconv_bwd: workspace too small for a prebuilt graph");
+    pn_rev_csr_in_workspace(workspace, B, N, &off, &rev);
+  } else {
     PN_PROF("edgeconv_bwd_csr", stream);
     const int rc = pn_build_rev_csr<IT>(idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
     if (rc != PN_OK) return rc;
@@ -1047,6 +1060,29 @@ extern "C" int pn_edgeconv_bwd_f32(const float* PQ, const int64_t* idx, const fl
   return edgeconv_bwd<int64_t>(PQ, idx, t, s1, argk, mean, rstd, c1c2, B, N, k, Cout, groups, per_sample, dense,
                                dPQ, workspace, workspace_bytes, stream_);
 }
+// The transposed graph of idx into ``workspace`` (pn_edgeconv_bwd_workspace(B, N, k) bytes), for
+// pn_edgeconv_bwd_prebuilt_*; idx_is_i32 selects the index width.
+extern "C" int pn_edgeconv_csr_build(const void* idx, int idx_is_i32, int B, int N, int k, void* workspace,
+                                     size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  PN_CHECK_ARG(idx && B > 0 && N > 0 && k > 0, "pn_edgeconv_csr_build: bad arguments");
+  const int* off = nullptr;
+  const uint32_t* rev = nullptr;
+  PN_PROF("edgeconv_bwd_csr", stream);
+  return idx_is_i32 ? pn_build_rev_csr<int32_t>((const int32_t*)idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev)
+                    : pn_build_rev_csr<int64_t>((const int64_t*)idx, B, N, k, workspace, workspace_bytes, stream, &off, &rev);
+}
+
+extern "C" int pn_edgeconv_bwd_prebuilt(const float* PQ, const void* idx, int idx_is_i32, const float* t, const float* s1,
+                                        const uint8_t* argk, const float* mean, const float* rstd, const float* c1c2,
+                                        int B, int N, int k, int Cout, int groups, int per_sample, int dense, float* dPQ,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+  return idx_is_i32 ? edgeconv_bwd<int32_t>(PQ, (const int32_t*)idx, t, s1, argk, mean, rstd, c1c2, B, N, k, Cout, groups,
+                                            per_sample, dense, dPQ, workspace, workspace_bytes, stream_, 1)
+                    : edgeconv_bwd<int64_t>(PQ, (const int64_t*)idx, t, s1, argk, mean, rstd, c1c2, B, N, k, Cout, groups,
+                                            per_sample, dense, dPQ, workspace, workspace_bytes, stream_, 1);
+}
+
 // the same on the library's int32 graph (pn_knn_graph_i32)
 extern "C" int pn_edgeconv_bwd_i32(const float* PQ, const int32_t* idx, const float* t,
                                    const float* s1, const uint8_t* argk, const float* mean,

@@ -591,6 +591,11 @@ static int knn_x3_level() {
   const char* e = getenv("PN_KNN_X3");
   return e ? atoi(e) : 2;
 }
+// piece products of the THRESHOLD pass: 3 (default, round 6: knn_x3.h) or 6 (PN_KNN_X3_P1=6, developer A/B)
+static int knn_x3_p1_products() {
+  const char* e = getenv("PN_KNN_X3_P1");
+  return (e && atoi(e) == 6) ? 6 : 3;
+}
 // 256 channels (ksteps 128; round 4): the squared-distance form only — kNN graphs of the widest edge-conv
 // layers (closed SplineNet) —, and only when the 128-query workgroups (one per CU: the resident queries take
 // 192 registers) fill the chip: measured (tools/kbench.py knnwide, N = 2 500, k = 10) 12 segments 0.85 ms
@@ -702,6 +707,8 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   float* xpm = x3p2 ? (float*)(base + w.xpm) : nullptr;
   float* xxo = x3p2 ? (float*)(base + w.xxo) : nullptr;
   const float x3A = 4.0f * (float)(p.Cp + 2) * 0x1p-24f;
+  const int np1 = knn_x3_p1_products();
+  const float x3A1 = np1 == 3 ? x3A + 3.1f * 0x1p-16f : x3A;
   if (x3p1) {
     PN_PROF("knn_x3_image", stream);
     PN_CHECK_HIP(hipMemsetAsync(xxmax, 0, (size_t)B * 4, stream));
@@ -738,28 +745,39 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
       dim3 g1(pn_cdiv(ntiles, tps1), pn_cdiv(p.Nqp, qpw), B);
       {
         PN_PROF(mode == 2 ? "sel_x3_pass1_dot" : (p.ksteps == 32 ? "knn_x3_pass1_c64" : "knn_x3_pass1_wide"), stream);
-#define KX_GO(NCH, QS, MD, TPS_, KIND_, GRID, TPSL, SUBCAP)                                                        \
-  hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, MD, TPS_, KIND_>), GRID, dim3(256), 0, stream, xq, xxq, Nq, p.Nqp, \
-                     img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP, (const unsigned*)xxmax)
+#define KX_GO_NP(NCH, QS, MD, TPS_, KIND_, NP_, GRID, TPSL, SUBCAP)                                                  \
+  hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, MD, TPS_, KIND_, NP_>), GRID, dim3(256), 0, stream, xq, xxq, Nq,  \
+                     p.Nqp, img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP,                 \
+                     (const unsigned*)xxmax)
+#define KX_GO(NCH, QS, MD, TPS_, KIND_, GRID, TPSL, SUBCAP) KX_GO_NP(NCH, QS, MD, TPS_, KIND_, 6, GRID, TPSL, SUBCAP)
+#define KX_GO1(NCH, QS, MD, TPS_)                            \
+  {                                                          \
+    if (np1 == 3)                                            \
+      KX_GO_NP(NCH, QS, MD, TPS_, 0, 3, g1, tps1, 0);        \
+    else                                                     \
+      KX_GO_NP(NCH, QS, MD, TPS_, 0, 6, g1, tps1, 0);        \
+  }
         if (mode == 0 && p.ksteps == 32)
-          KX_GO(8, 2, 0, 2, 0, g1, tps1, 0);
+          KX_GO1(8, 2, 0, 2)
         else if (mode == 0 && p.ksteps == 64)
-          KX_GO(16, 1, 0, 1, 0, g1, tps1, 0);
+          KX_GO1(16, 1, 0, 1)
         else if (mode == 0)
-          KX_GO(32, 1, 0, 1, 0, g1, tps1, 0);
+          KX_GO1(32, 1, 0, 1)
         else if (p.ksteps == 32)
-          KX_GO(8, 2, 2, 2, 0, g1, tps1, 0);
+          KX_GO1(8, 2, 2, 2)
         else
-          KX_GO(16, 1, 2, 1, 0, g1, tps1, 0);
+          KX_GO1(16, 1, 2, 1)
       }
       PN_CHECK_LAUNCH();
       {
         PN_PROF("knn_tau", stream);
         hipLaunchKernelGGL(pn_knn_tau_kernel, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream,
                            tilemax, Nq, p.Nqp, p.Ncp / 16, k, tau);
-        if (!approx_value)
+        // (the value selection collects in the arithmetic of a six-product threshold pass: no margin then; with the
+        // three-product pass its threshold is lowered by both passes' bounds like the graph's)
+        if (!approx_value || np1 == 3)
           hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq, Nq,
-                             p.Nqp, xxmax, x3A, mode, x3p2 ? 2.0f : 1.0f);
+                             p.Nqp, xxmax, x3A, mode, (x3p2 || approx_value) ? 2.0f : 1.0f, x3A1);
       }
       PN_CHECK_LAUNCH();
       if (approx_value) {

@@ -87,7 +87,13 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
 // KIND 0: tile maxima; KIND 1: collect the candidates with v~ >= tau (tau already lowered by the
 // margin) into the sub-list of (query, slice, half) like pass 2 of the fp32 engine — the keys carry
 // APPROXIMATE values, pn_knn_final_x3_kernel repairs what the approximation cannot decide.
-template <int NCH, int QSETS, int MODE, int TPS, int KIND>
+// NP: piece products per fp32 product.  6: the fp32-grade form above.  3 (round 6, the THRESHOLD pass only): h.h,
+// m.h and h.m — the dropped h.l, l.h and m.m terms are each below 2^-16 |q_c||c_c| per channel, in all
+// <= 3 * 2^-16 |q||c| (Cauchy-Schwarz); the pass only has to deliver a threshold that is certainly not above the
+// k-th largest value, so its error constant A1 = A + 3.1 * 2^-16 goes into the margin (pn_knn_x3_margin_kernel) and
+// the pass costs half the matrix-core work.  The collecting pass and the final sort keep six products: a wider
+// collecting window would hand every survivor to the exact re-evaluation of pn_knn_final_x3_kernel.
+template <int NCH, int QSETS, int MODE, int TPS, int KIND, int NP = 6>
 __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_WPE(NCH, MODE), KX_WPE(NCH, MODE)))) void pn_knn_x3_pass_kernel(
     const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
     const u32x4* __restrict__ PC, const float* __restrict__ xxc_, int Nc, int Ncp, int tiles_per_slice,
@@ -208,12 +214,19 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
             // (products outermost: consecutive MFMAs go to different accumulators)
 #define KX_P(ACC, A_, B_) _Pragma("unroll") for (int u = 0; u < QSETS; ++u) \
     ACC[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[u][s], ACC[u], 0, 0, 0)
-            KX_P(acs, al, qh);
-            KX_P(acc, ah, qh);
-            KX_P(sm2, ah, ql);
-            KX_P(acs, am, qm);
-            KX_P(sm2, am, qh);
-            KX_P(acs, ah, qm);
+            if (NP == 6) {
+              KX_P(acs, al, qh);
+              KX_P(acc, ah, qh);
+              KX_P(sm2, ah, ql);
+              KX_P(acs, am, qm);
+              KX_P(sm2, am, qh);
+              KX_P(acs, ah, qm);
+            } else {
+              static_assert(NP == 6 || (NP == 3 && KIND == 0), "three products: the threshold pass only");
+              KX_P(acc, ah, qh);
+              KX_P(sm2, am, qh);
+              KX_P(acs, ah, qm);
+            }
 #undef KX_P
           }
           if (NCH == 32) {
@@ -314,14 +327,15 @@ __device__ static inline float knx_eps(float nq, float nc, float A, int mode) {
   return (mode == 0 ? 2.0f * A * cross + 0x1p-21f * (nq + nc) : A * cross) * 1.0001f;
 }
 
-// ``times``: 1 when the collecting pass is exact, 2 when it runs on approximate values as well
+// tau <- tau - eps(A1) - (times - 1) eps(A): A1 the error constant of the threshold pass (= A with six products),
+// ``times``: 1 when the collecting pass is exact, 2 when it runs on approximate values (constant A) as well
 __global__ void pn_knn_x3_margin_kernel(float* __restrict__ tau, const float* __restrict__ xxq, int Nq, int Nqp,
-                                        const unsigned* __restrict__ xxmax, float A, int mode, float times) {
+                                        const unsigned* __restrict__ xxmax, float A, int mode, float times, float A1) {
   const int b = blockIdx.y;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= Nq) return;
   const float nq = xxq[(size_t)b * Nqp + q], nc = __uint_as_float(xxmax[b]);
-  const float eps = times * knx_eps(nq, nc, A, mode);
+  const float eps = knx_eps(nq, nc, A1, mode) + (times - 1.0f) * knx_eps(nq, nc, A, mode);
   const float t = tau[(size_t)b * Nqp + q];
   // round down: one more ulp of |t| + eps on top
   tau[(size_t)b * Nqp + q] = t - eps - 0x1p-22f * fabsf(t);

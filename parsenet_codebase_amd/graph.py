@@ -5,6 +5,7 @@ numerically heavy is a HIP kernel reached through ``kernels`` (C ABI).  Only tin
 per-channel reductions and the point-level GEMM are left to torch (rocBLAS).
 """
 import contextlib
+import os
 import threading
 import weakref
 
@@ -145,6 +146,21 @@ def graph_feature(x, idx):
 # --------------------------------------------------------------------------------------
 # fused edge convolution: conv1x1 -> norm -> LeakyReLU -> max_k
 # --------------------------------------------------------------------------------------
+# The transposed graph the backward gathers through depends on idx alone: it is built during the FORWARD pass on a
+# side stream (five small latency-bound launches, 0.13 ms per layer at cfg4's size, next to the following layer's
+# distance passes) instead of at the head of the layer's backward (round-5 verdict, item 3c).  Same kernels, same
+# lists, same results.  PARSENET_CSR_PREFETCH=0: build it in the backward as before (developer A/B).
+CSR_PREFETCH = os.environ.get("PARSENET_CSR_PREFETCH", "1") != "0"
+_CSR_STREAMS = {}
+
+
+def _csr_stream(dev):
+    s = _CSR_STREAMS.get(dev)
+    if s is None:
+        s = _CSR_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _EdgeConvNormMax(torch.autograd.Function):
     """PQ (B,N,2*Cout) point-level products, idx (B,N,k) -> out (B,Cout,N).
 
@@ -174,6 +190,16 @@ class _EdgeConvNormMax(torch.autograd.Function):
                                       slope)
         ctx.save_for_backward(PQ, idx, gamma, beta, yext, argk, s1, mean, rstd)
         ctx.cfg = (groups, per_sample, slope, dense, k)
+        ctx.csr = None
+        if CSR_PREFETCH and PQ.is_cuda and ctx.needs_input_grad[0]:
+            main, side = torch.cuda.current_stream(PQ.device), _csr_stream(PQ.device)
+            side.wait_stream(main)                       # idx was produced on main
+            with torch.cuda.stream(side):
+                csr = K.edgeconv_csr_build(idx)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            idx.record_stream(side)
+            ctx.csr = (csr, ready)
         ctx.mark_non_differentiable(stats)
         return out, stats
 
@@ -186,7 +212,14 @@ class _EdgeConvNormMax(torch.autograd.Function):
         # c1, c2 of the normalisation gradient (fixed-order partial sums, fp64 combination)
         t, dgamma, dbeta, c1c2 = K.edgeconv_bwd_stats(gout, yext, mean, rstd, gamma.detach(), beta.detach(), groups,
                                                       per_sample, dense, slope, k)
-        dPQ = K.edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense)
+        csr = None
+        if ctx.csr is not None:
+            csr, ready = ctx.csr
+            ctx.csr = None
+            main = torch.cuda.current_stream(PQ.device)
+            main.wait_event(ready)
+            csr.record_stream(main)                      # allocated on the side stream, consumed here
+        dPQ = K.edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense, csr=csr)
         return dPQ, None, dgamma, dbeta, None, None, None, None, None
 
 

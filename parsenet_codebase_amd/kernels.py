@@ -237,8 +237,25 @@ def edgeconv_bwd_prep(gout, yext, mean, rstd, gamma, beta, groups, per_sample, s
     return gz, yhat
 
 
-def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense):
-    """Edge-level normalisation gradient -> dPQ (B,N,2*Cout); see csrc/edge.hip."""
+def edgeconv_csr_build(idx):
+    """The transposed kNN graph of idx (B,N,k) for edgeconv_bwd(..., csr=...): a workspace tensor.  Depends on idx
+    alone — graph.py builds it during the forward pass on a side stream."""
+    require_cuda(idx)
+    idx = _graph_c(idx, "idx")
+    B, N, k = idx.shape
+    lib = _lib.load()
+    wsz = lib.pn_edgeconv_bwd_workspace(B, N, k)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=idx.device)
+    with _lib.on_device(idx.device):
+        rc = lib.pn_edgeconv_csr_build(ptr(idx), int(idx.dtype == torch.int32), B, N, k, ptr(ws), wsz,
+                                       current_stream(idx.device))
+    check(rc, "pn_edgeconv_csr_build")
+    return ws
+
+
+def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, dense, csr=None):
+    """Edge-level normalisation gradient -> dPQ (B,N,2*Cout); see csrc/edge.hip.  ``csr``: the workspace of
+    edgeconv_csr_build(idx) (the transposed graph, already built), else it is built here."""
     require_cuda(PQ, idx, t)
     B, N, C2 = PQ.shape
     Cout = C2 // 2
@@ -246,8 +263,18 @@ def edgeconv_bwd(PQ, idx, t, s1, argk, mean, rstd, c1c2, groups, per_sample, den
     dPQ = torch.empty_like(PQ)
     lib = _lib.load()
     wsz = lib.pn_edgeconv_bwd_workspace(B, N, k)
-    ws = torch.empty(wsz, dtype=torch.uint8, device=PQ.device)
     idx = _graph_c(idx, "idx")
+    if csr is not None:
+        if csr.numel() < wsz:
+            raise ValueError("edgeconv_bwd: the prebuilt graph does not belong to this idx")
+        with _lib.on_device(PQ.device):
+            rc = lib.pn_edgeconv_bwd_prebuilt(ptr(PQ), ptr(idx), int(idx.dtype == torch.int32), ptr(_f32c(t, "t")), ptr(s1),
+                                              ptr(argk), ptr(mean), ptr(rstd), ptr(_f32c(c1c2, "c1c2")), B, N, k, Cout,
+                                              groups, int(per_sample), int(dense), ptr(dPQ), ptr(csr), csr.numel(),
+                                              current_stream(PQ.device))
+        check(rc, "pn_edgeconv_bwd_prebuilt")
+        return dPQ
+    ws = torch.empty(wsz, dtype=torch.uint8, device=PQ.device)
     fn = lib.pn_edgeconv_bwd_i32 if idx.dtype == torch.int32 else lib.pn_edgeconv_bwd_f32
     with _lib.on_device(PQ.device):
         rc = fn(ptr(PQ), ptr(idx), ptr(_f32c(t, "t")), ptr(s1), ptr(argk), ptr(mean), ptr(rstd),

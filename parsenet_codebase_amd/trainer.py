@@ -26,6 +26,7 @@ import torch.distributed as dist
 from . import dp, synthetic
 from .encoders import DGCNNControlPoints, PrimitivesEmbeddingDGCNGn
 from .losses import EmbeddingLoss, evaluate_miou, primitive_loss
+from .workloads import _adam
 
 
 @dataclass
@@ -264,7 +265,7 @@ def train_parsenet(cfg, data=None, device=None, log=print, keep_points=7000, mod
     model = model if model is not None else build_parsenet(cfg, device)
     sync_module_from_rank0(model)
     bucket = dp.FlatGradBucket(model.parameters())
-    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    optimizer = _adam(model.parameters(), cfg.lr, bucket)      # FlatAdam on the GPU (optim.py), else torch's
     scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=4, min_lr=1e-4)
     data = data or open_dataset(cfg, cfg.batch_size, rank, augment=True,
                                 device=device if os.environ.get("PARSENET_DATA_ON_DEVICE") == "1" else None)
@@ -401,7 +402,7 @@ def train_parsenet_e2e(cfg, data=None, device=None, log=print, evaluation=None, 
     # one set of weights on every rank, the frozen SplineNets included
     sync_module_from_rank0(model, evaluation.fitter.closed_control_decoder, evaluation.fitter.open_control_decoder)
     bucket = dp.FlatGradBucket(model.parameters())
-    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    optimizer = _adam(model.parameters(), cfg.lr, bucket)      # FlatAdam on the GPU (optim.py), else torch's
     scheduler = ReduceLROnPlateau(optimizer, factor=0.5, patience=10, min_lr=1e-4)
     data = data or open_dataset(cfg, 1, rank, augment=False,
                                 device=device if os.environ.get("PARSENET_DATA_ON_DEVICE") == "1" else None)

@@ -38,6 +38,26 @@ def _clustered_embedding(n_clusters, N, noise, seed):
 _ORACLE = {}
 
 
+class _pinned_pretraining_recipe:
+    """The whole-step tests compare ONE step (losses, segmentations, gradients) of the product with the oracle's on
+    a network state that a recipe produces: PRETRAIN deterministic segmentation-only steps.  Which shapes have
+    partitions that both implementations agree on depends on that state bit for bit (a merge between two modes
+    flips with the last bit of an embedding), and the shape lists below were searched for the state this recipe
+    gives with torch.optim.Adam's fused kernel — the reference's optimizer object (train_parsenet.py:96).
+    optim.FlatAdam (round 6: one launch on flat buffers) rounds the same rule differently and trains ANOTHER
+    network over 600 steps, so the recipe keeps torch's optimizer; what is compared afterwards does not contain an
+    optimizer step (test_e2e_training_loop_against_the_oracle, below, runs FlatAdam against the oracle's Adam)."""
+
+    def __enter__(self):
+        from parsenet_codebase_amd import workloads
+        self.old = workloads.FLAT_ADAM
+        workloads.FLAT_ADAM = False
+
+    def __exit__(self, *exc):
+        from parsenet_codebase_amd import workloads
+        workloads.FLAT_ADAM = self.old
+
+
 def _host_memory_gb():
     try:
         with open("/proc/meminfo") as fh:
@@ -132,7 +152,8 @@ def test_whole_e2e_step_at_benchmark_size_against_the_oracle(gpu):
     torch.cuda.set_device(gpu)
     B, N = 4, 10000
     ids = list(synthetic.ANALYTIC_WELL_POSED_IDS[:4])
-    step = ParsenetE2EStep(gpu, batch=B, num_points=N, seed=0, pretrain_steps=PRETRAIN, shape_ids=ids)
+    with _pinned_pretraining_recipe():
+        step = ParsenetE2EStep(gpu, batch=B, num_points=N, seed=0, pretrain_steps=PRETRAIN, shape_ids=ids)
     state = {k: v.detach().cpu().clone() for k, v in step.model.state_dict().items()}
     fitter = step.evaluation.fitter
     # ---- oracle step ---------------------------------------------------------------------------
@@ -324,7 +345,8 @@ def test_whole_e2e_step_with_a_cylinder_and_splines_on_pinned_graphs(gpu, spline
     torch.cuda.set_device(gpu)
     B, N = 2, 10000
     ids = [int(os.environ.get("PARITY_SPLINE_SHAPE", spline_shape)), 48]
-    step = ParsenetE2EStep(gpu, batch=B, num_points=N, seed=0, pretrain_steps=PRETRAIN, shape_ids=ids)
+    with _pinned_pretraining_recipe():
+        step = ParsenetE2EStep(gpu, batch=B, num_points=N, seed=0, pretrain_steps=PRETRAIN, shape_ids=ids)
     state = {k: v.detach().cpu().clone() for k, v in step.model.state_dict().items()}
     fitter = step.evaluation.fitter
     ref = R.PrimitivesEmbeddingDGCNGn(embedding=True, emb_size=128, primitives=True, num_primitives=10,
