@@ -591,10 +591,17 @@ static int knn_x3_level() {
   const char* e = getenv("PN_KNN_X3");
   return e ? atoi(e) : 2;
 }
-// piece products of the THRESHOLD pass: 3 (default, round 6: knn_x3.h) or 6 (PN_KNN_X3_P1=6, developer A/B)
-static int knn_x3_p1_products() {
+// Piece products of the THRESHOLD pass (knn_x3.h): 3 for the dot-product form (the bandwidth's K-th neighbour on
+// unit rows: 0.51 -> 0.31 ms per launch of 4 shapes, cfg5 172.5 -> 174.7 shapes/s), 6 for the squared-distance form of
+// the kNN graphs.  Measured with 3 there too (tools/jobs/r6e.sh, profiles/r06_knn_p1_ab.txt): 0.32 -> 0.18 ms per
+// launch on the pre-trained network of cfg5, but on cfg4's network — early in training, flat regions of a shape
+// carry near-identical features — the four times wider window (A1 / A = 3.9 at 64 channels) sends so many rows over
+// their list capacity that the gated fallback scan costs 1.7 ms per layer: 513 -> 423 shapes/s.
+// PN_KNN_X3_P1 = 3 / 6 forces one form for both (developer A/B).
+static int knn_x3_p1_products(int mode) {
   const char* e = getenv("PN_KNN_X3_P1");
-  return (e && atoi(e) == 6) ? 6 : 3;
+  if (e && (atoi(e) == 6 || atoi(e) == 3)) return atoi(e);
+  return mode == 2 ? 3 : 6;
 }
 // 256 channels (ksteps 128; round 4): the squared-distance form only — kNN graphs of the widest edge-conv
 // layers (closed SplineNet) —, and only when the 128-query workgroups (one per CU: the resident queries take
@@ -707,7 +714,7 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   float* xpm = x3p2 ? (float*)(base + w.xpm) : nullptr;
   float* xxo = x3p2 ? (float*)(base + w.xxo) : nullptr;
   const float x3A = 4.0f * (float)(p.Cp + 2) * 0x1p-24f;
-  const int np1 = knn_x3_p1_products();
+  const int np1 = knn_x3_p1_products(mode);
   const float x3A1 = np1 == 3 ? x3A + 3.1f * 0x1p-16f : x3A;
   if (x3p1) {
     PN_PROF("knn_x3_image", stream);

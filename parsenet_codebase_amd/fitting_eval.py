@@ -25,10 +25,13 @@ numpy's generator is consumed in the reference's order — per shape: the shuffl
 then, segment by segment, the re-sampling draw and the draws of the refit — because every draw depends on
 counts only, which the host has after the two downloads.  The per-segment functions of fitting.py
 (``Evaluation.batched = False``) compute the same numbers one segment at a time; tests hold the two equal."""
+import os
+
 import numpy as np
 import torch
 from torch.profiler import record_function
 
+from . import _lsa_worker
 from . import kernels as K
 from . import mean_shift as MSM
 from ._lib import h2d
@@ -339,6 +342,7 @@ def fitting_losses_eval(ev, embedding, points, normals, labels, primitives, prim
             nu, nv = _fitter_bases(fitter, dev)
             groups = {"open": [j for j, (_, s) in enumerate(spl_segs) if s["kind"] == "open"],
                       "closed": [j for j, (_, s) in enumerate(spl_segs) if s["kind"] == "closed"]}
+            pending_groups = []
             for kind, js in groups.items():
                 if not js:
                     continue
@@ -353,8 +357,12 @@ def fitting_losses_eval(ev, embedding, points, normals, labels, primitives, prim
                     net = fitter.open_control_decoder if kind == "open" else fitter.closed_control_decoder
                     ctrl = net(pts_std.permute(0, 2, 1).contiguous(), w).reshape(len(js), 20, 20, 3)
                     rec = _BSplineEval.apply(ctrl, nu, nv, affine, kind == "closed")     # (S,900|930,3)
-                if if_optimize:
-                    rec = _refit_batch(kind, js, spl_segs, draws, P, ctrl, affine, rec)
+                # if_optimize: the refits of BOTH kinds are submitted (their matchings run on the assignment pool) before
+                # either is finished
+                pending_groups.append((js, _refit_submit(kind, js, spl_segs, draws, P, ctrl, affine, rec)
+                                       if if_optimize else (lambda rec=rec: rec)))
+            for js, fin in pending_groups:
+                rec = fin()
                 for t, j in enumerate(js):
                     recs[j] = rec[t:t + 1]
             # two-sided Chamfer with guard_sqrt on every nearest-neighbour distance (src/utils.py:326-358)
@@ -468,12 +476,50 @@ def _refit_draws(kind, a_max):
     return d
 
 
+# ---------------------------------------------------------------------------------------------
+# assignment pool: the Hungarian matchings of a batch's refits side by side
+# ---------------------------------------------------------------------------------------------
+_LSA_POOL = None
+REFIT_POOL = os.environ.get("PARSENET_REFIT_POOL", "1") != "0"
+
+
+def assignment_pool():
+    """A persistent pool of worker PROCESSES (spawned: they import numpy / scipy only, never torch) for the
+    linear_sum_assignment calls of the LS refit — scipy holds the GIL, threads would run them one after the other.
+    Sized by the CPUs the job may use (dp.usable_cpus(), at most 8).  None when PARSENET_REFIT_POOL=0 or a single CPU:
+    the caller then solves in place."""
+    global _LSA_POOL
+    if not REFIT_POOL:
+        return None
+    if _LSA_POOL is None:
+        import atexit
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        from .dp import usable_cpus
+        n = min(8, usable_cpus() - 1)
+        if n < 2:
+            return None
+        _LSA_POOL = ProcessPoolExecutor(max_workers=n, mp_context=multiprocessing.get_context("spawn"))
+        atexit.register(_LSA_POOL.shutdown, wait=False, cancel_futures=True)
+    return _LSA_POOL
+
+
 def _refit_batch(kind, js, spl_segs, draws, P, ctrl, affine, rec):
+    """The LS refit of one kind in one go (submit, then finish)."""
+    return _refit_submit(kind, js, spl_segs, draws, P, ctrl, affine, rec)()
+
+
+def _refit_submit(kind, js, spl_segs, draws, P, ctrl, affine, rec):
     """The LS refit (src/primitive_forward.py:153-296) of the segments ``js`` of one kind: samples of the
     predicted surface at the drawn parameters, the input points up-sampled (ragged, together) and re-sampled,
     the Hungarian matching per segment on the host (scipy), the 100 x 100 normal equations of all segments
     solved together, the refitted surfaces sampled on the regular grid.  Segments the reference does not refit
-    (closed, 200 members or fewer) keep their network prediction."""
+    (closed, 200 members or fewer) keep their network prediction.
+
+    Two phases (round 6): this function queues everything up to the distance matrices and hands them to the
+    assignment pool; the returned ``finish()`` collects the matchings and runs the solves.  The caller submits BOTH
+    kinds of a batch before it finishes either, so all matchings of the batch run side by side on the host's cores
+    (14.1 s -> see profiles/r06_named_kernels_kbench.txt per batch of 4 shapes, all of it scipy's assignment)."""
     from .approximation import fit_bezier_surface_fit_kronecker
     from .bspline import basis_matrix, uniform_knots
     from .fitting import boundary_parameterization, regular_parameterization, solve_dense
@@ -481,7 +527,7 @@ def _refit_batch(kind, js, spl_segs, draws, P, ctrl, affine, rec):
     dev = P.device
     todo = [t for t, j in enumerate(js) if "refit" in draws[j]]
     if not todo:
-        return rec
+        return lambda: rec
     S = len(todo)
     a_max = P.shape[1]
     su, sv = cfg["size_u"], cfg["size_v"]
@@ -502,6 +548,8 @@ def _refit_batch(kind, js, spl_segs, draws, P, ctrl, affine, rec):
     up, cnt = upsample_rounds(P[todo].reshape(S * a_max, 3), [a_max] * S, rounds)
     off = np.concatenate([[0], np.cumsum(cnt)])
     out = rec.clone()
+    pool = assignment_pool()
+    pending = []
     for q, t in enumerate(todo):
         d = draws[js[t]]["refit"]
         parameters = np.concatenate([d["uv"], bound], 0)
@@ -513,14 +561,21 @@ def _refit_batch(kind, js, spl_segs, draws, P, ctrl, affine, rec):
             inp = inp[h2d(d["sub"], dev)]
         inp = inp.double()
         dist = torch.cdist(samples, inp, compute_mode="donot_use_mm_for_euclid_dist")
-        _, cids = solve_dense(dist.cpu().numpy())
-        matched = inp[h2d(np.asarray(cids), dev)]
-        NU = torch.from_numpy(basis_matrix(parameters[:, 0], 10, cfg["degree"], ku2)).to(dev)
-        NV = torch.from_numpy(basis_matrix(parameters[:, 1], 10, cfg["degree"], ku2)).to(dev)
-        new_ctrl = fit_bezier_surface_fit_kronecker(matched, NU, NV)
-        pts = torch.einsum("ni,nj,ijc->nc", RU, RV, new_ctrl).float()
-        if kind == "closed":
-            pts = pts.reshape(30, 30, 3)
-            pts = torch.cat([pts, pts[0:1]], 0).reshape(930, 3)
-        out[t] = pts
-    return out
+        cost = dist.cpu().numpy()
+        job = pool.submit(_lsa_worker.solve, cost) if pool is not None else None
+        pending.append((t, parameters, inp, cost, job))
+
+    def finish():
+        for t, parameters, inp, cost, job in pending:
+            cids = job.result() if job is not None else solve_dense(cost)[1]
+            matched = inp[h2d(np.asarray(cids), dev)]
+            NU = torch.from_numpy(basis_matrix(parameters[:, 0], 10, cfg["degree"], ku2)).to(dev)
+            NV = torch.from_numpy(basis_matrix(parameters[:, 1], 10, cfg["degree"], ku2)).to(dev)
+            new_ctrl = fit_bezier_surface_fit_kronecker(matched, NU, NV)
+            pts = torch.einsum("ni,nj,ijc->nc", RU, RV, new_ctrl).float()
+            if kind == "closed":
+                pts = pts.reshape(30, 30, 3)
+                pts = torch.cat([pts, pts[0:1]], 0).reshape(930, 3)
+            out[t] = pts
+        return out
+    return finish

@@ -146,11 +146,14 @@ def graph_feature(x, idx):
 # --------------------------------------------------------------------------------------
 # fused edge convolution: conv1x1 -> norm -> LeakyReLU -> max_k
 # --------------------------------------------------------------------------------------
-# The transposed graph the backward gathers through depends on idx alone: it is built during the FORWARD pass on a
-# side stream (five small latency-bound launches, 0.13 ms per layer at cfg4's size, next to the following layer's
-# distance passes) instead of at the head of the layer's backward (round-5 verdict, item 3c).  Same kernels, same
-# lists, same results.  PARSENET_CSR_PREFETCH=0: build it in the backward as before (developer A/B).
-CSR_PREFETCH = os.environ.get("PARSENET_CSR_PREFETCH", "1") != "0"
+# The transposed graph the backward gathers through depends on idx alone, so it CAN be built during the forward pass
+# on a side stream (five small latency-bound launches, 0.13 ms per layer at cfg4's size) instead of at the head of
+# the layer's backward (round-5 verdict, item 3c).  Built and measured in round 6 (tools/jobs/r6e.sh, alternating on
+# one box): cfg5 22.93 / 22.86 ms per step with the prefetch against 23.01 / 22.92 without (inside the spread), cfg4
+# 9.44 / 9.48 against 9.21 / 9.19 — the side stream's launches run between the waves of the distance passes that
+# fill the chip and slow THEM down by more than the backward saves.  Same kernels, same lists, bit-identical
+# results (tests/test_edgeconv_gpu.py); opt-in: PARSENET_CSR_PREFETCH=1.
+CSR_PREFETCH = os.environ.get("PARSENET_CSR_PREFETCH", "0") == "1"
 _CSR_STREAMS = {}
 
 
