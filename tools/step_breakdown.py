@@ -24,9 +24,10 @@ groups = collections.OrderedDict([
     ("bandwidth / nms selection", ("pn_dotsel", "pn_sel", "dot_select", "pn_dot")),
     ("kNN", ("pn_knn",)),
     ("edge conv / group norm (HIP)", ("pn_edge", "pn_ecb", "pn_gn", "pn_transpose", "pn_moments", "pn_rev_")),
-    ("fused glue: triplet / memberships / affine (HIP)", ("pn_triplet", "pn_member", "pn_affine")),
+    ("fused glue: triplet / memberships / affine / Adam / gather (HIP)", ("pn_triplet", "pn_member", "pn_affine", "pn_adam", "pn_gather_flat", "pn_wmax", "pn_nms", "pn_kmeans", "pn_stats")),
     ("batched fits (HIP)", ("pn_wmom", "pn_primfit", "pn_cone", "pn_prim_residual", "pn_bspline", "pn_chamfer")),
     ("GEMM (rocBLAS / hipBLASLt; pn_gemm_x3: bf16 x 3)", ("Cijk", "gemm", "rocblas", "pn_gx", "gx_")),
+    ("other hand-written kernels (pn_*)", ("pn_",)),
     ("elementwise / reductions / sort (torch)", ("",)),
 ])
 detail = len(sys.argv) > 3 and sys.argv[3] == "detail"

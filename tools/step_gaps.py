@@ -10,7 +10,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = list(csv.DictReader(open(fn)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n or "pn_adam" in n]
 bursts = []
 for i in adam:
     if not bursts or i - bursts[-1][-1] > 50:

@@ -11,7 +11,7 @@ binw = float(sys.argv[3]) * 1e6 if len(sys.argv) > 3 else 2e6
 rows = list(csv.DictReader(open(fn)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n]
+adam = [i for i, n in enumerate(names) if "multi_tensor_apply" in n or "pn_adam" in n]
 bursts = []
 for i in adam:
     if not bursts or i - bursts[-1][-1] > 50:
