@@ -568,6 +568,7 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
 
 struct KnnWs {
   size_t xq, xxq, xc, xxc, tilemax, tau, cnt, flags, lists, v1, img, xxmax, xpm, xxo, total;
+  size_t mu, xpc, xxcc, xxoc, xxmaxc;     // centred passes of the kNN graph (knn_x3.h)
 };
 
 #include "knn_x3.h"
@@ -598,10 +599,18 @@ static int knn_x3_level() {
 // carry near-identical features — the four times wider window (A1 / A = 3.9 at 64 channels) sends so many rows over
 // their list capacity that the gated fallback scan costs 1.7 ms per layer: 513 -> 423 shapes/s.
 // PN_KNN_X3_P1 = 3 / 6 forces one form for both (developer A/B).
-static int knn_x3_p1_products(int mode) {
+// With CENTRED passes (below) the graphs' window shrinks by the ratio of the centred to the original norms and the
+// three-product threshold pass is the default for them as well.
+static int knn_x3_p1_products(int mode, bool centred) {
   const char* e = getenv("PN_KNN_X3_P1");
   if (e && (atoi(e) == 6 || atoi(e) == 3)) return atoi(e);
-  return mode == 2 ? 3 : 6;
+  return (mode == 2 || centred) ? 3 : 6;
+}
+// PN_KNN_X3_CENTRE=0: the approximate passes of a kNN graph on the rows as they are (round 5); default: on the rows
+// minus their per-channel mean (knn_x3.h)
+static bool knn_x3_centre() {
+  const char* e = getenv("PN_KNN_X3_CENTRE");
+  return !(e && atoi(e) == 0);
 }
 // 256 channels (ksteps 128; round 4): the squared-distance form only — kNN graphs of the widest edge-conv
 // layers (closed SplineNet) —, and only when the 128-query workgroups (one per CU: the resident queries take
@@ -650,6 +659,11 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
   // point-major fp32 rows + norms in original order: the exact repairs of the approximate final sort
   w.xpm = take(x3 && self ? (size_t)B * p.Ncp * p.Cp * 4 : 0);
   w.xxo = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
+  w.mu = take(x3 && self ? (size_t)B * p.Cp * 4 : 0);
+  w.xpc = take(x3 && self ? (size_t)B * p.Ncp * p.Cp * 4 : 0);
+  w.xxcc = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
+  w.xxoc = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
+  w.xxmaxc = take(x3 && self ? (size_t)B * 4 : 0);
   w.total = o;
   return w;
 }
@@ -714,23 +728,42 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   float* xpm = x3p2 ? (float*)(base + w.xpm) : nullptr;
   float* xxo = x3p2 ? (float*)(base + w.xxo) : nullptr;
   const float x3A = 4.0f * (float)(p.Cp + 2) * 0x1p-24f;
-  const int np1 = knn_x3_p1_products(mode);
+  // centred passes: the kNN graph of one set with both passes approximate (the exact engine never sees the centred rows)
+  const bool centre = x3p2 && knn_x3_centre();
+  // (needed: 2 Ao |q||c| >= 2 C 2^-24 |q||c| for the oracle's dot-product chain + 2^-23 * 2 |q||c| for its two closing
+  //  roundings, i.e. Ao >= (C + 2) 2^-24; the norms' share of those roundings sits in knx_eps's 2^-21 term)
+  const float x3Ao = centre ? (float)(p.Cp + 4) * 0x1p-24f : 0.f;
+  const int np1 = knn_x3_p1_products(mode, centre);
   const float x3A1 = np1 == 3 ? x3A + 3.1f * 0x1p-16f : x3A;
+  float* mu = centre ? (float*)(base + w.mu) : nullptr;
+  float* xpc = centre ? (float*)(base + w.xpc) : nullptr;
+  float* xxcc = centre ? (float*)(base + w.xxcc) : nullptr;
+  float* xxoc = centre ? (float*)(base + w.xxoc) : nullptr;
+  unsigned* xxmaxc = centre ? (unsigned*)(base + w.xxmaxc) : nullptr;
   if (x3p1) {
     PN_PROF("knn_x3_image", stream);
     PN_CHECK_HIP(hipMemsetAsync(xxmax, 0, (size_t)B * 4, stream));
+    if (centre) {
+      PN_CHECK_HIP(hipMemsetAsync(xxmaxc, 0, (size_t)B * 4, stream));
+      hipLaunchKernelGGL(pn_knn_x3_mean_kernel, dim3(p.Cp, B), dim3(256), 0, stream, (const float*)xc, p.Cp, p.Ncp, Nc, mu);
+    }
     dim3 ig(p.Ncp / 32, B);
     if (p.ksteps == 32)
       hipLaunchKernelGGL(pn_knn_x3_image_kernel<8>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
-                         xpm, xxo);
+                         xpm, xxo, (const float*)mu, xpc, xxcc, xxoc, xxmaxc);
     else if (p.ksteps == 64)
       hipLaunchKernelGGL(pn_knn_x3_image_kernel<16>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
-                         xpm, xxo);
+                         xpm, xxo, (const float*)mu, xpc, xxcc, xxoc, xxmaxc);
     else
       hipLaunchKernelGGL(pn_knn_x3_image_kernel<32>, ig, dim3(256), 0, stream, xc, xxc, p.Ncp, img, xxmax, Nc, perm_c,
-                         xpm, xxo);
+                         xpm, xxo, (const float*)mu, xpc, xxcc, xxoc, xxmaxc);
     PN_CHECK_LAUNCH();
   }
+  // what the approximate passes read: the centred copy, its norms and their maximum — or the rows as they are
+  const float* xq_a = centre ? (const float*)xpc : (const float*)xq;
+  const float* xxq_a = centre ? (const float*)xxcc : (const float*)xxq;
+  const float* xxc_a = centre ? (const float*)xxcc : (const float*)xxc;
+  const unsigned* xxmax_a = centre ? (const unsigned*)xxmaxc : (const unsigned*)xxmax;
   dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
   for (int pass = 0; pass < (argmax ? 1 : 2); ++pass) {
     const int collect = argmax ? 2 : pass;
@@ -753,9 +786,8 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
       {
         PN_PROF(mode == 2 ? "sel_x3_pass1_dot" : (p.ksteps == 32 ? "knn_x3_pass1_c64" : "knn_x3_pass1_wide"), stream);
 #define KX_GO_NP(NCH, QS, MD, TPS_, KIND_, NP_, GRID, TPSL, SUBCAP)                                                  \
-  hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, MD, TPS_, KIND_, NP_>), GRID, dim3(256), 0, stream, xq, xxq, Nq,  \
-                     p.Nqp, img, xxc, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP,                 \
-                     (const unsigned*)xxmax)
+  hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, MD, TPS_, KIND_, NP_>), GRID, dim3(256), 0, stream, xq_a, xxq_a,  \
+                     Nq, p.Nqp, img, xxc_a, Nc, p.Ncp, TPSL, tilemax, (const float*)tau, lists, cnt, SUBCAP, xxmax_a)
 #define KX_GO(NCH, QS, MD, TPS_, KIND_, GRID, TPSL, SUBCAP) KX_GO_NP(NCH, QS, MD, TPS_, KIND_, 6, GRID, TPSL, SUBCAP)
 #define KX_GO1(NCH, QS, MD, TPS_)                            \
   {                                                          \
@@ -783,8 +815,9 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         // (the value selection collects in the arithmetic of a six-product threshold pass: no margin then; with the
         // three-product pass its threshold is lowered by both passes' bounds like the graph's)
         if (!approx_value || np1 == 3)
-          hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq, Nq,
-                             p.Nqp, xxmax, x3A, mode, (x3p2 || approx_value) ? 2.0f : 1.0f, x3A1);
+          hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq_a, Nq,
+                             p.Nqp, xxmax_a, x3A, mode, (x3p2 || approx_value) ? 2.0f : 1.0f, x3A1, (const float*)xxq,
+                             (const unsigned*)xxmax, x3Ao);
       }
       PN_CHECK_LAUNCH();
       if (approx_value) {
@@ -837,15 +870,15 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         if (p.ksteps == 32)
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<64>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags, anyflag);
+                             x3A, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
         else if (p.ksteps == 64)
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<128>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags, anyflag);
+                             x3A, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
         else
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<256>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags, anyflag);
+                             x3A, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
       }
       PN_CHECK_LAUNCH();
       return PN_OK;
