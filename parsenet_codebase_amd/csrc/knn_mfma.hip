@@ -655,7 +655,7 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
   // candidate images + per-item largest squared norm of the bf16 x 3 pass 1 (both metrics qualify)
   const bool x3 = x3ws;
   w.img = take(x3 ? (size_t)B * p.Ncp * p.Cp * 6 : 0);
-  w.xxmax = take(x3 ? (size_t)B * 4 : 0);
+  w.xxmax = take(x3 ? (size_t)B * 8 : 0);      // B maxima of the original norms, then B of the centred ones: one memset
   // point-major fp32 rows + norms in original order: the exact repairs of the approximate final sort
   w.xpm = take(x3 && self ? (size_t)B * p.Ncp * p.Cp * 4 : 0);
   w.xxo = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
@@ -663,7 +663,7 @@ static KnnWs knn_mfma_ws(const KnnPlan& p, int B, int C, int Nq, int k, bool sel
   w.xpc = take(x3 && self ? (size_t)B * p.Ncp * p.Cp * 4 : 0);
   w.xxcc = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
   w.xxoc = take(x3 && self ? (size_t)B * p.Ncp * 4 : 0);
-  w.xxmaxc = take(x3 && self ? (size_t)B * 4 : 0);
+  w.xxmaxc = w.xxmax + (size_t)B * 4;
   w.total = o;
   return w;
 }
@@ -742,9 +742,8 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   unsigned* xxmaxc = centre ? (unsigned*)(base + w.xxmaxc) : nullptr;
   if (x3p1) {
     PN_PROF("knn_x3_image", stream);
-    PN_CHECK_HIP(hipMemsetAsync(xxmax, 0, (size_t)B * 4, stream));
+    PN_CHECK_HIP(hipMemsetAsync(xxmax, 0, (size_t)B * 8, stream));
     if (centre) {
-      PN_CHECK_HIP(hipMemsetAsync(xxmaxc, 0, (size_t)B * 4, stream));
       hipLaunchKernelGGL(pn_knn_x3_mean_kernel, dim3(p.Cp, B), dim3(256), 0, stream, (const float*)xc, p.Cp, p.Ncp, Nc, mu);
     }
     dim3 ig(p.Ncp / 32, B);

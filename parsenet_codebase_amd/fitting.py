@@ -448,7 +448,7 @@ def _spline_segment(input_points_, control_decoder, nu, nv, weights, wrap):
     w = weights.reshape(1, -1)
     pts_std, std, mean, R = standardize_segments(input_points_.detach().float(), w.detach().float())
     affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
-    ctrl = control_decoder(pts_std.permute(0, 2, 1).contiguous(), w).reshape(1, 20, 20, 3)
+    ctrl = control_decoder(K.transpose12(pts_std), w).reshape(1, 20, 20, 3)
     return _BSplineEval.apply(ctrl, nu, nv, affine, wrap), ctrl, affine
 
 

@@ -355,7 +355,7 @@ def fitting_losses_eval(ev, embedding, points, normals, labels, primitives, prim
                     pts_std, std, mean, R = standardize_segments(P, w)
                     affine = torch.cat([torch.linalg.inv(R) * std.unsqueeze(1), mean.unsqueeze(2)], 2).contiguous()
                     net = fitter.open_control_decoder if kind == "open" else fitter.closed_control_decoder
-                    ctrl = net(pts_std.permute(0, 2, 1).contiguous(), w).reshape(len(js), 20, 20, 3)
+                    ctrl = net(K.transpose12(pts_std), w).reshape(len(js), 20, 20, 3)
                     rec = _BSplineEval.apply(ctrl, nu, nv, affine, kind == "closed")     # (S,900|930,3)
                 # if_optimize: the refits of BOTH kinds are submitted (their matchings run on the assignment pool) before
                 # either is finished
