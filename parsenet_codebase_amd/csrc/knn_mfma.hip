@@ -735,6 +735,9 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   const float x3Ao = centre ? (float)(p.Cp + 4) * 0x1p-24f : 0.f;
   const int np1 = knn_x3_p1_products(mode, centre);
   const float x3A1 = np1 == 3 ? x3A + 3.1f * 0x1p-16f : x3A;
+  // the collecting pass of a centred graph follows the threshold pass's form (PN_KNN_X3_P2=6: six products there)
+  const int np2 = (centre && np1 == 3 && !(getenv("PN_KNN_X3_P2") && atoi(getenv("PN_KNN_X3_P2")) == 6)) ? 3 : 6;
+  const float x3A2 = np2 == 3 ? x3A1 : x3A;      // error constant of the collected keys
   float* mu = centre ? (float*)(base + w.mu) : nullptr;
   float* xpc = centre ? (float*)(base + w.xpc) : nullptr;
   float* xxcc = centre ? (float*)(base + w.xxcc) : nullptr;
@@ -815,8 +818,8 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         // three-product pass its threshold is lowered by both passes' bounds like the graph's)
         if (!approx_value || np1 == 3)
           hipLaunchKernelGGL(pn_knn_x3_margin_kernel, dim3(pn_cdiv(Nq, 256), B), dim3(256), 0, stream, tau, xxq_a, Nq,
-                             p.Nqp, xxmax_a, x3A, mode, (x3p2 || approx_value) ? 2.0f : 1.0f, x3A1, (const float*)xxq,
-                             (const unsigned*)xxmax, x3Ao);
+                             p.Nqp, xxmax_a, x3p2 ? x3A2 : x3A, mode, (x3p2 || approx_value) ? 2.0f : 1.0f, x3A1,
+                             (const float*)xxq, (const unsigned*)xxmax, x3Ao);
       }
       PN_CHECK_LAUNCH();
       if (approx_value) {
@@ -856,12 +859,20 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
       dim3 g2(S2, pn_cdiv(p.Nqp, qpw), B);
       {
         PN_PROF(p.ksteps == 32 ? "knn_x3_pass2_c64" : "knn_x3_pass2_wide", stream);
+#define KX_GO2(NCH, QS, TPS_)                                    \
+  {                                                              \
+    if (np2 == 3)                                                \
+      KX_GO_NP(NCH, QS, 0, TPS_, 1, 3, g2, tps2, subcap2);       \
+    else                                                         \
+      KX_GO_NP(NCH, QS, 0, TPS_, 1, 6, g2, tps2, subcap2);       \
+  }
         if (p.ksteps == 32)
-          KX_GO(8, 2, 0, 2, 1, g2, tps2, subcap2);
+          KX_GO2(8, 2, 2)
         else if (p.ksteps == 64)
-          KX_GO(16, 1, 0, 1, 1, g2, tps2, subcap2);
+          KX_GO2(16, 1, 1)
         else
-          KX_GO(32, 1, 0, 1, 1, g2, tps2, subcap2);
+          KX_GO2(32, 1, 1)
+#undef KX_GO2
       }
       PN_CHECK_LAUNCH();
       {
@@ -869,15 +880,15 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
         if (p.ksteps == 32)
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<64>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
+                             x3A2, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
         else if (p.ksteps == 64)
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<128>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
+                             x3A2, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
         else
           hipLaunchKernelGGL(pn_knn_final_x3_kernel<256>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
                              p.Nqp, k, S2, subcap2, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
-                             x3A, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
+                             x3A2, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
       }
       PN_CHECK_LAUNCH();
       return PN_OK;
