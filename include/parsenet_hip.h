@@ -306,23 +306,26 @@ int pn_meanshift_h2_iter_bwd_f32(const float* gy, const float* y, const float* q
  *   rows_bwd      : ra = sum_n gz, rb = sum_n gz*yhat per row, gz = gout*[z>0] (or gout if !relu).
  *   group_bwd     : c1c2 (B,groups,2) = group means of gamma*gz and gamma*gz*yhat.
  *   apply_bwd     : dy = rstd*(gamma*gz - c1 - yhat*c2); with gsp/arg non-NULL gz is the sparse
- *                   gradient gsp (B,C) placed at position arg (B,C) of every row (gout ignored). */
+ *                   gradient gsp (B,C) placed at position arg (B,C) of every row (gout ignored).
+ * rowbias (NULL, or C floats with rb_bstride = 0: one value per channel, or B * C floats with rb_bstride = C: one per
+ * (item, channel)): the four row kernels read y + rowbias[b * rb_bstride + c] — the preceding convolution's bias
+ * (src/PointNet.py:196, 268-284) added at load instead of by a pass of its own; the same fp32 addition. */
 int pn_gn_rows_fwd_f32(const float* y, int B, int C, int N, float* rsum, float* rsq, float* rmax,
-                       int* amax, float* rmin, int* amin, void* stream);
+                       int* amax, float* rmin, int* amin, const float* rowbias, int rb_bstride, void* stream);
 int pn_gn_group_moments_f32(const float* rsum, const float* rsq, int B, int C, int groups, int N,
                             float eps, float* mean, float* rstd, void* stream);
 int pn_gn_apply_fwd_f32(const float* y, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, int B, int C, int groups, int N, int relu, float* out,
-                        void* stream);
+                        const float* rowbias, int rb_bstride, void* stream);
 int pn_gn_rows_bwd_f32(const float* gout, const float* y, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int B, int C, int groups, int N,
-                       int relu, float* ra, float* rb, void* stream);
+                       int relu, float* ra, float* rb, const float* rowbias, int rb_bstride, void* stream);
 int pn_gn_group_bwd_f32(const float* ra, const float* rb, const float* gamma, int B, int C,
                         int groups, int N, float* c1c2, void* stream);
 int pn_gn_apply_bwd_f32(const float* gout, const float* y, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, const float* c1c2, int B, int C,
                         int groups, int N, int relu, const float* gsp, const int* arg, float* dy,
-                        void* stream);
+                        const float* rowbias, int rb_bstride, void* stream);
 
 /* ---- batched symmetric 3x3 eigen-decomposition (fp64) ---------------------------------
  * Serves the right singular vectors the primitive fits need (torch.svd of a tall n x 3 matrix in

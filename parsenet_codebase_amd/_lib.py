@@ -115,17 +115,18 @@ SIGNATURES = {
     "pn_meanshift_h2_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     "pn_meanshift_iter_bwd_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 9 + [c_void_p]),
     "pn_gn_rows_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pn_gn_group_moments_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                         c_void_p, c_void_p]),
     "pn_gn_apply_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                    c_int, c_int, c_void_p, c_void_p]),
+                                    c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "pn_gn_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                   c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                   c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "pn_gn_group_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p]),
     "pn_gn_apply_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p]),
     "pn_sym3_eig_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "pn_chamfer_nn_workspace": (c_size_t, [c_int, c_int, c_int]),
     "pn_chamfer_nn_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

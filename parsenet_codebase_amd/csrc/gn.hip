@@ -16,9 +16,14 @@
 // The max variant (bnmlp1 -> relu -> max over N) uses the monotonicity of norm + ReLU per
 // channel: only the row maximum (minimum where gamma < 0) is normalised; the backward places
 // the upstream gradient at the arg position and adds the dense mean/variance terms.
+// Round 6: every row kernel takes an optional ROW BIAS rb[b * bs + c] (bs = C: one value per (item, channel); bs = 0:
+// one per channel) that is added to y at load, e = fl(y + rb): the convolution's bias (src/PointNet.py:196, 268-284:
+// Conv1d(..., bias=True) followed by GroupNorm) and the per-item global term of conv1 are no longer written out by
+// a separate pass over the (B,C,N) tensor — the same fp32 addition, so the results are bit-identical.
 #include "common.h"
 
 #define GN_T 256
+#define GN_RB(ROW, C_) (rowbias ? rowbias[(size_t)((ROW) / (C_)) * rb_bstride + ((ROW) % (C_))] : 0.f)
 
 __device__ static inline float gn_block_sum(float v, float* sh) {
   v = pn_wave_sum(v);
@@ -36,10 +41,13 @@ __global__ __launch_bounds__(GN_T) void pn_gn_rows_fwd_kernel(const float* __res
                                                               float* __restrict__ rmax,
                                                               int* __restrict__ amax,
                                                               float* __restrict__ rmin,
-                                                              int* __restrict__ amin) {
+                                                              int* __restrict__ amin,
+                                                              const float* __restrict__ rowbias, int rb_bstride,
+                                                              int C) {
   __shared__ float sh[4];
   __shared__ unsigned long long shk[2][4];
   const size_t row = blockIdx.x;
+  const float rbv = GN_RB(row, C);
   const float* __restrict__ p = y + row * N;
   float s = 0.f, q = 0.f;
   float mx = -__builtin_inff(), mn = __builtin_inff();
@@ -47,7 +55,7 @@ __global__ __launch_bounds__(GN_T) void pn_gn_rows_fwd_kernel(const float* __res
   const int n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (N >> 2) : 0;
   for (int i = threadIdx.x; i < n4; i += GN_T) {
     const float4 v = reinterpret_cast<const float4*>(p)[i];
-    const float e[4] = {v.x, v.y, v.z, v.w};
+    const float e[4] = {v.x + rbv, v.y + rbv, v.z + rbv, v.w + rbv};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       s += e[u];
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(GN_T) void pn_gn_rows_fwd_kernel(const float* __res
     }
   }
   for (int i = 4 * n4 + threadIdx.x; i < N; i += GN_T) {
-    const float e = p[i];
+    const float e = p[i] + rbv;
     s += e;
     q = __builtin_fmaf(e, e, q);
     if (want_ext) {
@@ -124,8 +132,10 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int C,
                                                                int Cg, int N, int relu,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out,
+                                                               const float* __restrict__ rowbias, int rb_bstride) {
   const size_t row = blockIdx.x;
+  const float rbv = GN_RB(row, C);
   const int c = (int)(row % C);
   const int grp = (int)(row / Cg);  // (b*C + c) / Cg = b*G + c/Cg
   const float a = gamma[c] * rstd[grp];
@@ -136,10 +146,10 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_fwd_kernel(const float* __re
   const int n4 = al ? (N >> 2) : 0;
   for (int i = threadIdx.x; i < n4; i += GN_T) {
     float4 v = reinterpret_cast<const float4*>(p)[i];
-    v.x = __builtin_fmaf(v.x, a, sft);
-    v.y = __builtin_fmaf(v.y, a, sft);
-    v.z = __builtin_fmaf(v.z, a, sft);
-    v.w = __builtin_fmaf(v.w, a, sft);
+    v.x = __builtin_fmaf(v.x + rbv, a, sft);
+    v.y = __builtin_fmaf(v.y + rbv, a, sft);
+    v.z = __builtin_fmaf(v.z + rbv, a, sft);
+    v.w = __builtin_fmaf(v.w + rbv, a, sft);
     if (relu) {
       v.x = fmaxf(v.x, 0.f);
       v.y = fmaxf(v.y, 0.f);
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_fwd_kernel(const float* __re
     reinterpret_cast<float4*>(o)[i] = v;
   }
   for (int i = 4 * n4 + threadIdx.x; i < N; i += GN_T) {
-    float v = __builtin_fmaf(p[i], a, sft);
+    float v = __builtin_fmaf(p[i] + rbv, a, sft);
     o[i] = relu ? fmaxf(v, 0.f) : v;
   }
 }
@@ -158,9 +168,11 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_fwd_kernel(const float* __re
 __global__ __launch_bounds__(GN_T) void pn_gn_rows_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    int C, int Cg, int N, int relu, float* __restrict__ ra, float* __restrict__ rb) {
+    int C, int Cg, int N, int relu, float* __restrict__ ra, float* __restrict__ rb,
+    const float* __restrict__ rowbias, int rb_bstride) {
   __shared__ float sh[4];
   const size_t row = blockIdx.x;
+  const float rbv = GN_RB(row, C);
   const int c = (int)(row % C);
   const int grp = (int)(row / Cg);
   const float mu = mean[grp], r = rstd[grp], g = gamma[c], bt = beta[c];
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(GN_T) void pn_gn_rows_bwd_kernel(
   const float* __restrict__ pg = gout + row * N;
   float a = 0.f, b = 0.f;
   for (int i = threadIdx.x; i < N; i += GN_T) {
-    const float yh = (py[i] - mu) * r;
+    const float yh = ((py[i] + rbv) - mu) * r;
     const float z = __builtin_fmaf(g, yh, bt);
     const float gz = (!relu || z > 0.f) ? pg[i] : 0.f;
     a += gz;
@@ -205,8 +217,9 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ c1c2, int C, int Cg, int N, int relu, const float* __restrict__ gsp,
-    const int* __restrict__ arg, float* __restrict__ dy) {
+    const int* __restrict__ arg, float* __restrict__ dy, const float* __restrict__ rowbias, int rb_bstride) {
   const size_t row = blockIdx.x;
+  const float rbv = GN_RB(row, C);
   const int c = (int)(row % C);
   const int grp = (int)(row / Cg);
   const float mu = mean[grp], r = rstd[grp], g = gamma[c], bt = beta[c];
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_bwd_kernel(
     const int at = arg[row];
     const float gv = gsp[row];
     for (int i = threadIdx.x; i < N; i += GN_T) {
-      const float yh = (py[i] - mu) * r;
+      const float yh = ((py[i] + rbv) - mu) * r;
       float v = -c1 - yh * c2;
       if (i == at) v += g * gv;
       pd[i] = r * v;
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_bwd_kernel(
   } else {
     const float* __restrict__ pg = gout + row * N;
     for (int i = threadIdx.x; i < N; i += GN_T) {
-      const float yh = (py[i] - mu) * r;
+      const float yh = ((py[i] + rbv) - mu) * r;
       const float z = __builtin_fmaf(g, yh, bt);
       const float gz = (!relu || z > 0.f) ? pg[i] : 0.f;
       pd[i] = r * (g * gz - c1 - yh * c2);
@@ -234,14 +247,15 @@ __global__ __launch_bounds__(GN_T) void pn_gn_apply_bwd_kernel(
 }
 
 extern "C" int pn_gn_rows_fwd_f32(const float* y, int B, int C, int N, float* rsum, float* rsq,
-                                  float* rmax, int* amax, float* rmin, int* amin, void* stream_) {
+                                  float* rmax, int* amax, float* rmin, int* amin, const float* rowbias,
+                                  int rb_bstride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(y && rsum && rsq && B > 0 && C > 0 && N > 0, "pn_gn_rows_fwd_f32: bad arguments");
   const int want = rmax != nullptr;
   PN_CHECK_ARG(!want || (amax && rmin && amin), "pn_gn_rows_fwd_f32: incomplete extreme outputs");
   PN_PROF("gn_rows_fwd", stream);
   hipLaunchKernelGGL(pn_gn_rows_fwd_kernel, dim3(B * C), dim3(GN_T), 0, stream, y, N, rsum, rsq,
-                     want, rmax, amax, rmin, amin);
+                     want, rmax, amax, rmin, amin, rowbias, rb_bstride, C);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -260,12 +274,13 @@ extern "C" int pn_gn_group_moments_f32(const float* rsum, const float* rsq, int 
 
 extern "C" int pn_gn_apply_fwd_f32(const float* y, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, int B, int C, int groups,
-                                   int N, int relu, float* out, void* stream_) {
+                                   int N, int relu, float* out, const float* rowbias, int rb_bstride,
+                                   void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(y && mean && rstd && gamma && beta && out, "pn_gn_apply_fwd_f32: null pointer");
   PN_PROF("gn_apply_fwd", stream);
   hipLaunchKernelGGL(pn_gn_apply_fwd_kernel, dim3(B * C), dim3(GN_T), 0, stream, y, mean, rstd,
-                     gamma, beta, C, C / groups, N, relu, out);
+                     gamma, beta, C, C / groups, N, relu, out, rowbias, rb_bstride);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -273,12 +288,12 @@ extern "C" int pn_gn_apply_fwd_f32(const float* y, const float* mean, const floa
 extern "C" int pn_gn_rows_bwd_f32(const float* gout, const float* y, const float* mean,
                                   const float* rstd, const float* gamma, const float* beta, int B,
                                   int C, int groups, int N, int relu, float* ra, float* rb,
-                                  void* stream_) {
+                                  const float* rowbias, int rb_bstride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(gout && y && mean && rstd && gamma && beta && ra && rb, "pn_gn_rows_bwd_f32: null");
   PN_PROF("gn_rows_bwd", stream);
   hipLaunchKernelGGL(pn_gn_rows_bwd_kernel, dim3(B * C), dim3(GN_T), 0, stream, gout, y, mean, rstd,
-                     gamma, beta, C, C / groups, N, relu, ra, rb);
+                     gamma, beta, C, C / groups, N, relu, ra, rb, rowbias, rb_bstride);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -297,13 +312,14 @@ extern "C" int pn_gn_group_bwd_f32(const float* ra, const float* rb, const float
 extern "C" int pn_gn_apply_bwd_f32(const float* gout, const float* y, const float* mean,
                                    const float* rstd, const float* gamma, const float* beta,
                                    const float* c1c2, int B, int C, int groups, int N, int relu,
-                                   const float* gsp, const int* arg, float* dy, void* stream_) {
+                                   const float* gsp, const int* arg, float* dy, const float* rowbias,
+                                   int rb_bstride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   PN_CHECK_ARG(y && mean && rstd && gamma && beta && c1c2 && dy && (gout || (gsp && arg)),
                "pn_gn_apply_bwd_f32: null pointer");
   PN_PROF("gn_apply_bwd", stream);
   hipLaunchKernelGGL(pn_gn_apply_bwd_kernel, dim3(B * C), dim3(GN_T), 0, stream, gout, y, mean,
-                     rstd, gamma, beta, c1c2, C, C / groups, N, relu, gsp, arg, dy);
+                     rstd, gamma, beta, c1c2, C, C / groups, N, relu, gsp, arg, dy, rowbias, rb_bstride);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

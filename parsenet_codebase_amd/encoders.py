@@ -363,8 +363,10 @@ class DGCNNEncoderGn(nn.Module):
             x2 = graph.edge_conv_norm_max(x1, graph.knn_dilated(x1, k, k), self.conv2[0].weight, self.bn2, 0.2)
             x3 = graph.edge_conv_norm_max(x2, graph.knn_dilated(x2, k, k), self.conv3[0].weight, self.bn3, 0.2)
         x_features = torch.cat((x1, x2, x3), dim=1)
-        # GroupNorm + ReLU + max over the points in one pass (norm and ReLU are monotone per channel)
-        x4 = group_norm_relu_max(conv1x1(x_features, self.mlp1), self.bnmlp1)
+        # GroupNorm + ReLU + max over the points in one pass (norm and ReLU are monotone per channel); the
+        # convolution's bias is added inside the norm's kernels (round 6: no pass of its own over (B,1024,N))
+        x4 = group_norm_relu_max(weight_bmm(self.mlp1.weight[:, :, 0], x_features), self.bnmlp1,
+                                 rowbias=self.mlp1.bias)
         return x4, x_features
 
 
@@ -412,16 +414,19 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         ng = x.shape[1]
         w = self.conv1.weight[:, :, 0]
         glob = torch.addmm(self.conv1.bias, x, w[:, :ng].t())            # (B,512)
-        x = weight_bmm(w[:, ng:], first_layer_features) + glob.unsqueeze(2)
-        x = group_norm_relu(x, self.bn1)
-        x_all = group_norm_relu(conv1x1(x, self.conv2), self.bn2)
+        # the per-item global term and the biases of the layers that feed a GroupNorm are added inside the norm's
+        # kernels (norms.py ``rowbias``: the same fp32 addition at load, no pass of its own over (B,C,N))
+        x = group_norm_relu(weight_bmm(w[:, ng:], first_layer_features), self.bn1, rowbias=glob)
+        x_all = group_norm_relu(weight_bmm(self.conv2.weight[:, :, 0], x), self.bn2, rowbias=self.conv2.bias)
         embedding = None
         primitives_log_prob = None
         if self.embedding:
-            x = group_norm_relu(conv1x1(x_all, self.mlp_seg_prob1), self.bn_seg_prob1)
+            x = group_norm_relu(weight_bmm(self.mlp_seg_prob1.weight[:, :, 0], x_all), self.bn_seg_prob1,
+                                rowbias=self.mlp_seg_prob1.bias)
             embedding = conv1x1(x, self.mlp_seg_prob2)
         if self.primitives:
-            x = group_norm_relu(conv1x1(x_all, self.mlp_prim_prob1), self.bn_prim_prob1)
+            x = group_norm_relu(weight_bmm(self.mlp_prim_prob1.weight[:, :, 0], x_all), self.bn_prim_prob1,
+                                rowbias=self.mlp_prim_prob1.bias)
             primitives_log_prob = self.logsoftmax(conv1x1(x, self.mlp_prim_prob2))
         if compute_loss:
             lab = labels.data.cpu().numpy() if torch.is_tensor(labels) else labels

@@ -56,3 +56,36 @@ def test_group_norm_relu_max(gpu, B, C, N, G):
     assert _rel(o2, o1) < 1e-5
     assert _rel(y2.grad, g1[0]) < 2e-5
     assert _rel(gn.weight.grad, g1[1]) < 2e-5 and _rel(gn.bias.grad, g1[2]) < 2e-5
+
+
+@pytest.mark.parametrize("per_item", [False, True])
+@pytest.mark.parametrize("B,C,N,G", [(4, 256, 10000, 4), (2, 64, 333, 2), (3, 1024, 2001, 8)])
+def test_row_bias_inside_the_kernels_is_bit_identical_to_the_separate_addition(gpu, B, C, N, G, per_item):
+    """``rowbias``: the convolution's bias (C,) / conv1's per-item global term (B,C) added at load inside the
+    GroupNorm kernels (round 6) against adding it to the tensor first — the same fp32 addition: outputs, the
+    gradient w.r.t. the input, gamma, beta AND the bias are bit-identical, for the plain and the max variant."""
+    from parsenet_codebase_amd.norms import group_norm_relu, group_norm_relu_max
+    torch.manual_seed(B * C + N)
+    gn = torch.nn.GroupNorm(G, C).to(gpu)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C))
+        gn.bias.copy_(torch.randn(C) * 0.3)
+    y = torch.randn(B, C, N, device=gpu) * 1.5
+    bias0 = torch.randn((B, C) if per_item else (C,), device=gpu)
+    for fn, wshape in ((lambda t, rb: group_norm_relu(t, gn, True, rowbias=rb), (B, C, N)),
+                       (lambda t, rb: group_norm_relu_max(t, gn, rowbias=rb), (B, C))):
+        w = torch.randn(wshape, device=gpu)
+        res = []
+        for fused in (False, True):
+            gn.zero_grad()
+            yy = y.clone().requires_grad_(True)
+            bb = bias0.clone().requires_grad_(True)
+            if fused:
+                out = fn(yy, bb)
+            else:
+                out = fn(yy + (bb.unsqueeze(2) if per_item else bb.view(1, -1, 1)), None)
+            (out * w).sum().backward()
+            res.append([out.detach().clone(), yy.grad.clone(), bb.grad.clone(), gn.weight.grad.clone(),
+                        gn.bias.grad.clone()])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
