@@ -735,8 +735,11 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   const float x3Ao = centre ? (float)(p.Cp + 4) * 0x1p-24f : 0.f;
   const int np1 = knn_x3_p1_products(mode, centre);
   const float x3A1 = np1 == 3 ? x3A + 3.1f * 0x1p-16f : x3A;
-  // the collecting pass of a centred graph follows the threshold pass's form (PN_KNN_X3_P2=6: six products there)
-  const int np2 = (centre && np1 == 3 && !(getenv("PN_KNN_X3_P2") && atoi(getenv("PN_KNN_X3_P2")) == 6)) ? 3 : 6;
+  // The collecting pass keeps six products.  On three (PN_KNN_X3_P2=3, centred graphs only; bit-exact like the rest)
+  // it is 0.39 -> 0.31 ms per launch and cfg5 gains 0.4 %, but during cfg4's first training steps its wider window
+  // sends enough rows over their sub-list capacity for the gated fallback scan to cost 1.3 ms per step: 515 -> 440
+  // shapes/s (tools/jobs/r6h.sh, profiles/r06_knn_centre_ab.txt) — a cliff not worth 0.4 %.
+  const int np2 = (centre && np1 == 3 && getenv("PN_KNN_X3_P2") && atoi(getenv("PN_KNN_X3_P2")) == 3) ? 3 : 6;
   const float x3A2 = np2 == 3 ? x3A1 : x3A;      // error constant of the collected keys
   float* mu = centre ? (float*)(base + w.mu) : nullptr;
   float* xpc = centre ? (float*)(base + w.xpc) : nullptr;

@@ -165,10 +165,9 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
 // m.h and h.m — the dropped h.l, l.h and m.m terms are each below 2^-16 |q_c||c_c| per channel, in all
 // <= 3 * 2^-16 |q||c| (Cauchy-Schwarz); the pass only has to deliver a threshold that is certainly not above the
 // k-th largest value, so its error constant A1 = A + 3.1 * 2^-16 goes into the margin (pn_knn_x3_margin_kernel) and
-// the pass costs half the matrix-core work.  On CENTRED rows (below) the collecting pass of a graph runs on three
-// products as well: its keys then carry A1's bound, which on the centred norms is still tighter than the six-product
-// bound on the original ones, so the final sort re-evaluates fewer near-ties than in round 5.  Uncentred collecting
-// passes keep six products: the wider window would hand every survivor to the exact re-evaluation.
+// the pass costs half the matrix-core work.  The collecting pass keeps six products by default: its keys' bound decides
+// how many near-ties the final sort re-evaluates and how many rows overflow their sub-lists (on CENTRED rows three
+// products are available for it as an option, PN_KNN_X3_P2=3: measured a cliff on cfg4, knn_mfma.hip).
 template <int NCH, int QSETS, int MODE, int TPS, int KIND, int NP = 6>
 __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_WPE(NCH, MODE), KX_WPE(NCH, MODE)))) void pn_knn_x3_pass_kernel(
     const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
