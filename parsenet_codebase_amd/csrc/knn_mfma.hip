@@ -167,7 +167,8 @@ static void knn_prep_launch(hipStream_t stream, const float* x, int B, int C, in
     hipLaunchKernelGGL(pn_knn_prep_pm_kernel, dim3(pn_cdiv(Np, 64), B), dim3(256), 64 * (C + 1) * sizeof(float),
                        stream, x, C, N, Cp, Np, perm, xp, xxp);
   } else {
-    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(Np, 256), B), dim3(256), 0, stream, x, C, N, Cp, Np,
+    // (64-thread workgroups: a thread walks all channels of its column; 4 x 10 000 columns are 628 workgroups, not 160)
+    hipLaunchKernelGGL(pn_knn_prep_kernel, dim3(pn_cdiv(Np, 64), B), dim3(64), 0, stream, x, C, N, Cp, Np,
                        mode, point_major, perm, xp, xxp);
   }
 }

@@ -536,7 +536,10 @@ static int ksk_run(const KskPlan& p, const float* x, int B, int C, int N, int k,
   u64* lists = (u64*)(base + p.lists);
   {
     PN_PROF("knn_prep", stream);
-    hipLaunchKernelGGL(pn_knn_smallk_prep_kernel, dim3(pn_cdiv(p.Np, 256), B), dim3(256), 0, stream, x, C, N,
+    // one thread walks ALL channels of its column (the norm is one fma chain): 64-thread workgroups, so that 6 x 5 000
+    // columns are 474 workgroups on the 256 CUs instead of 120 (the launch is latency-bound: 0.57 ms of a cfg5 step
+    // in twelve such launches)
+    hipLaunchKernelGGL(pn_knn_smallk_prep_kernel, dim3(pn_cdiv(p.Np, 64), B), dim3(64), 0, stream, x, C, N,
                        2 * p.ksx, p.Np, xp);
   }
   PN_CHECK_LAUNCH();
