@@ -345,20 +345,11 @@ def standardize_segments(P2, w):
     Returns (points (S,n,3), std (S,3), mean (S,3), R (S,3,3)); one download (covariances)."""
     S, n, _ = P2.shape
     with torch.no_grad():
-        hi = w > 0.8
-        cnt = hi.sum(1, keepdim=True)
-        # (the top-half fallback is computed unconditionally: deciding on the host whether any segment needs it —
-        # the counts could ride with the covariances — was built in round 5 and costs a second round trip in
-        # EVERY cfg5 step: some spline segment of a batch always has fewer than 400 memberships above 0.8)
+        # selection (w > 0.8, or the top quarter / half of the memberships when fewer than 400 qualify), weighted mean
+        # and covariance of the selected points in ONE launch; rotation, extents and scaling in another (csrc/fused.hip:
+        # pn_standardize_*; round 5: 31 tensor-library launches with a topk over half of every row)
         kf = n // 4 if n >= 7500 else n // 2
-        top = torch.topk(w, kf, dim=1)[1]
-        fb = torch.zeros_like(hi).scatter_(1, top, torch.ones_like(top, dtype=torch.bool))
-        sel = torch.where(cnt < 400, fb, hi)
-        self_ = sel.float()
-        wsel = w * self_
-        mean = (P2 * wsel.unsqueeze(2)).sum(1) / (wsel.sum(1, keepdim=True) + EPS)
-        Pc = P2 - mean.unsqueeze(1)
-        cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
+        sel, mean, cov = K.standardize_select(P2, w, max(kf, 1), EPS)
         cov_h, slot = pinned_like(cov.shape, cov.dtype, hold=True)   # host step of the reference: download ...
         try:
             cov_h.copy_(cov, non_blocking=True)
@@ -371,12 +362,7 @@ def standardize_segments(P2, w):
         finally:
             _PinnedRing.release(slot)
         R = h2d(rot, P2.device)                                    # ... upload
-        Pr = torch.bmm(Pc, R.transpose(1, 2))
-        wp = Pr * w.unsqueeze(2)
-        big = torch.full_like(wp, float("inf"))
-        selx = sel.unsqueeze(2)
-        std = torch.abs(torch.where(selx, wp, -big).max(1)[0] - torch.where(selx, wp, big).min(1)[0])
-        pts = Pr / (std.unsqueeze(1) + EPS)
+        pts, std = K.standardize_apply(P2, w, sel, mean, R, EPS)
     return pts, std, mean, R
 
 

@@ -642,6 +642,35 @@ def gemm_x3(img_a, M, x, bias=None):
     return out
 
 
+def standardize_select(P, w, kf, eps):
+    """Device part of standardize_point_torch BEFORE the host's eigen-decomposition, for S segments at once
+    (csrc/fused.hip): P (S,n,3), w (S,n) -> (sel (S,n) uint8, mean (S,3), cov (S,3,3))."""
+    require_cuda(P, w)
+    P, w = _f32c(P, "P"), _f32c(w, "w")
+    S, n, _ = P.shape
+    sel = torch.empty((S, n), dtype=torch.uint8, device=P.device)
+    mean = torch.empty((S, 3), dtype=torch.float32, device=P.device)
+    cov = torch.empty((S, 3, 3), dtype=torch.float32, device=P.device)
+    with _lib.on_device(P.device):
+        rc = _lib.load().pn_standardize_select_f32(ptr(P), ptr(w), S, n, int(kf), float(eps), ptr(sel), ptr(mean), ptr(cov),
+                                                   current_stream(P.device))
+    check(rc, "pn_standardize_select_f32")
+    return sel, mean, cov
+
+
+def standardize_apply(P, w, sel, mean, R, eps):
+    """... and AFTER it: (pts (S,n,3), std (S,3))."""
+    P, w, R = _f32c(P, "P"), _f32c(w, "w"), _f32c(R, "R")
+    S, n, _ = P.shape
+    pts = torch.empty_like(P)
+    std = torch.empty((S, 3), dtype=torch.float32, device=P.device)
+    with _lib.on_device(P.device):
+        rc = _lib.load().pn_standardize_apply_f32(ptr(P), ptr(w), ptr(sel), ptr(mean), ptr(R), S, n, float(eps), ptr(pts),
+                                                  ptr(std), current_stream(P.device))
+    check(rc, "pn_standardize_apply_f32")
+    return pts, std
+
+
 def gemm_x3_cat(img_a, M, xs, bias=None):
     """gemm_x3 applied to the concatenation of xs (a list of 1 to 4 tensors (B,C_s,N), every C_s a multiple of 8)
     along the channels — without writing the concatenation (src/model.py:150 builds it with torch.cat)."""
