@@ -392,3 +392,35 @@ def test_standardisation_with_and_without_the_top_half_fallback(gpu):
             assert float((R[i].cpu() - R0).abs().max()) < 1e-5
             assert float((mean[i].cpu() - m0).abs().max()) < 1e-5 and float((std[i].cpu() - s0.reshape(3)).abs().max()) < 1e-5
             assert float((pts[i].cpu() - p0).abs().max()) < 1e-4 * float(p0.abs().max())
+
+
+@pytest.mark.parametrize("n", [5000, 8000, 700, 40])
+def test_fallback_selection_takes_exactly_kf_memberships_with_ties_to_the_smaller_index(gpu, n):
+    """pn_standardize_select_f32's fallback (fewer than 400 memberships above 0.8; src/fitting_utils.py:517-523): the
+    kf = n // 2 (n // 4 from 7 500 points on) largest memberships — exactly kf of them even when the kf-th value is
+    shared by many points (memberships that are exactly EPS), ties going to the smaller index; mean and covariance
+    are those of the selection (float64 reference), and a row with enough confident points takes the plain rule."""
+    from parsenet_codebase_amd import kernels as K
+    rng = np.random.RandomState(n)
+    S = 3
+    P = rng.randn(S, n, 3).astype(np.float32)
+    w = (0.7 * rng.rand(S, n)).astype(np.float32)
+    w[0, rng.rand(n) < 0.6] = np.float32(1e-8)                  # a mass of equal values across the kf-th rank
+    w[1, : n // 3] = np.float32(0.25)                            # another tie block
+    w[2, : min(n, 450)] = 0.9                                    # the plain rule when n >= 400 confident points exist
+    kf = n // 4 if n >= 7500 else n // 2
+    sel, mean, cov = K.standardize_select(torch.from_numpy(P).to(gpu), torch.from_numpy(w).to(gpu), kf, 1e-8)
+    sel, mean, cov = sel.cpu().numpy().astype(bool), mean.cpu().numpy(), cov.cpu().numpy()
+    for s in range(S):
+        if (w[s] > 0.8).sum() >= 400:
+            want = w[s] > 0.8
+        else:
+            order = np.lexsort((np.arange(n), -w[s].astype(np.float64)))      # value descending, then index ascending
+            want = np.zeros(n, bool)
+            want[order[:kf]] = True
+        assert np.array_equal(sel[s], want), (s, int(sel[s].sum()), int(want.sum()))
+        ws = w[s].astype(np.float64) * want
+        m = (P[s].astype(np.float64) * ws[:, None]).sum(0) / (ws.sum() + 1e-8)
+        assert np.abs(mean[s] - m).max() < 1e-5
+        Pc = (P[s] - mean[s]).astype(np.float64)[want]
+        assert np.abs(cov[s] - Pc.T @ Pc).max() < 1e-4 * np.abs(Pc.T @ Pc).max()
