@@ -596,17 +596,16 @@ int pn_weighted_max_fwd_f32(const float* x, const float* scale, const float* shi
 int pn_weighted_max_bwd_f32(const float* g, const int* idx, const float* val, int S, int C, int N, float* gw,
                             void* stream);
 
-/* Standardisation of S spline segments (src/fitting_utils.py:512-553, standardize_point_torch), the device parts on
- * either side of the reference's host step (the minor axis by LAPACK geev + the rotation to +x):
+/* Standardisation of S spline segments (src/fitting_utils.py:512-553, standardize_point_torch): the two steps that
+ * are not arithmetic on the points (mean, covariance and rotation stay tensor expressions: csrc/fused.hip says why).
  *   select: sel (S,n) bytes = w > 0.8, or — fewer than 400 such points — the kf largest memberships (ties to the
- *           smaller index); mean (S,3) = sum(P w sel) / (sum(w sel) + eps); cov (S,3,3) of the selected centred points;
- *   apply : pts (S,n,3) = R (P - mean) / (std + eps), std (S,3) = | max - min | over the selected points of the
- *           weighted rotated coordinates.
- * P (S,n,3), w (S,n) fp32; one 256-thread workgroup per segment, fixed-order reductions (fp64 sums). */
-int pn_standardize_select_f32(const float* P, const float* w, int S, int n, int kf, float eps, unsigned char* sel,
-                              float* mean, float* cov, void* stream);
-int pn_standardize_apply_f32(const float* P, const float* w, const unsigned char* sel, const float* mean, const float* R,
-                             int S, int n, float eps, float* pts, float* stdv, void* stream);
+ *           smaller index);
+ *   scale : std (S,3) = | max - min | over the selected points of Pr * w per axis, pts (S,n,3) = Pr / (std + eps),
+ *           Pr (S,n,3) the rotated centred points.
+ * w (S,n) fp32; one 256-thread workgroup per segment; exact operations, bit-identical to the tensor-library form. */
+int pn_standardize_select_f32(const float* w, int S, int n, int kf, unsigned char* sel, void* stream);
+int pn_standardize_scale_f32(const float* Pr, const float* w, const unsigned char* sel, int S, int n, float eps,
+                             float* pts, float* stdv, void* stream);
 /* Adam (torch.optim.Adam's defaults and update rule: train_parsenet.py:96, train_parsenet_e2e.py:88,
  * train_open_splines.py:81) on ONE flat fp32 buffer of n parameters: p, the gradients g and both moments m, v are
  * contiguous arrays of n floats; step = the 1-based count of this update.  One launch for the whole model. */

@@ -80,10 +80,9 @@ SIGNATURES = {
     "pn_gemm_x3_weight_image_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_gemm_x3_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
-    "pn_standardize_select_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
-                                          c_void_p]),
-    "pn_standardize_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
-                                         c_void_p, c_void_p, c_void_p]),
+    "pn_standardize_select_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pn_standardize_scale_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                                         c_void_p]),
     "pn_gather_flat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "pn_adam_flat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),

@@ -696,27 +696,20 @@ extern "C" int pn_affine_act_bwd_f32(const float* gy, const float* y, const floa
 }
 
 // =============================================================================================
-// Standardisation of the spline segments (src/fitting_utils.py:512-553, standardize_point_torch) for S segments:
-//   select the confident points (w > 0.8; fewer than 400 of them: the kf largest memberships instead), weighted mean,
-//   covariance of the selected centred points -> [host: minor axis by LAPACK geev, rotation to +x] -> rotate, extent
-//   of the weighted selected points per axis, scale.
-// Round 5 ran this as 31 tensor-library launches per step (a topk over half of every row among them); here the part
-// before the host step is one launch and the part after it another, one 256-thread workgroup per segment, every
-// reduction a fixed tree (fp64 sums, rounded once).
+// Standardisation of the spline segments (src/fitting_utils.py:512-553, standardize_point_torch) for S segments: the
+// two parts that are NOT arithmetic on the points —
+//   select: the confident points (w > 0.8; fewer than 400 of them: the kf largest memberships instead — round 5 ran a
+//           topk over half of every row for this, 0.084 ms, plus a scatter and a where), as a byte mask;
+//   scale : extent | max - min | of the weighted rotated SELECTED points per axis and the division by it.
+// Weighted mean, centring, covariance and the rotation stay the tensor expressions (and rocBLAS products) of round 5
+// ON PURPOSE: LAPACK's geev, which the reference uses for the minor axis, returns an eigenvector whose SIGN flips
+// with the last bit of the covariance on the evidence boxes (tools/probes/std_sign_probe.py: a covariance summed in
+// fp64 instead of by the fp32 GEMM turns the fixture's frame by 180 degrees), so the covariance keeps the bits it had.
+// One 256-thread workgroup per segment; max / min / select are exact operations: results are bit-identical to the
+// tensor-library form.
 // =============================================================================================
 #define STD_T 256
 
-__device__ static inline double std_block_sum(double v, double* sh) {
-  __syncthreads();
-  sh[threadIdx.x] = v;
-  __syncthreads();
-#pragma unroll
-  for (int o = STD_T / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  return sh[0];
-}
 __device__ static inline int std_block_count(int v, int* shi) {
   __syncthreads();
   shi[threadIdx.x] = v;
@@ -729,117 +722,71 @@ __device__ static inline int std_block_count(int v, int* shi) {
   return shi[0];
 }
 
-// sel (S,n) bytes, mean (S,3), cov (S,3,3).  kf: size of the fallback selection (n / 4 or n / 2).
-// Ties at the kf-th largest membership go to the smaller index (torch.topk leaves them unspecified).
-__global__ __launch_bounds__(STD_T) void pn_std_select_kernel(const float* __restrict__ P, const float* __restrict__ w,
-                                                              int n, int kf, float eps, unsigned char* __restrict__ sel,
-                                                              float* __restrict__ mean, float* __restrict__ cov) {
-  __shared__ double shd[STD_T];
+// sel (S,n) bytes.  kf: size of the fallback selection (n / 4 or n / 2).  Ties at the kf-th largest membership go
+// to the smaller index (torch.topk leaves them unspecified).
+__global__ __launch_bounds__(STD_T) void pn_std_select_kernel(const float* __restrict__ w, int n, int kf,
+                                                              unsigned char* __restrict__ sel) {
   __shared__ int shi[STD_T];
   const int s = blockIdx.x, t = threadIdx.x;
   const float* __restrict__ ws = w + (size_t)s * n;
-  const float* __restrict__ Ps = P + (size_t)s * n * 3;
   unsigned char* __restrict__ ss = sel + (size_t)s * n;
   int c = 0;
   for (int i = t; i < n; i += STD_T) c += ws[i] > 0.8f ? 1 : 0;
   const int cnt = std_block_count(c, shi);
   if (cnt >= 400) {
     for (int i = t; i < n; i += STD_T) ss[i] = ws[i] > 0.8f ? 1 : 0;
-  } else {
-    // the kf-th largest membership: largest T with #(ord(w) >= T) >= kf, bit by bit
-    uint32_t T = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-      const uint32_t cand = T | (1u << bit);
-      int cc = 0;
-      for (int i = t; i < n; i += STD_T) cc += pn_f2ord(ws[i]) >= cand ? 1 : 0;
-      if (std_block_count(cc, shi) >= kf) T = cand;
-    }
-    int ab = 0;
-    for (int i = t; i < n; i += STD_T) ab += pn_f2ord(ws[i]) > T ? 1 : 0;
-    int need_eq = kf - std_block_count(ab, shi);       // ties at T: the first need_eq in index order
-    for (int base = 0; base < n; base += STD_T) {
-      const int i = base + t;
-      const uint32_t o = i < n ? pn_f2ord(ws[i]) : 0u;
-      const int tie = (i < n && o == T) ? 1 : 0;
-      // exclusive rank of this tie among the ties of the chunk (index order = thread order)
+    return;
+  }
+  // the kf-th largest membership: largest T with #(ord(w) >= T) >= kf, bit by bit
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = T | (1u << bit);
+    int cc = 0;
+    for (int i = t; i < n; i += STD_T) cc += pn_f2ord(ws[i]) >= cand ? 1 : 0;
+    if (std_block_count(cc, shi) >= kf) T = cand;
+  }
+  int ab = 0;
+  for (int i = t; i < n; i += STD_T) ab += pn_f2ord(ws[i]) > T ? 1 : 0;
+  int need_eq = kf - std_block_count(ab, shi);       // ties at T: the first need_eq in index order
+  for (int base = 0; base < n; base += STD_T) {
+    const int i = base + t;
+    const uint32_t o = i < n ? pn_f2ord(ws[i]) : 0u;
+    const int tie = (i < n && o == T) ? 1 : 0;
+    // inclusive rank of this tie among the ties of the chunk (index order = thread order)
+    __syncthreads();
+    shi[t] = tie;
+    __syncthreads();
+    for (int d = 1; d < STD_T; d <<= 1) {
+      const int v = t >= d ? shi[t - d] : 0;
       __syncthreads();
-      shi[t] = tie;
+      shi[t] += v;
       __syncthreads();
-      for (int d = 1; d < STD_T; d <<= 1) {
-        const int v = t >= d ? shi[t - d] : 0;
-        __syncthreads();
-        shi[t] += v;
-        __syncthreads();
-      }
-      const int incl = shi[t], total = shi[STD_T - 1];
-      if (i < n) ss[i] = (o > T || (tie && incl - 1 < need_eq)) ? 1 : 0;
-      need_eq -= total < need_eq ? total : need_eq;
     }
-  }
-  __syncthreads();
-  // weighted mean over the selection
-  double sw = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-  for (int i = t; i < n; i += STD_T) {
-    if (ss[i]) {
-      const float wi = ws[i];
-      sw += (double)wi;
-      sx += (double)(Ps[3 * i] * wi);
-      sy += (double)(Ps[3 * i + 1] * wi);
-      sz += (double)(Ps[3 * i + 2] * wi);
-    }
-  }
-  const float fw = (float)std_block_sum(sw, shd) + eps;
-  const float mx = (float)std_block_sum(sx, shd) / fw;
-  const float my = (float)std_block_sum(sy, shd) / fw;
-  const float mz = (float)std_block_sum(sz, shd) / fw;
-  // covariance of the selected centred points
-  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-  for (int i = t; i < n; i += STD_T) {
-    if (ss[i]) {
-      const double x = (double)(Ps[3 * i] - mx), y = (double)(Ps[3 * i + 1] - my), z = (double)(Ps[3 * i + 2] - mz);
-      c00 += x * x, c01 += x * y, c02 += x * z, c11 += y * y, c12 += y * z, c22 += z * z;
-    }
-  }
-  const float v00 = (float)std_block_sum(c00, shd), v01 = (float)std_block_sum(c01, shd);
-  const float v02 = (float)std_block_sum(c02, shd), v11 = (float)std_block_sum(c11, shd);
-  const float v12 = (float)std_block_sum(c12, shd), v22 = (float)std_block_sum(c22, shd);
-  if (t == 0) {
-    mean[3 * s] = mx, mean[3 * s + 1] = my, mean[3 * s + 2] = mz;
-    float* cv = cov + 9 * (size_t)s;
-    cv[0] = v00, cv[1] = v01, cv[2] = v02, cv[3] = v01, cv[4] = v11, cv[5] = v12, cv[6] = v02, cv[7] = v12, cv[8] = v22;
+    const int incl = shi[t], total = shi[STD_T - 1];
+    if (i < n) ss[i] = (o > T || (tie && incl - 1 < need_eq)) ? 1 : 0;
+    need_eq -= total < need_eq ? total : need_eq;
   }
 }
 
-// pts (S,n,3) = R (P - mean) / (std + eps), std (S,3) = | max - min | of the weighted rotated SELECTED points per axis
-__global__ __launch_bounds__(STD_T) void pn_std_apply_kernel(const float* __restrict__ P, const float* __restrict__ w,
-                                                             const unsigned char* __restrict__ sel,
-                                                             const float* __restrict__ mean, const float* __restrict__ R,
-                                                             int n, float eps, float* __restrict__ pts,
-                                                             float* __restrict__ stdv) {
+// Pr (S,n,3) rotated centred points -> std (S,3) = | max - min | over the selected points of Pr * w per axis,
+// pts (S,n,3) = Pr / (std + eps)
+__global__ __launch_bounds__(STD_T) void pn_std_scale_kernel(const float* __restrict__ Pr, const float* __restrict__ w,
+                                                             const unsigned char* __restrict__ sel, int n, float eps,
+                                                             float* __restrict__ pts, float* __restrict__ stdv) {
   __shared__ float shm[6][STD_T];
   const int s = blockIdx.x, t = threadIdx.x;
   const float* __restrict__ ws = w + (size_t)s * n;
-  const float* __restrict__ Ps = P + (size_t)s * n * 3;
+  const float* __restrict__ Ps = Pr + (size_t)s * n * 3;
   const unsigned char* __restrict__ ss = sel + (size_t)s * n;
   float* __restrict__ os = pts + (size_t)s * n * 3;
-  const float mx = mean[3 * s], my = mean[3 * s + 1], mz = mean[3 * s + 2];
-  float r[9];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) r[e] = R[9 * (size_t)s + e];
   float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   for (int i = t; i < n; i += STD_T) {
-    const float x = Ps[3 * i] - mx, y = Ps[3 * i + 1] - my, z = Ps[3 * i + 2] - mz;
-    float pr[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      pr[a] = __builtin_fmaf(z, r[3 * a + 2], __builtin_fmaf(y, r[3 * a + 1], x * r[3 * a]));
-    os[3 * i] = pr[0], os[3 * i + 1] = pr[1], os[3 * i + 2] = pr[2];      // rotated; scaled below
     if (ss[i]) {
       const float wi = ws[i];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float v = pr[a] * wi;
+        const float v = Ps[3 * i + a] * wi;
         hi[a] = fmaxf(hi[a], v);
         lo[a] = fminf(lo[a], v);
       }
@@ -865,27 +812,26 @@ __global__ __launch_bounds__(STD_T) void pn_std_apply_kernel(const float* __rest
 #pragma unroll
   for (int a = 0; a < 3; ++a) sd[a] = fabsf(shm[a][0] - shm[3 + a][0]);
   if (t < 3) stdv[3 * s + t] = sd[t];
-  for (int i = t; i < n; i += STD_T) {      // (this thread wrote these rows itself)
+  for (int i = t; i < n; i += STD_T) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) os[3 * i + a] = os[3 * i + a] / (sd[a] + eps);
+    for (int a = 0; a < 3; ++a) os[3 * i + a] = Ps[3 * i + a] / (sd[a] + eps);
   }
 }
 
-extern "C" int pn_standardize_select_f32(const float* P, const float* w, int S, int n, int kf, float eps,
-                                         unsigned char* sel, float* mean, float* cov, void* stream) {
-  PN_CHECK_ARG(P && w && sel && mean && cov && S > 0 && n > 0 && kf >= 1 && kf <= n,
-               "pn_standardize_select_f32: bad arguments (S=%d n=%d kf=%d)", S, n, kf);
+extern "C" int pn_standardize_select_f32(const float* w, int S, int n, int kf, unsigned char* sel, void* stream) {
+  PN_CHECK_ARG(w && sel && S > 0 && n > 0 && kf >= 1 && kf <= n, "pn_standardize_select_f32: bad arguments (S=%d n=%d kf=%d)",
+               S, n, kf);
   PN_PROF("standardize", (hipStream_t)stream);
-  hipLaunchKernelGGL(pn_std_select_kernel, dim3(S), dim3(STD_T), 0, (hipStream_t)stream, P, w, n, kf, eps, sel, mean, cov);
+  hipLaunchKernelGGL(pn_std_select_kernel, dim3(S), dim3(STD_T), 0, (hipStream_t)stream, w, n, kf, sel);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
 
-extern "C" int pn_standardize_apply_f32(const float* P, const float* w, const unsigned char* sel, const float* mean,
-                                        const float* R, int S, int n, float eps, float* pts, float* stdv, void* stream) {
-  PN_CHECK_ARG(P && w && sel && mean && R && pts && stdv && S > 0 && n > 0, "pn_standardize_apply_f32: bad arguments");
+extern "C" int pn_standardize_scale_f32(const float* Pr, const float* w, const unsigned char* sel, int S, int n, float eps,
+                                        float* pts, float* stdv, void* stream) {
+  PN_CHECK_ARG(Pr && w && sel && pts && stdv && S > 0 && n > 0, "pn_standardize_scale_f32: bad arguments");
   PN_PROF("standardize", (hipStream_t)stream);
-  hipLaunchKernelGGL(pn_std_apply_kernel, dim3(S), dim3(STD_T), 0, (hipStream_t)stream, P, w, sel, mean, R, n, eps, pts, stdv);
+  hipLaunchKernelGGL(pn_std_scale_kernel, dim3(S), dim3(STD_T), 0, (hipStream_t)stream, Pr, w, sel, n, eps, pts, stdv);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -345,11 +345,18 @@ def standardize_segments(P2, w):
     Returns (points (S,n,3), std (S,3), mean (S,3), R (S,3,3)); one download (covariances)."""
     S, n, _ = P2.shape
     with torch.no_grad():
-        # selection (w > 0.8, or the top quarter / half of the memberships when fewer than 400 qualify), weighted mean
-        # and covariance of the selected points in ONE launch; rotation, extents and scaling in another (csrc/fused.hip:
-        # pn_standardize_*; round 5: 31 tensor-library launches with a topk over half of every row)
+        # the selection (w > 0.8, or the top quarter / half of the memberships when fewer than 400 qualify) and, below,
+        # extents + scaling as one launch each (csrc/fused.hip: pn_standardize_*; round 5: a topk over half of every row
+        # and 31 launches in all).  Mean, covariance and rotation keep round 5's expressions — and bits: the sign of
+        # LAPACK's eigenvector follows the last bit of the covariance (tools/probes/std_sign_probe.py)
         kf = n // 4 if n >= 7500 else n // 2
-        sel, mean, cov = K.standardize_select(P2, w, max(kf, 1), EPS)
+        self_ = K.standardize_select(w, max(kf, 1))
+        selb = self_
+        self_ = self_.float()
+        wsel = w * self_
+        mean = (P2 * wsel.unsqueeze(2)).sum(1) / (wsel.sum(1, keepdim=True) + EPS)
+        Pc = P2 - mean.unsqueeze(1)
+        cov = torch.bmm((Pc * self_.unsqueeze(2)).transpose(1, 2), Pc)
         cov_h, slot = pinned_like(cov.shape, cov.dtype, hold=True)   # host step of the reference: download ...
         try:
             cov_h.copy_(cov, non_blocking=True)
@@ -362,7 +369,8 @@ def standardize_segments(P2, w):
         finally:
             _PinnedRing.release(slot)
         R = h2d(rot, P2.device)                                    # ... upload
-        pts, std = K.standardize_apply(P2, w, sel, mean, R, EPS)
+        Pr = torch.bmm(Pc, R.transpose(1, 2))
+        pts, std = K.standardize_scale(Pr, w, selb, EPS)
     return pts, std, mean, R
 
 

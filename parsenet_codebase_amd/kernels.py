@@ -642,32 +642,30 @@ def gemm_x3(img_a, M, x, bias=None):
     return out
 
 
-def standardize_select(P, w, kf, eps):
-    """Device part of standardize_point_torch BEFORE the host's eigen-decomposition, for S segments at once
-    (csrc/fused.hip): P (S,n,3), w (S,n) -> (sel (S,n) uint8, mean (S,3), cov (S,3,3))."""
-    require_cuda(P, w)
-    P, w = _f32c(P, "P"), _f32c(w, "w")
-    S, n, _ = P.shape
-    sel = torch.empty((S, n), dtype=torch.uint8, device=P.device)
-    mean = torch.empty((S, 3), dtype=torch.float32, device=P.device)
-    cov = torch.empty((S, 3, 3), dtype=torch.float32, device=P.device)
-    with _lib.on_device(P.device):
-        rc = _lib.load().pn_standardize_select_f32(ptr(P), ptr(w), S, n, int(kf), float(eps), ptr(sel), ptr(mean), ptr(cov),
-                                                   current_stream(P.device))
+def standardize_select(w, kf):
+    """The confident points of S segments (src/fitting_utils.py:515-523): w (S,n) -> byte mask (S,n): w > 0.8, or
+    the kf largest memberships of a row with fewer than 400 such points (ties to the smaller index)."""
+    require_cuda(w)
+    w = _f32c(w, "w")
+    S, n = w.shape
+    sel = torch.empty((S, n), dtype=torch.uint8, device=w.device)
+    with _lib.on_device(w.device):
+        rc = _lib.load().pn_standardize_select_f32(ptr(w), S, n, int(kf), ptr(sel), current_stream(w.device))
     check(rc, "pn_standardize_select_f32")
-    return sel, mean, cov
+    return sel
 
 
-def standardize_apply(P, w, sel, mean, R, eps):
-    """... and AFTER it: (pts (S,n,3), std (S,3))."""
-    P, w, R = _f32c(P, "P"), _f32c(w, "w"), _f32c(R, "R")
-    S, n, _ = P.shape
-    pts = torch.empty_like(P)
-    std = torch.empty((S, 3), dtype=torch.float32, device=P.device)
-    with _lib.on_device(P.device):
-        rc = _lib.load().pn_standardize_apply_f32(ptr(P), ptr(w), ptr(sel), ptr(mean), ptr(R), S, n, float(eps), ptr(pts),
-                                                  ptr(std), current_stream(P.device))
-    check(rc, "pn_standardize_apply_f32")
+def standardize_scale(Pr, w, sel, eps):
+    """Pr (S,n,3) rotated centred points -> (pts (S,n,3) = Pr / (std + eps), std (S,3) = | max - min | of the
+    weighted selected points per axis): src/fitting_utils.py:545-552."""
+    Pr, w = _f32c(Pr, "Pr"), _f32c(w, "w")
+    S, n, _ = Pr.shape
+    pts = torch.empty_like(Pr)
+    std = torch.empty((S, 3), dtype=torch.float32, device=Pr.device)
+    with _lib.on_device(Pr.device):
+        rc = _lib.load().pn_standardize_scale_f32(ptr(Pr), ptr(w), ptr(sel), S, n, float(eps), ptr(pts), ptr(std),
+                                                  current_stream(Pr.device))
+    check(rc, "pn_standardize_scale_f32")
     return pts, std
 
 

@@ -398,8 +398,8 @@ def test_standardisation_with_and_without_the_top_half_fallback(gpu):
 def test_fallback_selection_takes_exactly_kf_memberships_with_ties_to_the_smaller_index(gpu, n):
     """pn_standardize_select_f32's fallback (fewer than 400 memberships above 0.8; src/fitting_utils.py:517-523): the
     kf = n // 2 (n // 4 from 7 500 points on) largest memberships — exactly kf of them even when the kf-th value is
-    shared by many points (memberships that are exactly EPS), ties going to the smaller index; mean and covariance
-    are those of the selection (float64 reference), and a row with enough confident points takes the plain rule."""
+    shared by many points (memberships that are exactly EPS), ties going to the smaller index; a row with enough
+    confident points takes the plain rule; extents and scaling equal the tensor expressions bit for bit."""
     from parsenet_codebase_amd import kernels as K
     rng = np.random.RandomState(n)
     S = 3
@@ -409,8 +409,7 @@ def test_fallback_selection_takes_exactly_kf_memberships_with_ties_to_the_smalle
     w[1, : n // 3] = np.float32(0.25)                            # another tie block
     w[2, : min(n, 450)] = 0.9                                    # the plain rule when n >= 400 confident points exist
     kf = n // 4 if n >= 7500 else n // 2
-    sel, mean, cov = K.standardize_select(torch.from_numpy(P).to(gpu), torch.from_numpy(w).to(gpu), kf, 1e-8)
-    sel, mean, cov = sel.cpu().numpy().astype(bool), mean.cpu().numpy(), cov.cpu().numpy()
+    sel = K.standardize_select(torch.from_numpy(w).to(gpu), kf).cpu().numpy().astype(bool)
     for s in range(S):
         if (w[s] > 0.8).sum() >= 400:
             want = w[s] > 0.8
@@ -419,8 +418,12 @@ def test_fallback_selection_takes_exactly_kf_memberships_with_ties_to_the_smalle
             want = np.zeros(n, bool)
             want[order[:kf]] = True
         assert np.array_equal(sel[s], want), (s, int(sel[s].sum()), int(want.sum()))
-        ws = w[s].astype(np.float64) * want
-        m = (P[s].astype(np.float64) * ws[:, None]).sum(0) / (ws.sum() + 1e-8)
-        assert np.abs(mean[s] - m).max() < 1e-5
-        Pc = (P[s] - mean[s]).astype(np.float64)[want]
-        assert np.abs(cov[s] - Pc.T @ Pc).max() < 1e-4 * np.abs(Pc.T @ Pc).max()
+    # extents and scaling: bit-identical to the tensor expressions
+    Pr = torch.from_numpy(P).to(gpu)
+    wt, st = torch.from_numpy(w).to(gpu), torch.from_numpy(sel).to(gpu)
+    pts, std = K.standardize_scale(Pr, wt, st.to(torch.uint8), 1e-7)
+    wp = Pr * wt.unsqueeze(2)
+    big = torch.full_like(wp, float("inf"))
+    sx = st.unsqueeze(2)
+    std0 = torch.abs(torch.where(sx, wp, -big).max(1)[0] - torch.where(sx, wp, big).min(1)[0])
+    assert torch.equal(std, std0) and torch.equal(pts, Pr / (std0.unsqueeze(1) + 1e-7))
