@@ -703,8 +703,9 @@ extern "C" int pn_affine_act_bwd_f32(const float* gy, const float* y, const floa
 //   scale : extent | max - min | of the weighted rotated SELECTED points per axis and the division by it.
 // Weighted mean, centring, covariance and the rotation stay the tensor expressions (and rocBLAS products) of round 5
 // ON PURPOSE: LAPACK's geev, which the reference uses for the minor axis, returns an eigenvector whose SIGN flips
-// with the last bit of the covariance on the evidence boxes (tools/probes/std_sign_probe.py: a covariance summed in
-// fp64 instead of by the fp32 GEMM turns the fixture's frame by 180 degrees), so the covariance keeps the bits it had.
+// with the last bits of the covariance on the evidence boxes (tools/probes/std_sign_probe.py, profiles/r06_std_sign_probe.txt:
+// the matrix a fully fused kernel produced — fp64 sums, 3-7 ulp away in the off-diagonals — turns the fixture's frame by
+// 180 degrees), so the covariance keeps the bits it had.
 // One 256-thread workgroup per segment; max / min / select are exact operations: results are bit-identical to the
 // tensor-library form.
 // =============================================================================================

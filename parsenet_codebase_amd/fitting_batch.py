@@ -348,7 +348,7 @@ def standardize_segments(P2, w):
         # the selection (w > 0.8, or the top quarter / half of the memberships when fewer than 400 qualify) and, below,
         # extents + scaling as one launch each (csrc/fused.hip: pn_standardize_*; round 5: a topk over half of every row
         # and 31 launches in all).  Mean, covariance and rotation keep round 5's expressions — and bits: the sign of
-        # LAPACK's eigenvector follows the last bit of the covariance (tools/probes/std_sign_probe.py)
+        # LAPACK's eigenvector follows the last bits of the covariance (profiles/r06_std_sign_probe.txt)
         kf = n // 4 if n >= 7500 else n // 2
         self_ = K.standardize_select(w, max(kf, 1))
         selb = self_

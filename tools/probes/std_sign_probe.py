@@ -5,9 +5,11 @@ covariance from geev and rotates it to +x; the eigenvector's sign is whatever LA
 golden standardisation case, forms the covariance as round 5's fp32 expressions do (rocBLAS product), and asks the
 box's own LAPACK for the minor axis of (i) that matrix, (ii) the same sums accumulated in float64 and rounded once,
 (iii) the matrix a fused kernel of this round produced for the same data (fp64 sums around an fp64-summed mean; it
-differs from (i) in the 7th-8th digit) and (iv) (i) with single entries moved by +-1 / +-2 ulp.  On the evidence box
-(iii) and a share of (iv) come out with the OPPOSITE sign — the canonical frame of the spline patch turns by 180
-degrees — which is why fitting_batch.standardize_segments keeps the fp32 expressions (and their bits) for mean,
+differs from (i) by 3 ... 7 ulp in the off-diagonal entries) and (iv) (i) with single entries moved by +-1 / +-2 ulp.
+On the evidence box (iii) comes out with the OPPOSITE sign — the canonical frame of the spline patch turns by 180
+degrees, the golden R and the end-to-end loss against the oracle move with it — while (ii) and all of (iv) keep it
+(profiles/r06_std_sign_probe.txt): the sign is a discontinuous function of the matrix a few ulp away from this
+input.  That is why fitting_batch.standardize_segments keeps the fp32 expressions (and their bits) for mean,
 covariance and rotation and fuses only the selection and the extents (csrc/fused.hip: pn_standardize_*)."""
 import os
 import sys
