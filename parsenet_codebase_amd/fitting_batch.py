@@ -339,6 +339,9 @@ def host_minor_axis_rotations(cov):
     return out
 
 
+STD_FUSED = os.environ.get("PARSENET_STD_FUSED", "1") != "0"
+
+
 def standardize_segments(P2, w):
     """standardize_point_torch (src/fitting_utils.py:512-553) for S segments at once.
     P2 (S,n,3) sub-sampled points of each segment's shape, w (S,n) memberships (+EPS).
@@ -350,9 +353,16 @@ def standardize_segments(P2, w):
         # and 31 launches in all).  Mean, covariance and rotation keep round 5's expressions — and bits: the sign of
         # LAPACK's eigenvector follows the last bits of the covariance (profiles/r06_std_sign_probe.txt)
         kf = n // 4 if n >= 7500 else n // 2
-        self_ = K.standardize_select(w, max(kf, 1))
-        selb = self_
-        self_ = self_.float()
+        if STD_FUSED:
+            selb = K.standardize_select(w, max(kf, 1))
+            self_ = selb.float()
+        else:               # PARSENET_STD_FUSED=0 (developer A/B): round 5's tensor expressions
+            hi = w > 0.8
+            cnt = hi.sum(1, keepdim=True)
+            top = torch.topk(w, kf, dim=1)[1]
+            fb = torch.zeros_like(hi).scatter_(1, top, torch.ones_like(top, dtype=torch.bool))
+            selb = torch.where(cnt < 400, fb, hi)
+            self_ = selb.float()
         wsel = w * self_
         mean = (P2 * wsel.unsqueeze(2)).sum(1) / (wsel.sum(1, keepdim=True) + EPS)
         Pc = P2 - mean.unsqueeze(1)
@@ -370,7 +380,14 @@ def standardize_segments(P2, w):
             _PinnedRing.release(slot)
         R = h2d(rot, P2.device)                                    # ... upload
         Pr = torch.bmm(Pc, R.transpose(1, 2))
-        pts, std = K.standardize_scale(Pr, w, selb, EPS)
+        if STD_FUSED:
+            pts, std = K.standardize_scale(Pr, w, selb, EPS)
+        else:
+            wp = Pr * w.unsqueeze(2)
+            big = torch.full_like(wp, float("inf"))
+            selx = selb.unsqueeze(2)
+            std = torch.abs(torch.where(selx, wp, -big).max(1)[0] - torch.where(selx, wp, big).min(1)[0])
+            pts = Pr / (std.unsqueeze(1) + EPS)
     return pts, std, mean, R
 
 
