@@ -711,28 +711,42 @@ extern "C" int pn_affine_act_bwd_f32(const float* gy, const float* y, const floa
 // =============================================================================================
 #define STD_T 256
 
+// block-wide sum of small non-negative counts: wave sums by shuffle, four partials through LDS (two barriers)
 __device__ static inline int std_block_count(int v, int* shi) {
-  __syncthreads();
-  shi[threadIdx.x] = v;
-  __syncthreads();
 #pragma unroll
-  for (int o = STD_T / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) shi[threadIdx.x] += shi[threadIdx.x + o];
-    __syncthreads();
-  }
-  return shi[0];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return shi[0] + shi[1] + shi[2] + shi[3];
 }
 
 // sel (S,n) bytes.  kf: size of the fallback selection (n / 4 or n / 2).  Ties at the kf-th largest membership go
-// to the smaller index (torch.topk leaves them unspecified).
+// to the smaller index (torch.topk leaves them unspecified).  The row's order-preserving integer images live in
+// registers (STD_E per thread, n <= 256 STD_E; longer rows re-read them from memory): a round of the bisection is
+// STD_E compares and one block count.
+#define STD_E 40
 __global__ __launch_bounds__(STD_T) void pn_std_select_kernel(const float* __restrict__ w, int n, int kf,
                                                               unsigned char* __restrict__ sel) {
   __shared__ int shi[STD_T];
   const int s = blockIdx.x, t = threadIdx.x;
   const float* __restrict__ ws = w + (size_t)s * n;
   unsigned char* __restrict__ ss = sel + (size_t)s * n;
+  const bool in_regs = n <= STD_T * STD_E;
+  uint32_t v[STD_E];
   int c = 0;
-  for (int i = t; i < n; i += STD_T) c += ws[i] > 0.8f ? 1 : 0;
+#pragma unroll
+  for (int e = 0; e < STD_E; ++e) {
+    const int i = e * STD_T + t;
+    v[e] = 0u;                                   // (below every real image: never counted)
+    if (in_regs && i < n) {
+      const float x = ws[i];
+      v[e] = pn_f2ord(x);
+      c += x > 0.8f ? 1 : 0;
+    }
+  }
+  if (!in_regs)
+    for (int i = t; i < n; i += STD_T) c += ws[i] > 0.8f ? 1 : 0;
   const int cnt = std_block_count(c, shi);
   if (cnt >= 400) {
     for (int i = t; i < n; i += STD_T) ss[i] = ws[i] > 0.8f ? 1 : 0;
@@ -743,7 +757,12 @@ __global__ __launch_bounds__(STD_T) void pn_std_select_kernel(const float* __res
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t cand = T | (1u << bit);
     int cc = 0;
-    for (int i = t; i < n; i += STD_T) cc += pn_f2ord(ws[i]) >= cand ? 1 : 0;
+    if (in_regs) {
+#pragma unroll
+      for (int e = 0; e < STD_E; ++e) cc += v[e] >= cand ? 1 : 0;
+    } else {
+      for (int i = t; i < n; i += STD_T) cc += pn_f2ord(ws[i]) >= cand ? 1 : 0;
+    }
     if (std_block_count(cc, shi) >= kf) T = cand;
   }
   int ab = 0;
@@ -758,9 +777,9 @@ __global__ __launch_bounds__(STD_T) void pn_std_select_kernel(const float* __res
     shi[t] = tie;
     __syncthreads();
     for (int d = 1; d < STD_T; d <<= 1) {
-      const int v = t >= d ? shi[t - d] : 0;
+      const int u = t >= d ? shi[t - d] : 0;
       __syncthreads();
-      shi[t] += v;
+      shi[t] += u;
       __syncthreads();
     }
     const int incl = shi[t], total = shi[STD_T - 1];
