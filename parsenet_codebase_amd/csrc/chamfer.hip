@@ -337,6 +337,13 @@ static int chamfer_one_side(const float* q, const int* qoff, int Nq, long long t
   // enough workgroups to cover 256 CUs several times over, but never split a candidate range
   // below 256 points
   int splits = pn_cdiv(4096, (long long)qblocks * B);
+  // (PN_CHAMFER_DIRECT_WGS, developer A/B: from this many query workgroups on, ONE candidate range per query — no
+  //  64-bit atomic merge, no memset and no unpack launch; 0 = never)
+  {
+    const char* e = getenv("PN_CHAMFER_DIRECT_WGS");
+    const long long direct_from = e ? atoll(e) : 384;
+    if (direct_from > 0 && (long long)qblocks * B >= direct_from) splits = 1;
+  }
   const int max_splits = pn_cdiv(Nc, 256);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
