@@ -337,11 +337,13 @@ static int chamfer_one_side(const float* q, const int* qoff, int Nq, long long t
   // enough workgroups to cover 256 CUs several times over, but never split a candidate range
   // below 256 points
   int splits = pn_cdiv(4096, (long long)qblocks * B);
-  // (PN_CHAMFER_DIRECT_WGS, developer A/B: from this many query workgroups on, ONE candidate range per query — no
-  //  64-bit atomic merge, no memset and no unpack launch; 0 = never)
+  // (ONE candidate range per query as soon as the query workgroups alone number a few hundred — no 64-bit atomic
+  //  merge, no memset, no unpack launch — was measured in round 6, tools/jobs/r6k.sh: 32 x 1600 x 700 0.047 against
+  //  0.037 ms with the split ranges, 0.079 from 128 workgroups on: the waves' scans get three times longer and the
+  //  chip is not full; PN_CHAMFER_DIRECT_WGS=<n> re-enables it for an A/B)
   {
     const char* e = getenv("PN_CHAMFER_DIRECT_WGS");
-    const long long direct_from = e ? atoll(e) : 384;
+    const long long direct_from = e ? atoll(e) : 0;
     if (direct_from > 0 && (long long)qblocks * B >= direct_from) splits = 1;
   }
   const int max_splits = pn_cdiv(Nc, 256);
