@@ -486,7 +486,7 @@ REFIT_POOL = os.environ.get("PARSENET_REFIT_POOL", "1") != "0"
 def assignment_pool():
     """A persistent pool of worker PROCESSES (spawned: they import numpy / scipy only, never torch) for the
     linear_sum_assignment calls of the LS refit — scipy holds the GIL, threads would run them one after the other.
-    Sized by the CPUs the job may use (dp.usable_cpus(), at most 8).  None when PARSENET_REFIT_POOL=0 or a single CPU:
+    Sized by the CPUs the job may use (dp.usable_cpus() - 1, at most 16).  None when PARSENET_REFIT_POOL=0 or a single CPU:
     the caller then solves in place."""
     global _LSA_POOL
     if not REFIT_POOL:
@@ -496,7 +496,7 @@ def assignment_pool():
         import multiprocessing
         from concurrent.futures import ProcessPoolExecutor
         from .dp import usable_cpus
-        n = min(8, usable_cpus() - 1)
+        n = min(16, usable_cpus() - 1)      # (a batch of 4 shapes has up to 16 spline segments: one matching per worker)
         if n < 2:
             return None
         _LSA_POOL = ProcessPoolExecutor(max_workers=n, mp_context=multiprocessing.get_context("spawn"))
