@@ -239,6 +239,12 @@ size_t pn_meanshift_x3_plan_core_bytes(int B, int N);
 int pn_kmeans_assign_f32(const float* x, const float* cen, int B, int N, int D, int K, int* lab, void* stream);
 int pn_kmeans_centres_f32(const float* x, const int* lab, const float* old, int B, int N, int D, int K,
                           float* cen, void* stream);
+/* The locality order itself (mean_shift.locality_order; no counterpart in the reference): perm (B,N) int64 = the
+ * STABLE argsort of key[n] = rank[home[fine[n]]] * F + fine[n] — rank (B,P) int32 position of a coarse cell in the
+ * chain, home (B,F) int32 coarse cell of a fine cell, fine (B,N) int32 fine cell of a point — as a counting sort
+ * over the F <= 768 cells, one launch.  Identical to the tensor library's argsort(stable=True) of the keys. */
+int pn_cell_order_i32(const int* rank, const int* home, const int* fine, int B, int N, int P, int F,
+                      long long* perm, void* stream);
 int pn_meanshift_x3_tileinfo_f32(const float* z, int B, int N, int D, float* cen, float* rho, float* cnt,
                                  void* stream);
 int pn_meanshift_x3_plan_f32(const float* cenQ, const float* rhoQ, const float* cenX, const float* rhoX,
@@ -320,6 +326,14 @@ int pn_gn_apply_fwd_f32(const float* y, const float* mean, const float* rstd, co
 int pn_gn_rows_bwd_f32(const float* gout, const float* y, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int B, int C, int groups, int N,
                        int relu, float* ra, float* rb, const float* rowbias, int rb_bstride, void* stream);
+/* The (B,C) tail of max_n relu(GroupNorm(y)) (src/PointNet.py:199-201: bnmlp1 + relu + max over the points, taken
+ * on the row extrema): extremum by the sign of gamma, (ext - mean) * rstd, gamma * yhat + beta, relu — and of its
+ * backward pass: gz = g * (z > 0), rb = gz * yhat.  The tensor-library operations they replace, separately rounded. */
+int pn_gn_max_finish_f32(const float* rmax, const int* amax, const float* rmin, const int* amin,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         int B, int C, int groups, float* yhat, float* z, int* arg, float* out, void* stream);
+int pn_gn_max_bwd_prep_f32(const float* g, const float* z, const float* yhat, int B, int C, float* gz, float* rb,
+                           void* stream);
 int pn_gn_group_bwd_f32(const float* ra, const float* rb, const float* gamma, int B, int C,
                         int groups, int N, float* c1c2, void* stream);
 int pn_gn_apply_bwd_f32(const float* gout, const float* y, const float* mean, const float* rstd,

@@ -97,6 +97,9 @@ SIGNATURES = {
     "pn_meanshift_rows_scatter_add_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_x3_plan_bytes": (c_size_t, [c_int, c_int]),
     "pn_meanshift_x3_plan_core_bytes": (c_size_t, [c_int, c_int]),
+    "pn_gn_max_finish_f32": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int] + [c_void_p] * 5),
+    "pn_gn_max_bwd_prep_f32": (c_int, [c_void_p] * 3 + [c_int, c_int] + [c_void_p] * 3),
+    "pn_cell_order_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_kmeans_assign_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_kmeans_centres_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pn_meanshift_chain_order_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -323,3 +323,59 @@ extern "C" int pn_gn_apply_bwd_f32(const float* gout, const float* y, const floa
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
+
+// ---- the (B,C) tail of max_n relu(GroupNorm(y)) ------------------------------------------------------------------
+// norms._GroupNormReLUMax picked the row extremum by the sign of gamma, normalised it, applied the affine map and
+// the ReLU as ten tensor-library launches on B x C values (and four more in the backward pass); one launch each
+// here, the same fp32 operations in the same order (no contraction: separately rounded multiply and add).
+__global__ __launch_bounds__(256) void pn_gn_max_finish_kernel(const float* __restrict__ rmax, const int* __restrict__ amax,
+                                                               const float* __restrict__ rmin, const int* __restrict__ amin,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int BC, int C, int groups, float* __restrict__ yhat,
+                                                               float* __restrict__ z, int* __restrict__ arg,
+                                                               float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BC) return;
+  const int c = i % C, b = i / C, g = b * groups + c / (C / groups);
+  const float ga = gamma[c];
+  const bool pos = ga >= 0.f;
+  const float ext = pos ? rmax[i] : rmin[i];
+  arg[i] = pos ? amax[i] : amin[i];
+  const float yh = __fmul_rn(__fsub_rn(ext, mean[g]), rstd[g]);
+  const float zz = __fadd_rn(__fmul_rn(ga, yh), beta[c]);
+  yhat[i] = yh;
+  z[i] = zz;
+  out[i] = zz < 0.f ? 0.f : zz;          // relu as the tensor library's clamp: a NaN stays a NaN, -0 stays -0
+}
+
+__global__ __launch_bounds__(256) void pn_gn_max_bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                                 const float* __restrict__ yhat, int BC,
+                                                                 float* __restrict__ gz, float* __restrict__ rb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BC) return;
+  const float v = __fmul_rn(g[i], z[i] > 0.f ? 1.f : 0.f);
+  gz[i] = v;
+  rb[i] = __fmul_rn(v, yhat[i]);
+}
+
+extern "C" int pn_gn_max_finish_f32(const float* rmax, const int* amax, const float* rmin, const int* amin,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                    int B, int C, int groups, float* yhat, float* z, int* arg, float* out,
+                                    void* stream) {
+  PN_CHECK_ARG(rmax && amax && rmin && amin && mean && rstd && gamma && beta && yhat && z && arg && out && B > 0 &&
+               C > 0 && groups > 0 && C % groups == 0, "pn_gn_max_finish_f32: bad arguments");
+  hipLaunchKernelGGL(pn_gn_max_finish_kernel, dim3(pn_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, rmax, amax,
+                     rmin, amin, mean, rstd, gamma, beta, B * C, C, groups, yhat, z, arg, out);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+extern "C" int pn_gn_max_bwd_prep_f32(const float* g, const float* z, const float* yhat, int B, int C, float* gz,
+                                      float* rb, void* stream) {
+  PN_CHECK_ARG(g && z && yhat && gz && rb && B > 0 && C > 0, "pn_gn_max_bwd_prep_f32: bad arguments");
+  hipLaunchKernelGGL(pn_gn_max_bwd_prep_kernel, dim3(pn_cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, g, z, yhat,
+                     B * C, gz, rb);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

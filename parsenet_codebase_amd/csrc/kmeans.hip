@@ -143,3 +143,103 @@ extern "C" int pn_kmeans_centres_f32(const float* x, const int* lab, const float
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
+
+// ---- the order itself: a stable counting sort by cell ---------------------------------------------------------
+// Points are filed by key = rank[home[fine]] * F + fine (mean_shift.locality_order): every fine cell has ONE key,
+// so the stable argsort of the keys is a counting sort over the F cells taken in key order.  One workgroup of
+// 16 waves per cloud: cell positions (F^2 / 1024 comparisons a thread), per-wave histograms of contiguous
+// element ranges, a scan over (cell position, wave), then every wave files its range in index order — inside a
+// group of 64 elements a lane's slot is the number of equal cells on lower lanes (ballots), so the result is THE
+// stable permutation, identical to the tensor library's argsort(stable=True) (which took 16 launches).
+#define KO_WAVES 16
+#define KO_MAXF 768
+
+__global__ __launch_bounds__(KO_WAVES * 64) void pn_cell_order_kernel(const int* __restrict__ rank, const int* __restrict__ home,
+                                                                      const int* __restrict__ fine, int N, int P, int F,
+                                                                      long long* __restrict__ perm) {
+  extern __shared__ int ko_lds[];
+  int* key = ko_lds;                    // [F] key of a cell
+  int* pos = key + F;                   // [F] position of a cell in key order
+  int* at = pos + F;                    // [F] cell at a position
+  int* start = at + F;                  // [F] first slot of the cell at a position (exclusive scan of the counts)
+  volatile int* hist = start + F;       // [KO_WAVES][F] count, then next free slot, of (wave, cell)
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int* rk = rank + (size_t)b * P;
+  const int* hm = home + (size_t)b * F;
+  const int* fn = fine + (size_t)b * N;
+  long long* out = perm + (size_t)b * N;
+  for (int f = tid; f < F; f += blockDim.x) key[f] = rk[hm[f]] * F + f;
+  for (int i = tid; i < KO_WAVES * F; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int f = tid; f < F; f += blockDim.x) {
+    const int kf = key[f];
+    int p = 0;
+    for (int g = 0; g < F; ++g) p += key[g] < kf;
+    pos[f] = p;
+    at[p] = f;
+  }
+  const int per = (N + KO_WAVES - 1) / KO_WAVES;
+  const int lo = w * per, hi = min(N, lo + per);
+  for (int i = lo + lane; i < hi; i += 64) atomicAdd((int*)&hist[w * F + fn[i]], 1);
+  __syncthreads();
+  // slots of a cell: its waves in order; cells in key order.  One thread per position sums its waves, a
+  // single wave scans the F totals (F <= 768: twelve values a lane).
+  for (int p = tid; p < F; p += blockDim.x) {
+    const int f = at[p];
+    int s = 0;
+    for (int v = 0; v < KO_WAVES; ++v) s += hist[v * F + f];
+    start[p] = s;
+  }
+  __syncthreads();
+  if (w == 0) {
+    const int each = (F + 63) / 64;
+    int s = 0;
+    for (int j = 0; j < each; ++j) { const int p = lane * each + j; if (p < F) s += start[p]; }
+    int incl = s;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    int run = incl - s;
+    for (int j = 0; j < each; ++j) {
+      const int p = lane * each + j;
+      if (p < F) { const int c = start[p]; start[p] = run; run += c; }
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < F; p += blockDim.x) {
+    const int f = at[p];
+    int run = start[p];
+    for (int v = 0; v < KO_WAVES; ++v) { const int c = hist[v * F + f]; hist[v * F + f] = run; run += c; }
+  }
+  __syncthreads();
+  volatile int* mine = hist + w * F;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < hi;
+    const int f = valid ? fn[i] : -1;
+    unsigned long long left = __ballot(valid);
+    int dst = 0;
+    while (left) {
+      const int leader = __ffsll((long long)left) - 1;
+      const int lf = __shfl(f, leader);
+      const unsigned long long m = __ballot(valid && f == lf);
+      if (valid && f == lf) dst = mine[lf] + __popcll(m & ((1ull << lane) - 1ull));
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) mine[lf] = mine[lf] + __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      left &= ~m;
+    }
+    if (valid) out[dst] = i;
+  }
+}
+
+extern "C" int pn_cell_order_i32(const int* rank, const int* home, const int* fine, int B, int N, int P, int F,
+                                 long long* perm, void* stream) {
+  PN_CHECK_ARG(rank && home && fine && perm && B > 0 && N > 0 && P > 0, "pn_cell_order_i32: bad arguments");
+  PN_CHECK_ARG(F > 0 && F <= KO_MAXF, "pn_cell_order_i32: %d cells unsupported (at most %d)", F, KO_MAXF);
+  PN_CHECK_ARG((long long)P * F < (1ll << 31), "pn_cell_order_i32: keys of %d x %d cells do not fit 32 bits", P, F);
+  PN_PROF("cell_order", (hipStream_t)stream);
+  const size_t lds = (size_t)(4 + KO_WAVES) * F * sizeof(int);
+  hipLaunchKernelGGL(pn_cell_order_kernel, dim3(B), dim3(KO_WAVES * 64), lds, (hipStream_t)stream, rank, home, fine, N, P, F,
+                     perm);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}

@@ -129,8 +129,9 @@ def weight_bmm(w, x, bias=None):
 def conv1x1(x, conv):
     """nn.Conv1d(kernel_size=1) applied as a plain GEMM (rocBLAS) instead of a MIOpen convolution:
     same arithmetic, no per-shape algorithm search (the fitting stage feeds a new point count for
-    every segment)."""
-    return weight_bmm(conv.weight[:, :, 0], x, conv.bias)
+    every segment).  The weight goes in as a VIEW (flatten), not as ``weight[:, :, 0]``: a select's backward node
+    fills a zero tensor and copies the gradient into it, two launches per weight and step for the same bits."""
+    return weight_bmm(conv.weight.flatten(1), x, conv.bias)
 
 
 def batch_norm_1d(x, bn):
@@ -209,7 +210,7 @@ def conv_bn_act(x, conv, bn, act, slope=0.0):
     if aff is None:
         y = batch_norm_1d(conv1x1(x, conv), bn)
         return F.relu(y) if act == "relu" else F.leaky_relu(y, slope) if act == "leaky" else y
-    return _AffineAct.apply(weight_bmm(conv.weight[:, :, 0], x), aff[0], aff[1], _ACT[act], slope)
+    return _AffineAct.apply(weight_bmm(conv.weight.flatten(1), x), aff[0], aff[1], _ACT[act], slope)
 
 
 class _WeightedMax(torch.autograd.Function):
@@ -286,7 +287,7 @@ class DGCNNControlPoints(nn.Module):
                 idx = graph.knn(x, self.k)
             x = graph.edge_conv_norm_max(x, idx, conv[0].weight, bn, slope=0.2)
             feats.append(x)
-        w5 = self.conv5[0].weight[:, :, 0]
+        w5 = self.conv5[0].weight.flatten(1)
         aff = _frozen_affine(self.conv5[0], self.bn5, feats[0])
         npts = feats[0].shape[2]
         grad5 = torch.is_grad_enabled() and (any(f.requires_grad for f in feats) or self.conv5[0].weight.requires_grad)
@@ -365,7 +366,7 @@ class DGCNNEncoderGn(nn.Module):
         x_features = torch.cat((x1, x2, x3), dim=1)
         # GroupNorm + ReLU + max over the points in one pass (norm and ReLU are monotone per channel); the
         # convolution's bias is added inside the norm's kernels (round 6: no pass of its own over (B,1024,N))
-        x4 = group_norm_relu_max(weight_bmm(self.mlp1.weight[:, :, 0], x_features), self.bnmlp1,
+        x4 = group_norm_relu_max(weight_bmm(self.mlp1.weight.flatten(1), x_features), self.bnmlp1,
                                  rowbias=self.mlp1.bias)
         return x4, x_features
 
@@ -412,20 +413,20 @@ class PrimitivesEmbeddingDGCNGn(nn.Module):
         # conv1 on cat(global repeated over N, local): the global part is the same for every
         # point, so it is applied once per item and broadcast (same sum, 5x fewer FLOPs)
         ng = x.shape[1]
-        w = self.conv1.weight[:, :, 0]
+        w = self.conv1.weight.flatten(1)
         glob = torch.addmm(self.conv1.bias, x, w[:, :ng].t())            # (B,512)
         # the per-item global term and the biases of the layers that feed a GroupNorm are added inside the norm's
         # kernels (norms.py ``rowbias``: the same fp32 addition at load, no pass of its own over (B,C,N))
         x = group_norm_relu(weight_bmm(w[:, ng:], first_layer_features), self.bn1, rowbias=glob)
-        x_all = group_norm_relu(weight_bmm(self.conv2.weight[:, :, 0], x), self.bn2, rowbias=self.conv2.bias)
+        x_all = group_norm_relu(weight_bmm(self.conv2.weight.flatten(1), x), self.bn2, rowbias=self.conv2.bias)
         embedding = None
         primitives_log_prob = None
         if self.embedding:
-            x = group_norm_relu(weight_bmm(self.mlp_seg_prob1.weight[:, :, 0], x_all), self.bn_seg_prob1,
+            x = group_norm_relu(weight_bmm(self.mlp_seg_prob1.weight.flatten(1), x_all), self.bn_seg_prob1,
                                 rowbias=self.mlp_seg_prob1.bias)
             embedding = conv1x1(x, self.mlp_seg_prob2)
         if self.primitives:
-            x = group_norm_relu(weight_bmm(self.mlp_prim_prob1.weight[:, :, 0], x_all), self.bn_prim_prob1,
+            x = group_norm_relu(weight_bmm(self.mlp_prim_prob1.weight.flatten(1), x_all), self.bn_prim_prob1,
                                 rowbias=self.mlp_prim_prob1.bias)
             primitives_log_prob = self.logsoftmax(conv1x1(x, self.mlp_prim_prob2))
         if compute_loss:

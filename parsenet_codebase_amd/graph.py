@@ -226,6 +226,25 @@ class _EdgeConvNormMax(torch.autograd.Function):
         return dPQ, None, dgamma, dbeta, None, None, None, None, None
 
 
+class _EdgeWeight(torch.autograd.Function):
+    """w (Cout, 2C) = [Wa | Wb] -> (C, 2Cout) = [Wa ; Wb - Wa]^T, the operand of the one GEMM on points.  The
+    backward pass forms dWa = Ga - Gb (autograd's Ga + (-Gb): the same fp32 value) and dWb = Gb in two launches;
+    slicing, subtracting and concatenating through autograd took ten per layer and step (two zero fills, two
+    copies, a negation and two additions among them)."""
+
+    @staticmethod
+    def forward(ctx, w, C):
+        wa, wb = w[:, :C], w[:, C:]
+        return torch.cat([wa, wb - wa], 0).t()
+
+    @staticmethod
+    def backward(ctx, g):
+        gt = g.t()                                          # (2Cout, C)
+        co = gt.shape[0] // 2
+        ga, gb = gt[:co], gt[co:]
+        return torch.cat([ga - gb, gb], 1), None
+
+
 def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
     """One DGCNN edge-conv layer on the kNN graph ``idx``:
     max_k LeakyReLU(norm(conv1x1(cat(x_j - x_i, x_i)))) -> (B,Cout,N).
@@ -246,8 +265,7 @@ def edge_conv_norm_max(x, idx, weight, norm, slope=0.2):
     if hit is not None and hit[0] == key:
         wcat_t = hit[1]                                    # frozen layer (the SplineNets of the fitting stage)
     else:
-        wa, wb = w[:, :C], w[:, C:]
-        wcat_t = torch.cat([wa, wb - wa], 0).t()           # (C, 2Cout)
+        wcat_t = _EdgeWeight.apply(w, C)                    # (C, 2Cout)
         if frozen:
             wcat_t = wcat_t.detach().contiguous()
             frozen_cache(norm)["wcat"] = (key, wcat_t)

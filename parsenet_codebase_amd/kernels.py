@@ -455,9 +455,28 @@ def kmeans_centres(x, lab, old):
     return cen
 
 
-def meanshift_chain_order(sim):
-    """sim (B,128,128) similarities of cell centres -> (B,128) int64 position of every cell in the
-    greedy nearest-neighbour chain that starts at cell 0."""
+CELL_ORDER_MAX_CELLS = 768
+
+
+def cell_order(rank, home, fine):
+    """Stable argsort of rank[home[fine]] * F + fine as ONE counting-sort launch: rank (B,P), home (B,F), fine (B,N),
+    all int32 -> (B,N) int64.  F <= CELL_ORDER_MAX_CELLS."""
+    require_cuda(rank, home, fine)
+    for t, nm in ((rank, "rank"), (home, "home"), (fine, "fine")):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise ValueError("cell_order: %s must be a contiguous int32 tensor" % nm)
+    B, N = fine.shape
+    perm = torch.empty((B, N), dtype=torch.int64, device=fine.device)
+    with _lib.on_device(fine.device):
+        rc = _lib.load().pn_cell_order_i32(ptr(rank), ptr(home), ptr(fine), B, N, rank.shape[1], home.shape[1],
+                                           ptr(perm), current_stream(fine.device))
+    check(rc, "pn_cell_order_i32")
+    return perm
+
+
+def meanshift_chain_order(sim, as_long=True):
+    """sim (B,128,128) similarities of cell centres -> (B,128) int64 (int32 with ``as_long=False``) position of
+    every cell in the greedy nearest-neighbour chain that starts at cell 0."""
     require_cuda(sim)
     sim = _f32c(sim, "sim")
     B, P, _ = sim.shape
@@ -465,7 +484,7 @@ def meanshift_chain_order(sim):
     with _lib.on_device(sim.device):
         rc = _lib.load().pn_meanshift_chain_order_f32(ptr(sim), B, P, ptr(rank), current_stream(sim.device))
     check(rc, "pn_meanshift_chain_order_f32")
-    return rank.long()
+    return rank.long() if as_long else rank
 
 
 def meanshift_x3_plan_bytes(B, N):

@@ -95,6 +95,18 @@ KMEANS_KERNELS = os.environ.get("PARSENET_MS_KMEANS_KERNELS", "1") != "0"   # (0
 FINE_CELLS = int(os.environ.get("PARSENET_MS_FINE", "384"))    # second-level cells of the locality order (0: off)
 
 
+ORDER_KERNEL = os.environ.get("PARSENET_MS_ORDER_KERNEL", "1") != "0"       # (0: the tensor library's argsort, A/B)
+_SEEDS = {}
+
+
+def _seed_rows(N, K_, device):
+    """Evenly spaced row indices, the seeds of a k-means (cached: two launches per call otherwise)."""
+    hit = _SEEDS.get((N, K_, device))
+    if hit is None:
+        hit = _SEEDS[(N, K_, device)] = torch.linspace(0, N - 1, K_, device=device).long()
+    return hit
+
+
 def locality_order(x, lloyd=2):
     """A permutation (B,N) that puts points of the same region of the sphere next to each other:
     128 cells (spherical k-means: evenly spaced rows of x as seeds, ``lloyd`` refinement steps)
@@ -126,19 +138,25 @@ def locality_order(x, lloyd=2):
         return torch.where(nrm > 1e-6, acc / nrm.clamp_min(1e-6), old)      # empty cell: keep its seed
 
     def kmeans(K_):
-        cen = x[:, torch.linspace(0, N - 1, K_, device=x.device).long()].contiguous()
+        cen = x[:, _seed_rows(N, K_, x.device)].contiguous()
         lab = assign(x, cen)
         for _ in range(lloyd):
             cen = centres(x, lab, K_, cen)
             lab = assign(x, cen)
         return cen, lab
     cen, coarse = kmeans(P)
-    rank = K.meanshift_chain_order(torch.bmm(cen, cen.transpose(1, 2)))       # (B,P)
-    if FINE_CELLS <= P or N < 8 * FINE_CELLS:
+    two_level = not (FINE_CELLS <= P or N < 8 * FINE_CELLS)
+    one_launch = fused and two_level and ORDER_KERNEL and FINE_CELLS <= K.CELL_ORDER_MAX_CELLS
+    rank = K.meanshift_chain_order(torch.bmm(cen, cen.transpose(1, 2)), as_long=not one_launch)       # (B,P)
+    if not two_level:
         return torch.argsort(torch.gather(rank, 1, coarse.long()), dim=1, stable=True)
     cen2, fine = kmeans(FINE_CELLS)
-    fine = fine.long()
-    home = assign(cen2, cen).long()                                            # (B,FINE): coarse cell of a fine centre
+    home = assign(cen2, cen)                                                   # (B,FINE): coarse cell of a fine centre
+    if one_launch:
+        # every fine cell has ONE key: the stable argsort is a counting sort over the cells (csrc/kmeans.hip), one
+        # launch where conversions, gathers, the key arithmetic and the tensor library's sort took 23
+        return K.cell_order(rank, home, fine)
+    fine, home = fine.long(), home.long()
     key = torch.gather(rank, 1, torch.gather(home, 1, fine)).long() * FINE_CELLS + fine
     return torch.argsort(key, dim=1, stable=True)
 

@@ -1,10 +1,16 @@
 """GroupNorm (+ReLU) (+max over points) on channel-first (B,C,N) tensors through the row-per-block
 HIP kernels of csrc/gn.hip, with autograd.  Numerically these are torch.nn.GroupNorm followed by
 ReLU (and max over N); see the kernel file for why they exist."""
+import os
+
 import torch
 
 from . import _lib
 from ._lib import check, current_stream, ptr, require_cuda
+
+
+# the (B,C) tail of _GroupNormReLUMax as one launch each way (0: the tensor-library expressions, A/B and parity test)
+MAX_TAIL_KERNELS = os.environ.get("PARSENET_GN_MAX_TAIL", "1") != "0"
 
 
 def _f(t):
@@ -133,23 +139,41 @@ class _GroupNormReLUMax(torch.autograd.Function):
         rb_c = None if rowbias is None else _f(rowbias.detach())
         rsum, rsq, (rmax, amax, rmin, amin) = _rows_fwd(y, True, rb_c)
         mean, rstd = _group_moments(rsum, rsq, groups, N, eps)
-        Cg = C // groups
-        pos = gamma_c.view(1, C) >= 0
-        ext = torch.where(pos, rmax, rmin)
-        arg = torch.where(pos, amax, amin).contiguous()
-        yhat = (ext - mean.repeat_interleave(Cg, 1)) * rstd.repeat_interleave(Cg, 1)
-        z = gamma_c.view(1, C) * yhat + beta_c.view(1, C)
+        if MAX_TAIL_KERNELS:
+            yhat, z, out = torch.empty_like(rmax), torch.empty_like(rmax), torch.empty_like(rmax)
+            arg = torch.empty_like(amax)
+            with _lib.on_device(y.device):
+                rc = _lib.load().pn_gn_max_finish_f32(ptr(rmax), ptr(amax), ptr(rmin), ptr(amin), ptr(mean), ptr(rstd),
+                                                      ptr(gamma_c), ptr(beta_c), B, C, groups, ptr(yhat), ptr(z),
+                                                      ptr(arg), ptr(out), current_stream(y.device))
+            check(rc, "pn_gn_max_finish_f32")
+        else:
+            Cg = C // groups
+            pos = gamma_c.view(1, C) >= 0
+            ext = torch.where(pos, rmax, rmin)
+            arg = torch.where(pos, amax, amin).contiguous()
+            yhat = (ext - mean.repeat_interleave(Cg, 1)) * rstd.repeat_interleave(Cg, 1)
+            z = gamma_c.view(1, C) * yhat + beta_c.view(1, C)
+            out = torch.relu(z)
         ctx.save_for_backward(y, gamma_c, beta_c, mean, rstd, yhat, z, arg, rb_c)
         ctx.groups = groups
-        return torch.relu(z)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         y, gamma, beta, mean, rstd, yhat, z, arg, rowbias = ctx.saved_tensors
         groups = ctx.groups
         B, C, N = y.shape
-        gz = (g * (z > 0)).contiguous().float()
-        rb = (gz * yhat).contiguous()
+        if MAX_TAIL_KERNELS and g.dtype == torch.float32:
+            g = g.contiguous()
+            gz, rb = torch.empty_like(z), torch.empty_like(z)
+            with _lib.on_device(y.device):
+                rc = _lib.load().pn_gn_max_bwd_prep_f32(ptr(g), ptr(z), ptr(yhat), B, C, ptr(gz), ptr(rb),
+                                                        current_stream(y.device))
+            check(rc, "pn_gn_max_bwd_prep_f32")
+        else:
+            gz = (g * (z > 0)).contiguous().float()
+            rb = (gz * yhat).contiguous()
         c1c2 = _group_bwd(gz, rb, gamma, groups, N)
         dy = _apply_bwd(None, y, mean, rstd, gamma, beta, c1c2, groups, True, gsp=gz, arg=arg, rowbias=rowbias)
         return dy, rb.sum(0), gz.sum(0), None, None, _rowbias_grad(dy, rowbias, ctx.needs_input_grad[5])

@@ -163,6 +163,8 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     (torch.distributed.run) and rank 0 reports the world size it observed."""
     import json
     import subprocess
+    if torch.cuda.device_count() == 1:
+        pytest.skip("a one-GPU box: rank 1 has no device (the launch path is covered on CPU ranks and by the driver)")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"],
                        capture_output=True, text=True, env=env, timeout=300)
@@ -830,3 +832,20 @@ def test_a_genuine_tie_between_occupied_segments_keeps_the_matched_iou(monkeypat
         assert [s["kind"] for s in segs] == ["prim"] * 3
     assert seen == {(0, 1, 2), (1, 0, 2)}               # both optima occur, nothing else
     assert len(sious) == 1                               # the matched IoU does not depend on which
+
+
+def test_edge_weight_function_matches_the_autograd_composition_bit_for_bit():
+    """graph._EdgeWeight: [Wa | Wb] -> [Wa ; Wb - Wa]^T with a two-launch backward pass against slicing, subtracting
+    and concatenating through autograd (ten launches per layer): operand and weight gradient identical."""
+    from parsenet_codebase_amd.graph import _EdgeWeight
+    g = torch.Generator().manual_seed(5)
+    for Cout, C in ((64, 3), (64, 64), (128, 64)):
+        w0 = torch.randn(Cout, 2 * C, generator=g)
+        up = torch.randn(C, 2 * Cout, generator=g)
+        wa = w0.clone().requires_grad_(True)
+        ref = torch.cat([wa[:, :C], wa[:, C:] - wa[:, :C]], 0).t()
+        (ref * up).sum().backward()
+        wb = w0.clone().requires_grad_(True)
+        got = _EdgeWeight.apply(wb, C)
+        (got * up).sum().backward()
+        assert torch.equal(got, ref) and torch.equal(wb.grad, wa.grad)

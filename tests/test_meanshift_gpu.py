@@ -637,6 +637,45 @@ def test_kmeans_kernels_of_the_locality_order(gpu, N, K_):
     assert bool(empty.any()) and torch.equal(new[empty], cen[empty])      # (the duplicated centre's cell, at least)
 
 
+@pytest.mark.parametrize("N,P,F", [(10000, 128, 384), (10007, 128, 768), (700, 16, 5), (64, 4, 64), (3, 2, 2)])
+def test_cell_order_is_the_stable_argsort_of_the_cell_keys(gpu, N, P, F):
+    """csrc/kmeans.hip pn_cell_order_i32 = argsort(rank[home[fine]] * F + fine, stable=True), bit for bit; with empty
+    cells, a cloud shorter than the 16 waves' ranges, and element counts that are no multiple of 64."""
+    from parsenet_codebase_amd import kernels as K
+    torch.cuda.set_device(gpu)
+    g = torch.Generator().manual_seed(N + F)
+    B = 3
+    rank = torch.stack([torch.randperm(P, generator=g) for _ in range(B)]).int().to(gpu)
+    home = torch.randint(0, P, (B, F), generator=g).int().to(gpu)
+    fine = torch.randint(0, F, (B, N), generator=g).int()
+    if F > 4:
+        fine[fine == 3] = 4                                      # an empty cell
+        fine[1, : N // 2] = 1                                    # one crowded cell: every lane of a group in it
+    fine = fine.to(gpu)
+    got = K.cell_order(rank, home, fine)
+    key = torch.gather(rank.long(), 1, torch.gather(home.long(), 1, fine.long())) * F + fine.long()
+    assert got.dtype == torch.int64 and torch.equal(got, torch.argsort(key, dim=1, stable=True))
+    with pytest.raises(Exception):
+        K.cell_order(rank, torch.zeros((B, 769), dtype=torch.int32, device=gpu), fine)
+
+
+def test_locality_order_with_and_without_the_order_kernel(gpu):
+    """mean_shift.locality_order: the one-launch counting sort gives the permutation the tensor-library path gives."""
+    from parsenet_codebase_amd import mean_shift as M
+    torch.cuda.set_device(gpu)
+    x = torch.stack([_clustered(10000, 9, 30 + b)[0] for b in range(2)]).to(gpu)
+    old = M.ORDER_KERNEL
+    try:
+        M.ORDER_KERNEL = True
+        a = M.locality_order(x)
+        M.ORDER_KERNEL = False
+        b = M.locality_order(x)
+    finally:
+        M.ORDER_KERNEL = old
+    assert a.dtype == b.dtype and torch.equal(a, b)
+    assert torch.equal(a.sort(1).values, torch.arange(10000, device=gpu).expand(2, -1))
+
+
 @pytest.mark.parametrize("d,kernel_type", [(64, "gaussian"), (64, "epa"), (128, "epa")])
 def test_other_embedding_widths_and_the_epanechnikov_kernel_against_the_oracle(gpu, d, kernel_type):
     """src/mean_shift.py:45-79 with an embedding that is not 128 wide and / or the Epanechnikov kernel

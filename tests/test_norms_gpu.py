@@ -89,3 +89,33 @@ def test_row_bias_inside_the_kernels_is_bit_identical_to_the_separate_addition(g
                         gn.bias.grad.clone()])
         for a, b in zip(*res):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,C,N,G", [(4, 1024, 10000, 8), (3, 64, 301, 2)])
+def test_max_variant_tail_kernels_are_bit_identical_to_the_tensor_expressions(gpu, B, C, N, G):
+    """csrc/gn.hip pn_gn_max_finish_f32 / pn_gn_max_bwd_prep_f32 (round 6: the (B,C) tail of the max variant as one
+    launch each way) against the ten + four tensor-library operations they replace (PARSENET_GN_MAX_TAIL=0): output
+    and every gradient bit for bit, with gammas of both signs and a zero gamma."""
+    from parsenet_codebase_amd import norms
+    torch.manual_seed(C + N)
+    gn = torch.nn.GroupNorm(G, C).to(gpu)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C))
+        gn.weight[5] = 0.0
+        gn.bias.copy_(torch.randn(C) * 0.3)
+    y = torch.randn(B, C, N, device=gpu) * 1.5
+    w = torch.randn(B, C, device=gpu)
+    res = []
+    old = norms.MAX_TAIL_KERNELS
+    try:
+        for on in (False, True):
+            norms.MAX_TAIL_KERNELS = on
+            gn.zero_grad()
+            yy = y.clone().requires_grad_(True)
+            out = norms.group_norm_relu_max(yy, gn)
+            (out * w).sum().backward()
+            res.append([out.detach().clone(), yy.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()])
+    finally:
+        norms.MAX_TAIL_KERNELS = old
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
