@@ -34,6 +34,7 @@ from . import kernels as K
 from . import mean_shift as MSM
 from ._lib import _PinnedRing, h2d, pinned_like, wait_event
 from .dp import FitStatusError
+from .losses import normalized_rows
 
 EPS = float(np.finfo(np.float32).eps)
 SPLINE_TYPES = (0, 2, 6, 7, 9, 8)
@@ -542,7 +543,7 @@ def _fitting_stage(ev, embedding, points, normals, labels, primitives, primitive
     points, normals = points.contiguous(), normals.contiguous()
     # (contiguous ONCE: the callers hand over a permuted view of the network's (B,128,N) output and the bandwidth, the
     # iterations and the memberships each made their own (B,N,128) copy of it)
-    emb = torch.nn.functional.normalize(embedding, p=2, dim=2).contiguous()
+    emb = normalized_rows(embedding).contiguous()        # (shared with the embedding loss of the same step)
     fitter = ev.fitter
 
     # ---- clustering, all shapes ---------------------------------------------------------

@@ -1,10 +1,45 @@
 """Training losses of the segmentation network (src/segment_loss.py)."""
+import os
+import weakref
+
 import numpy as np
 import torch
 
 from . import kernels as K
 from ._lib import h2d
 import torch.nn.functional as F
+
+
+# Opt-in: measured on one box (tools/jobs/r6p.sh, two processes each way) the shared node made the cfg5 step SLOWER,
+# 177.8 against 180.7 shapes/s, with the same mean-shift launch durations — fewer kernels but a different order of
+# the backward nodes around the step's host synchronisation points.  Off by default.
+SHARE_NORMALIZE = os.environ.get("PARSENET_SHARE_NORMALIZE", "0") != "0"
+_NORMALIZED = []          # at most one entry: weak references to the source's base and to the result, version, view geometry
+
+
+def normalized_rows(x):
+    """torch.nn.functional.normalize(x, p=2, dim=2), evaluated ONCE per tensor when SHARE_NORMALIZE is set.  The embedding loss
+    (src/segment_loss.py:45) and the fitting stage (src/residual_utils.py:108) both normalise the network's embedding — the
+    same tensor expression on the same view twice a step, forward and backward (~0.08 ms on 4 x 10 000 x 128).  The
+    second caller gets the first caller's result (same bits; its gradient reaches the embedding through one
+    normalisation node instead of two).  The entry is keyed by the identity of the underlying tensor (a weak
+    reference: a freed tensor never matches), its version counter (an in-place write invalidates it), the view's
+    geometry and the autograd mode; it holds the result weakly (alive as long as the first user's graph is).
+    Both users must take part in the SAME backward pass, as the end-to-end step's single ``loss.backward()`` does: a backward pass in between frees the shared node and the second one raises
+    autograd's "backward through the graph a second time" (PARSENET_SHARE_NORMALIZE=1 turns the sharing on)."""
+    if not SHARE_NORMALIZE or x.dim() != 3:
+        return torch.nn.functional.normalize(x, p=2, dim=2)
+    base = x._base if x._base is not None else x
+    mode = bool(torch.is_grad_enabled() and x.requires_grad)
+    geo = (tuple(x.shape), tuple(x.stride()), x.storage_offset(), x.dtype, mode)
+    if _NORMALIZED:
+        ref, ver, g, rres = _NORMALIZED[0]
+        res = rres()                 # (weak: the entry keeps neither the 20 MB result nor its graph alive)
+        if res is not None and ref() is base and ver == base._version and g == geo:
+            return res
+    res = torch.nn.functional.normalize(x, p=2, dim=2)
+    _NORMALIZED[:] = [(weakref.ref(base), base._version, geo, weakref.ref(res))]
+    return res
 
 
 FUSED = True        # False: the tensor-expression form of the same arithmetic (tests compare the two)
@@ -45,7 +80,7 @@ class EmbeddingLoss:
         B, _, N = output.shape
         dev = output.device
         labels = np.asarray(labels)
-        out = F.normalize(output.permute(0, 2, 1), p=2, dim=2)
+        out = normalized_rows(output.permute(0, 2, 1))          # (shared with the fitting stage of the same step)
         if self.if_mean_shift:
             from .mean_shift import MeanShift
             ms = MeanShift()
