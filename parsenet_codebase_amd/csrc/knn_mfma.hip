@@ -517,8 +517,18 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+#define KX_FUSED_K 10       // one-pass form of the bf16 x 3 graph (knn_x3.h, KIND 2): neighbours at most
+#define KX_SEED_TILES 16    // ... tiles whose group maxima seed its running threshold before anything is collected
+// PN_KNN_FUSED (read at every call): 1 = kNN graphs with k <= 10 at 64 / 128 / 256 channels and >= 2 048 points take the
+// one-pass bf16 x 3 form instead of the exact one-pass kernel of knn_smallk.h; 0 (default until measured): they do not.
+// PN_KNN_FUSED_NP = 6: six piece products instead of three.
+static bool knn_fused_on() {
+  const char* e = getenv("PN_KNN_FUSED");
+  return e && atoi(e) != 0;
+}
+
 struct KnnPlan {
-  bool fast;
+  bool fast, fused;
   int ksteps, qsets, Cp, Nqp, Ncp, S, tiles_per_slice, subcap, B, k;
 };
 
@@ -563,6 +573,8 @@ static KnnPlan knn_mfma_plan(int mode, int B, int C, int Nq, int Nc, int k, bool
     // expected survivors per sub-list ~ 1.1-1.3 k / (2 S); leave generous head-room
     p.subcap = (int)pn_align_up(3 * k / (2 * p.S) + 16, 8);
     if (2 * p.S * p.subcap > KNN_CAP) p.subcap = KNN_CAP / (2 * p.S);
+    p.fused = mode == 0 && !want_value && k <= KX_FUSED_K && p.ksteps >= 32 && p.Ncp >= 2048 &&
+              ntiles >= 4 * KX_SEED_TILES && Nq == Nc && knn_fused_on();
   }
   return p;
 }
@@ -623,6 +635,7 @@ static bool knn_x3_pass1(const KnnPlan& p, int mode, bool dot_form = false) {
   // 128 channels with a small k (the SplineNets' graphs, k = 10): the final sort on approximate keys costs
   // more than the passes save (12 segments of 2 500 points: 0.61 against 0.52 ms on the fp32 engine)
   const bool wide128 = p.ksteps == 64 && (mode != 0 || dot_form || p.k >= 32);
+  if (p.fused && mode == 0 && !dot_form && on >= 2) return true;      // the one-pass form (any of the three widths)
   return on && p.fast && (mode == 0 || (mode == 2 && on >= 3)) && (p.ksteps == 32 || wide128 || wide256) &&
          p.Ncp >= 2048;
 }
@@ -770,6 +783,47 @@ static int select_run(const KnnPlan& p, const KnnWs& w, int mode, bool self, con
   const float* xxq_a = centre ? (const float*)xxcc : (const float*)xxq;
   const float* xxc_a = centre ? (const float*)xxcc : (const float*)xxc;
   const unsigned* xxmax_a = centre ? (const unsigned*)xxmaxc : (const unsigned*)xxmax;
+  if (p.fused && x3p2) {
+    // ---- one pass: running threshold + collection, then the final sort with exact repairs (knn_x3.h, KIND 2) ----
+    const char* ne = getenv("PN_KNN_FUSED_NP");
+    const int npf = (ne && atoi(ne) == 6) ? 6 : 3;
+    const float Af = npf == 3 ? x3A + 3.1f * 0x1p-16f : x3A;
+    const int qpw = 128 * p.qsets, ntiles = p.Ncp / 32, subcapf = KNN_CAP / 2;
+    dim3 gf(1, pn_cdiv(p.Nqp, qpw), B);
+    {
+      PN_PROF(p.ksteps == 32 ? "knn_x3_fused_c64" : "knn_x3_fused_wide", stream);
+#define KX_GOF(NCH, QS, TPS_, NP_)                                                                                       \
+  hipLaunchKernelGGL((pn_knn_x3_pass_kernel<NCH, QS, 0, TPS_, 2, NP_>), gf, dim3(256), 0, stream, xq_a, xxq_a, Nq, p.Nqp, \
+                     img, xxc_a, Nc, p.Ncp, ntiles, tilemax, (const float*)tau, lists, cnt, subcapf, xxmax_a,           \
+                     (const float*)xxq, (const unsigned*)xxmax, Af, x3Ao)
+      if (p.ksteps == 32) {
+        if (npf == 3) KX_GOF(8, 2, 2, 3); else KX_GOF(8, 2, 2, 6);
+      } else if (p.ksteps == 64) {
+        if (npf == 3) KX_GOF(16, 1, 1, 3); else KX_GOF(16, 1, 1, 6);
+      } else {
+        if (npf == 3) KX_GOF(32, 1, 1, 3); else KX_GOF(32, 1, 1, 6);
+      }
+#undef KX_GOF
+    }
+    PN_CHECK_LAUNCH();
+    {
+      PN_PROF("knn_final", stream);
+      if (p.ksteps == 32)
+        hipLaunchKernelGGL(pn_knn_final_x3_kernel<64>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                           p.Nqp, k, 1, subcapf, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
+                           Af, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
+      else if (p.ksteps == 64)
+        hipLaunchKernelGGL(pn_knn_final_x3_kernel<128>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                           p.Nqp, k, 1, subcapf, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
+                           Af, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
+      else
+        hipLaunchKernelGGL(pn_knn_final_x3_kernel<256>, dim3(pn_cdiv(Nq, 4), B), dim3(256), 0, stream, lists, cnt, Nq,
+                           p.Nqp, k, 1, subcapf, perm_q, perm_c, (const float*)xpm, (const float*)xxo, xxmax, Nc,
+                           Af, out_idx, flags, anyflag, (const float*)xxoc, (const unsigned*)xxmaxc, x3Ao);
+    }
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+  }
   dim3 grid(p.S, pn_cdiv(p.Nqp, 32 * p.qsets * 4), B);
   for (int pass = 0; pass < (argmax ? 1 : 2); ++pass) {
     const int collect = argmax ? 2 : pass;
@@ -1183,12 +1237,12 @@ static int knn_dispatch(int mode, const float* x, int B, int C, int N, int k, Kn
   PN_CHECK_ARG(mode == 0 || C == 6, "pn_knn_pn: points+normals metric needs C=6, got %d", C);
   PN_CHECK_ARG(workspace && workspace_bytes >= pn_knn_workspace(B, C, N, k),
                "pn_knn: workspace too small");
-  {
+  const KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
+  if (!(p.fused && knn_x3_level() >= 2)) {
     // small k (the SplineNets' graphs): one distance pass, the k best of a lane in registers (knn_smallk.h)
     const KskPlan sk = ksk_plan(mode, B, C, N, k);
     if (sk.ok) return ksk_run(sk, x, B, C, N, k, idx.p, idx.is32, (char*)workspace, stream);
   }
-  const KnnPlan p = knn_mfma_plan(mode, B, C, N, N, k, false);
   if (!p.fast)
     return pn_knn_v1_launch(mode, x, B, C, N, k, idx, workspace, workspace_bytes, stream, nullptr);
   const KnnWs w = knn_mfma_ws(p, B, C, N, k, true, true);

@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
 // the MFMAs of the other, and the two waves of a SIMD are not in lock step.  (One 8-wave workgroup
 // per CU measured 63 % wave residency and 38 % MFMA utilisation.)
 // A step of the loop handles TPS consecutive tiles (one barrier, one batch of LDS DMA).
+// eps_q of the header of this file (one thread per query where it is applied)
+__device__ static inline float knx_eps(float nq, float nc, float A, int mode) {
+  nq = fmaxf(nq, 0.f);      // (centred norms can sit a rounding below zero)
+  nc = fmaxf(nc, 0.f);
+  const float cross = sqrtf(nq * nc) * 1.000001f;
+  return (mode == 0 ? 2.0f * A * cross + 0x1p-21f * (nq + nc) : A * cross) * 1.0001f;
+}
+
 #define KX_NW 4
 // (the 128-channel dot-product variant needs 165 registers: three workgroups per CU)
 // (256 channels, NCH = 32: the resident queries alone are 192 registers — one wave per SIMD with the whole
@@ -168,12 +176,25 @@ __global__ __launch_bounds__(256) void pn_knn_x3_image_kernel(const float* __res
 // the pass costs half the matrix-core work.  The collecting pass keeps six products by default: its keys' bound decides
 // how many near-ties the final sort re-evaluates and how many rows overflow their sub-lists (on CENTRED rows three
 // products are available for it as an option, PN_KNN_X3_P2=3: measured a cliff on cfg4, knn_mfma.hip).
+// KIND 2 (round 6, small k — the SplineNets' graphs, k <= KX_FUSED_K): threshold and collection in ONE pass over the
+// candidates, no tile-maxima array, no threshold kernel, no margin kernel.  A lane (query, half h) keeps the
+// KX_FUSED_K largest GROUP MAXIMA it has seen (a group = the 16 candidates of its half of a tile): KX_FUSED_K
+// different candidates have v~ >= the smallest of them, so the k-th largest exact value is >= that - eps_q, and a
+// member of the exact result has v~ >= that - 2 eps_q: the lane collects every candidate above the CURRENT such bound
+// (the bound only rises: testing against an earlier one is conservative).  eps_q as in pn_knn_x3_margin_kernel with
+// both passes approximate: eps(A; the norms the values were formed from) + eps(Ao; original norms) on centred rows.
+// The first KX_SEED_TILES tiles are evaluated twice — once for their group maxima only, so that the collection
+// starts with a threshold instead of taking 160 candidates per lane unconditionally.  One slice (gridDim.x = 1).
+// pn_knn_final_x3_kernel decides as for the two-pass form.  xxq_o / xxmax_o / A_ / Ao_: KIND 2 only.
 template <int NCH, int QSETS, int MODE, int TPS, int KIND, int NP = 6>
 __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_WPE(NCH, MODE), KX_WPE(NCH, MODE)))) void pn_knn_x3_pass_kernel(
     const float* __restrict__ xq, const float* __restrict__ xxq_, int Nq, int Nqp,
     const u32x4* __restrict__ PC, const float* __restrict__ xxc_, int Nc, int Ncp, int tiles_per_slice,
     float* __restrict__ tilemax, const float* __restrict__ tau, u64* __restrict__ lists,
-    int* __restrict__ counts, int subcap, const unsigned* __restrict__ xxmax) {
+    int* __restrict__ counts, int subcap, const unsigned* __restrict__ xxmax,
+    const float* __restrict__ xxq_o = nullptr, const unsigned* __restrict__ xxmax_o = nullptr, float A_ = 0.f,
+    float Ao_ = 0.f) {
+  static_assert(KIND != 2 || MODE == 0, "the fused form is built for the squared-distance metric");
   constexpr int CP = 8 * NCH, KS = NCH / 2, PIECE = 32 * NCH, IMG = 3 * PIECE;
   constexpr int CHUNKS = TPS * IMG / 64;   // 1 KiB DMA chunks per step
   static_assert(CHUNKS % KX_NW == 0 && (TPS == 1 || TPS == 2 || TPS == 4), "chunks are dealt evenly to the waves");
@@ -233,9 +254,10 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     xxq[u] = MODE == 0 ? xxq_[(size_t)b * Nqp + qcl] : 0.f;
   }
   float tq[QSETS], hq[QSETS];
-  const float xxc_max = (KIND == 1 && MODE == 0) ? __uint_as_float(xxmax[b]) : 0.f;
+  const float xxc_max = (KIND >= 1 && MODE == 0) ? __uint_as_float(xxmax[b]) : 0.f;
   int mycnt[QSETS];
   u64* sub[QSETS];
+  float top[QSETS][KX_FUSED_K], low2[QSETS];      // KIND 2: the lane's largest group maxima, 2 eps_q
 #pragma unroll
   for (int u = 0; u < QSETS; ++u) {
     const int q = q0 + 32 * u + col;
@@ -244,12 +266,38 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     // threshold of the dot-product form of the test, with 2^-20 of the magnitudes involved as slack
     hq[u] = 0.5f * (tq[u] + xxq[u]) - 0x1p-20f * (fabsf(tq[u]) + xxq[u] + xxc_max);
     mycnt[u] = 0;
-    sub[u] = KIND == 1 ? lists + ((((size_t)b * Nqp + qcl) * gridDim.x + slice) * 2 + h) * (size_t)subcap : nullptr;
+    sub[u] = KIND >= 1 ? lists + ((((size_t)b * Nqp + qcl) * gridDim.x + slice) * 2 + h) * (size_t)subcap : nullptr;
+    low2[u] = 0.f;
+    if (KIND == 2) {
+      float e = knx_eps(xxq[u], xxc_max, A_, 0);
+      if (Ao_ > 0.f) e += knx_eps(xxq_o[(size_t)b * Nqp + qcl], __uint_as_float(xxmax_o[b]), Ao_, 0);
+      low2[u] = 2.0f * e;
+#pragma unroll
+      for (int t = 0; t < KX_FUSED_K; ++t) top[u][t] = -__builtin_inff();
+      if (q >= Nq) low2[u] = -__builtin_inff();     // a padding query collects nothing (its bound: a NaN, every test false)
+    }
   }
 
-  for (int m0 = t_begin; m0 < t_end; m0 += TPS) {
+  // KIND 2 walks the tiles t_begin .. t_begin + seed - 1 first (group maxima only), then all of them; the other kinds
+  // walk them once (vm = m0)
+  const int ntl = t_end - t_begin;
+  const int seed = KIND == 2 ? min(KX_SEED_TILES, ntl & ~(TPS - 1)) : 0;
+  static_assert(KX_SEED_TILES % 4 == 0, "whole steps");
+  const int vend = KIND == 2 ? seed + ntl : t_end;
+  for (int vm = KIND == 2 ? 0 : t_begin; vm < vend; vm += TPS) {
+    const int m0 = KIND == 2 ? t_begin + (vm < seed ? vm : vm - seed) : vm;
+    const bool seeding = KIND == 2 && vm < seed;
+    const bool fresh = KIND == 2 && (seeding || vm - seed >= seed);     // group maxima not counted yet
     __syncthreads();  // the batch of step m0 landed; every wave is done with the previous one
-    if (m0 + TPS < t_end) KX_STAGE(m0 + TPS, cur ^ 1);
+    if (KIND == 2) {
+      const int vn = vm + TPS;
+      if (vn < vend) {
+        const int mn = t_begin + (vn < seed ? vn : vn - seed);
+        KX_STAGE(mn, cur ^ 1);
+      }
+    } else if (m0 + TPS < t_end) {
+      KX_STAGE(m0 + TPS, cur ^ 1);
+    }
     if (wave_on) {
       float tmv[QSETS][TPS];
 #pragma unroll
@@ -332,6 +380,41 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
                 if (tail && j0 + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) v = -__builtin_inff();
                 tm = fmaxf(tm, v);
               }
+            } else if (KIND == 2) {
+              float d[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                d[r] = acc[u][r] + acs[u][r];
+                float v = __builtin_fmaf(2.0f, d[r], -xxj[r]) - xxq[u];
+                if (tail && j0 + (r & 3) + 8 * (r >> 2) + 4 * h >= Nc) v = -__builtin_inff();
+                tm = fmaxf(tm, v);
+              }
+              if (fresh) {
+                float x = tm;
+#pragma unroll
+                for (int t = 0; t < KX_FUSED_K; ++t) {
+                  const float hi = fmaxf(top[u][t], x);
+                  x = fminf(top[u][t], x);
+                  top[u][t] = hi;
+                }
+              }
+              if (!seeding) {
+                const float t0 = top[u][KX_FUSED_K - 1] - low2[u];
+                const float tl = t0 - 0x1p-22f * fabsf(t0);                       // (-inf stays -inf: everything passes)
+                const float hqv = 0.5f * (tl + xxq[u]) - 0x1p-20f * (fabsf(tl) + xxq[u] + xxc_max);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const float thr = __builtin_fmaf(0.5f, xxj[r], hqv);
+                  if (d[r] >= thr) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = __builtin_fmaf(2.0f, d[r], -xxj[r]) - xxq[u];
+                    if (v >= tl && j0 + row < Nc) {
+                      if (mycnt[u] < subcap) sub[u][mycnt[u]] = knn_key(v, j0 + row);
+                      ++mycnt[u];
+                    }
+                  }
+                }
+              }
             } else {
               // (collecting the 16 outcomes in a per-lane bit mask and appending after the loop —
               // the round-2 verdict's suggestion — was measured in round 3: 0.27 instead of 0.25 ms per
@@ -387,7 +470,7 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
     cur ^= 1;
   }
 #undef KX_STAGE
-  if (KIND == 1 && wave_on) {
+  if (KIND >= 1 && wave_on) {
 #pragma unroll
     for (int u = 0; u < QSETS; ++u) {
       const int q = q0 + 32 * u + col;
@@ -396,13 +479,6 @@ __global__ __launch_bounds__(64 * KX_NW) __attribute__((amdgpu_waves_per_eu(KX_W
   }
 }
 
-// tau <- tau - eps_q (see the header of this file); one thread per query
-__device__ static inline float knx_eps(float nq, float nc, float A, int mode) {
-  nq = fmaxf(nq, 0.f);      // (centred norms can sit a rounding below zero)
-  nc = fmaxf(nc, 0.f);
-  const float cross = sqrtf(nq * nc) * 1.000001f;
-  return (mode == 0 ? 2.0f * A * cross + 0x1p-21f * (nq + nc) : A * cross) * 1.0001f;
-}
 
 // tau <- tau - eps(A1) - (times - 1) eps(A): A1 the error constant of the threshold pass (= A with six products),
 // ``times``: 1 when the collecting pass is exact, 2 when it runs on approximate values (constant A) as well
@@ -489,7 +565,18 @@ __global__ __launch_bounds__(256) void pn_knn_final_x3_kernel(
   }
   const int n = __builtin_amdgcn_readlane(inc, 63);
   bool bad = __ballot(myc > subcap) != 0 || n > KNN_CAP;
-  if (!bad) {
+  if (!bad && nsub <= 8) {
+    // few long sub-lists (the one-pass form: two per query): the whole wave copies one list after the other
+    for (int s2 = 0; s2 < nsub; ++s2) {
+      const int cs = __shfl(myc, s2, 64), os = __shfl(inc - myc, s2, 64);
+      const u64* lp = lists + (ql * nsub + s2) * (size_t)subcap;
+      for (int e = lane; e < cs; e += 64) {
+        const u64 key = lp[e];
+        const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
+        keys[os + e] = (key & 0xffffffff00000000ull) | (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
+      }
+    }
+  } else if (!bad) {
     int cmax = myc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));

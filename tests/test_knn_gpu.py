@@ -185,3 +185,46 @@ def test_small_k_ties_and_the_two_pass_engine_agree(gpu, monkeypatch):
         old = _gpu_knn(x, k, gpu)
         monkeypatch.delenv("PN_KNN_SMALLK")
         assert np.array_equal(got, old)
+
+
+@pytest.mark.parametrize("np_", ["3", "6"])
+@pytest.mark.parametrize("B,C,N,k", [(2, 64, 5000, 10), (1, 128, 5000, 10), (1, 256, 4100, 10), (3, 100, 2100, 7),
+                                     (1, 40, 2049, 1), (2, 128, 2500, 10)])
+def test_one_pass_bf16_graph_for_small_k_bit_exact(gpu, B, C, N, k, np_, monkeypatch):
+    """PN_KNN_FUSED=1 (csrc/knn_x3.h, KIND 2): threshold and collection of the bf16 x 3 graph in ONE pass (running
+    threshold from a lane's largest group maxima, exact repairs in the final sort) against the C oracle — features with
+    a large common offset (what centring is for) and very different channel scales, three and six piece products,
+    point counts with a ragged last tile, k below the list length the lanes keep."""
+    from oracle import cbind
+    rng = np.random.RandomState(31 * C + N + k)
+    x = (rng.uniform(-1, 1, (B, C, N)) * rng.uniform(0.2, 3.0, (B, C, 1)) + rng.uniform(0.0, 4.0, (B, C, 1))).astype(np.float32)
+    monkeypatch.setenv("PN_KNN_FUSED", "1")
+    monkeypatch.setenv("PN_KNN_FUSED_NP", np_)
+    got = _gpu_knn(x, k, gpu)
+    want = cbind.knn(x, k, 0)
+    assert got.shape == (B, N, k)
+    assert np.array_equal(got, want), "mismatching rows: %d" % (got != want).any(-1).sum()
+
+
+def test_one_pass_bf16_graph_on_ties_clusters_and_degenerate_input(gpu, monkeypatch):
+    """The one-pass form on data the approximation cannot decide: coincident points (every distance tied: the rows
+    overflow their lists, are flagged and redone by the gated scan), tight clusters (hundreds of candidates inside
+    the 2-eps window: all re-evaluated exactly), a lattice with exact ties; and the same graph as the exact one-pass
+    kernel (PN_KNN_FUSED=0) on a SplineNet-like input."""
+    from oracle import cbind
+    rng = np.random.RandomState(41)
+    coin = np.zeros((1, 64, 2100), np.float32)
+    coin[0, :, 1000:] = 0.5
+    centres = rng.uniform(-1, 1, (1, 128, 12)).astype(np.float32)
+    lab = rng.randint(0, 12, 3000)
+    tight = (centres[:, :, lab] + 1e-4 * rng.normal(size=(1, 128, 3000))).astype(np.float32) + 3.0
+    lat = np.repeat((rng.randint(-8, 9, (2, 4, 2500)) / 16.0).astype(np.float32), 16, axis=1)      # 64 channels
+    feat = np.maximum(rng.normal(size=(2, 64, 5000)) + 0.5, 0.0).astype(np.float32)                # post-ReLU features
+    for x, k in ((coin, 10), (tight, 10), (lat, 10), (feat, 10)):
+        monkeypatch.setenv("PN_KNN_FUSED", "1")
+        got = _gpu_knn(x, k, gpu)
+        monkeypatch.setenv("PN_KNN_FUSED", "0")
+        ref = _gpu_knn(x, k, gpu)
+        assert np.array_equal(got, ref), "mismatching rows: %d" % (got != ref).any(-1).sum()
+        if x.shape[2] <= 3000:
+            assert np.array_equal(got, cbind.knn(x, k, 0))

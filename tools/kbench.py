@@ -130,8 +130,9 @@ def bench_smallk():
                          (12, 64, 5000, 10), (32, 3, 700, 10), (32, 64, 700, 10), (32, 128, 700, 10), (32, 256, 700, 10)]:
         x = torch.randn(B, C, N, device=dev) * (0.5 + torch.rand(B, C, 1, device=dev))
         out = {}
-        for lvl in ("1", "0"):
-            os.environ["PN_KNN_SMALLK"] = lvl
+        for lvl in ("f", "1", "0"):         # f: the one-pass bf16 x 3 form (PN_KNN_FUSED=1) where its plan applies
+            os.environ["PN_KNN_SMALLK"] = "0" if lvl == "0" else "1"
+            os.environ["PN_KNN_FUSED"] = "1" if lvl == "f" else "0"
             ms = timeit(lambda: kernels.knn(x, k, "feature"))
             out[lvl] = (ms, kernels.knn(x, k, "feature"))
             _lib.prof_enable(True)
@@ -139,13 +140,14 @@ def bench_smallk():
             for _ in range(5):
                 kernels.knn(x, k, "feature")
             torch.cuda.synchronize()
-            print("    PN_KNN_SMALLK=%s: " % lvl + "  ".join("%s %.3f" % (kn, t / calls) for kn, (t, calls) in sorted(_lib.prof_results().items())))
+            print("    %s: " % {"f": "PN_KNN_FUSED=1", "1": "PN_KNN_SMALLK=1", "0": "PN_KNN_SMALLK=0"}[lvl] + "  ".join("%s %.3f" % (kn, t / calls) for kn, (t, calls) in sorted(_lib.prof_results().items())))
             _lib.prof_enable(False)
         os.environ.pop("PN_KNN_SMALLK")
-        same = bool((out["1"][1] == out["0"][1]).all())
+        os.environ.pop("PN_KNN_FUSED")
+        same = bool((out["1"][1] == out["0"][1]).all()) and bool((out["1"][1] == out["f"][1]).all())
         gf = B * N * N * (2 * C + 3) / 1e9
-        print("knn B=%d C=%d N=%d k=%d: one pass %.3f ms (%.1f TFLOP/s), two-pass engine %.3f ms, same graph: %s"
-              % (B, C, N, k, out["1"][0], gf / out["1"][0], out["0"][0], same))
+        print("knn B=%d C=%d N=%d k=%d: one pass %.3f ms (%.1f TFLOP/s), two-pass engine %.3f ms, one-pass bf16 x 3 form "
+              "%.3f ms, same graph: %s" % (B, C, N, k, out["1"][0], gf / out["1"][0], out["0"][0], out["f"][0], same))
 
 
 def bench_knn64():
