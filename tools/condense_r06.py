@@ -100,6 +100,8 @@ pmc(["pmc_named_TCC_HIT_sum", "pmc_named_FETCH_SIZE", "pmc_named_WRITE_SIZE", "p
     os.path.join(P, "r06_named_kernels_pmc.csv"), ("pn_edgeconv_reduce_kernel", "pn_edgeconv_bwd_gather_kernel", "pn_knn_smallk_kernel", "pn_rev_"))
 copy("torch_sites.txt", "r06_cfg5_torch_sites.txt", head=110)
 copy("host_cprofile.txt", "r06_cfg5_host_cprofile.txt", head=70)
+copy("op_lines.txt", "r06_op_lines.txt", head=110)
+copy("copy_census.txt", "r06_copy_census.txt", head=110)
 copy("host.txt", "r06_host.txt")
 copy("kbench.log", "r06_named_kernels_kbench.txt")
 copy("clock_sysfs.txt", "r06_clock_sysfs_sampler.txt")

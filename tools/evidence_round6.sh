@@ -73,6 +73,8 @@ timeout 300 python tools/probes/clock_under_load.py 4 > $O/clock_sysfs.txt 2>&1
 PARSENET_FORCE_COLLECTIVE=1 WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 timeout 900 python bench.py --no-cpu-baseline --no-dense > $O/bench_cfg5_forced_collective.json 2> $O/bench_cfg5_forced_collective.err
 timeout 600 python tools/torch_sites.py > $O/torch_sites.txt 2>&1
 timeout 600 python tools/host_cprofile.py > $O/host_cprofile.txt 2>&1
+timeout 600 python tools/probes/op_lines.py > $O/op_lines.txt 2>&1
+timeout 600 python tools/probes/copy_census.py > $O/copy_census.txt 2>&1
 fi
 tail -2 $O/smoke.log; cat $O/host.txt; grep -i "passed\|failed\|^rc " $O/pytest.log | cut -c1-300; tail -n 1 $O/det_cfg*.txt
 for f in bench_cfg5 bench_cfg5_b bench_cfg5_c bench_cfg4 bench_cfg2 bench_cfg3; do cut -c1-260 $O/$f.json; done

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, call r: the covariance download of the spline standardisation queued before the primitives' fits
+# (PARSENET_STD_EARLY existed only in the tree this call ran on: the change was measured and reverted, profiles/r06_host_overlap_ab.txt)
 # (PARSENET_STD_EARLY); groups of shapes in the fitting stage re-measured (PARSENET_FIT_CHUNKS=2, last measured in round 3)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
