@@ -463,13 +463,19 @@ __global__ __launch_bounds__(256) void pn_knn_final_kernel(
     const int off = inc - myc;
     if (cmax <= nsub) {   // short lists (kNN graphs): a lane per list
       const u64* lp = lists + (ql * nsub + lane) * (size_t)subcap;
-      for (int e = 0; e < cmax; ++e) {
-        if (e < myc) {
-          const u64 key = lp[e];
-          // candidate index: permuted -> original, so that ties order by the caller's indices
-          const int jp = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
-          keys[off + e] = (key & 0xffffffff00000000ull) |
-                          (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
+      // (eight loads in flight, then their stores: the one-by-one form paid a memory latency per entry)
+      for (int e0 = 0; e0 < cmax; e0 += 8) {
+        u64 kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = e0 + u < myc ? lp[e0 + u] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (e0 + u < myc) {
+            // candidate index: permuted -> original, so that ties order by the caller's indices
+            const int jp = (int)(0xffffffffu - (uint32_t)(kk[u] & 0xffffffffu));
+            keys[off + e0 + u] = (kk[u] & 0xffffffff00000000ull) |
+                                 (u64)(0xffffffffu - (uint32_t)knn_perm(perm_c, jp));
+          }
         }
       }
     } else {              // long lists (K-th value of hundreds): the lanes over the entries of a list
