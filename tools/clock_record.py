@@ -34,8 +34,8 @@ print("  => matrix pipe busy %.3f of the cycles in which a SIMD has its two wave
 print("     the difference is the launch's ramp and tail (workgroups with list lengths of their own finish at different times)")
 print("""
 Reading: the round-5 claim ("0.69 of the resident cycles busy, the rest is the power-limited clock") holds in part.  The chip
-runs this kernel at %.2f GHz, %.2f of the data-sheet clock (the boxes of the pool differ by a few percent: 2.00 GHz and 464.9 us on
-the box of the previous evidence run, the same cycle count): that is %.2f of the distance to the peak and not the kernel's.
+runs this kernel at %.2f GHz, %.2f of the data-sheet clock (the boxes of the pool differ by a few percent: the evidence runs of the round
+measured 1.94 GHz / 477.5 us, 2.00 GHz / 464.9 us and 2.05 GHz / 453.7 us for the same cycle count): that is %.2f of the distance to the peak and not the kernel's.
 Of the cycles it has, the matrix pipe is busy %.2f: %.2f are ramp and tail of the planned launch, the remaining %.2f are the
 kernel's own — barrier and DMA waits between the two GEMMs of a tile pair and the elementwise stage (exp, row sums) issued
 beside the MFMAs.
